@@ -1,0 +1,261 @@
+#!/usr/bin/env python
+"""bench.py -- pre-training step throughput of the MI355X-native MultiMAE engine.
+
+Metric (BASELINE.json): pre-train images/sec (whole node), ViT-B RGB+D+S 224^2, 98 visible tokens,
+bs 256 / GPU, 1/2/4/8 MI355X.  One "step" = what run_pretraining_multimae.py:500-537 does per
+iteration: masked forward (Dirichlet sampling, alphas 1.0) -> 4 masked losses (rgb MSE, depth L1,
+semseg CE in the fp32 adapter, norm-pix MSE) -> backward -> gradient all-reduce (N > 1) ->
+AdamW(betas .9/.95, wd .05 on every tensor).  Synthetic inputs resident in HBM, random-init weights.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 5
+
+Prints ONE JSON line (rank 0) with the driver's contract plus "roofline" and "cpu_baseline".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+ALG_GFLOP_PER_IMG = {'cfg3': 65.4, 'cfg2': 57.4}   # GEMM flops fwd+bwd, visible-patch embedding (SURVEY 8d / BASELINE.md 2)
+PEAK_BF16_TFLOPS = 2500.0                            # dense MFMA bf16, MI355X_MICROARCH.md
+
+
+def build_model(cfg: str):
+    import multimae_amd as M
+    doms = ['rgb', 'depth', 'semseg'] if cfg == 'cfg3' else ['rgb']
+    ins = {}
+    for d in doms:
+        if d == 'semseg':
+            ins[d] = M.SemSegInputAdapter(num_classes=133, dim_class_emb=64, interpolate_class_emb=False, stride_level=4,
+                                          patch_size_full=16)
+        else:
+            ins[d] = M.PatchedInputAdapter(num_channels=3 if d == 'rgb' else 1, stride_level=1, patch_size_full=16)
+    outs = {}
+    for key, task in [(d, d) for d in doms] + [('norm_rgb', 'rgb')]:
+        ch = {'rgb': 3, 'depth': 1, 'semseg': 133}[task]
+        outs[key] = M.SpatialOutputAdapter(num_channels=ch, stride_level=4 if task == 'semseg' else 1, patch_size_full=16,
+                                           dim_tokens=256, depth=2, num_heads=8, use_task_queries=True, task=task,
+                                           context_tasks=list(doms), use_xattn=True)
+    model = M.create_model('pretrain_multimae_base', input_adapters=ins, output_adapters=outs, num_global_tokens=1,
+                           drop_path_rate=0.0)
+    return model.train(), doms
+
+
+def synthetic_batch(doms, B, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = {}
+    if 'rgb' in doms:
+        x['rgb'] = torch.randn(B, 3, 224, 224, device=device, generator=g)
+    if 'depth' in doms:
+        x['depth'] = torch.randn(B, 1, 224, 224, device=device, generator=g)
+    if 'semseg' in doms:
+        x['semseg'] = torch.randint(0, 133, (B, 56, 56), device=device, generator=g)
+    return x
+
+
+def loss_fns():
+    import multimae_amd as M
+    return {'rgb': M.MaskedMSELoss(16, 1), 'depth': M.MaskedL1Loss(16, 1), 'semseg': M.MaskedCrossEntropyLoss(16, 4),
+            'norm_rgb': M.MaskedMSELoss(16, 1, norm_pix=True)}
+
+
+def cpu_baseline(cfg: str, sample_B: int, steps: int):
+    """The oracle (CPU restatement pinned to the reference, oracle/multimae_oracle.py) timed on the host
+    cores: the same step (fwd -> 4 losses -> backward -> AdamW) in fp32."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import multimae_oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model, doms = build_model(cfg)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    train = {n for n, p in model.named_parameters() if p.requires_grad}
+    del model
+    ocfg = orc.standard_config(doms)
+    torch.manual_seed(0)
+    x = {}
+    if 'rgb' in doms:
+        x['rgb'] = torch.randn(sample_B, 3, 224, 224)
+    if 'depth' in doms:
+        x['depth'] = torch.randn(sample_B, 1, 224, 224)
+    if 'semseg' in doms:
+        x['semseg'] = torch.randint(0, 133, (sample_B, 56, 56))
+    m = {n: torch.zeros_like(sd[n]) for n in train}
+    v = {n: torch.zeros_like(sd[n]) for n in train}
+    times = []
+    for step in range(1, steps + 2):
+        t0 = time.perf_counter()
+        dist, tn, an = orc.draw_mask_randoms(sample_B, [196] * len(doms), 1.0)
+        spt = orc.samples_per_task_from_dirichlet(dist, 98)
+        mask_all, ik, ir = orc.masks_from_noise(spt, tn, an, 98)
+        sdo = {k: (t.requires_grad_(True) if k in train else t) for k, t in sd.items()}
+        preds = orc.multimae_forward(x, sdo, ocfg, ik, ir)
+        loss = sum(orc.pretrain_losses(preds, x, mask_all, ocfg, {d: 196 for d in doms}).values())
+        loss.backward()
+        with torch.no_grad():
+            grads = {n: sdo[n].grad for n in train}
+            for n in train:
+                sdo[n].requires_grad_(False)
+            orc.adamw_step({n: sd[n] for n in train}, grads, m, v, step, 1e-4, 0.05)
+            for n in train:
+                sd[n].grad = None
+        times.append(time.perf_counter() - t0)
+    times = sorted(times[1:])
+    med = times[len(times) // 2]
+    return {'value': round(sample_B / med, 3), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{steps} timed steps (median) of the same {cfg} step at B={sample_B}, fp32, oracle/multimae_oracle.py + torch autograd, '
+                      f'{cores} threads'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=256, help='per-GPU batch')
+    ap.add_argument('--config', default='cfg3', choices=['cfg3', 'cfg2'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-batch', type=int, default=16)
+    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    import multimae_amd as M
+    from multimae_amd import ops
+    from multimae_amd.dist import GradAllReducer, attach, broadcast_parameters
+    from multimae_amd.optim import FusedAdamW
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, f'launch with torch.distributed.run --nproc-per-node {args.gpus}'
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+
+    torch.manual_seed(0 + rank)                                   # run_pretraining_multimae.py:300
+    model, doms = build_model(args.config)
+    model.to(device)
+    arena = model.build_arena()
+    reducer = None
+    if world > 1:
+        broadcast_parameters(arena)
+        reducer = GradAllReducer.for_arena(arena)
+        attach(model, reducer)
+    M.engine.set_precision(args.precision)
+    M.engine.set_direct_grads(True)
+    B = args.batch
+    lr = 1e-4 * B * world / 256                                   # blr * global_bs / 256 (:372-373)
+    opt = FusedAdamW(model, lr=lr, betas=(0.9, 0.95), weight_decay=0.05)
+    x = synthetic_batch(doms, B, device, seed=rank)
+    tgt = dict(x, norm_rgb=x['rgb'])
+    fns = loss_fns()
+    fp32_adapters = ['semseg'] if 'semseg' in doms else []
+    last = {}
+
+    def step():
+        opt.zero_grad()
+        preds, masks = model(x, num_encoded_tokens=98, alphas=1.0, sample_tasks_uniformly=False, fp32_output_adapters=fp32_adapters)
+        mk = dict(masks, norm_rgb=masks['rgb'])
+        losses = {k: fns[k](preds[k].float(), tgt[k], mask=mk[k]) for k in preds}
+        loss = sum(losses.values())
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+        last['loss'] = loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ms_per_step = dt / args.steps * 1e3
+    img_s = B * world * args.steps / dt
+    final_loss = float(last['loss'])
+
+    # per-kernel timing pass (outside the timed region): HIP events around every MFMA GEMM launch
+    roof = None
+    if not args.no_kernel_timing:
+        rec = []
+        orig = ops.gemm
+
+        def timed_gemm(A, Bm, C, Mm, N, K, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(A, Bm, C, Mm, N, K, **kw)
+            e1.record()
+            rec.append((e0, e1, 2.0 * Mm * N * K * kw.get('batch', 1), A.dtype))
+        ops.gemm = timed_gemm
+        import multimae_amd.functions as F_
+        step()
+        torch.cuda.synchronize()
+        ops.gemm = orig
+        tot_ms = {torch.bfloat16: 0.0, torch.float32: 0.0}
+        tot_fl = {torch.bfloat16: 0.0, torch.float32: 0.0}
+        cnt = {torch.bfloat16: 0, torch.float32: 0}
+        for e0, e1, fl, dt_ in rec:
+            tot_ms[dt_] += e0.elapsed_time(e1)
+            tot_fl[dt_] += fl
+            cnt[dt_] += 1
+        dom = torch.bfloat16 if args.precision == 'bf16' else torch.float32
+        peak = PEAK_BF16_TFLOPS if dom == torch.bfloat16 else 157.3
+        ach = tot_fl[dom] / (tot_ms[dom] * 1e-3) / 1e12 if tot_ms[dom] > 0 else 0.0
+        roof = {'bound': 'mfma', 'kernel': 'gemm_bf16_kernel (all MFMA GEMM launches of one step)' if dom == torch.bfloat16 else 'gemm_f32_kernel',
+                'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
+                'launches_per_step': cnt[dom], 'gemm_ms_per_step': round(tot_ms[dom], 3),
+                'gemm_gflop_per_step': round(tot_fl[dom] / 1e9, 1),
+                'f32_adapter_gemm_ms_per_step': round(tot_ms[torch.float32], 3) if dom == torch.bfloat16 else None,
+                'f32_adapter_gemm_tflops': round(tot_fl[torch.float32] / max(tot_ms[torch.float32], 1e-9) / 1e9, 2) if dom == torch.bfloat16 else None,
+                'whole_step_frac_of_peak': round(ALG_GFLOP_PER_IMG[args.config] * 1e9 * B / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        M.engine.set_direct_grads(False)
+        cpu = cpu_baseline(args.config, args.cpu_sample_batch, args.cpu_steps)
+
+    if rank == 0:
+        out = {
+            'metric': 'pre-train images/sec (whole node), ViT-B RGB+D+S 224^2 98-vis-tok' if args.config == 'cfg3'
+                      else 'pre-train images/sec (whole node), ViT-B RGB-only 224^2 98-vis-tok',
+            'value': round(img_s, 1), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.precision if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
+            'config': {'workload': f'BASELINE.json configs[{2 if args.config == "cfg3" else 1}]: ViT-B, '
+                                   + ('RGB+depth+semseg' if args.config == 'cfg3' else 'RGB-only')
+                                   + ', 224^2, Dirichlet alpha=1.0, 98 visible tokens, 4 cross-attention decoders (dim 256, depth 2), '
+                                     'fp32 semseg adapter, AdamW; fwd+losses+bwd+optimizer',
+                       'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}'},
+            'final_loss': round(final_loss, 5),
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,273 @@
+/*
+ * mmae.h -- C ABI of libmmae_hip.so, the MI355X (gfx950) kernel library under the
+ * MultiMAE pre-training engine.
+ *
+ * The reference (EPFL-VILAB MultiMAE) has no FFI: every arithmetic step of its hot
+ * path is a PyTorch ATen call made from multimae/*.py.  Each entry point below is
+ * therefore the HIP replacement for a group of ATen calls, and cites the reference
+ * call site it stands in for (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain C: raw device pointers, sizes, a hipStream_t passed as void*.  No torch
+ *     types, no C++ ABI coupling.
+ *   - return 0 on success, a negative MMAE_E* code on a rejected argument; never
+ *     throws, never allocates device memory, never synchronises.
+ *   - re-entrant and thread-safe (autograd calls backward from another thread).
+ *   - "act" tensors are bf16 (dtype code 1) or f32 (dtype code 0): MMAE_BF16 is the
+ *     speed mode, MMAE_F32 the exact-f32 parity mode (f32-input MFMA).
+ *   - all row-major; "ld*" are leading dimensions in ELEMENTS.
+ */
+#ifndef MMAE_H
+#define MMAE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMAE_ABI_VERSION 1
+
+#define MMAE_F32  0
+#define MMAE_BF16 1
+
+#define MMAE_EINVAL   (-1)   /* bad argument (shape / alignment / dtype)        */
+#define MMAE_ELAUNCH  (-2)   /* hipLaunchKernel reported an error               */
+#define MMAE_ESUPPORT (-3)   /* combination not implemented by this build       */
+
+int mmae_abi_version(void);
+/* last HIP error string seen by this thread's launches (static storage). */
+const char* mmae_last_error(void);
+
+/* ------------------------------------------------------------------------- *
+ * GEMM  C[M,N] (+)= alpha * A[M,K] . B[N,K]^T  with fused epilogue.
+ * Replaces: nn.Linear / F.linear (multimae_utils.py:143-153,165-180,192-212;
+ * output_adapters.py:138-139,154,258,274), nn.Conv2d-as-patch-linear
+ * (input_adapters.py:88-91,110,206-209,232), q@k^T and attn@v
+ * (multimae_utils.py:175-179,206-210) and every autograd dX / dW product of them.
+ *
+ * a_trans = 0: A stored [M][K] (k contiguous);  1: stored [K][M] (m contiguous).
+ * b_trans = 0: B stored [N][K] (k contiguous);  1: stored [K][N] (n contiguous).
+ * Batched: z in [0, batch): zo = z / batch_inner, zi = z % batch_inner;
+ *          X_z = X + zo * sX_outer + zi * sX_inner  (elements).
+ * Epilogue (in this order): v = alpha*acc; v += bias[n]; epi; v += resid[m,n];
+ *          C = accumulate ? C + v : v.
+ *   epi = MMAE_EPI_GELU : aux[m,n] = v (pre-activation, act dtype); v = gelu_erf(v)
+ *   epi = MMAE_EPI_DGELU: v *= gelu_erf'(aux[m,n])
+ * bf16 operands need lda/ldb % 8 == 0 and 16-byte aligned bases; a k-contiguous
+ * operand may have any K as long as the bytes up to the next multiple of 8 along
+ * k are readable and finite*0-safe (the engine zero-pads).
+ * ------------------------------------------------------------------------- */
+#define MMAE_EPI_NONE  0
+#define MMAE_EPI_GELU  1
+#define MMAE_EPI_DGELU 2
+
+typedef struct mmae_gemm_desc {
+    const void* A; const void* B; void* C;
+    int32_t ab_dtype;            /* MMAE_F32 | MMAE_BF16 */
+    int32_t c_dtype;             /* MMAE_F32 | MMAE_BF16 */
+    int32_t M, N, K;
+    int32_t a_trans, b_trans;
+    int64_t lda, ldb, ldc;
+    int32_t batch, batch_inner;
+    int64_t sA_outer, sA_inner, sB_outer, sB_inner, sC_outer, sC_inner;
+    const float* bias;           /* [N] or NULL */
+    const float* resid;          /* f32 [M][ldr] or NULL (unbatched only) */
+    int64_t ldr;
+    void* aux;                   /* act-dtype [M][ldaux] or NULL */
+    int64_t ldaux;
+    int32_t aux_dtype;
+    int32_t epi;
+    int32_t accumulate;          /* C += v (c_dtype must be f32) */
+    float alpha;
+    int32_t tile;                /* 0 = auto, 1 = 128x128, 2 = 256x128 */
+} mmae_gemm_desc;
+
+int mmae_gemm(const mmae_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * LayerNorm (biased variance, eps inside rsqrt), rows of width D.
+ * Replaces nn.LayerNorm(eps=1e-6): multimae_utils.py:222,225,230-231;
+ * output_adapters.py:120-122,265-266.
+ *   fwd:  y = (x-mean)*rstd*gamma+beta;   x f32 [R][D]; y act dtype; saves mean,rstd
+ *   bwd:  dx_out = (dx_in ? dx_in : 0) + LN'(dy);  also writes an act-dtype copy
+ *         dx_act (may be NULL); accumulates per-block partial dgamma/dbeta into
+ *         part[nblk][2][D] (nblk = mmae_layernorm_bwd_nblk(R)), reduced by
+ *         mmae_colsum_partials.
+ * ------------------------------------------------------------------------- */
+int mmae_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype,
+                       float* mean, float* rstd, int64_t R, int D, float eps, void* stream);
+int mmae_layernorm_bwd_nblk(int64_t R);
+int mmae_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma,
+                       const float* mean, const float* rstd, const float* dx_in, float* dx_out,
+                       void* dx_act, int dx_act_dtype, float* part, int64_t R, int D, void* stream);
+/* out[c] (+)= sum_r part[r][c], part f32 [nrows][ncols] */
+int mmae_colsum_partials(const float* part, float* out, int nrows, int ncols, int accumulate, void* stream);
+
+/* column sums of an activation-gradient matrix: out[n] (+)= sum_m dy[m][n]
+ * (bias gradients of every Linear).  dy act dtype [M][ld].  ws: f32 scratch of
+ * mmae_colsum_ws_elems(M, N) elements. */
+int64_t mmae_colsum_ws_elems(int64_t M, int N);
+int mmae_colsum(const void* dy, int dtype, int64_t M, int N, int64_t ld, float* out, int accumulate,
+                float* ws, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Row softmax over materialised attention scores (unfused attention path and the
+ * f32 parity mode).  Replaces attn.softmax(dim=-1), multimae_utils.py:176,207.
+ *   fwd: P[r][0:n] = softmax(scale * S[r][0:n]); P[r][n:ldp] = 0.  S f32, P act dtype.
+ *   bwd: dS = scale * P .* (dP - sum_j dP_j P_j); dS[r][n:ld] = 0.  dP f32, dS act dtype.
+ * ------------------------------------------------------------------------- */
+int mmae_softmax_fwd(const float* S, int64_t lds_, void* P, int p_dtype, int64_t ldp, int64_t rows, int n,
+                     float scale, void* stream);
+int mmae_softmax_bwd(const void* P, int p_dtype, int64_t ldp, const float* dP, int64_t lddp, void* dS,
+                     int64_t ldds, int64_t rows, int n, float scale, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Casts.  f32 master weights -> act-dtype shadows (optionally transposed so that
+ * dX = dY.W is again an "NT" product).
+ * ------------------------------------------------------------------------- */
+int mmae_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int mmae_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+/* dst[c][r] = src[r][c], src f32 [rows][cols]; dst act dtype [cols][rows] */
+int mmae_transpose_cast(const float* src, void* dst, int dst_dtype, int rows, int cols, void* stream);
+/* y (+)= a*x elementwise, f32 */
+int mmae_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Mask sampler: deterministic core of MultiMAE.generate_random_masks
+ * (multimae/multimae.py:191-216).  The random draws are INPUTS (the reference draws
+ * Dirichlet on the CPU generator, :187, and the noise with torch.rand on the
+ * device, :195,204) so a CPU-generated stream reproduces the reference bit for bit.
+ *   samples_per_task  int64 [B][T]      round(p * num_encoded) (:189)
+ *   task_noise        f32   [B][Ntot]   per-task noise, tasks concatenated
+ *   all_noise         f32   [B][Ntot]
+ *   task_offsets      int32 [T+1]       host array: start of each task in Ntot
+ * outputs (int64): mask_all [B][Ntot] (0 = visible), ids_keep [B][n_keep],
+ *                  ids_restore [B][Ntot].  Ties broken by lower index first.
+ * ------------------------------------------------------------------------- */
+int mmae_mask_sample(const int64_t* samples_per_task, const float* task_noise, const float* all_noise,
+                     const int32_t* task_offsets_host, int T, int B, int Ntot, int n_keep,
+                     int64_t* mask_all, int64_t* ids_keep, int64_t* ids_restore, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Gather-first patch embedding.  Replaces PatchedInputAdapter.forward
+ * (input_adapters.py:97-119) / SemSegInputAdapter.forward (:215-241) followed by
+ * torch.gather(ids_keep) and the global-token concat (multimae.py:340-347), for the
+ * kept tokens only.
+ *
+ * mmae_patch_rows builds, for every kept token (b, r), one row of width Ktot =
+ * sum_t C_t*ph_t*pw_t: the flattened patch in Conv2d-weight column order (c, i, j)
+ * placed in the owner task's segment [k_off, k_off + C*ph*pw), zeros elsewhere.  One
+ * GEMM against the K-concatenated projection weights then embeds all modalities.
+ *   kind 0: data = f32 [B][C][H][W];  kind 1: data = int64 class ids [B][H][W]
+ *   looked up in emb f32 [n_cls][C] (C = dim_class_emb).
+ * task_offsets_host int32 [T+1]: first token index of each task in the concatenated
+ * token axis (host memory; baked into the launch).
+ * ------------------------------------------------------------------------- */
+typedef struct mmae_patch_src {
+    const void* data;
+    const float* emb;
+    int32_t kind, C, H, W, ph, pw, k_off;
+} mmae_patch_src;
+
+int mmae_patch_rows(const mmae_patch_src* srcs_host, const int32_t* task_offsets_host, int T, const int64_t* sel,
+                    void* rows, int rows_dtype, int B, int n_sel, int Ktot, void* stream);
+/* d_emb[cls][e] += d_rows[row][k_off + e*ph*pw + i*pw + j] over the selected tokens in
+ * [tok_off, tok_off + n_patches); d_rows act dtype [B*n_sel][ld].  (float atomics) */
+int mmae_semseg_emb_bwd(const void* d_rows, int rows_dtype, int64_t ld, const int64_t* cls, const int64_t* sel, float* d_emb,
+                        int B, int H, int W, int E, int ph, int pw, int n_sel, int k_off, int tok_off, int n_patches, int n_cls,
+                        void* stream);
+/* tok[b][r][:] = proj[b*n_sel+r][:] + bias_t[:] + pos_t[p][:] (t, p = owner task / patch of
+ * sel[b][r]); tok[b][n_sel+g][:] = global_tok[g][:].  tok f32 [B][n_sel+G][D];
+ * bias / pos: host arrays of T device pointers (pos_t f32 [n_patches_t][D]). */
+int mmae_tokens_assemble(float* tok, const float* proj, const float* const* bias_host, const float* const* pos_host,
+                         const int32_t* task_offsets_host, int T, const int64_t* sel, const float* global_tok, int B, int n_sel,
+                         int G, int D, void* stream);
+/* backward: d_proj[b*n_sel+r][:] = d_tok[b][r][:] (act dtype); part f32 [nblk][T+G][D] holds
+ * per-workgroup column sums (rows 0..T-1: bias_t, rows T..T+G-1: global tokens), to be reduced
+ * with mmae_colsum_partials.  nblk = mmae_tokens_assemble_bwd_nblk(B); needs T+G <= 8. */
+int mmae_tokens_assemble_bwd_nblk(int B);
+int mmae_tokens_assemble_bwd(const float* d_tok, void* d_proj, int proj_dtype, const int32_t* task_offsets_host, int T,
+                             const int64_t* sel, float* part, int B, int n_sel, int G, int D, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Decoder query / context builder.  Replaces SpatialOutputAdapter.
+ * get_queries_and_context + generate_context_embeddings, output_adapters.py:160-234
+ * (use_task_queries path), without materialising the (B, Ntot, D) tensor.
+ *   ctx      f32 [B][n_keep+G][D]   proj_context output
+ *   queries  f32 [B][n_q][D]:  q[b][j] = (vis ? ctx[b][ids_restore[b][q_off+j]] : mask_token)
+ *                                        + task_emb[q_task] + pos[j]
+ *   context  f32 [B][n_keep+G][D]: c[b][r] = ctx[b][r] + task_emb[task(ids_keep[b][r])]
+ *                                        + pos[ids_keep[b][r] - off(task)];  global rows copied.
+ *   task_emb f32 [T][D]; pos f32 [n_patch][D] (same table for every task: all tasks share
+ *  the decoder's N_H x N_W grid, output_adapters.py:172-175); task_offsets int32 [T+1] (host).
+ * ------------------------------------------------------------------------- */
+int mmae_decoder_build(const float* ctx, const int64_t* ids_keep, const int64_t* ids_restore,
+                       const float* mask_token, const float* task_emb, const float* pos,
+                       const int32_t* task_offsets_host, int T, int q_task, int B, int n_keep, int G, int D,
+                       int n_q, float* queries, float* context, void* stream);
+/* backward: d_ctx (f32, overwritten) from d_queries/d_context; parameter gradients are
+ * accumulated through partials: part f32 [nblk][T+1][D] (rows 0..T-1 task_emb, row T
+ * mask_token), nblk = mmae_decoder_build_bwd_nblk(B). */
+int mmae_decoder_build_bwd_nblk(int B);
+int mmae_decoder_build_bwd(const float* d_queries, const float* d_context, const int64_t* ids_keep,
+                           const int64_t* ids_restore, const int32_t* task_offsets_host, int T, int q_task,
+                           int B, int n_keep, int G, int D, int n_q, float* d_ctx, float* part, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Patch <-> image layout.  Replaces einops.rearrange 'b (nh nw) (c ph pw) ->
+ * b c (nh ph) (nw pw)', output_adapters.py:277-280, and its transpose for autograd.
+ * ------------------------------------------------------------------------- */
+int mmae_unpatchify(const float* patches, float* img, int B, int C, int nh, int nw, int ph, int pw, void* stream);
+int mmae_patchify(const float* img, void* patches, int patches_dtype, int B, int C, int nh, int nw, int ph, int pw,
+                  void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Masked losses.  Replace MaskedMSELoss / MaskedL1Loss (criterion.py:84-114,
+ * 141-171, incl. norm_pix :88-95) and MaskedCrossEntropyLoss (:37-57).
+ *   pred/target f32 [B][C][H][W] (CE: logits [B][C][H][W], target int64 [B][H][W]);
+ *   mask int64 [B][nh*nw] (1 = contributes), patch = H/nh.
+ *   per_sample f32 [B][2]: (sum of masked per-pixel errors, number of masked pixels)
+ *   loss f32 [2] = (mean over samples with count>0 of sum/count  (nanmean semantics),
+ *                   number of such samples);
+ *   stats f32 [B][nh*nw][2]: (mean, rstd) of the target patch when norm_pix.
+ * kind: 0 = MSE, 1 = L1.
+ * bwd: d_pred = upstream * d loss / d pred (zeros on unmasked pixels).
+ * ------------------------------------------------------------------------- */
+int mmae_loss_split(void);   /* workgroups per sample: partial is f32 [B][mmae_loss_split()] */
+int mmae_masked_pixel_loss_fwd(const float* pred, const float* target, const int64_t* mask, int kind, int norm_pix,
+                               int B, int C, int H, int W, int patch, float* stats, float* partial, float* per_sample,
+                               float* loss, void* stream);
+int mmae_masked_pixel_loss_bwd(const float* pred, const float* target, const int64_t* mask, int kind, int norm_pix,
+                               int B, int C, int H, int W, int patch, const float* stats, const float* per_sample,
+                               const float* loss, const float* upstream, float* d_pred, void* stream);
+int mmae_masked_ce_fwd(const float* logits, const int64_t* target, const int64_t* mask, int B, int C, int H, int W,
+                       int patch, float* lse, float* partial, float* per_sample, float* loss, void* stream);
+int mmae_masked_ce_bwd(const float* logits, const int64_t* target, const int64_t* mask, int B, int C, int H, int W,
+                       int patch, const float* lse, const float* per_sample, const float* loss, const float* upstream,
+                       float* d_logits, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Optimiser step on flat arenas.  Replaces get_grad_norm_ / clip_grad_norm_
+ * (utils/native_scaler.py:22-35,49-62) and torch.optim.AdamW.step as configured by
+ * utils/optim_factory.py:138-174 (decoupled weight decay on every tensor).
+ *   mmae_sumsq: out[0] (+)= sum x^2   (ws: f32 scratch >= 1024 elements)
+ *   mmae_adamw: p,g,m,v f32 [n]; grad_scale multiplies g first (clipping);
+ *               optional act-dtype shadow of the updated parameters.
+ *               If skip_flag (device int32) is non-null and *skip_flag != 0 the step
+ *               is a no-op (non-finite / skip_grad handling without a host sync).
+ * ------------------------------------------------------------------------- */
+int mmae_sumsq(const float* x, int64_t n, float* out, float* ws, void* stream);
+int mmae_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+               float eps, float weight_decay, int step, const float* grad_scale_dev, const int32_t* skip_flag,
+               void* shadow, int shadow_dtype, void* stream);
+
+/* hardware probes used by tests/ to pin instruction semantics the kernels rely on */
+int mmae_probe_tr16(const uint16_t* lds_image_1024, const uint32_t* lane_byte_addr_64, uint16_t* out_64x4,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMAE_H */

@@ -1,0 +1,119 @@
+"""ctypes binding of libmmae_hip.so (C ABI declared in include/mmae.h).
+
+The prototypes are parsed from the header at import time, so the Python side can
+never drift from the ABI, and ``declared_symbols()`` lets the tests check that the
+built library exports every declared entry point.
+
+There is NO fallback: if the shared library is missing or a kernel reports an
+error, the call raises.  (The product path must fail loudly without the HIP
+extension -- the CPU oracle under oracle/ is test infrastructure only.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Tuple
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(_PKG), 'include', 'mmae.h')
+LIB_PATH = os.path.join(_PKG, 'libmmae_hip.so')
+
+F32, BF16 = 0, 1
+EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
+
+
+class GemmDesc(ctypes.Structure):
+    """mirror of mmae_gemm_desc"""
+    _fields_ = [
+        ('A', ctypes.c_void_p), ('B', ctypes.c_void_p), ('C', ctypes.c_void_p),
+        ('ab_dtype', ctypes.c_int32), ('c_dtype', ctypes.c_int32),
+        ('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32),
+        ('a_trans', ctypes.c_int32), ('b_trans', ctypes.c_int32),
+        ('lda', ctypes.c_int64), ('ldb', ctypes.c_int64), ('ldc', ctypes.c_int64),
+        ('batch', ctypes.c_int32), ('batch_inner', ctypes.c_int32),
+        ('sA_outer', ctypes.c_int64), ('sA_inner', ctypes.c_int64),
+        ('sB_outer', ctypes.c_int64), ('sB_inner', ctypes.c_int64),
+        ('sC_outer', ctypes.c_int64), ('sC_inner', ctypes.c_int64),
+        ('bias', ctypes.c_void_p), ('resid', ctypes.c_void_p), ('ldr', ctypes.c_int64),
+        ('aux', ctypes.c_void_p), ('ldaux', ctypes.c_int64),
+        ('aux_dtype', ctypes.c_int32), ('epi', ctypes.c_int32), ('accumulate', ctypes.c_int32),
+        ('alpha', ctypes.c_float), ('tile', ctypes.c_int32),
+    ]
+
+
+class PatchSrc(ctypes.Structure):
+    """mirror of mmae_patch_src"""
+    _fields_ = [
+        ('data', ctypes.c_void_p), ('emb', ctypes.c_void_p),
+        ('kind', ctypes.c_int32), ('C', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32),
+        ('ph', ctypes.c_int32), ('pw', ctypes.c_int32), ('k_off', ctypes.c_int32),
+    ]
+
+
+_SCALARS = {
+    'int': ctypes.c_int, 'int32_t': ctypes.c_int32, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float,
+    'size_t': ctypes.c_size_t,
+}
+_RET = {'int': ctypes.c_int, 'int64_t': ctypes.c_int64, 'const char*': ctypes.c_char_p}
+
+
+def _parse_header(path: str) -> Dict[str, Tuple[object, List[object]]]:
+    src = open(path).read()
+    src = re.sub(r'/\*.*?\*/', ' ', src, flags=re.S)
+    src = re.sub(r'//[^\n]*', ' ', src)
+    src = re.sub(r'typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;', ' ', src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r'(const\s+char\s*\*|int64_t|int)\s+(mmae_\w+)\s*\(([^)]*)\)\s*;', src):
+        ret = re.sub(r'\s+', ' ', m.group(1)).replace(' *', '*')
+        name, args = m.group(2), m.group(3).strip()
+        argtypes = []
+        if args and args != 'void':
+            for a in args.split(','):
+                a = a.strip()
+                if '*' in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    ty = a.split()[-2] if len(a.split()) >= 2 else a
+                    argtypes.append(_SCALARS[ty])
+        protos[name] = (_RET[ret], argtypes)
+    return protos
+
+
+_PROTOS = _parse_header(HEADER) if os.path.exists(HEADER) else {}
+_lib = None
+
+
+def declared_symbols() -> List[str]:
+    return sorted(_PROTOS)
+
+
+def load() -> ctypes.CDLL:
+    """Load libmmae_hip.so (once) and attach prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} not found: the MI355X kernel library is not built. '
+            'Run `python -c "import __graft_entry__ as g; g.build()"` (or `make -C multimae_amd/csrc`). '
+            'multimae_amd has no CPU / PyTorch fallback by design.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (ret, argtypes) in _PROTOS.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = ret
+        fn.argtypes = argtypes
+    if lib.mmae_abi_version() != 1:
+        raise RuntimeError('libmmae_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+class KernelError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().mmae_last_error()
+        raise KernelError(f'{what} failed (rc={rc}): {msg.decode() if msg else "?"}')

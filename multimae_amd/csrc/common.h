@@ -1,0 +1,80 @@
+// Shared device/host helpers for the gfx950 kernels of libmmae_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mmae.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define MMAE_WAVE 64
+
+void mmae_set_error(const char* msg);
+int mmae_check_launch(const char* what);
+
+#define MMAE_REQUIRE(cond, msg) do { if (!(cond)) { mmae_set_error(msg); return MMAE_EINVAL; } } while (0)
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) -------------------------------
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);   // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+}
+
+// typed element access: T is float or uint16_t (bf16 bits)
+template <typename T> struct ActT;
+template <> struct ActT<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct ActT<uint16_t> {
+    static __device__ __forceinline__ float ld(const uint16_t* p) { return bf16_bits_to_f32(*p); }
+    static __device__ __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_bf16_bits(v); }
+};
+
+// load/store 4 consecutive act elements (16-byte / 8-byte aligned)
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4(const uint16_t* p) {
+    i32x2 r = *reinterpret_cast<const i32x2*>(p);
+    f32x4 o;
+    o[0] = __uint_as_float(((uint32_t)r[0]) << 16); o[1] = __uint_as_float(((uint32_t)r[0]) & 0xffff0000u);
+    o[2] = __uint_as_float(((uint32_t)r[1]) << 16); o[3] = __uint_as_float(((uint32_t)r[1]) & 0xffff0000u);
+    return o;
+}
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void st4(uint16_t* p, f32x4 v) {
+    i32x2 r; r[0] = (int)pack_bf16x2(v[0], v[1]); r[1] = (int)pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<i32x2*>(p) = r;
+}
+
+// ---- exact (erf) GELU as nn.GELU() computes it -------------------------------------------
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ---- wave / block reductions ---------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,80 @@
+// Kernel-argument block and fused epilogue shared by the bf16 and f32 MFMA GEMM kernels.
+#pragma once
+#include "common.h"
+
+struct GemmArgs {
+    const void* A; const void* B; void* C;
+    int M, N, K;
+    long long lda, ldb, ldc;
+    int nb_inner;
+    long long sAo, sAi, sBo, sBi, sCo, sCi;
+    const float* bias;
+    const float* resid; long long ldr;
+    void* aux; long long ldaux;
+    int c_f32, aux_f32, epi, accumulate, vec;
+    float alpha;
+    int tiles_n;
+};
+
+// The kernels compute D[i = n][j = m] (B fragment as the MFMA "A" operand) so that one lane
+// owns 4 consecutive n for a fixed m: a row-per-lane epilogue with 8/16-byte accesses.
+// acc holds columns n .. n+3 of row m.
+__device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, char* Cz, int m, int n, f32x4 acc) {
+    if (m >= g.M || n >= g.N) return;
+    const int cnt = (g.N - n) < 4 ? (g.N - n) : 4;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = acc[j] * g.alpha;
+    const bool full = g.vec && (cnt == 4);
+    if (g.bias) {
+        if (full) { f32x4 b = ld4(g.bias + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += b[j];
+        } else { for (int j = 0; j < cnt; ++j) v[j] += g.bias[n + j]; }
+    }
+    if (g.epi == MMAE_EPI_GELU) {
+        const long long ao = (long long)m * g.ldaux + n;
+        if (g.aux_f32) {
+            float* a = (float*)g.aux + ao;
+            if (full) { f32x4 t = {v[0], v[1], v[2], v[3]}; st4(a, t); } else for (int j = 0; j < cnt; ++j) a[j] = v[j];
+        } else {
+            uint16_t* a = (uint16_t*)g.aux + ao;
+            if (full) { f32x4 t = {v[0], v[1], v[2], v[3]}; st4(a, t); } else for (int j = 0; j < cnt; ++j) a[j] = f32_to_bf16_bits(v[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+    } else if (g.epi == MMAE_EPI_DGELU) {
+        const long long ao = (long long)m * g.ldaux + n;
+        float p[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.aux_f32) {
+            const float* a = (const float*)g.aux + ao;
+            if (full) { f32x4 t = ld4(a); p[0] = t[0]; p[1] = t[1]; p[2] = t[2]; p[3] = t[3]; } else for (int j = 0; j < cnt; ++j) p[j] = a[j];
+        } else {
+            const uint16_t* a = (const uint16_t*)g.aux + ao;
+            if (full) { f32x4 t = ld4(a); p[0] = t[0]; p[1] = t[1]; p[2] = t[2]; p[3] = t[3]; } else for (int j = 0; j < cnt; ++j) p[j] = bf16_bits_to_f32(a[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(p[j]);
+    }
+    if (g.resid) {
+        const float* r = g.resid + (long long)m * g.ldr + n;
+        if (full) { f32x4 t = ld4(r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += t[j];
+        } else { for (int j = 0; j < cnt; ++j) v[j] += r[j]; }
+    }
+    const long long co = (long long)m * g.ldc + n;
+    if (g.c_f32) {
+        float* c = (float*)Cz + co;
+        if (g.accumulate) {
+            if (full) { f32x4 t = ld4(c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += t[j];
+            } else { for (int j = 0; j < cnt; ++j) v[j] += c[j]; }
+        }
+        if (full) { f32x4 t = {v[0], v[1], v[2], v[3]}; st4(c, t); } else for (int j = 0; j < cnt; ++j) c[j] = v[j];
+    } else {
+        uint16_t* c = (uint16_t*)Cz + co;
+        if (full) { f32x4 t = {v[0], v[1], v[2], v[3]}; st4(c, t); } else for (int j = 0; j < cnt; ++j) c[j] = f32_to_bf16_bits(v[j]);
+    }
+}

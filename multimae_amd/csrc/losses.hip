@@ -1,0 +1,289 @@
+// Masked reconstruction losses (criterion.py) and the flat-arena optimiser step.
+//
+// Loss definition reproduced exactly: for every sample,
+// sum over masked pixels of the channel-mean error divided by the number of masked pixels;
+// the loss is the mean of that over samples that have at least one masked token (nanmean).
+#include <math.h>
+#include "common.h"
+
+namespace {
+
+constexpr int LSPLIT = 8;   // workgroups per sample
+
+// block reduce of two floats over 256 threads; result valid in thread 0
+__device__ __forceinline__ void block_sum2(float& a, float& b) {
+    __shared__ float ra[4], rb[4];
+    a = wave_sum(a); b = wave_sum(b);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { ra[w] = a; rb[w] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) { a = (ra[0] + ra[1]) + (ra[2] + ra[3]); b = (rb[0] + rb[1]) + (rb[2] + rb[3]); }
+    __syncthreads();
+}
+
+// pixel losses.  grid (LSPLIT, B).  Each wave takes one masked patch at a time.
+// stats[b][p] = (mean, rstd) of the target patch (norm_pix).  partial[b][split] = sum of errors.
+__global__ void __launch_bounds__(256) pixel_loss_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                             const long long* __restrict__ mask, int kind, int norm_pix, int C, int H,
+                                                             int W, int P, float* __restrict__ stats, float* __restrict__ partial) {
+    const int b = blockIdx.y, nh = H / P, nw = W / P, np = nh * nw;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int npix = P * P, nval = npix * C;
+    float acc = 0.f;
+    for (int p = blockIdx.x * 4 + w; p < np; p += LSPLIT * 4) {
+        if (mask[(long long)b * np + p] == 0) continue;
+        const int py = p / nw, px = p % nw;
+        float mu = 0.f, rs = 1.f;
+        if (norm_pix) {
+            float s = 0.f;
+            for (int e = lane; e < nval; e += 64) {
+                const int c = e / npix, ij = e % npix;
+                s += target[(((long long)b * C + c) * H + py * P + ij / P) * W + px * P + ij % P];
+            }
+            mu = wave_sum(s) / (float)nval;
+            float q = 0.f;
+            for (int e = lane; e < nval; e += 64) {
+                const int c = e / npix, ij = e % npix;
+                const float d = target[(((long long)b * C + c) * H + py * P + ij / P) * W + px * P + ij % P] - mu;
+                q += d * d;
+            }
+            const float var = wave_sum(q) / (float)(nval - 1);     // unbiased (criterion.py:92)
+            rs = 1.0f / sqrtf(var + 1e-6f);
+            if (lane == 0) { stats[((long long)b * np + p) * 2] = mu; stats[((long long)b * np + p) * 2 + 1] = rs; }
+        }
+        float s = 0.f;
+        for (int e = lane; e < nval; e += 64) {
+            const int c = e / npix, ij = e % npix;
+            const long long a = (((long long)b * C + c) * H + py * P + ij / P) * W + px * P + ij % P;
+            const float t = (target[a] - mu) * rs;
+            const float d = pred[a] - t;
+            s += kind == 0 ? d * d : fabsf(d);
+        }
+        acc += wave_sum(s);
+    }
+    float dummy = 0.f;
+    block_sum2(acc, dummy);
+    if (threadIdx.x == 0) partial[(long long)b * LSPLIT + blockIdx.x] = acc / (float)C;
+}
+
+// per_sample[b] = (sum, count); loss = mean over samples with count > 0 of sum / count.
+// aux[0] = number of such samples (used by backward).  Single workgroup.
+__global__ void __launch_bounds__(256) loss_finalize_kernel(const float* __restrict__ partial, const long long* __restrict__ mask, int B,
+                                                            int np, int pix_per_patch, float* __restrict__ per_sample,
+                                                            float* __restrict__ loss) {
+    float tot = 0.f, nvalid = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        float s = 0.f;
+        for (int i = 0; i < LSPLIT; ++i) s += partial[(long long)b * LSPLIT + i];
+        int cnt = 0;
+        for (int p = 0; p < np; ++p) cnt += mask[(long long)b * np + p] != 0;
+        const float c = (float)cnt * (float)pix_per_patch;
+        per_sample[b * 2] = s; per_sample[b * 2 + 1] = c;
+        if (cnt > 0) { tot += s / c; nvalid += 1.f; }
+    }
+    block_sum2(tot, nvalid);
+    if (threadIdx.x == 0) { loss[0] = nvalid > 0.f ? tot / nvalid : 0.f; loss[1] = nvalid; }
+}
+
+// d_pred.  thread per pixel-run element; grid over B*C*H*W.
+__global__ void pixel_loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target, const long long* __restrict__ mask,
+                                      int kind, int norm_pix, int C, int H, int W, int P, const float* __restrict__ stats,
+                                      const float* __restrict__ per_sample, const float* __restrict__ loss, const float* __restrict__ upstream,
+                                      float* __restrict__ d_pred, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % W); long long r = i / W;
+    const int y = (int)(r % H); r /= H;
+    const long long b = r / C;
+    const int nw = W / P, np = (H / P) * nw, p = (y / P) * nw + x / P;
+    float g = 0.f;
+    if (mask[b * np + p] != 0) {
+        float mu = 0.f, rs = 1.f;
+        if (norm_pix) { mu = stats[(b * np + p) * 2]; rs = stats[(b * np + p) * 2 + 1]; }
+        const float d = pred[i] - (target[i] - mu) * rs;
+        const float wgt = upstream[0] / (loss[1] * per_sample[b * 2 + 1] * (float)C);
+        g = wgt * (kind == 0 ? 2.f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)));
+    }
+    d_pred[i] = g;
+}
+
+// cross entropy.  thread per pixel, channel planes strided by H*W (coalesced across pixels).
+__global__ void __launch_bounds__(256) ce_fwd_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
+                                                     const long long* __restrict__ mask, int C, int H, int W, int P,
+                                                     float* __restrict__ lse, float* __restrict__ partial) {
+    const int b = blockIdx.y, HW = H * W, nw = W / P, np = (H / P) * nw;
+    float acc = 0.f;
+    for (int px = blockIdx.x * 256 + threadIdx.x; px < HW; px += LSPLIT * 256) {
+        const int y = px / W, x = px % W;
+        if (mask[(long long)b * np + (y / P) * nw + x / P] == 0) continue;
+        const float* l = logits + (long long)b * C * HW + px;
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, l[(long long)c * HW]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(l[(long long)c * HW] - mx);
+        const float ls = mx + logf(s);
+        lse[(long long)b * HW + px] = ls;
+        acc += ls - l[target[(long long)b * HW + px] * HW];
+    }
+    float dummy = 0.f;
+    block_sum2(acc, dummy);
+    if (threadIdx.x == 0) partial[(long long)b * LSPLIT + blockIdx.x] = acc;
+}
+
+__global__ void ce_bwd_kernel(const float* __restrict__ logits, const long long* __restrict__ target, const long long* __restrict__ mask,
+                              int C, int H, int W, int P, const float* __restrict__ lse, const float* __restrict__ per_sample,
+                              const float* __restrict__ loss, const float* __restrict__ upstream, float* __restrict__ d_logits,
+                              long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;    // over B*C*H*W
+    if (i >= total) return;
+    const int HW = H * W;
+    const int px = (int)(i % HW); long long r = i / HW;
+    const int c = (int)(r % C); const long long b = r / C;
+    const int y = px / W, x = px % W, nw = W / P, np = (H / P) * nw;
+    float g = 0.f;
+    if (mask[b * np + (y / P) * nw + x / P] != 0) {
+        const float wgt = upstream[0] / (loss[1] * per_sample[b * 2 + 1]);
+        const float sm = expf(logits[i] - lse[b * HW + px]);
+        g = wgt * (sm - (target[b * HW + px] == c ? 1.f : 0.f));
+    }
+    d_logits[i] = g;
+}
+
+// ---- optimiser ----------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sumsq_stage1(const float* __restrict__ x, long long n, float* __restrict__ ws) {
+    float s = 0.f, d = 0.f;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
+        if (i + 4 <= n) { const f32x4 v = ld4(x + i); s += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]); }
+        else for (long long j = i; j < n; ++j) s += x[j] * x[j];
+    }
+    block_sum2(s, d);
+    if (threadIdx.x == 0) ws[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) sumsq_stage2(const float* __restrict__ ws, int nb, float* __restrict__ out) {
+    float s = 0.f, d = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) s += ws[i];
+    block_sum2(s, d);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+template <typename ST>
+__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2_sqrt, const float* __restrict__ grad_scale,
+                                                    const int* __restrict__ skip, ST* __restrict__ shadow) {
+    if (skip && *skip) return;
+    const float gs = grad_scale ? *grad_scale : 1.f;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
+        if (i + 4 <= n) {
+            f32x4 pv = ld4(p + i), mv = ld4(m + i), vv = ld4(v + i);
+            const f32x4 gv = ld4(g + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float gj = gv[j] * gs;
+                pv[j] *= (1.f - lr * wd);
+                mv[j] = b1 * mv[j] + (1.f - b1) * gj;
+                vv[j] = b2 * vv[j] + (1.f - b2) * gj * gj;
+                const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+                pv[j] -= (lr / bc1) * (mv[j] / denom);
+            }
+            st4(p + i, pv); st4(m + i, mv); st4(v + i, vv);
+            if (shadow) st4(shadow + i, pv);
+        } else {
+            for (long long j = i; j < n; ++j) {
+                const float gj = g[j] * gs;
+                float pj = p[j] * (1.f - lr * wd);
+                const float mj = b1 * m[j] + (1.f - b1) * gj, vj = b2 * v[j] + (1.f - b2) * gj * gj;
+                pj -= (lr / bc1) * (mj / (sqrtf(vj) / bc2_sqrt + eps));
+                p[j] = pj; m[j] = mj; v[j] = vj;
+                if (shadow) ActT<ST>::st(shadow + j, pj);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mmae_masked_pixel_loss_fwd(const float* pred, const float* target, const int64_t* mask, int kind, int norm_pix, int B, int C,
+                               int H, int W, int patch, float* stats, float* partial, float* per_sample, float* loss, void* stream) {
+    MMAE_REQUIRE(pred && target && mask && partial && per_sample && loss, "pixel_loss_fwd: null pointer");
+    MMAE_REQUIRE(!norm_pix || stats, "pixel_loss_fwd: norm_pix needs stats");
+    MMAE_REQUIRE(patch > 0 && H % patch == 0 && W % patch == 0 && (kind == 0 || kind == 1), "pixel_loss_fwd: bad geometry");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pixel_loss_fwd_kernel, dim3(LSPLIT, B), dim3(256), 0, st, pred, target, (const long long*)mask, kind, norm_pix, C, H,
+                       W, patch, stats, partial);
+    int rc = mmae_check_launch("pixel_loss_fwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, partial, (const long long*)mask, B, (H / patch) * (W / patch),
+                       patch * patch, per_sample, loss);
+    return mmae_check_launch("loss_finalize");
+}
+
+int mmae_masked_pixel_loss_bwd(const float* pred, const float* target, const int64_t* mask, int kind, int norm_pix, int B, int C,
+                               int H, int W, int patch, const float* stats, const float* per_sample, const float* loss,
+                               const float* upstream, float* d_pred, void* stream) {
+    MMAE_REQUIRE(pred && target && mask && per_sample && loss && upstream && d_pred, "pixel_loss_bwd: null pointer");
+    const long long total = (long long)B * C * H * W;
+    hipLaunchKernelGGL(pixel_loss_bwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, pred, target,
+                       (const long long*)mask, kind, norm_pix, C, H, W, patch, stats, per_sample, loss, upstream, d_pred, total);
+    return mmae_check_launch("pixel_loss_bwd");
+}
+
+int mmae_masked_ce_fwd(const float* logits, const int64_t* target, const int64_t* mask, int B, int C, int H, int W, int patch,
+                       float* lse, float* partial, float* per_sample, float* loss, void* stream) {
+    MMAE_REQUIRE(logits && target && mask && lse && partial && per_sample && loss, "ce_fwd: null pointer");
+    MMAE_REQUIRE(patch > 0 && H % patch == 0 && W % patch == 0, "ce_fwd: bad geometry");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(LSPLIT, B), dim3(256), 0, st, logits, (const long long*)target, (const long long*)mask, C, H, W,
+                       patch, lse, partial);
+    int rc = mmae_check_launch("ce_fwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, partial, (const long long*)mask, B, (H / patch) * (W / patch),
+                       patch * patch, per_sample, loss);
+    return mmae_check_launch("loss_finalize");
+}
+
+int mmae_masked_ce_bwd(const float* logits, const int64_t* target, const int64_t* mask, int B, int C, int H, int W, int patch,
+                       const float* lse, const float* per_sample, const float* loss, const float* upstream, float* d_logits,
+                       void* stream) {
+    MMAE_REQUIRE(logits && target && mask && lse && per_sample && loss && upstream && d_logits, "ce_bwd: null pointer");
+    const long long total = (long long)B * C * H * W;
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, logits, (const long long*)target,
+                       (const long long*)mask, C, H, W, patch, lse, per_sample, loss, upstream, d_logits, total);
+    return mmae_check_launch("ce_bwd");
+}
+
+int mmae_loss_split(void) { return LSPLIT; }
+
+int mmae_sumsq(const float* x, int64_t n, float* out, float* ws, void* stream) {
+    MMAE_REQUIRE(x && out && ws && n > 0, "sumsq: bad argument");
+    MMAE_REQUIRE((uintptr_t)x % 16 == 0, "sumsq: unaligned");
+    long long nb = cdiv64(n, 1024);
+    if (nb > 1024) nb = 1024;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_stage1, dim3((unsigned)nb), dim3(256), 0, st, x, (long long)n, ws);
+    int rc = mmae_check_launch("sumsq_stage1");
+    if (rc) return rc;
+    hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(256), 0, st, ws, (int)nb, out);
+    return mmae_check_launch("sumsq_stage2");
+}
+
+int mmae_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+               float weight_decay, int step, const float* grad_scale_dev, const int32_t* skip_flag, void* shadow, int shadow_dtype,
+               void* stream) {
+    MMAE_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw: bad argument");
+    MMAE_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0), "adamw: unaligned");
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    long long nb = cdiv64(n, 1024);
+    if (nb > 8192) nb = 8192;
+    hipStream_t st = (hipStream_t)stream;
+    if (shadow && shadow_dtype == MMAE_BF16)
+        hipLaunchKernelGGL((adamw_kernel<uint16_t>), dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale_dev, (const int*)skip_flag, (uint16_t*)shadow);
+    else
+        hipLaunchKernelGGL((adamw_kernel<float>), dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale_dev, (const int*)skip_flag, (float*)shadow);
+    return mmae_check_launch("adamw");
+}
+
+}  // extern "C"

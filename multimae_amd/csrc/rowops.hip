@@ -1,0 +1,402 @@
+// HBM-bound row kernels: LayerNorm fwd/bwd, row softmax fwd/bwd, column sums, casts.
+// One 64-lane wavefront per row, 16-byte vector accesses, shuffle reductions (no LDS on the
+// per-row critical path).  Roofline for all of them is HBM bytes / 8 TB/s.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm forward.  x f32 [R][D] -> y act [R][D], mean/rstd f32 [R].  D % 4 == 0, D <= 1024.
+// lane l owns float4 chunks l, l+64, l+128, l+192 of the row (NV chunks).
+// ------------------------------------------------------------------------------------------
+template <int NV, typename YT>
+__global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, YT* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                     long long R, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const float* xr = x + row * D;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) { v[i] = ld4(xr + c); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+        else { v[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mu; q += d * d; }
+        }
+    }
+    const float var = wave_sum(q) / (float)D;
+    const float rs = 1.0f / sqrtf(var + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    YT* yr = y + row * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+            const f32x4 g = ld4(gamma + c), b = ld4(beta + c);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
+            st4(yr + c, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm backward.  Each block walks rows block-stride; each wave keeps dgamma/dbeta
+// partial sums for its column chunks in registers; the 4 waves are combined through LDS and
+// the block writes part[blk][0][D] (dgamma) and part[blk][1][D] (dbeta).
+// ------------------------------------------------------------------------------------------
+template <int NV, typename DT, typename AT>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const DT* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ dx_in,
+                                                     float* __restrict__ dx_out, AT* __restrict__ dx_act,
+                                                     float* __restrict__ part, long long R, int D) {
+    __shared__ float red[4][2][1024];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    f32x4 g[NV], dg[NV], db[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        g[i] = (c < D) ? ld4(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (long long row = (long long)blockIdx.x * 4 + w; row < R; row += (long long)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        const DT* dyr = dy + row * D;
+        const float* xr = x + row * D;
+        f32x4 xh[NV], dh[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < D) {
+                const f32x4 d = ld4(dyr + c), xv = ld4(xr + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xh[i][j] = (xv[j] - mu) * rs;
+                    dh[i][j] = d[j] * g[i][j];
+                    s1 += dh[i][j];
+                    s2 += dh[i][j] * xh[i][j];
+                    dg[i][j] += d[j] * xh[i][j];
+                    db[i][j] += d[j];
+                }
+            } else { xh[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dh[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
+        const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < D) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = rs * (dh[i][j] - c1 - xh[i][j] * c2);
+                if (dx_in) { const f32x4 a = ld4(dx_in + row * D + c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] += a[j];
+                }
+                st4(dx_out + row * D + c, o);
+                if (dx_act) st4(dx_act + row * D + c, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { red[w][0][c + j] = dg[i][j]; red[w][1][c + j] = db[i][j]; }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * D; c += 256) {
+        const int k = c / D, cc = c % D;
+        part[((long long)blockIdx.x * 2 + k) * D + cc] = (red[0][k][cc] + red[1][k][cc]) + (red[2][k][cc] + red[3][k][cc]);
+    }
+}
+
+// out[c] (+)= sum_r part[r][c].  One thread per column, rows summed in order (deterministic).
+__global__ void colsum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int nrows, int ncols,
+                                       int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = 0;
+    for (; r + 4 <= nrows; r += 4) {
+        s0 += part[(long long)(r + 0) * ncols + c]; s1 += part[(long long)(r + 1) * ncols + c];
+        s2 += part[(long long)(r + 2) * ncols + c]; s3 += part[(long long)(r + 3) * ncols + c];
+    }
+    for (; r < nrows; ++r) s0 += part[(long long)r * ncols + c];
+    const float s = (s0 + s1) + (s2 + s3);
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// column sums of dy [M][ld] (N columns, N % 4 == 0): grid (ceil(N/256), NSPLIT); thread owns 4 columns.
+template <typename DT>
+__global__ void __launch_bounds__(256) colsum_kernel(const DT* __restrict__ dy, long long M, int N, long long ld,
+                                                     float* __restrict__ ws) {
+    __shared__ f32x4 red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (c < N) {
+        for (long long r = (long long)blockIdx.y * 4 + w; r < M; r += (long long)gridDim.y * 4) {
+            const f32x4 v = ld4(dy + r * ld + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += v[j];
+        }
+    }
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && c < N) {
+        f32x4 t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = (red[0][lane][j] + red[1][lane][j]) + (red[2][lane][j] + red[3][lane][j]);
+        st4(ws + (long long)blockIdx.y * N + c, t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Row softmax over materialised scores, n <= 256.  One wave per row; lane l owns l, l+64, ...
+// ------------------------------------------------------------------------------------------
+template <typename PT>
+__global__ void __launch_bounds__(256) softmax_fwd_kernel(const float* __restrict__ S, long long lds_, PT* __restrict__ P,
+                                                          long long ldp, long long rows, int n, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* s = S + row * lds_;
+    float v[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = (c < n) ? s[c] * scale : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = (lane + 64 * i < n) ? expf(v[i] - mx) : 0.f; sum += v[i]; }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    PT* p = P + row * ldp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < ldp) ActT<PT>::st(p + c, (c < n) ? v[i] * inv : 0.f);
+    }
+}
+
+template <typename PT>
+__global__ void __launch_bounds__(256) softmax_bwd_kernel(const PT* __restrict__ P, long long ldp,
+                                                          const float* __restrict__ dP, long long lddp,
+                                                          PT* __restrict__ dS, long long ldds, long long rows, int n,
+                                                          float scale) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float p[4], d[4], dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        p[i] = (c < n) ? ActT<PT>::ld(P + row * ldp + c) : 0.f;
+        d[i] = (c < n) ? dP[row * lddp + c] : 0.f;
+        dot += p[i] * d[i];
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < ldds) ActT<PT>::st(dS + row * ldds + c, (c < n) ? scale * p[i] * (d[i] - dot) : 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// casts / transposes / axpy
+// ------------------------------------------------------------------------------------------
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ s, uint16_t* __restrict__ d, long long n) {
+    const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const long long step = (long long)gridDim.x * blockDim.x * 4;
+    for (long long i = i4; i < n; i += step) {
+        if (i + 4 <= n) st4(d + i, ld4(s + i));
+        else for (long long j = i; j < n; ++j) d[j] = f32_to_bf16_bits(s[j]);
+    }
+}
+__global__ void cast_bf16_f32_kernel(const uint16_t* __restrict__ s, float* __restrict__ d, long long n) {
+    const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const long long step = (long long)gridDim.x * blockDim.x * 4;
+    for (long long i = i4; i < n; i += step) {
+        if (i + 4 <= n) st4(d + i, ld4(s + i));
+        else for (long long j = i; j < n; ++j) d[j] = bf16_bits_to_f32(s[j]);
+    }
+}
+// dst[c][r] = src[r][c]; 64x64 tiles through LDS (+1 pad), coalesced on both sides.
+template <typename DT>
+__global__ void __launch_bounds__(256) transpose_cast_kernel(const float* __restrict__ src, DT* __restrict__ dst, int rows,
+                                                             int cols) {
+    __shared__ float t[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        t[i][tx] = (r < rows && c < cols) ? src[(long long)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) ActT<DT>::st(dst + (long long)c * rows + r, t[tx][i]);
+    }
+}
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long long n) {
+    const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const long long step = (long long)gridDim.x * blockDim.x * 4;
+    for (long long i = i4; i < n; i += step) {
+        if (i + 4 <= n) {
+            f32x4 yv = ld4(y + i); const f32x4 xv = ld4(x + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) yv[j] += a * xv[j];
+            st4(y + i, yv);
+        } else for (long long j = i; j < n; ++j) y[j] += a * x[j];
+    }
+}
+
+inline int stream_grid(long long n_vec4) { long long b = (n_vec4 + 255) / 256; return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); }
+
+}  // namespace
+
+extern "C" {
+
+int mmae_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
+                       float* rstd, int64_t R, int D, float eps, void* stream) {
+    MMAE_REQUIRE(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
+    MMAE_REQUIRE(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm_fwd: D must be a multiple of 4 in [4,1024]");
+    MMAE_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)gamma % 16 == 0) && ((uintptr_t)beta % 16 == 0) && ((uintptr_t)y % 8 == 0),
+                 "layernorm_fwd: unaligned pointer");
+    if (R <= 0) return 0;
+    const int nv = (D + 255) / 256;
+    dim3 grid((unsigned)cdiv64(R, 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define LN_FWD(NV)                                                                                                        \
+    if (y_dtype == MMAE_BF16) hipLaunchKernelGGL((ln_fwd_kernel<NV, uint16_t>), grid, block, 0, st, x, gamma, beta,       \
+                                                  (uint16_t*)y, mean, rstd, (long long)R, D, eps);                       \
+    else hipLaunchKernelGGL((ln_fwd_kernel<NV, float>), grid, block, 0, st, x, gamma, beta, (float*)y, mean, rstd,        \
+                            (long long)R, D, eps);
+    switch (nv) { case 1: LN_FWD(1) break; case 2: LN_FWD(2) break; case 3: LN_FWD(3) break; default: LN_FWD(4) break; }
+#undef LN_FWD
+    return mmae_check_launch("layernorm_fwd");
+}
+
+int mmae_layernorm_bwd_nblk(int64_t R) { const int64_t b = cdiv64(R, 4); return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }
+
+int mmae_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
+                       const float* rstd, const float* dx_in, float* dx_out, void* dx_act, int dx_act_dtype, float* part,
+                       int64_t R, int D, void* stream) {
+    MMAE_REQUIRE(dy && x && gamma && mean && rstd && dx_out && part, "layernorm_bwd: null pointer");
+    MMAE_REQUIRE(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm_bwd: D must be a multiple of 4 in [4,1024]");
+    MMAE_REQUIRE(R > 0, "layernorm_bwd: empty");
+    const int nv = (D + 255) / 256;
+    dim3 grid(mmae_layernorm_bwd_nblk(R)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const bool dyb = dy_dtype == MMAE_BF16, axb = dx_act_dtype == MMAE_BF16;
+#define LN_BWD(NV, DT, AT)                                                                                                \
+    hipLaunchKernelGGL((ln_bwd_kernel<NV, DT, AT>), grid, block, 0, st, (const DT*)dy, x, gamma, mean, rstd, dx_in, dx_out, \
+                       (AT*)dx_act, part, (long long)R, D)
+#define LN_BWD_T(NV)                                                                                                      \
+    if (dyb && axb) LN_BWD(NV, uint16_t, uint16_t); else if (dyb) LN_BWD(NV, uint16_t, float);                           \
+    else if (axb) LN_BWD(NV, float, uint16_t); else LN_BWD(NV, float, float);
+    switch (nv) { case 1: LN_BWD_T(1) break; case 2: LN_BWD_T(2) break; case 3: LN_BWD_T(3) break; default: LN_BWD_T(4) break; }
+#undef LN_BWD_T
+#undef LN_BWD
+    return mmae_check_launch("layernorm_bwd");
+}
+
+int mmae_colsum_partials(const float* part, float* out, int nrows, int ncols, int accumulate, void* stream) {
+    MMAE_REQUIRE(part && out && nrows > 0 && ncols > 0, "colsum_partials: bad argument");
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((ncols + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, out, nrows,
+                       ncols, accumulate);
+    return mmae_check_launch("colsum_partials");
+}
+
+static int colsum_nsplit(int64_t M) { const int64_t s = cdiv64(M, 64); return (int)(s < 1 ? 1 : (s > 128 ? 128 : s)); }
+int64_t mmae_colsum_ws_elems(int64_t M, int N) { return (int64_t)colsum_nsplit(M) * N; }
+
+int mmae_colsum(const void* dy, int dtype, int64_t M, int N, int64_t ld, float* out, int accumulate, float* ws,
+                void* stream) {
+    MMAE_REQUIRE(dy && out && ws && M > 0 && N > 0, "colsum: bad argument");
+    MMAE_REQUIRE(N % 4 == 0 && ld % 4 == 0, "colsum: N and ld must be multiples of 4");
+    const int ns = colsum_nsplit(M);
+    dim3 grid((N + 255) / 256, ns), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MMAE_BF16) hipLaunchKernelGGL((colsum_kernel<uint16_t>), grid, block, 0, st, (const uint16_t*)dy, (long long)M, N, (long long)ld, ws);
+    else hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, st, (const float*)dy, (long long)M, N, (long long)ld, ws);
+    int rc = mmae_check_launch("colsum");
+    if (rc) return rc;
+    return mmae_colsum_partials(ws, out, ns, N, accumulate, stream);
+}
+
+int mmae_softmax_fwd(const float* S, int64_t lds_, void* P, int p_dtype, int64_t ldp, int64_t rows, int n, float scale,
+                     void* stream) {
+    MMAE_REQUIRE(S && P && rows > 0, "softmax_fwd: bad argument");
+    MMAE_REQUIRE(n >= 1 && n <= 256 && ldp >= n && ldp <= 256 && lds_ >= n, "softmax_fwd: need 1 <= n <= ld <= 256");
+    dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (p_dtype == MMAE_BF16) hipLaunchKernelGGL((softmax_fwd_kernel<uint16_t>), grid, block, 0, st, S, (long long)lds_, (uint16_t*)P, (long long)ldp, (long long)rows, n, scale);
+    else hipLaunchKernelGGL((softmax_fwd_kernel<float>), grid, block, 0, st, S, (long long)lds_, (float*)P, (long long)ldp, (long long)rows, n, scale);
+    return mmae_check_launch("softmax_fwd");
+}
+
+int mmae_softmax_bwd(const void* P, int p_dtype, int64_t ldp, const float* dP, int64_t lddp, void* dS, int64_t ldds,
+                     int64_t rows, int n, float scale, void* stream) {
+    MMAE_REQUIRE(P && dP && dS && rows > 0, "softmax_bwd: bad argument");
+    MMAE_REQUIRE(n >= 1 && n <= 256 && ldp >= n && ldds >= n && ldds <= 256 && lddp >= n, "softmax_bwd: need 1 <= n <= ld <= 256");
+    dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (p_dtype == MMAE_BF16) hipLaunchKernelGGL((softmax_bwd_kernel<uint16_t>), grid, block, 0, st, (const uint16_t*)P, (long long)ldp, dP, (long long)lddp, (uint16_t*)dS, (long long)ldds, (long long)rows, n, scale);
+    else hipLaunchKernelGGL((softmax_bwd_kernel<float>), grid, block, 0, st, (const float*)P, (long long)ldp, dP, (long long)lddp, (float*)dS, (long long)ldds, (long long)rows, n, scale);
+    return mmae_check_launch("softmax_bwd");
+}
+
+int mmae_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    MMAE_REQUIRE(src && dst && n >= 0, "cast: bad argument");
+    MMAE_REQUIRE(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 8 == 0), "cast: unaligned");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)dst, (long long)n);
+    return mmae_check_launch("cast_f32_to_bf16");
+}
+int mmae_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream) {
+    MMAE_REQUIRE(src && dst && n >= 0, "cast: bad argument");
+    MMAE_REQUIRE(((uintptr_t)src % 8 == 0) && ((uintptr_t)dst % 16 == 0), "cast: unaligned");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, dst, (long long)n);
+    return mmae_check_launch("cast_bf16_to_f32");
+}
+int mmae_transpose_cast(const float* src, void* dst, int dst_dtype, int rows, int cols, void* stream) {
+    MMAE_REQUIRE(src && dst && rows > 0 && cols > 0, "transpose_cast: bad argument");
+    dim3 grid((cols + 63) / 64, (rows + 63) / 64), block(256);
+    if (dst_dtype == MMAE_BF16) hipLaunchKernelGGL((transpose_cast_kernel<uint16_t>), grid, block, 0, (hipStream_t)stream, src, (uint16_t*)dst, rows, cols);
+    else hipLaunchKernelGGL((transpose_cast_kernel<float>), grid, block, 0, (hipStream_t)stream, src, (float*)dst, rows, cols);
+    return mmae_check_launch("transpose_cast");
+}
+int mmae_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream) {
+    MMAE_REQUIRE(y && x && n >= 0, "axpy: bad argument");
+    MMAE_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0), "axpy: unaligned");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(axpy_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, y, x, a, (long long)n);
+    return mmae_check_launch("axpy");
+}
+
+}  // extern "C"

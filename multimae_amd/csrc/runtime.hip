@@ -1,0 +1,64 @@
+// ABI bookkeeping (version, per-thread error string) and the GEMM entry point's argument
+// validation / dtype dispatch.
+#include <stdio.h>
+#include <string.h>
+#include "gemm_common.h"
+
+static thread_local char g_err[256] = "";
+
+void mmae_set_error(const char* msg) {
+    strncpy(g_err, msg, sizeof(g_err) - 1);
+    g_err[sizeof(g_err) - 1] = 0;
+}
+
+int mmae_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+        return MMAE_ELAUNCH;
+    }
+    return 0;
+}
+
+int mmae_gemm_bf16_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st);
+int mmae_gemm_f32_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st);
+
+extern "C" {
+
+int mmae_abi_version(void) { return MMAE_ABI_VERSION; }
+const char* mmae_last_error(void) { return g_err; }
+
+int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
+    MMAE_REQUIRE(d && d->A && d->B && d->C, "gemm: null operand");
+    MMAE_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: empty problem");
+    MMAE_REQUIRE(d->batch >= 1 && d->batch <= 65535 && d->batch_inner >= 1, "gemm: bad batch");
+    MMAE_REQUIRE(d->ab_dtype == MMAE_F32 || d->ab_dtype == MMAE_BF16, "gemm: bad ab_dtype");
+    MMAE_REQUIRE(d->c_dtype == MMAE_F32 || d->c_dtype == MMAE_BF16, "gemm: bad c_dtype");
+    MMAE_REQUIRE(!(d->accumulate && d->c_dtype != MMAE_F32), "gemm: accumulate needs f32 C");
+    MMAE_REQUIRE(!(d->epi != MMAE_EPI_NONE && !d->aux), "gemm: epilogue needs aux");
+    MMAE_REQUIRE(!(d->resid && d->batch != 1), "gemm: residual is unbatched only");
+    GemmArgs g;
+    g.A = d->A; g.B = d->B; g.C = d->C;
+    g.M = d->M; g.N = d->N; g.K = d->K;
+    g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc;
+    g.nb_inner = d->batch_inner;
+    g.sAo = d->sA_outer; g.sAi = d->sA_inner; g.sBo = d->sB_outer; g.sBi = d->sB_inner;
+    g.sCo = d->sC_outer; g.sCi = d->sC_inner;
+    g.bias = d->bias; g.resid = d->resid; g.ldr = d->ldr;
+    g.aux = d->aux; g.ldaux = d->ldaux;
+    g.c_f32 = d->c_dtype == MMAE_F32; g.aux_f32 = d->aux_dtype == MMAE_F32;
+    g.epi = d->epi; g.accumulate = d->accumulate; g.alpha = d->alpha;
+    g.tiles_n = 0;
+    // vector (4-element) epilogue accesses need every touched row start 4-element aligned
+    bool vec = (d->ldc % 4 == 0) && (d->sC_outer % 4 == 0) && (d->sC_inner % 4 == 0) &&
+               ((uintptr_t)d->C % 16 == 0);
+    if (d->bias) vec = vec && ((uintptr_t)d->bias % 16 == 0);
+    if (d->resid) vec = vec && (d->ldr % 4 == 0) && ((uintptr_t)d->resid % 16 == 0);
+    if (d->aux) vec = vec && (d->ldaux % 4 == 0) && ((uintptr_t)d->aux % 16 == 0);
+    g.vec = vec ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->ab_dtype == MMAE_BF16) return mmae_gemm_bf16_impl(d, g, st);
+    return mmae_gemm_f32_impl(d, g, st);
+}
+
+}  // extern "C"

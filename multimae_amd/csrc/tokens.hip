@@ -1,0 +1,466 @@
+// Token-level kernels of the MultiMAE path: mask sampler, gather-first patch rows, token
+// assembly, decoder query/context builder, patch <-> image layout.  All HBM / latency bound;
+// integer outputs (masks, ids) are exact.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_TASKS = 8;
+
+struct TaskTable { int off[MAX_TASKS + 1]; int T; };
+
+__device__ __forceinline__ int task_of(const TaskTable& tt, int idx) {
+    int t = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_TASKS; ++i) if (i < tt.T && idx >= tt.off[i]) t = i;
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------
+// Mask sampler (multimae.py:191-216).  One workgroup per sample; O(N^2) rank counting in LDS
+// (N = 588: 0.35 M compares per sample) instead of 5 device-wide argsorts.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mask_sample_kernel(const long long* __restrict__ spt, const float* __restrict__ task_noise,
+                                                          const float* __restrict__ all_noise, const TaskTable tt, int Ntot,
+                                                          int n_keep, long long* __restrict__ mask_all,
+                                                          long long* __restrict__ ids_keep, long long* __restrict__ ids_restore) {
+    extern __shared__ float sm[];
+    float* noise = sm;                     // [Ntot] per-task noise, later the global keys
+    int* order = (int*)(sm + Ntot);        // [Ntot] argsort of the per-task noise (local index)
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int j = tid; j < Ntot; j += 256) noise[j] = task_noise[(long long)b * Ntot + j];
+    __syncthreads();
+    // per-task stable rank -> order[off + rank] = local index
+    for (int j = tid; j < Ntot; j += 256) {
+        const int t = task_of(tt, j), lo = tt.off[t], hi = tt.off[t + 1];
+        const float v = noise[j];
+        int rank = 0;
+        for (int i = lo; i < hi; ++i) { const float u = noise[i]; rank += (u < v) || (u == v && i < j); }
+        order[lo + rank] = j - lo;
+    }
+    __syncthreads();
+    // reference quirk: SORTED POSITION j is kept iff order[j] < k_t; key = mask + noise2 (fp32 add)
+    for (int j = tid; j < Ntot; j += 256) {
+        const int t = task_of(tt, j);
+        const int pre = (order[j] < (int)spt[(long long)b * tt.T + t]) ? 0 : 1;
+        noise[j] = (float)pre + all_noise[(long long)b * Ntot + j];
+    }
+    __syncthreads();
+    for (int j = tid; j < Ntot; j += 256) {
+        const float v = noise[j];
+        int rank = 0;
+        for (int i = 0; i < Ntot; ++i) { const float u = noise[i]; rank += (u < v) || (u == v && i < j); }
+        ids_restore[(long long)b * Ntot + j] = rank;
+        mask_all[(long long)b * Ntot + j] = rank < n_keep ? 0 : 1;
+        if (rank < n_keep) ids_keep[(long long)b * n_keep + rank] = j;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Gather-first patch rows.  rows[b*n_sel + r] is the concatenation over tasks of the flattened
+// patch (Conv2d weight column order c,i,j), non-zero only in the segment of the task that owns
+// token sel[b][r].  One wave per (row, 256-column slab).
+// ------------------------------------------------------------------------------------------
+struct PatchSrc {
+    const void* data;      // f32 [B][C][H][W]  or  int64 [B][H][W] (semseg)
+    const float* emb;      // semseg: f32 [n_cls][C]
+    int kind, C, H, W, ph, pw, k_off, k_len;
+};
+struct PatchSrcs { PatchSrc s[MAX_TASKS]; };
+
+template <typename RT>
+__global__ void __launch_bounds__(256) patch_rows_kernel(const PatchSrcs src, const TaskTable tt, const long long* __restrict__ sel,
+                                                         RT* __restrict__ rows, long long n_rows, int n_sel, int Ktot) {
+    const long long row = blockIdx.x;
+    const int b = (int)(row / n_sel);
+    const int idx = (int)sel[row];
+    const int t = task_of(tt, idx);
+    const PatchSrc& s = src.s[t];
+    const int p = idx - tt.off[t];
+    const int nw = s.W / s.pw;
+    const int py = p / nw, px = p % nw;
+    RT* out = rows + row * Ktot;
+    for (int k = threadIdx.x; k < Ktot; k += 256) {
+        float v = 0.f;
+        const int kk = k - s.k_off;
+        if (kk >= 0 && kk < s.k_len) {
+            const int c = kk / (s.ph * s.pw), ij = kk % (s.ph * s.pw), i = ij / s.pw, j = ij % s.pw;
+            const int y = py * s.ph + i, x = px * s.pw + j;
+            if (s.kind == 0) v = ((const float*)s.data)[(((long long)b * s.C + c) * s.H + y) * s.W + x];
+            else { const long long cls = ((const long long*)s.data)[((long long)b * s.H + y) * s.W + x]; v = s.emb[cls * s.C + c]; }
+        }
+        ActT<RT>::st(out + k, v);
+    }
+}
+
+// d_emb[cls][e] += d_rows[row][k_off + e*ph*pw + i*pw + j] over all semseg-owned selected tokens.
+// LDS-privatised table per workgroup, flushed with global atomics.
+template <typename RT>
+__global__ void __launch_bounds__(256) semseg_emb_bwd_kernel(const RT* __restrict__ d_rows, long long ld, const long long* __restrict__ cls,
+                                                             const long long* __restrict__ sel, float* __restrict__ d_emb, long long n_rows,
+                                                             int n_sel, int H, int W, int E, int ph, int pw, int k_off, int tok_off,
+                                                             int n_patches, int n_cls) {
+    extern __shared__ float tab[];   // [n_cls*E]
+    for (int i = threadIdx.x; i < n_cls * E; i += 256) tab[i] = 0.f;
+    __syncthreads();
+    const int nw = W / pw, klen = E * ph * pw;
+    for (long long row = blockIdx.x; row < n_rows; row += gridDim.x) {
+        const int p = (int)sel[row] - tok_off;
+        if (p < 0 || p >= n_patches) continue;
+        const int b = (int)(row / n_sel), py = p / nw, px = p % nw;
+        for (int k = threadIdx.x; k < klen; k += 256) {
+            const int e = k / (ph * pw), ij = k % (ph * pw), i = ij / pw, j = ij % pw;
+            const long long c = cls[((long long)b * H + py * ph + i) * W + px * pw + j];
+            atomicAdd(&tab[c * E + e], ActT<RT>::ld(d_rows + row * ld + k_off + k));
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_cls * E; i += 256) { const float v = tab[i]; if (v != 0.f) atomicAdd(&d_emb[i], v); }
+}
+
+// tok[b][r][:] = proj[b*n_sel+r][:] + bias_t[:] + pos_t[p][:]   (t = owner of sel[b][r]);
+// tok[b][n_sel+g][:] = global[g][:]
+struct TaskVecs { const float* bias[MAX_TASKS]; const float* pos[MAX_TASKS]; };
+
+__global__ void __launch_bounds__(256) tokens_assemble_kernel(float* __restrict__ tok, const float* __restrict__ proj, const TaskVecs tv,
+                                                              const TaskTable tt, const long long* __restrict__ sel,
+                                                              const float* __restrict__ global_tok, int n_sel, int G, int D) {
+    const long long rowg = blockIdx.x;               // over B*(n_sel+G)
+    const int b = (int)(rowg / (n_sel + G)), r = (int)(rowg % (n_sel + G));
+    float* o = tok + rowg * D;
+    if (r >= n_sel) {
+        const float* gsrc = global_tok + (long long)(r - n_sel) * D;
+        for (int c = threadIdx.x * 4; c < D; c += 1024) st4(o + c, ld4(gsrc + c));
+        return;
+    }
+    const int idx = (int)sel[(long long)b * n_sel + r];
+    const int t = task_of(tt, idx);
+    const float* pr = proj + ((long long)b * n_sel + r) * D;
+    const float* bi = tv.bias[t];
+    const float* po = tv.pos[t] + (long long)(idx - tt.off[t]) * D;
+    for (int c = threadIdx.x * 4; c < D; c += 1024) {
+        const f32x4 a = ld4(pr + c), b4 = ld4(bi + c), p4 = ld4(po + c);
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = a[j] + b4[j] + p4[j];
+        st4(o + c, v);
+    }
+}
+
+// backward: d_proj (act dtype) = d_tok rows of the kept tokens; per-block partial column sums
+// part[blk][t][D] for the T task biases and part[blk][T+g][D] for the global tokens.
+template <typename PT>
+__global__ void __launch_bounds__(256) tokens_assemble_bwd_kernel(const float* __restrict__ d_tok, PT* __restrict__ d_proj, const TaskTable tt,
+                                                                  const long long* __restrict__ sel, float* __restrict__ part, int B,
+                                                                  int n_sel, int G, int D) {
+    // thread owns columns c = tid*4 + 1024*q (q < 1 for D <= 1024)
+    const int c = threadIdx.x * 4;
+    f32x4 acc[MAX_TASKS];
+#pragma unroll
+    for (int i = 0; i < MAX_TASKS; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const long long n_rows = (long long)B * (n_sel + G);
+    for (long long rowg = blockIdx.x; rowg < n_rows; rowg += gridDim.x) {
+        const int b = (int)(rowg / (n_sel + G)), r = (int)(rowg % (n_sel + G));
+        if (c >= D) continue;
+        const f32x4 v = ld4(d_tok + rowg * D + c);
+        int slot;
+        if (r < n_sel) {
+            st4(d_proj + ((long long)b * n_sel + r) * D + c, v);
+            slot = task_of(tt, (int)sel[(long long)b * n_sel + r]);
+        } else slot = tt.T + (r - n_sel);
+#pragma unroll
+        for (int i = 0; i < MAX_TASKS; ++i) if (i == slot) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] += v[j];
+        }
+    }
+    if (c < D) {
+        const int ns = tt.T + G;
+#pragma unroll
+        for (int i = 0; i < MAX_TASKS; ++i) if (i < ns) st4(part + ((long long)blockIdx.x * ns + i) * D + c, acc[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Decoder query / context builder (output_adapters.py:160-234, use_task_queries path)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) decoder_build_kernel(const float* __restrict__ ctx, const long long* __restrict__ ids_keep,
+                                                            const long long* __restrict__ ids_restore, const float* __restrict__ mask_token,
+                                                            const float* __restrict__ task_emb, const float* __restrict__ pos, const TaskTable tt,
+                                                            int q_task, int n_keep, int G, int D, int n_q, int Ntot,
+                                                            float* __restrict__ queries, float* __restrict__ context) {
+    const int rows_per_b = n_q + n_keep + G;
+    const int b = blockIdx.x / rows_per_b, rr = blockIdx.x % rows_per_b;
+    const int NC = n_keep + G;
+    if (rr < n_q) {
+        const int j = rr;
+        const long long rank = ids_restore[(long long)b * Ntot + tt.off[q_task] + j];
+        const float* base = (rank < n_keep) ? ctx + ((long long)b * NC + rank) * D : mask_token;
+        const float* te = task_emb + (long long)q_task * D;
+        const float* pe = pos + (long long)j * D;
+        float* o = queries + ((long long)b * n_q + j) * D;
+        for (int c = threadIdx.x * 4; c < D; c += 1024) {
+            const f32x4 a = ld4(base + c), t4 = ld4(te + c), p4 = ld4(pe + c);
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = a[k] + (t4[k] + p4[k]);
+            st4(o + c, v);
+        }
+    } else {
+        const int r = rr - n_q;
+        const float* src = ctx + ((long long)b * NC + r) * D;
+        float* o = context + ((long long)b * NC + r) * D;
+        if (r >= n_keep) { for (int c = threadIdx.x * 4; c < D; c += 1024) st4(o + c, ld4(src + c)); return; }
+        const int idx = (int)ids_keep[(long long)b * n_keep + r];
+        const int t = task_of(tt, idx);
+        const float* te = task_emb + (long long)t * D;
+        const float* pe = pos + (long long)(idx - tt.off[t]) * D;
+        for (int c = threadIdx.x * 4; c < D; c += 1024) {
+            const f32x4 a = ld4(src + c), t4 = ld4(te + c), p4 = ld4(pe + c);
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = a[k] + (t4[k] + p4[k]);
+            st4(o + c, v);
+        }
+    }
+}
+
+// backward.  Workgroup per sample-chunk; thread owns 4 columns.  d_ctx rows are each written
+// exactly once (kept row r: d_context[r] + d_queries[its query] if the query task owns it).
+__global__ void __launch_bounds__(256) decoder_build_bwd_kernel(const float* __restrict__ d_queries, const float* __restrict__ d_context,
+                                                                const long long* __restrict__ ids_keep, const long long* __restrict__ ids_restore,
+                                                                const TaskTable tt, int q_task, int B, int n_keep, int G, int D, int n_q,
+                                                                int Ntot, float* __restrict__ d_ctx, float* __restrict__ part) {
+    const int c = threadIdx.x * 4;
+    const int NC = n_keep + G;
+    f32x4 acc[MAX_TASKS + 1];
+#pragma unroll
+    for (int i = 0; i <= MAX_TASKS; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < D) {
+        for (int b = blockIdx.x; b < B; b += gridDim.x) {
+            // context rows
+            for (int r = 0; r < NC; ++r) {
+                f32x4 v = ld4(d_context + ((long long)b * NC + r) * D + c);
+                if (r < n_keep) {
+                    const int idx = (int)ids_keep[(long long)b * n_keep + r];
+                    const int t = task_of(tt, idx);
+#pragma unroll
+                    for (int i = 0; i < MAX_TASKS; ++i) if (i == t) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[i][k] += v[k];
+                    }
+                    if (t == q_task) {
+                        const f32x4 q = ld4(d_queries + ((long long)b * n_q + (idx - tt.off[t])) * D + c);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] += q[k];
+                    }
+                }
+                st4(d_ctx + ((long long)b * NC + r) * D + c, v);
+            }
+            // query rows: task embedding of the query task + mask token of the masked ones
+            for (int j = 0; j < n_q; ++j) {
+                const f32x4 q = ld4(d_queries + ((long long)b * n_q + j) * D + c);
+                const bool vis = ids_restore[(long long)b * Ntot + tt.off[q_task] + j] < n_keep;
+#pragma unroll
+                for (int i = 0; i < MAX_TASKS; ++i) if (i == q_task) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[i][k] += q[k];
+                }
+                if (!vis) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[MAX_TASKS][k] += q[k];
+                }
+            }
+        }
+        const int ns = tt.T + 1;
+#pragma unroll
+        for (int i = 0; i < MAX_TASKS; ++i) if (i < tt.T) st4(part + ((long long)blockIdx.x * ns + i) * D + c, acc[i]);
+        st4(part + ((long long)blockIdx.x * ns + tt.T) * D + c, acc[MAX_TASKS]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 'b (nh nw) (c ph pw) -> b c (nh ph) (nw pw)' and back.  Thread per image pixel-run of pw.
+// ------------------------------------------------------------------------------------------
+__global__ void unpatchify_kernel(const float* __restrict__ pat, float* __restrict__ img, int C, int nh, int nw, int ph, int pw,
+                                  long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over B*C*H*W
+    if (i >= total) return;
+    const int W = nw * pw, H = nh * ph;
+    const int x = (int)(i % W); long long r = i / W;
+    const int y = (int)(r % H); r /= H;
+    const int c = (int)(r % C); const long long b = r / C;
+    const int py = y / ph, iy = y % ph, px = x / pw, ix = x % pw;
+    img[i] = pat[((b * nh + py) * nw + px) * ((long long)C * ph * pw) + ((long long)c * ph + iy) * pw + ix];
+}
+template <typename PT>
+__global__ void patchify_kernel(const float* __restrict__ img, PT* __restrict__ pat, int C, int nh, int nw, int ph, int pw,
+                                long long total) {
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over B*N*(C*ph*pw)
+    if (o >= total) return;
+    const int KP = C * ph * pw;
+    const int k = (int)(o % KP); long long r = o / KP;
+    const int px = (int)(r % nw); r /= nw;
+    const int py = (int)(r % nh); const long long b = r / nh;
+    const int c = k / (ph * pw), iy = (k / pw) % ph, ix = k % pw;
+    const int W = nw * pw, H = nh * ph;
+    ActT<PT>::st(pat + o, img[((b * C + c) * H + py * ph + iy) * W + px * pw + ix]);
+}
+
+// hardware probe: what does ds_read_b64_tr_b16 return for a given LDS image / lane addresses
+__global__ void probe_tr16_kernel(const uint16_t* __restrict__ image, const uint32_t* __restrict__ addr, uint16_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint16_t lds[1024];
+    for (int i = threadIdx.x; i < 1024; i += 64) lds[i] = image[i];
+    __syncthreads();
+    const char* p = (const char*)lds + addr[threadIdx.x];
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = (uint16_t)v[j];
+}
+
+int fill_tt(TaskTable& tt, const int32_t* off_host, int T) {
+    if (T < 1 || T > MAX_TASKS) return -1;
+    tt.T = T;
+    for (int i = 0; i <= MAX_TASKS; ++i) tt.off[i] = off_host[i <= T ? i : T];
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mmae_mask_sample(const int64_t* samples_per_task, const float* task_noise, const float* all_noise,
+                     const int32_t* task_offsets_host, int T, int B, int Ntot, int n_keep, int64_t* mask_all,
+                     int64_t* ids_keep, int64_t* ids_restore, void* stream) {
+    MMAE_REQUIRE(samples_per_task && task_noise && all_noise && task_offsets_host && mask_all && ids_keep && ids_restore,
+                 "mask_sample: null pointer");
+    TaskTable tt;
+    MMAE_REQUIRE(fill_tt(tt, task_offsets_host, T) == 0, "mask_sample: 1 <= T <= 8");
+    MMAE_REQUIRE(B > 0 && Ntot > 0 && Ntot <= 8192 && n_keep >= 0 && n_keep <= Ntot && tt.off[T] == Ntot, "mask_sample: bad sizes");
+    hipLaunchKernelGGL(mask_sample_kernel, dim3(B), dim3(256), (size_t)Ntot * 8, (hipStream_t)stream,
+                       (const long long*)samples_per_task, task_noise, all_noise, tt, Ntot, n_keep, (long long*)mask_all,
+                       (long long*)ids_keep, (long long*)ids_restore);
+    return mmae_check_launch("mask_sample");
+}
+
+int mmae_patch_rows(const mmae_patch_src* srcs, const int32_t* task_offsets_host, int T, const int64_t* sel, void* rows,
+                    int rows_dtype, int B, int n_sel, int Ktot, void* stream) {
+    MMAE_REQUIRE(srcs && task_offsets_host && sel && rows && B > 0 && n_sel > 0 && Ktot > 0, "patch_rows: bad argument");
+    TaskTable tt;
+    MMAE_REQUIRE(fill_tt(tt, task_offsets_host, T) == 0, "patch_rows: 1 <= T <= 8");
+    PatchSrcs ps;
+    for (int t = 0; t < MAX_TASKS; ++t) {
+        const mmae_patch_src& s = srcs[t < T ? t : 0];
+        MMAE_REQUIRE(s.data && s.ph > 0 && s.pw > 0 && s.H % s.ph == 0 && s.W % s.pw == 0, "patch_rows: bad source");
+        MMAE_REQUIRE(s.kind == 0 || s.emb, "patch_rows: semseg source needs the class embedding");
+        MMAE_REQUIRE((s.H / s.ph) * (s.W / s.pw) == tt.off[(t < T ? t : 0) + 1] - tt.off[t < T ? t : 0], "patch_rows: patch count != task tokens");
+        ps.s[t] = PatchSrc{s.data, s.emb, s.kind, s.C, s.H, s.W, s.ph, s.pw, s.k_off, s.C * s.ph * s.pw};
+    }
+    const long long n_rows = (long long)B * n_sel;
+    hipStream_t st = (hipStream_t)stream;
+    if (rows_dtype == MMAE_BF16) hipLaunchKernelGGL((patch_rows_kernel<uint16_t>), dim3((unsigned)n_rows), dim3(256), 0, st, ps, tt, (const long long*)sel, (uint16_t*)rows, n_rows, n_sel, Ktot);
+    else hipLaunchKernelGGL((patch_rows_kernel<float>), dim3((unsigned)n_rows), dim3(256), 0, st, ps, tt, (const long long*)sel, (float*)rows, n_rows, n_sel, Ktot);
+    return mmae_check_launch("patch_rows");
+}
+
+int mmae_semseg_emb_bwd(const void* d_rows, int rows_dtype, int64_t ld, const int64_t* cls, const int64_t* sel, float* d_emb,
+                        int B, int H, int W, int E, int ph, int pw, int n_sel, int k_off, int tok_off, int n_patches, int n_cls,
+                        void* stream) {
+    MMAE_REQUIRE(d_rows && cls && sel && d_emb && B > 0 && n_cls > 0 && E > 0, "semseg_emb_bwd: bad argument");
+    MMAE_REQUIRE((size_t)n_cls * E * 4 <= 160 * 1024, "semseg_emb_bwd: embedding table exceeds LDS");
+    const long long n_rows = (long long)B * n_sel;
+    const int grid = (int)(n_rows < 512 ? n_rows : 512);
+    const size_t lds = (size_t)n_cls * E * 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (rows_dtype == MMAE_BF16) {
+        hipFuncSetAttribute((const void*)semseg_emb_bwd_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((semseg_emb_bwd_kernel<uint16_t>), dim3(grid), dim3(256), lds, st, (const uint16_t*)d_rows, (long long)ld, (const long long*)cls, (const long long*)sel, d_emb, n_rows, n_sel, H, W, E, ph, pw, k_off, tok_off, n_patches, n_cls);
+    } else {
+        hipFuncSetAttribute((const void*)semseg_emb_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((semseg_emb_bwd_kernel<float>), dim3(grid), dim3(256), lds, st, (const float*)d_rows, (long long)ld, (const long long*)cls, (const long long*)sel, d_emb, n_rows, n_sel, H, W, E, ph, pw, k_off, tok_off, n_patches, n_cls);
+    }
+    return mmae_check_launch("semseg_emb_bwd");
+}
+
+int mmae_tokens_assemble(float* tok, const float* proj, const float* const* bias, const float* const* pos,
+                         const int32_t* task_offsets_host, int T, const int64_t* sel, const float* global_tok, int B, int n_sel,
+                         int G, int D, void* stream) {
+    MMAE_REQUIRE(tok && proj && bias && pos && sel && (G == 0 || global_tok), "tokens_assemble: null pointer");
+    MMAE_REQUIRE(D % 4 == 0 && D <= 1024 && B > 0 && n_sel > 0 && G >= 0, "tokens_assemble: bad sizes");
+    TaskTable tt;
+    MMAE_REQUIRE(fill_tt(tt, task_offsets_host, T) == 0, "tokens_assemble: 1 <= T <= 8");
+    TaskVecs tv;
+    for (int t = 0; t < MAX_TASKS; ++t) { tv.bias[t] = bias[t < T ? t : 0]; tv.pos[t] = pos[t < T ? t : 0]; }
+    hipLaunchKernelGGL(tokens_assemble_kernel, dim3((unsigned)((long long)B * (n_sel + G))), dim3(256), 0, (hipStream_t)stream, tok,
+                       proj, tv, tt, (const long long*)sel, global_tok, n_sel, G, D);
+    return mmae_check_launch("tokens_assemble");
+}
+
+int mmae_tokens_assemble_bwd_nblk(int B) { return B < 256 ? B : 256; }
+
+int mmae_tokens_assemble_bwd(const float* d_tok, void* d_proj, int proj_dtype, const int32_t* task_offsets_host, int T,
+                             const int64_t* sel, float* part, int B, int n_sel, int G, int D, void* stream) {
+    MMAE_REQUIRE(d_tok && d_proj && sel && part, "tokens_assemble_bwd: null pointer");
+    MMAE_REQUIRE(D % 4 == 0 && D <= 1024 && T + G <= MAX_TASKS, "tokens_assemble_bwd: bad sizes");
+    TaskTable tt;
+    MMAE_REQUIRE(fill_tt(tt, task_offsets_host, T) == 0, "tokens_assemble_bwd: 1 <= T <= 8");
+    const int nblk = mmae_tokens_assemble_bwd_nblk(B);
+    hipStream_t st = (hipStream_t)stream;
+    if (proj_dtype == MMAE_BF16) hipLaunchKernelGGL((tokens_assemble_bwd_kernel<uint16_t>), dim3(nblk), dim3(256), 0, st, d_tok, (uint16_t*)d_proj, tt, (const long long*)sel, part, B, n_sel, G, D);
+    else hipLaunchKernelGGL((tokens_assemble_bwd_kernel<float>), dim3(nblk), dim3(256), 0, st, d_tok, (float*)d_proj, tt, (const long long*)sel, part, B, n_sel, G, D);
+    return mmae_check_launch("tokens_assemble_bwd");
+}
+
+int mmae_decoder_build(const float* ctx, const int64_t* ids_keep, const int64_t* ids_restore, const float* mask_token,
+                       const float* task_emb, const float* pos, const int32_t* task_offsets_host, int T, int q_task, int B,
+                       int n_keep, int G, int D, int n_q, float* queries, float* context, void* stream) {
+    MMAE_REQUIRE(ctx && ids_keep && ids_restore && mask_token && task_emb && pos && queries && context, "decoder_build: null pointer");
+    MMAE_REQUIRE(D % 4 == 0 && D <= 1024 && B > 0, "decoder_build: bad sizes");
+    TaskTable tt;
+    MMAE_REQUIRE(fill_tt(tt, task_offsets_host, T) == 0 && q_task >= 0 && q_task < T, "decoder_build: bad task table");
+    MMAE_REQUIRE(tt.off[q_task + 1] - tt.off[q_task] == n_q, "decoder_build: n_q != tokens of the query task");
+    hipLaunchKernelGGL(decoder_build_kernel, dim3((unsigned)((long long)B * (n_q + n_keep + G))), dim3(256), 0, (hipStream_t)stream, ctx,
+                       (const long long*)ids_keep, (const long long*)ids_restore, mask_token, task_emb, pos, tt, q_task, n_keep, G, D,
+                       n_q, tt.off[T], queries, context);
+    return mmae_check_launch("decoder_build");
+}
+
+int mmae_decoder_build_bwd_nblk(int B) { return B < 256 ? B : 256; }
+
+int mmae_decoder_build_bwd(const float* d_queries, const float* d_context, const int64_t* ids_keep, const int64_t* ids_restore,
+                           const int32_t* task_offsets_host, int T, int q_task, int B, int n_keep, int G, int D, int n_q,
+                           float* d_ctx, float* part, void* stream) {
+    MMAE_REQUIRE(d_queries && d_context && ids_keep && ids_restore && d_ctx && part, "decoder_build_bwd: null pointer");
+    MMAE_REQUIRE(D % 4 == 0 && D <= 1024 && B > 0, "decoder_build_bwd: bad sizes");
+    TaskTable tt;
+    MMAE_REQUIRE(fill_tt(tt, task_offsets_host, T) == 0 && q_task >= 0 && q_task < T, "decoder_build_bwd: bad task table");
+    hipLaunchKernelGGL(decoder_build_bwd_kernel, dim3(mmae_decoder_build_bwd_nblk(B)), dim3(256), 0, (hipStream_t)stream, d_queries,
+                       d_context, (const long long*)ids_keep, (const long long*)ids_restore, tt, q_task, B, n_keep, G, D, n_q,
+                       tt.off[T], d_ctx, part);
+    return mmae_check_launch("decoder_build_bwd");
+}
+
+int mmae_unpatchify(const float* patches, float* img, int B, int C, int nh, int nw, int ph, int pw, void* stream) {
+    MMAE_REQUIRE(patches && img && B > 0 && C > 0, "unpatchify: bad argument");
+    const long long total = (long long)B * C * nh * ph * nw * pw;
+    hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, patches, img, C, nh, nw,
+                       ph, pw, total);
+    return mmae_check_launch("unpatchify");
+}
+
+int mmae_patchify(const float* img, void* patches, int patches_dtype, int B, int C, int nh, int nw, int ph, int pw, void* stream) {
+    MMAE_REQUIRE(patches && img && B > 0 && C > 0, "patchify: bad argument");
+    const long long total = (long long)B * C * nh * ph * nw * pw;
+    hipStream_t st = (hipStream_t)stream;
+    if (patches_dtype == MMAE_BF16) hipLaunchKernelGGL((patchify_kernel<uint16_t>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, img, (uint16_t*)patches, C, nh, nw, ph, pw, total);
+    else hipLaunchKernelGGL((patchify_kernel<float>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, img, (float*)patches, C, nh, nw, ph, pw, total);
+    return mmae_check_launch("patchify");
+}
+
+int mmae_probe_tr16(const uint16_t* lds_image_1024, const uint32_t* lane_byte_addr_64, uint16_t* out_64x4, void* stream) {
+    MMAE_REQUIRE(lds_image_1024 && lane_byte_addr_64 && out_64x4, "probe_tr16: null pointer");
+    hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, lds_image_1024, lane_byte_addr_64, out_64x4);
+    return mmae_check_launch("probe_tr16");
+}
+
+}  // extern "C"

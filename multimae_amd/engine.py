@@ -1,0 +1,187 @@
+"""Engine state: activation precision, flat parameter arenas and bf16 weight shadows.
+
+Memory layout (MI355X-first): all parameters of a model live in ONE flat fp32 HBM
+arena (each tensor 64-element aligned), their gradients in a second arena of the same
+layout and -- in bf16 speed mode -- a bf16 *shadow* arena that the GEMMs read.  The
+``nn.Parameter`` objects are views into the arenas, so ``state_dict()`` / checkpoints
+keep the reference's key/shape layout while
+
+  * zero_grad is one memset, the gradient all-reduce runs over a few large contiguous
+    buckets, AdamW + grad-norm are single launches over the arena,
+  * the f32 -> bf16 weight refresh is one cast launch per step (or free: the fused
+    AdamW writes the shadow itself).
+"""
+from __future__ import annotations
+
+import contextlib
+from typing import Dict, Iterable, List, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+
+ALIGN = 64  # elements
+
+_state = {
+    'act_dtype': torch.bfloat16,     # bf16 speed mode | float32 exact parity mode
+    'direct_grads': False,           # backward accumulates straight into p.grad and returns None
+}
+
+
+def act_dtype() -> torch.dtype:
+    return _state['act_dtype']
+
+
+def set_precision(mode: str) -> None:
+    """'bf16' (default): bf16 MFMA operands, fp32 accumulate/residual/softmax/LN/loss.
+    'fp32': every operand f32 on the exact-f32 MFMA path (parity mode, 1/16 the rate)."""
+    if mode not in ('bf16', 'fp32'):
+        raise ValueError(mode)
+    _state['act_dtype'] = torch.bfloat16 if mode == 'bf16' else torch.float32
+
+
+@contextlib.contextmanager
+def precision(mode: str):
+    old = _state['act_dtype']
+    set_precision(mode)
+    try:
+        yield
+    finally:
+        _state['act_dtype'] = old
+
+
+def direct_grads() -> bool:
+    return _state['direct_grads']
+
+
+def set_direct_grads(flag: bool) -> None:
+    """True: the hand-written backward accumulates weight gradients directly into the
+    arena-backed ``p.grad`` (no autograd AccumulateGrad pass, no temporaries) and reports
+    None to autograd.  Use with ParamArena + FusedAdamW / GradAllReducer (not with
+    torch DDP, whose hooks need autograd-delivered gradients)."""
+    _state['direct_grads'] = bool(flag)
+
+
+class ParamArena:
+    """Flat fp32 parameter / gradient arenas (+ optional bf16 shadow) for one module tree."""
+
+    def __init__(self, module: nn.Module, device: Optional[torch.device] = None):
+        params = [(n, p) for n, p in module.named_parameters()]
+        if not params:
+            raise ValueError('module has no parameters')
+        device = device or params[0][1].device
+        self.device = device
+        self.names: List[str] = []
+        self.offsets: Dict[str, int] = {}
+        self.sizes: Dict[str, int] = {}
+        self.trainable: Dict[str, bool] = {}
+        # trainable tensors first (so optimiser / all-reduce touch one contiguous prefix)
+        ordered = [(n, p) for n, p in params if p.requires_grad] + [(n, p) for n, p in params if not p.requires_grad]
+        off = 0
+        for n, p in ordered:
+            self.names.append(n)
+            self.offsets[n] = off
+            self.sizes[n] = p.numel()
+            self.trainable[n] = p.requires_grad
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            if p.requires_grad:
+                self.n_trainable = off
+        self.numel = off
+        self.param = torch.zeros(self.numel, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(self.n_trainable, device=device, dtype=torch.float32)
+        self.shadow: Optional[torch.Tensor] = None
+        self._shadow_token = False
+        self._views: Dict[int, torch.Tensor] = {}
+        self._shadow_views: Dict[int, torch.Tensor] = {}
+        self._params: Dict[str, nn.Parameter] = {}
+        with torch.no_grad():
+            for n, p in ordered:
+                o, s = self.offsets[n], self.sizes[n]
+                view = self.param[o:o + s].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                if p.requires_grad:
+                    p.grad = self.grad[o:o + s].view(p.shape)
+                self._params[n] = p
+                self._views[id(p)] = view
+        module._mmae_arena = self
+
+    # -- integrity -----------------------------------------------------------------
+    def intact(self) -> bool:
+        """False if someone re-materialised the parameters (e.g. module.to(...)) after the arena
+        was built."""
+        for n, p in self._params.items():
+            if p.data_ptr() != self.param.data_ptr() + 4 * self.offsets[n]:
+                return False
+        return True
+
+    def rebind_grads(self) -> None:
+        """(re)point every p.grad at the gradient arena (after zero_grad(set_to_none=True))."""
+        for n, p in self._params.items():
+            if p.requires_grad:
+                o, s = self.offsets[n], self.sizes[n]
+                p.grad = self.grad[o:o + s].view(p.shape)
+
+    def zero_grad(self) -> None:
+        self.grad.zero_()
+
+    # -- shadows -------------------------------------------------------------------
+    def refresh_shadow(self) -> None:
+        """bf16 copy of the whole parameter arena (one cast launch)."""
+        if self.shadow is None:
+            self.shadow = torch.empty(self.numel, device=self.device, dtype=torch.bfloat16)
+        if self._shadow_token:          # produced by the fused optimiser for exactly these values
+            self._shadow_token = False
+            return
+        ops.cast_into(self.param, self.shadow)
+
+    def mark_shadow_fresh(self) -> None:
+        self._shadow_token = True
+
+    def weight(self, p: nn.Parameter, dtype: torch.dtype) -> torch.Tensor:
+        """act-dtype view of parameter p (the f32 master itself in fp32 mode)."""
+        if dtype == torch.float32:
+            return p.data
+        key = id(p)
+        v = self._shadow_views.get(key)
+        if v is None or v.data_ptr() != self.shadow.data_ptr() + 2 * self._off_of(p):
+            o = self._off_of(p)
+            v = self.shadow[o:o + p.numel()].view(p.shape)
+            self._shadow_views[key] = v
+        return v
+
+    def _off_of(self, p: nn.Parameter) -> int:
+        return (p.data_ptr() - self.param.data_ptr()) // 4
+
+
+def arena_of(module: nn.Module) -> Optional[ParamArena]:
+    a = getattr(module, '_mmae_arena', None)
+    if a is not None and not a.intact():
+        return None
+    return a
+
+
+class WeightCache:
+    """Per-forward provider of act-dtype weights.
+
+    With an arena: one cast for everything.  Without (stand-alone sub-modules, tests):
+    cast the individual parameter on demand and memoise for the duration of one forward."""
+
+    def __init__(self, arena: Optional[ParamArena], dtype: torch.dtype):
+        self.arena, self.dtype = arena, dtype
+        self._memo: Dict[int, torch.Tensor] = {}
+        if arena is not None and dtype == torch.bfloat16:
+            arena.refresh_shadow()
+
+    def __call__(self, p: torch.Tensor) -> torch.Tensor:
+        if self.dtype == torch.float32:
+            return p.detach()
+        if self.arena is not None and id(p) in self.arena._views:
+            return self.arena.weight(p, self.dtype)
+        k = id(p)
+        w = self._memo.get(k)
+        if w is None:
+            w = ops.cast(p.detach().contiguous(), self.dtype)
+            self._memo[k] = w
+        return w

@@ -1,0 +1,555 @@
+"""Hand-scheduled forward/backward of the MultiMAE hot path as module-level autograd Functions.
+
+Each Function launches a fixed sequence of HIP kernels (see ops.py) for its forward and a
+hand-written sequence for its backward -- torch autograd only links the few module-level
+nodes together (embed -> encoder stack -> 4 output adapters -> losses), it never
+differentiates through individual ops.  Activations are kept (never recomputed): at ViT-B,
+B=256 they total ~8 GB of the 288 GB HBM.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import engine, ops
+from .ops import AttnView, EPI_DGELU, EPI_GELU
+
+Tensor = torch.Tensor
+
+
+class GradSink:
+    """Where parameter gradients go: straight into the arena-backed p.grad (direct mode, returns
+    None to autograd) or into fresh tensors handed back to autograd."""
+
+    def __init__(self, direct: bool):
+        self.direct = direct
+
+    def _target(self, p: Tensor):
+        if self.direct and p.grad is not None:
+            return p.grad, True
+        return torch.empty(p.shape, device=p.device, dtype=torch.float32), False
+
+    def weight(self, p: Tensor, dy: Tensor, x: Tensor, x_off: int = 0, ldx: Optional[int] = None, K: Optional[int] = None):
+        """dW[N,K] = dy[M,N]^T x[M,K]"""
+        if not p.requires_grad:
+            return None
+        tgt, acc = self._target(p)
+        M, N = dy.shape
+        K = K if K is not None else x.shape[1]
+        ops.gemm(dy, x, tgt, N, K, M, lda=N, ldb=ldx if ldx is not None else x.shape[1], ldc=K, a_trans=True, b_trans=True,
+                 b_off=x_off, accumulate=acc)
+        return None if acc else tgt
+
+    def bias(self, p: Tensor, dy: Tensor):
+        if not p.requires_grad:
+            return None
+        tgt, acc = self._target(p)
+        ops.colsum(dy, tgt, acc)
+        return None if acc else tgt
+
+    def vec(self, p: Tensor, g: Tensor):
+        """g already holds the f32 gradient (any shape with p.numel() elements)."""
+        if not p.requires_grad:
+            return None
+        if self.direct and p.grad is not None:
+            ops.axpy_(p.grad, g.contiguous(), 1.0)
+            return None
+        return g.reshape(p.shape)
+
+
+def _new(shape, like: Tensor, dtype):
+    return torch.empty(shape, device=like.device, dtype=dtype)
+
+
+# ------------------------------------------------------------------------------------------
+# transformer block (multimae_utils.py:217-232) on 2-D [B*N, D] activations
+# ------------------------------------------------------------------------------------------
+BLOCK_PARAMS = ('norm1.weight', 'norm1.bias', 'attn.qkv.weight', 'attn.qkv.bias', 'attn.proj.weight', 'attn.proj.bias',
+                'norm2.weight', 'norm2.bias', 'mlp.fc1.weight', 'mlp.fc1.bias', 'mlp.fc2.weight', 'mlp.fc2.bias')
+
+
+def block_fwd(x: Tensor, P: Sequence[Tensor], wc, heads: int, eps: float, act, B: int, N: int, save: bool):
+    n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b = P
+    R, D = x.shape
+    hd = D // heads
+    ln1, mean1, rstd1 = ops.layernorm_fwd(x, n1w, n1b, eps, act)
+    qkv = ops.linear_fwd(ln1, wc(qkvw), qkvb, _new((R, 3 * D), x, act))
+    ao = _new((R, D), x, act)
+    Pm = ops.attention_fwd(AttnView(qkv, 0, 3 * D, N), AttnView(qkv, D, 3 * D, N), AttnView(qkv, 2 * D, 3 * D, N),
+                           AttnView(ao, 0, D, N), B, heads, hd, hd ** -0.5)
+    x1 = ops.linear_fwd(ao, wc(projw), projb, _new((R, D), x, torch.float32), resid=x)
+    ln2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w, n2b, eps, act)
+    Hd = fc1w.shape[0]
+    hpre = _new((R, Hd), x, act)
+    hact = ops.linear_fwd(ln2, wc(fc1w), fc1b, _new((R, Hd), x, act), aux=hpre, epi=EPI_GELU)
+    x2 = ops.linear_fwd(hact, wc(fc2w), fc2b, _new((R, D), x, torch.float32), resid=x1)
+    saved = (x, ln1, mean1, rstd1, qkv, Pm, ao, x1, ln2, mean2, rstd2, hpre, hact) if save else None
+    return x2, saved
+
+
+def block_bwd(dx: Tensor, dx_act: Tensor, saved, P: Sequence[Tensor], wc, sink: GradSink, heads: int, act, B: int, N: int):
+    """dx f32 [R,D] (+ its act-dtype copy) -> (dx0, dx0_act, 12 parameter grads)."""
+    n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b = P
+    x0, ln1, mean1, rstd1, qkv, Pm, ao, x1, ln2, mean2, rstd2, hpre, hact = saved
+    R, D = x0.shape
+    hd = D // heads
+    lnact = None if act == torch.float32 else act
+    # MLP
+    d_hpre = ops.linear_dx(dx_act, wc(fc2w), _new(hpre.shape, dx, act), aux=hpre, epi=EPI_DGELU)
+    g_fc2w = sink.weight(fc2w, dx_act, hact)
+    g_fc2b = sink.bias(fc2b, dx_act)
+    d_ln2 = ops.linear_dx(d_hpre, wc(fc1w), _new((R, D), dx, act))
+    g_fc1w = sink.weight(fc1w, d_hpre, ln2)
+    g_fc1b = sink.bias(fc1b, d_hpre)
+    dx1, dx1_act, dg2, db2 = ops.layernorm_bwd(d_ln2, x1, n2w, mean2, rstd2, dx, lnact)
+    if dx1_act is None:
+        dx1_act = dx1
+    # attention
+    d_ao = ops.linear_dx(dx1_act, wc(projw), _new((R, D), dx, act))
+    g_projw = sink.weight(projw, dx1_act, ao)
+    g_projb = sink.bias(projb, dx1_act)
+    d_qkv = _new((R, 3 * D), dx, act)
+    ops.attention_bwd(AttnView(qkv, 0, 3 * D, N), AttnView(qkv, D, 3 * D, N), AttnView(qkv, 2 * D, 3 * D, N), Pm,
+                      AttnView(d_ao, 0, D, N), AttnView(d_qkv, 0, 3 * D, N), AttnView(d_qkv, D, 3 * D, N),
+                      AttnView(d_qkv, 2 * D, 3 * D, N), B, heads, hd, hd ** -0.5)
+    d_ln1 = ops.linear_dx(d_qkv, wc(qkvw), _new((R, D), dx, act))
+    g_qkvw = sink.weight(qkvw, d_qkv, ln1)
+    g_qkvb = sink.bias(qkvb, d_qkv)
+    dx0, dx0_act, dg1, db1 = ops.layernorm_bwd(d_ln1, x0, n1w, mean1, rstd1, dx1, lnact)
+    if dx0_act is None:
+        dx0_act = dx0
+    grads = (sink.vec(n1w, dg1), sink.vec(n1b, db1), g_qkvw, g_qkvb, g_projw, g_projb, sink.vec(n2w, dg2), sink.vec(n2b, db2),
+             g_fc1w, g_fc1b, g_fc2w, g_fc2b)
+    return dx0, dx0_act, grads
+
+
+class _Cfg:
+    """bag of static (non-tensor) arguments for a Function call"""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class EncoderStackFn(torch.autograd.Function):
+    """L transformer blocks in one autograd node.  forward(cfg, x[B,N,D] f32, *params(12 per layer))"""
+
+    @staticmethod
+    def forward(ctx, cfg: _Cfg, x: Tensor, *params: Tensor):
+        ops._require_gpu(x, 'encoder input')
+        B, N, D = x.shape
+        L = len(params) // 12
+        save = any(ctx.needs_input_grad)
+        h = x.contiguous().view(B * N, D)
+        saved, outs = [], []
+        for l in range(L):
+            h, s = block_fwd(h, params[12 * l:12 * l + 12], cfg.wc, cfg.heads, cfg.eps, cfg.act, B, N, save)
+            saved.append(s)
+            if cfg.all_layers:
+                outs.append(h.view(B, N, D))
+        ctx.cfg, ctx.saved, ctx.params, ctx.shape = cfg, saved, params, (B, N, D)
+        if cfg.all_layers:
+            return tuple(outs)
+        return h.view(B, N, D)
+
+    @staticmethod
+    def backward(ctx, *douts: Tensor):
+        cfg, params = ctx.cfg, ctx.params
+        B, N, D = ctx.shape
+        L = len(params) // 12
+        sink = GradSink(engine.direct_grads())
+        grads: List[Optional[Tensor]] = [None] * (12 * L)
+        dx, dx_act = None, None
+        for l in reversed(range(L)):
+            dl = douts[l] if cfg.all_layers else (douts[0] if l == L - 1 else None)
+            if dl is not None:
+                dl = dl.contiguous().view(B * N, D)
+                dx = dl if dx is None else ops.axpy_(dx, dl, 1.0)
+                dx_act = None
+            if dx is None:
+                continue
+            if dx_act is None:
+                dx_act = ops.cast(dx, cfg.act)
+            dx, dx_act, g = block_bwd(dx, dx_act, ctx.saved[l], params[12 * l:12 * l + 12], cfg.wc, sink, cfg.heads, cfg.act, B, N)
+            grads[12 * l:12 * l + 12] = g
+            ctx.saved[l] = None
+            if cfg.on_layer_done is not None:
+                cfg.on_layer_done(l)
+        return (None, dx.view(B, N, D), *grads)
+
+
+# ------------------------------------------------------------------------------------------
+# gather-first patch embedding (input adapters + token select + global tokens)
+# ------------------------------------------------------------------------------------------
+class EmbedFn(torch.autograd.Function):
+    """forward(cfg, sel[B,n_sel] int64, global_tokens|None, *per task: data, proj.weight, proj.bias, class_emb|None)
+
+    cfg.tasks: list of dicts (kind, C, H, W, ph, pw, k_off, K, n_patches, pos [n_patches, D] f32)
+    cfg.task_offsets, cfg.D, cfg.G, cfg.wc, cfg.act
+    """
+
+    @staticmethod
+    def forward(ctx, cfg: _Cfg, sel: Tensor, global_tokens: Optional[Tensor], *tens: Tensor):
+        T = len(cfg.tasks)
+        B, n_sel = sel.shape
+        D, G, act, wc = cfg.D, cfg.G, cfg.act, cfg.wc
+        data, ws, bs, embs = tens[0::4], tens[1::4], tens[2::4], tens[3::4]
+        Ktot = sum(t['K'] for t in cfg.tasks)
+        srcs = []
+        for t, d, e in zip(cfg.tasks, data, embs):
+            ops._require_gpu(d, 'input tensor')
+            srcs.append(dict(data=d.contiguous(), emb=e, kind=t['kind'], C=t['C'], H=t['H'], W=t['W'], ph=t['ph'], pw=t['pw'],
+                             k_off=t['k_off']))
+        sel = sel.contiguous()
+        rows = ops.patch_rows(srcs, cfg.task_offsets, sel, B, n_sel, Ktot, act)
+        proj = torch.empty((B * n_sel, D), device=sel.device, dtype=torch.float32)
+        for i, (t, w) in enumerate(zip(cfg.tasks, ws)):
+            ops.gemm(rows, wc(w).view(D, t['K']), proj, B * n_sel, D, t['K'], lda=Ktot, ldb=t['K'], ldc=D, a_off=t['k_off'],
+                     accumulate=(i > 0))
+        gt = global_tokens.detach().reshape(G, D) if G > 0 else None
+        tok = ops.tokens_assemble(proj, [b.detach() for b in bs], [t['pos'] for t in cfg.tasks], cfg.task_offsets, sel, gt,
+                                  B, n_sel, G, D)
+        ctx.cfg, ctx.sel, ctx.rows = cfg, sel, rows
+        ctx.tens, ctx.gt = tens, global_tokens
+        ctx.srcs = srcs
+        return tok
+
+    @staticmethod
+    def backward(ctx, d_tok: Tensor):
+        cfg, sel, rows, tens = ctx.cfg, ctx.sel, ctx.rows, ctx.tens
+        T = len(cfg.tasks)
+        B, n_sel = sel.shape
+        D, G, act, wc = cfg.D, cfg.G, cfg.act, cfg.wc
+        Ktot = rows.shape[1]
+        sink = GradSink(engine.direct_grads())
+        d_proj, sums = ops.tokens_assemble_bwd(d_tok.contiguous(), cfg.task_offsets, sel, B, n_sel, G, D, act)
+        out: List[Optional[Tensor]] = []
+        for i, t in enumerate(cfg.tasks):
+            w, b, emb = tens[4 * i + 1], tens[4 * i + 2], tens[4 * i + 3]
+            gw = sink.weight(w, d_proj, rows, x_off=t['k_off'], ldx=Ktot, K=t['K'])
+            if gw is not None:
+                gw = gw.view(w.shape)
+            gb = sink.vec(b, sums[i])
+            ge = None
+            if emb is not None and emb.requires_grad:
+                d_rows = ops.linear_dx(d_proj, wc(w).view(D, t['K']), torch.empty((B * n_sel, t['K']), device=sel.device, dtype=act))
+                ge_buf = torch.zeros(emb.shape, device=sel.device, dtype=torch.float32)
+                s = ctx.srcs[i]
+                ops.semseg_emb_bwd(d_rows, s['data'], sel, ge_buf, B=B, H=t['H'], W=t['W'], E=t['C'], ph=t['ph'], pw=t['pw'],
+                                   n_sel=n_sel, k_off=0, tok_off=cfg.task_offsets[i], n_patches=t['n_patches'], n_cls=emb.shape[0])
+                ge = sink.vec(emb, ge_buf)
+            out += [None, gw, gb, ge]
+        g_glob = None
+        if G > 0 and ctx.gt is not None and ctx.gt.requires_grad:
+            g_glob = sink.vec(ctx.gt, sums[T:T + G].reshape(ctx.gt.shape))
+        return (None, None, g_glob, *out)
+
+
+# ------------------------------------------------------------------------------------------
+# SpatialOutputAdapter (output_adapters.py:236-282)
+# ------------------------------------------------------------------------------------------
+def _lin_fwd(x, w, b, wc, out_dtype, **kw):
+    return ops.linear_fwd(x, wc(w), b, torch.empty((x.shape[0], w.shape[0]), device=x.device, dtype=out_dtype), **kw)
+
+
+class SpatialAdapterFn(torch.autograd.Function):
+    """forward(cfg, enc[B,NC,Denc] f32, ids_keep, ids_restore, *params)
+
+    params order: mask_token, task_emb_0..T-1 (one per INPUT task, None if absent), then
+      q.w,q.b, kv.w,kv.b, proj.w,proj.b, ctxn.w,ctxn.b, qn.w,qn.b, outn.w,outn.b,
+      fc1.w,fc1.b, fc2.w,fc2.b, [12 per transformer block]*depth, out_proj.w,out_proj.b,
+      proj_context.w, proj_context.b
+    cfg: act, wc, heads, eps, task_offsets, q_task, G, D, pos [n_q, D], depth, C, nh, nw, ph, pw
+    """
+
+    @staticmethod
+    def forward(ctx, cfg: _Cfg, enc: Tensor, ids_keep: Tensor, ids_restore: Tensor, *params):
+        ops._require_gpu(enc, 'encoder tokens')
+        act, wc, D, G, heads, eps = cfg.act, cfg.wc, cfg.D, cfg.G, cfg.heads, cfg.eps
+        T = len(cfg.task_offsets) - 1
+        B, NC, Denc = enc.shape
+        n_keep = NC - G
+        n_q = cfg.task_offsets[cfg.q_task + 1] - cfg.task_offsets[cfg.q_task]
+        mask_token = params[0]
+        temb = params[1:1 + T]
+        (qw, qb, kvw, kvb, pw_, pb, cnw, cnb, qnw, qnb, onw, onb, f1w, f1b, f2w, f2b) = params[1 + T:17 + T]
+        blocks = params[17 + T:17 + T + 12 * cfg.depth]
+        ow, ob, pcw, pcb = params[17 + T + 12 * cfg.depth:]
+        dev = enc.device
+        save = any(ctx.needs_input_grad)
+
+        enc2 = enc.contiguous().view(B * NC, Denc)
+        enc_act = ops.cast(enc2, act)
+        ctx_tok = _lin_fwd(enc_act, pcw, pcb, wc, torch.float32)                        # :258
+        te = torch.zeros((T, D), device=dev, dtype=torch.float32)
+        for i, t in enumerate(temb):
+            if t is not None:
+                te[i].copy_(t.detach().reshape(D))
+        queries, context = ops.decoder_build(ctx_tok, ids_keep, ids_restore, mask_token.detach().reshape(D), te, cfg.pos,
+                                             cfg.task_offsets, cfg.q_task, B, n_keep, G, D, n_q)   # :183-234
+        qn, qmean, qrstd = ops.layernorm_fwd(queries, qnw, qnb, eps, act)
+        cn, cmean, crstd = ops.layernorm_fwd(context, cnw, cnb, eps, act)
+        q = _lin_fwd(qn, qw, qb, wc, act)
+        kv = _lin_fwd(cn, kvw, kvb, wc, act)
+        hd = D // heads
+        xo = torch.empty((B * n_q, D), device=dev, dtype=act)
+        Pm = ops.attention_fwd(AttnView(q, 0, D, n_q), AttnView(kv, 0, 2 * D, NC), AttnView(kv, D, 2 * D, NC),
+                               AttnView(xo, 0, D, n_q), B, heads, hd, hd ** -0.5)
+        x = _lin_fwd(xo, pw_, pb, wc, torch.float32)                                    # :265, no residual
+        on, omean, orstd = ops.layernorm_fwd(x, onw, onb, eps, act)
+        hpre = torch.empty((B * n_q, f1w.shape[0]), device=dev, dtype=act)
+        hact = _lin_fwd(on, f1w, f1b, wc, act, aux=hpre, epi=EPI_GELU)
+        x1 = _lin_fwd(hact, f2w, f2b, wc, torch.float32, resid=x)                       # :266
+        h, bsaved = x1, []
+        for l in range(cfg.depth):
+            h, s = block_fwd(h, blocks[12 * l:12 * l + 12], wc, heads, eps, act, B, n_q, save)   # :271
+            bsaved.append(s)
+        h_act = ops.cast(h, act)
+        pat = _lin_fwd(h_act, ow, ob, wc, torch.float32)                                # :274
+        img = ops.unpatchify(pat, B, cfg.C, cfg.nh, cfg.nw, cfg.ph, cfg.pw)             # :277-280
+        if save:
+            ctx.saved = (enc_act, queries, context, qn, qmean, qrstd, cn, cmean, crstd, q, kv, Pm, xo, x, on, omean, orstd,
+                         hpre, hact, h_act, bsaved)
+        ctx.cfg, ctx.params, ctx.ids = cfg, params, (ids_keep, ids_restore)
+        ctx.dims = (B, NC, Denc, n_keep, n_q, T)
+        return img
+
+    @staticmethod
+    def backward(ctx, d_img: Tensor):
+        cfg, params = ctx.cfg, ctx.params
+        ids_keep, ids_restore = ctx.ids
+        B, NC, Denc, n_keep, n_q, T = ctx.dims
+        act, wc, D, G, heads = cfg.act, cfg.wc, cfg.D, cfg.G, cfg.heads
+        lnact = None if act == torch.float32 else act
+        (enc_act, queries, context, qn, qmean, qrstd, cn, cmean, crstd, q, kv, Pm, xo, x, on, omean, orstd, hpre, hact, h_act,
+         bsaved) = ctx.saved
+        mask_token = params[0]
+        temb = params[1:1 + T]
+        (qw, qb, kvw, kvb, pw_, pb, cnw, cnb, qnw, qnb, onw, onb, f1w, f1b, f2w, f2b) = params[1 + T:17 + T]
+        blocks = params[17 + T:17 + T + 12 * cfg.depth]
+        ow, ob, pcw, pcb = params[17 + T + 12 * cfg.depth:]
+        dev = d_img.device
+        sink = GradSink(engine.direct_grads())
+        hd = D // heads
+
+        d_pat = ops.patchify(d_img, cfg.C, cfg.nh, cfg.nw, cfg.ph, cfg.pw, act)         # [B*n_q, C*ph*pw]
+        g_ow, g_ob = sink.weight(ow, d_pat, h_act), sink.bias(ob, d_pat)
+        dh_act = ops.linear_dx(d_pat, wc(ow), torch.empty((B * n_q, D), device=dev, dtype=act))
+        dh = ops.cast(dh_act, torch.float32)
+        bgrads: List[Optional[Tensor]] = [None] * (12 * cfg.depth)
+        for l in reversed(range(cfg.depth)):
+            dh, dh_act, g = block_bwd(dh, dh_act, bsaved[l], blocks[12 * l:12 * l + 12], wc, sink, heads, act, B, n_q)
+            bgrads[12 * l:12 * l + 12] = g
+        # x1 = x + mlp(out_norm(x))
+        d_hpre = ops.linear_dx(dh_act, wc(f2w), torch.empty(hpre.shape, device=dev, dtype=act), aux=hpre, epi=EPI_DGELU)
+        g_f2w, g_f2b = sink.weight(f2w, dh_act, hact), sink.bias(f2b, dh_act)
+        d_on = ops.linear_dx(d_hpre, wc(f1w), torch.empty((B * n_q, D), device=dev, dtype=act))
+        g_f1w, g_f1b = sink.weight(f1w, d_hpre, on), sink.bias(f1b, d_hpre)
+        dx, dx_act, g_onw, g_onb = ops.layernorm_bwd(d_on, x, onw, omean, orstd, dh, lnact)
+        if dx_act is None:
+            dx_act = dx
+        # x = proj(attn(q, k, v))
+        d_xo = ops.linear_dx(dx_act, wc(pw_), torch.empty((B * n_q, D), device=dev, dtype=act))
+        g_pw, g_pb = sink.weight(pw_, dx_act, xo), sink.bias(pb, dx_act)
+        d_q = torch.empty((B * n_q, D), device=dev, dtype=act)
+        d_kv = torch.empty((B * NC, 2 * D), device=dev, dtype=act)
+        ops.attention_bwd(AttnView(q, 0, D, n_q), AttnView(kv, 0, 2 * D, NC), AttnView(kv, D, 2 * D, NC), Pm,
+                          AttnView(d_xo, 0, D, n_q), AttnView(d_q, 0, D, n_q), AttnView(d_kv, 0, 2 * D, NC),
+                          AttnView(d_kv, D, 2 * D, NC), B, heads, hd, hd ** -0.5)
+        d_qn = ops.linear_dx(d_q, wc(qw), torch.empty((B * n_q, D), device=dev, dtype=act))
+        g_qw, g_qb = sink.weight(qw, d_q, qn), sink.bias(qb, d_q)
+        d_cn = ops.linear_dx(d_kv, wc(kvw), torch.empty((B * NC, D), device=dev, dtype=act))
+        g_kvw, g_kvb = sink.weight(kvw, d_kv, cn), sink.bias(kvb, d_kv)
+        d_queries, _, g_qnw, g_qnb = ops.layernorm_bwd(d_qn, queries, qnw, qmean, qrstd, None, None)
+        d_context, _, g_cnw, g_cnb = ops.layernorm_bwd(d_cn, context, cnw, cmean, crstd, None, None)
+        d_ctx, sums = ops.decoder_build_bwd(d_queries, d_context, ids_keep, ids_restore, cfg.task_offsets, cfg.q_task, B, n_keep, G, D,
+                                            n_q)
+        d_ctx_act = ops.cast(d_ctx, act)
+        g_pcw, g_pcb = sink.weight(pcw, d_ctx_act, enc_act), sink.bias(pcb, d_ctx_act)
+        d_enc = ops.linear_dx(d_ctx_act, wc(pcw), torch.empty((B * NC, Denc), device=dev, dtype=torch.float32))
+        g_mask = sink.vec(mask_token, sums[T])
+        g_temb = [sink.vec(t, sums[i]) if t is not None else None for i, t in enumerate(temb)]
+        ctx.saved = None
+        grads = [g_mask, *g_temb, g_qw, g_qb, g_kvw, g_kvb, g_pw, g_pb, sink.vec(cnw, g_cnw), sink.vec(cnb, g_cnb),
+                 sink.vec(qnw, g_qnw), sink.vec(qnb, g_qnb), sink.vec(onw, g_onw), sink.vec(onb, g_onb), g_f1w, g_f1b, g_f2w, g_f2b,
+                 *bgrads, g_ow, g_ob, g_pcw, g_pcb]
+        if cfg.on_done is not None:
+            cfg.on_done()
+        return (None, d_enc.view(B, NC, Denc), None, None, *grads)
+
+
+# ------------------------------------------------------------------------------------------
+# generic single ops as autograd nodes (stand-alone Linear / LayerNorm / attention modules)
+# ------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg: _Cfg, x: Tensor, w: Tensor, b: Optional[Tensor]):
+        ops._require_gpu(x, 'linear input')
+        shp = x.shape
+        x2 = ops.cast(x.contiguous().view(-1, shp[-1]), cfg.act)
+        y = ops.linear_fwd(x2, cfg.wc(w), b.detach() if b is not None else None,
+                           torch.empty((x2.shape[0], w.shape[0]), device=x.device, dtype=torch.float32))
+        ctx.cfg, ctx.x2, ctx.w, ctx.b, ctx.shp = cfg, x2, w, b, shp
+        return y.view(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        cfg, x2, w, b = ctx.cfg, ctx.x2, ctx.w, ctx.b
+        sink = GradSink(engine.direct_grads())
+        dy2 = ops.cast(dy.contiguous().view(-1, w.shape[0]), cfg.act)
+        dx = ops.linear_dx(dy2, cfg.wc(w), torch.empty((dy2.shape[0], w.shape[1]), device=dy.device, dtype=torch.float32))
+        return None, dx.view(ctx.shp), sink.weight(w, dy2, x2), (sink.bias(b, dy2) if b is not None else None)
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor, b: Tensor, eps: float):
+        ops._require_gpu(x, 'layernorm input')
+        shp = x.shape
+        x2 = x.contiguous().view(-1, shp[-1]).float()
+        y, mean, rstd = ops.layernorm_fwd(x2, w.detach(), b.detach(), eps, torch.float32)
+        ctx.save_for_backward(x2, w, mean, rstd)
+        ctx.shp, ctx.wb = shp, (w, b)
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x2, w, mean, rstd = ctx.saved_tensors
+        sink = GradSink(engine.direct_grads())
+        dx, _, dg, db = ops.layernorm_bwd(dy.contiguous().view(x2.shape).float(), x2, w.detach(), mean, rstd, None, None)
+        return dx.view(ctx.shp), sink.vec(ctx.wb[0], dg), sink.vec(ctx.wb[1], db), None
+
+
+class AttentionCoreFn(torch.autograd.Function):
+    """softmax(q k^T scale) v on packed activations; used by the stand-alone Attention / CrossAttention modules."""
+
+    @staticmethod
+    def forward(ctx, q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, act):
+        B, Nq, D = q.shape
+        Nk = k.shape[1]
+        hd = D // heads
+        qa, ka, va = (ops.cast(t.contiguous().view(-1, D), act) for t in (q, k, v))
+        o = torch.empty((B * Nq, D), device=q.device, dtype=act)
+        Pm = ops.attention_fwd(AttnView(qa, 0, D, Nq), AttnView(ka, 0, D, Nk), AttnView(va, 0, D, Nk), AttnView(o, 0, D, Nq), B, heads,
+                               hd, scale)
+        ctx.saved = (qa, ka, va, Pm)
+        ctx.dims = (B, Nq, Nk, D, heads, hd, scale, act)
+        return ops.cast(o, torch.float32).view(B, Nq, D)
+
+    @staticmethod
+    def backward(ctx, d_o: Tensor):
+        qa, ka, va, Pm = ctx.saved
+        B, Nq, Nk, D, heads, hd, scale, act = ctx.dims
+        do = ops.cast(d_o.contiguous().view(-1, D), act)
+        dq = torch.empty((B * Nq, D), device=d_o.device, dtype=act)
+        dk = torch.empty((B * Nk, D), device=d_o.device, dtype=act)
+        dv = torch.empty((B * Nk, D), device=d_o.device, dtype=act)
+        ops.attention_bwd(AttnView(qa, 0, D, Nq), AttnView(ka, 0, D, Nk), AttnView(va, 0, D, Nk), Pm, AttnView(do, 0, D, Nq),
+                          AttnView(dq, 0, D, Nq), AttnView(dk, 0, D, Nk), AttnView(dv, 0, D, Nk), B, heads, hd, scale)
+        f = torch.float32
+        return ops.cast(dq, f).view(B, Nq, D), ops.cast(dk, f).view(B, Nk, D), ops.cast(dv, f).view(B, Nk, D), None, None, None
+
+
+class MlpFn(torch.autograd.Function):
+    """fc1 -> exact-erf GELU (fused epilogue) -> fc2, multimae_utils.py:147-155."""
+
+    @staticmethod
+    def forward(ctx, cfg: _Cfg, x: Tensor, f1w: Tensor, f1b: Tensor, f2w: Tensor, f2b: Tensor):
+        ops._require_gpu(x, 'mlp input')
+        shp = x.shape
+        x2 = ops.cast(x.contiguous().view(-1, shp[-1]), cfg.act)
+        hpre = torch.empty((x2.shape[0], f1w.shape[0]), device=x.device, dtype=cfg.act)
+        hact = _lin_fwd(x2, f1w, f1b.detach(), cfg.wc, cfg.act, aux=hpre, epi=EPI_GELU)
+        y = _lin_fwd(hact, f2w, f2b.detach(), cfg.wc, torch.float32)
+        ctx.cfg, ctx.saved, ctx.params, ctx.shp = cfg, (x2, hpre, hact), (f1w, f1b, f2w, f2b), shp
+        return y.view(*shp[:-1], f2w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        cfg = ctx.cfg
+        x2, hpre, hact = ctx.saved
+        f1w, f1b, f2w, f2b = ctx.params
+        sink = GradSink(engine.direct_grads())
+        dy2 = ops.cast(dy.contiguous().view(-1, f2w.shape[0]), cfg.act)
+        d_hpre = ops.linear_dx(dy2, cfg.wc(f2w), torch.empty(hpre.shape, device=dy.device, dtype=cfg.act), aux=hpre, epi=EPI_DGELU)
+        dx = ops.linear_dx(d_hpre, cfg.wc(f1w), torch.empty((dy2.shape[0], f1w.shape[1]), device=dy.device, dtype=torch.float32))
+        return (None, dx.view(ctx.shp), sink.weight(f1w, d_hpre, x2), sink.bias(f1b, d_hpre), sink.weight(f2w, dy2, hact),
+                sink.bias(f2b, dy2))
+
+
+# ------------------------------------------------------------------------------------------
+# masked losses (criterion.py)
+# ------------------------------------------------------------------------------------------
+def _loss_bufs(B: int, dev):
+    from . import _lib
+    ns = _lib.load().mmae_loss_split()
+    f = torch.float32
+    return (torch.empty((B, ns), device=dev, dtype=f), torch.empty((B, 2), device=dev, dtype=f),
+            torch.empty((2,), device=dev, dtype=f))
+
+
+class MaskedPixelLossFn(torch.autograd.Function):
+    """MaskedMSELoss / MaskedL1Loss (criterion.py:84-114,141-171).  kind 0 = MSE, 1 = L1."""
+
+    @staticmethod
+    def forward(ctx, pred: Tensor, target: Tensor, mask: Tensor, kind: int, norm_pix: bool, patch: int):
+        from . import _lib
+        ops._require_gpu(pred, 'loss input')
+        pred = pred.contiguous().float()
+        target = target.contiguous().float()
+        mask = mask.contiguous().long()
+        B, C, H, W = pred.shape
+        partial, per_sample, loss = _loss_bufs(B, pred.device)
+        np_ = (H // patch) * (W // patch)
+        stats = torch.empty((B, np_, 2), device=pred.device, dtype=torch.float32) if norm_pix else None
+        ops.check(_lib.load().mmae_masked_pixel_loss_fwd(pred.data_ptr(), target.data_ptr(), mask.data_ptr(), kind, int(norm_pix), B, C, H,
+                                                         W, patch, ops._p(stats), partial.data_ptr(), per_sample.data_ptr(),
+                                                         loss.data_ptr(), ops._stream()), 'masked_pixel_loss_fwd')
+        ctx.saved = (pred, target, mask, stats, per_sample, loss)
+        ctx.args = (kind, norm_pix, patch)
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        from . import _lib
+        pred, target, mask, stats, per_sample, loss = ctx.saved
+        kind, norm_pix, patch = ctx.args
+        B, C, H, W = pred.shape
+        d_pred = torch.empty_like(pred)
+        up = g.contiguous().float().reshape(1)
+        ops.check(_lib.load().mmae_masked_pixel_loss_bwd(pred.data_ptr(), target.data_ptr(), mask.data_ptr(), kind, int(norm_pix), B, C, H,
+                                                         W, patch, ops._p(stats), per_sample.data_ptr(), loss.data_ptr(), up.data_ptr(),
+                                                         d_pred.data_ptr(), ops._stream()), 'masked_pixel_loss_bwd')
+        return d_pred, None, None, None, None, None
+
+
+class MaskedCEFn(torch.autograd.Function):
+    """MaskedCrossEntropyLoss (criterion.py:37-57), label_smoothing = 0."""
+
+    @staticmethod
+    def forward(ctx, logits: Tensor, target: Tensor, mask: Tensor, patch: int):
+        from . import _lib
+        ops._require_gpu(logits, 'loss input')
+        logits = logits.contiguous().float()
+        target = target.contiguous().long()
+        mask = mask.contiguous().long()
+        B, C, H, W = logits.shape
+        partial, per_sample, loss = _loss_bufs(B, logits.device)
+        lse = torch.empty((B, H, W), device=logits.device, dtype=torch.float32)
+        ops.check(_lib.load().mmae_masked_ce_fwd(logits.data_ptr(), target.data_ptr(), mask.data_ptr(), B, C, H, W, patch, lse.data_ptr(),
+                                                 partial.data_ptr(), per_sample.data_ptr(), loss.data_ptr(), ops._stream()), 'masked_ce_fwd')
+        ctx.saved = (logits, target, mask, lse, per_sample, loss)
+        ctx.patch = patch
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        from . import _lib
+        logits, target, mask, lse, per_sample, loss = ctx.saved
+        B, C, H, W = logits.shape
+        d = torch.empty_like(logits)
+        up = g.contiguous().float().reshape(1)
+        ops.check(_lib.load().mmae_masked_ce_bwd(logits.data_ptr(), target.data_ptr(), mask.data_ptr(), B, C, H, W, ctx.patch,
+                                                 lse.data_ptr(), per_sample.data_ptr(), loss.data_ptr(), up.data_ptr(), d.data_ptr(),
+                                                 ops._stream()), 'masked_ce_bwd')
+        return d, None, None, None

@@ -1,0 +1,232 @@
+"""Building blocks of the MI355X-native MultiMAE engine (mirror of the reference's
+``multimae/multimae_utils.py`` API: same class names, constructor arguments, parameter names
+and registration order -- so ``state_dict`` keys and seeded initialisation are identical --
+but every forward/backward is a hand-written HIP kernel sequence, see functions.py).
+
+Reference: multimae/multimae_utils.py:29-45 (sincos), :48-102 (trunc_normal_), :105-135
+(DropPath), :138-155 (Mlp), :158-182 (Attention), :185-214 (CrossAttention), :217-232 (Block).
+"""
+from __future__ import annotations
+
+import math
+import warnings
+
+import torch
+from torch import nn
+
+from . import engine
+from .functions import (AttentionCoreFn, EncoderStackFn, LayerNormFn, LinearFn, MlpFn, _Cfg)
+
+
+def pair(t):
+    return t if isinstance(t, tuple) else (t, t)
+
+
+def build_2d_sincos_posemb(h, w, embed_dim=1024, temperature=10000.):
+    """(1, embed_dim, h, w) fixed sin-cos table (MoCo-v3 layout as used by the reference:
+    channel quarters [sin(r w_k), cos(r w_k), sin(c w_k), cos(c w_k)] for row r / column c on
+    square grids; for h != w the reference's flatten-then-reshape order is reproduced)."""
+    assert embed_dim % 4 == 0, 'Embed dimension must be divisible by 4 for 2D sin-cos position embedding'
+    q = embed_dim // 4
+    omega = 1. / (temperature ** (torch.arange(q, dtype=torch.float32) / q))
+    a = torch.arange(w, dtype=torch.float32).repeat_interleave(h)     # flat f = i*h + j -> i
+    b = torch.arange(h, dtype=torch.float32).repeat(w)                # -> j
+    oa, ob = a[:, None] * omega[None, :], b[:, None] * omega[None, :]
+    emb = torch.cat([torch.sin(oa), torch.cos(oa), torch.sin(ob), torch.cos(ob)], dim=1)
+    return emb.reshape(h, w, embed_dim).permute(2, 0, 1).unsqueeze(0).contiguous()
+
+
+def trunc_normal_(tensor, mean=0., std=1., a=-2., b=2.):
+    """Truncated normal by inverse-CDF sampling (the timm/PyTorch recipe the reference vendors:
+    uniform in [2*Phi(l)-1, 2*Phi(u)-1] -> erfinv -> scale -> clamp); same RNG consumption, so a
+    seeded construction reproduces the reference's initial weights bit for bit."""
+    def cdf(x):
+        return (1. + math.erf(x / math.sqrt(2.))) / 2.
+    if (mean < a - 2 * std) or (mean > b + 2 * std):
+        warnings.warn('mean is more than 2 std from [a, b] in trunc_normal_', stacklevel=2)
+    with torch.no_grad():
+        lo, hi = cdf((a - mean) / std), cdf((b - mean) / std)
+        tensor.uniform_(2 * lo - 1, 2 * hi - 1)
+        tensor.erfinv_()
+        tensor.mul_(std * math.sqrt(2.))
+        tensor.add_(mean)
+        tensor.clamp_(min=a, max=b)
+    return tensor
+
+
+def set_root(root: nn.Module) -> None:
+    """Let every sub-module find the model that owns the parameter arena (weak reference, stored
+    outside nn.Module's attribute registry)."""
+    import weakref
+    ref = weakref.ref(root)
+    for m in root.modules():
+        object.__setattr__(m, '_mmae_root', ref)
+
+
+def root_of(module: nn.Module) -> nn.Module:
+    ref = getattr(module, '_mmae_root', None)
+    r = ref() if ref is not None else None
+    return r if r is not None else module
+
+
+def _cfg(module: nn.Module, act=None, **kw) -> _Cfg:
+    act = act or engine.act_dtype()
+    arena = engine.arena_of(root_of(module))
+    return _Cfg(act=act, wc=engine.WeightCache(arena, act), **kw)
+
+
+class Linear(nn.Linear):
+    """nn.Linear parameter container whose forward is the MFMA GEMM kernel (fp32 in / fp32 out
+    at the module boundary; the engine's fused paths bypass this and feed bf16 directly)."""
+
+    def forward(self, x):
+        return LinearFn.apply(_cfg(self), x, self.weight, self.bias)
+
+
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm parameter container; forward = wave-per-row HIP kernel."""
+
+    def forward(self, x):
+        return LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+
+
+def drop_path(x, drop_prob: float = 0., training: bool = False):
+    """Stochastic depth per sample (multimae_utils.py:105-122).  Identity at the pre-training
+    default (rate 0); the Bernoulli mask is a (B,1,..) broadcast multiply."""
+    if drop_prob == 0. or not training:
+        return x
+    keep = 1 - drop_prob
+    shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+    mask = (keep + torch.rand(shape, dtype=x.dtype, device=x.device)).floor_()
+    return x.div(keep) * mask
+
+
+class DropPath(nn.Module):
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        return drop_path(x, self.drop_prob, self.training)
+
+    def extra_repr(self) -> str:
+        return 'p={}'.format(self.drop_prob)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        if act_layer is not nn.GELU:
+            raise NotImplementedError('the HIP engine fuses exact-erf GELU into the fc1 epilogue; other activations are not built')
+        self.fc1 = Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+        if drop != 0.:
+            raise NotImplementedError('dropout > 0 is not implemented in the HIP engine (pre-training uses 0)')
+
+    def forward(self, x):
+        return MlpFn.apply(_cfg(self), x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        if attn_drop != 0. or proj_drop != 0.:
+            raise NotImplementedError('attention/projection dropout > 0 is not implemented in the HIP engine')
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = head_dim ** -0.5
+        self.qkv = Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        qkv = self.qkv(x)
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        o = AttentionCoreFn.apply(q, k, v, self.num_heads, self.scale, engine.act_dtype())
+        return self.proj(o)
+
+
+class CrossAttention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        if attn_drop != 0. or proj_drop != 0.:
+            raise NotImplementedError('attention/projection dropout > 0 is not implemented in the HIP engine')
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = head_dim ** -0.5
+        self.q = Linear(dim, dim, bias=qkv_bias)
+        self.kv = Linear(dim, dim * 2, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    def forward(self, x, context):
+        C = x.shape[-1]
+        q = self.q(x)
+        kv = self.kv(context)
+        o = AttentionCoreFn.apply(q, kv[..., :C], kv[..., C:], self.num_heads, self.scale, engine.act_dtype())
+        return self.proj(o)
+
+
+def block_params(blk: 'Block'):
+    return [blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight, blk.attn.proj.bias,
+            blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias]
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, drop=0., attn_drop=0.,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.norm1 = _as_hip_norm(norm_layer, dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = _as_hip_norm(norm_layer, dim)
+        mlp_hidden_dim = int(dim * mlp_ratio)
+        self.mlp = Mlp(in_features=dim, hidden_features=mlp_hidden_dim, act_layer=act_layer, drop=drop)
+        if not qkv_bias:
+            raise NotImplementedError('qkv_bias=False is not built (every reference factory uses True)')
+
+    def forward(self, x):
+        if isinstance(self.drop_path, nn.Identity) or not self.training:
+            cfg = _cfg(self, heads=self.attn.num_heads, eps=self.norm1.eps, all_layers=False, on_layer_done=None)
+            return EncoderStackFn.apply(cfg, x, *block_params(self))
+        # stochastic depth: per-sample residual scaling needs the two branches separately
+        x = x + self.drop_path(self.attn(self.norm1(x)))
+        x = x + self.drop_path(self.mlp(self.norm2(x)))
+        return x
+
+
+def _as_hip_norm(norm_layer, dim):
+    """Instantiate the caller's norm_layer and make sure it is the HIP LayerNorm container."""
+    m = norm_layer(dim)
+    if isinstance(m, LayerNorm):
+        return m
+    if isinstance(m, nn.LayerNorm):
+        h = LayerNorm(dim, eps=m.eps)
+        return h
+    raise NotImplementedError(f'norm layer {type(m)} is not built in the HIP engine')
+
+
+def run_blocks(blocks, x, root=None, all_layers=False, on_layer_done=None):
+    """Run a sequence of Blocks as ONE autograd node (the encoder / decoder_transformer fast path)."""
+    blocks = list(blocks)
+    if not blocks:
+        return [] if all_layers else x
+    if any((not isinstance(b.drop_path, nn.Identity)) and b.training for b in blocks):
+        outs = []
+        for b in blocks:
+            x = b(x)
+            outs.append(x)
+        return outs if all_layers else x
+    b0 = blocks[0]
+    cfg = _cfg(b0 if root is None else root, heads=b0.attn.num_heads, eps=b0.norm1.eps, all_layers=all_layers,
+               on_layer_done=on_layer_done)
+    params = [p for b in blocks for p in block_params(b)]
+    out = EncoderStackFn.apply(cfg, x, *params)
+    return list(out) if all_layers else out

@@ -1,0 +1,368 @@
+"""Thin Python launchers for the HIP kernels (torch tensors in, raw pointers out).
+
+PyTorch is used here only for device memory (caching allocator) and the current
+HIP stream; every arithmetic step is a kernel of libmmae_hip.so.  Nothing in this
+module has a CPU or torch-op fallback: tensors must live on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, EPI_NONE, EPI_GELU, EPI_DGELU, GemmDesc, PatchSrc, check
+
+Tensor = torch.Tensor
+
+
+def _require_gpu(t: Tensor, name: str = 'tensor') -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f'multimae_amd: {name} is on {t.device}; the engine runs on MI355X HIP kernels only '
+                           '(no CPU / PyTorch fallback). Move the model and inputs to a GPU.')
+
+
+def dcode(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f'unsupported activation dtype {dtype}')
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# --------------------------------------------------------------------------- GEMM --
+def gemm(A: Tensor, B: Tensor, C: Tensor, M: int, N: int, K: int, *, lda: int, ldb: int, ldc: int,
+         a_trans: bool = False, b_trans: bool = False, a_off: int = 0, b_off: int = 0, c_off: int = 0,
+         batch: int = 1, batch_inner: int = 1, sA=(0, 0), sB=(0, 0), sC=(0, 0),
+         bias: Optional[Tensor] = None, resid: Optional[Tensor] = None, ldr: int = 0,
+         aux: Optional[Tensor] = None, ldaux: int = 0, epi: int = EPI_NONE, accumulate: bool = False,
+         alpha: float = 1.0, tile: int = 0) -> None:
+    """C[M,N] (+)= alpha * A[M,K] . B[N,K]^T with the fused epilogue of mmae_gemm.
+    *_off are element offsets into the tensors' storage views (column offsets into packed qkv etc.)."""
+    _require_gpu(A, 'gemm A')
+    assert A.dtype == B.dtype, (A.dtype, B.dtype)
+    d = GemmDesc()
+    esz_ab, esz_c = A.element_size(), C.element_size()
+    d.A = A.data_ptr() + a_off * esz_ab
+    d.B = B.data_ptr() + b_off * esz_ab
+    d.C = C.data_ptr() + c_off * esz_c
+    d.ab_dtype, d.c_dtype = dcode(A.dtype), dcode(C.dtype)
+    d.M, d.N, d.K = M, N, K
+    d.a_trans, d.b_trans = int(a_trans), int(b_trans)
+    d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.batch, d.batch_inner = batch, batch_inner
+    d.sA_outer, d.sA_inner = sA
+    d.sB_outer, d.sB_inner = sB
+    d.sC_outer, d.sC_inner = sC
+    d.bias = _p(bias)
+    d.resid, d.ldr = _p(resid), ldr
+    d.aux, d.ldaux = _p(aux), ldaux
+    d.aux_dtype = dcode(aux.dtype) if aux is not None else F32
+    d.epi, d.accumulate, d.alpha, d.tile = epi, int(accumulate), alpha, tile
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() >= N
+    if resid is not None:
+        assert resid.dtype == torch.float32
+    check(_lib.load().mmae_gemm(ctypes.byref(d), _stream()), 'mmae_gemm')
+
+
+def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], out: Tensor, *, resid: Optional[Tensor] = None,
+               aux: Optional[Tensor] = None, epi: int = EPI_NONE, tile: int = 0) -> Tensor:
+    """out[M,N] = x[M,K] @ w[N,K]^T + bias (+ epilogue).  x, w act dtype, contiguous 2-D."""
+    M, K = x.shape
+    N = w.shape[0]
+    gemm(x, w, out, M, N, K, lda=K, ldb=K, ldc=N, bias=bias, resid=resid, ldr=N, aux=aux, ldaux=N, epi=epi, tile=tile)
+    return out
+
+
+def linear_dx(dy: Tensor, w: Tensor, out: Tensor, *, aux: Optional[Tensor] = None, epi: int = EPI_NONE) -> Tensor:
+    """out[M,K] = dy[M,N] @ w[N,K]   (w read through the transposing LDS path)."""
+    M, N = dy.shape
+    K = w.shape[1]
+    gemm(dy, w, out, M, K, N, lda=N, ldb=K, ldc=K, b_trans=True, aux=aux, ldaux=K, epi=epi)
+    return out
+
+
+def linear_dw(dy: Tensor, x: Tensor, dw: Tensor, accumulate: bool) -> Tensor:
+    """dw[N,K] (+)= dy[M,N]^T @ x[M,K]   (both operands k-strided)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    gemm(dy, x, dw, N, K, M, lda=N, ldb=K, ldc=K, a_trans=True, b_trans=True, accumulate=accumulate)
+    return dw
+
+
+# ------------------------------------------------------------------- row kernels --
+def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out_dtype: torch.dtype):
+    _require_gpu(x, 'layernorm input')
+    R, D = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y = torch.empty((R, D), device=x.device, dtype=out_dtype)
+    mean = torch.empty((R,), device=x.device, dtype=torch.float32)
+    rstd = torch.empty((R,), device=x.device, dtype=torch.float32)
+    check(_lib.load().mmae_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), dcode(out_dtype),
+                                         mean.data_ptr(), rstd.data_ptr(), R, D, eps, _stream()), 'layernorm_fwd')
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dx_in: Optional[Tensor],
+                  act_dtype: Optional[torch.dtype]):
+    """returns dx (f32, = dx_in + LN'(dy)), dx_act (act copy or None), dgamma, dbeta (f32 [D])."""
+    R, D = x.shape
+    lib = _lib.load()
+    nblk = lib.mmae_layernorm_bwd_nblk(R)
+    part = torch.empty((nblk, 2, D), device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x)
+    dx_act = torch.empty((R, D), device=x.device, dtype=act_dtype) if act_dtype is not None else None
+    check(lib.mmae_layernorm_bwd(dy.data_ptr(), dcode(dy.dtype), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                 rstd.data_ptr(), _p(dx_in), dx.data_ptr(), _p(dx_act),
+                                 dcode(act_dtype) if act_dtype is not None else F32, part.data_ptr(), R, D, _stream()),
+          'layernorm_bwd')
+    dgb = torch.empty((2 * D,), device=x.device, dtype=torch.float32)
+    check(lib.mmae_colsum_partials(part.data_ptr(), dgb.data_ptr(), nblk, 2 * D, 0, _stream()), 'colsum_partials')
+    return dx, dx_act, dgb[:D], dgb[D:]
+
+
+def colsum(dy: Tensor, out: Tensor, accumulate: bool) -> Tensor:
+    """out[n] (+)= sum_m dy[m][n]"""
+    M, N = dy.shape
+    lib = _lib.load()
+    ws = torch.empty((lib.mmae_colsum_ws_elems(M, N),), device=dy.device, dtype=torch.float32)
+    check(lib.mmae_colsum(dy.data_ptr(), dcode(dy.dtype), M, N, dy.stride(0), out.data_ptr(), int(accumulate),
+                          ws.data_ptr(), _stream()), 'colsum')
+    return out
+
+
+def reduce_partials(part: Tensor, out: Tensor, accumulate: bool) -> Tensor:
+    nrows = part.shape[0]
+    ncols = part.numel() // nrows
+    check(_lib.load().mmae_colsum_partials(part.data_ptr(), out.data_ptr(), nrows, ncols, int(accumulate), _stream()),
+          'colsum_partials')
+    return out
+
+
+def softmax_fwd(S: Tensor, P: Tensor, rows: int, n: int, scale: float) -> None:
+    check(_lib.load().mmae_softmax_fwd(S.data_ptr(), S.shape[-1], P.data_ptr(), dcode(P.dtype), P.shape[-1], rows, n, scale,
+                                       _stream()), 'softmax_fwd')
+
+
+def softmax_bwd(P: Tensor, dP: Tensor, dS: Tensor, rows: int, n: int, scale: float) -> None:
+    check(_lib.load().mmae_softmax_bwd(P.data_ptr(), dcode(P.dtype), P.shape[-1], dP.data_ptr(), dP.shape[-1], dS.data_ptr(),
+                                       dS.shape[-1], rows, n, scale, _stream()), 'softmax_bwd')
+
+
+def cast(x: Tensor, dtype: torch.dtype) -> Tensor:
+    """f32 <-> bf16 cast kernel (identity if already that dtype)."""
+    if x.dtype == dtype:
+        return x
+    _require_gpu(x, 'cast input')
+    x = x.contiguous()
+    y = torch.empty(x.shape, device=x.device, dtype=dtype)
+    lib = _lib.load()
+    if dtype == torch.bfloat16:
+        check(lib.mmae_cast_f32_to_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), 'cast_f32_to_bf16')
+    else:
+        check(lib.mmae_cast_bf16_to_f32(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), 'cast_bf16_to_f32')
+    return y
+
+
+def cast_into(src: Tensor, dst: Tensor) -> None:
+    lib = _lib.load()
+    assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
+    check(lib.mmae_cast_f32_to_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), 'cast_f32_to_bf16')
+
+
+def axpy_(y: Tensor, x: Tensor, a: float = 1.0) -> Tensor:
+    assert y.dtype == torch.float32 and x.dtype == torch.float32 and y.numel() == x.numel()
+    check(_lib.load().mmae_axpy_f32(y.data_ptr(), x.data_ptr(), a, y.numel(), _stream()), 'axpy')
+    return y
+
+
+# ------------------------------------------------------------- attention (unfused) --
+class AttnView:
+    """A (B, N, heads, hd) operand living inside a packed 2-D activation [B*N, ld] at column `col`."""
+    __slots__ = ('t', 'col', 'ld', 'N')
+
+    def __init__(self, t: Tensor, col: int, ld: int, N: int):
+        self.t, self.col, self.ld, self.N = t, col, ld, N
+
+
+def attention_fwd(q: AttnView, k: AttnView, v: AttnView, out: AttnView, B: int, H: int, hd: int, scale: float):
+    """softmax(q k^T * scale) v via batched MFMA GEMMs + row softmax.  Returns P (saved for backward).
+    multimae_utils.py:175-179 / 206-210."""
+    Nq, Nk = q.N, k.N
+    Np = round_up(Nk, 8)
+    dev, act = q.t.device, q.t.dtype
+    S = torch.empty((B, H, Nq, Np), device=dev, dtype=torch.float32)
+    gemm(q.t, k.t, S, Nq, Nk, hd, lda=q.ld, ldb=k.ld, ldc=Np, a_off=q.col, b_off=k.col,
+         batch=B * H, batch_inner=H, sA=(Nq * q.ld, hd), sB=(Nk * k.ld, hd), sC=(H * Nq * Np, Nq * Np))
+    P = torch.empty((B, H, Nq, Np), device=dev, dtype=act)
+    softmax_fwd(S, P, B * H * Nq, Nk, scale)
+    gemm(P, v.t, out.t, Nq, hd, Nk, lda=Np, ldb=v.ld, ldc=out.ld, b_trans=True, b_off=v.col, c_off=out.col,
+         batch=B * H, batch_inner=H, sA=(H * Nq * Np, Nq * Np), sB=(Nk * v.ld, hd), sC=(Nq * out.ld, hd))
+    return P
+
+
+def attention_bwd(q: AttnView, k: AttnView, v: AttnView, P: Tensor, d_out: AttnView, dq: AttnView, dk: AttnView,
+                  dv: AttnView, B: int, H: int, hd: int, scale: float) -> None:
+    Nq, Nk = q.N, k.N
+    Np = P.shape[-1]
+    dev, act = q.t.device, q.t.dtype
+    bh = dict(batch=B * H, batch_inner=H)
+    sP = (H * Nq * Np, Nq * Np)
+    # dP = dO V^T
+    dP = torch.empty((B, H, Nq, Np), device=dev, dtype=torch.float32)
+    gemm(d_out.t, v.t, dP, Nq, Nk, hd, lda=d_out.ld, ldb=v.ld, ldc=Np, a_off=d_out.col, b_off=v.col,
+         sA=(Nq * d_out.ld, hd), sB=(Nk * v.ld, hd), sC=sP, **bh)
+    dS = torch.empty((B, H, Nq, Np), device=dev, dtype=act)
+    softmax_bwd(P, dP, dS, B * H * Nq, Nk, scale)
+    # dV = P^T dO
+    gemm(P, d_out.t, dv.t, Nk, hd, Nq, lda=Np, ldb=d_out.ld, ldc=dv.ld, a_trans=True, b_trans=True, b_off=d_out.col,
+         c_off=dv.col, sA=sP, sB=(Nq * d_out.ld, hd), sC=(Nk * dv.ld, hd), **bh)
+    # dQ = dS K
+    gemm(dS, k.t, dq.t, Nq, hd, Nk, lda=Np, ldb=k.ld, ldc=dq.ld, b_trans=True, b_off=k.col, c_off=dq.col,
+         sA=sP, sB=(Nk * k.ld, hd), sC=(Nq * dq.ld, hd), **bh)
+    # dK = dS^T Q
+    gemm(dS, q.t, dk.t, Nk, hd, Nq, lda=Np, ldb=q.ld, ldc=dk.ld, a_trans=True, b_trans=True, b_off=q.col,
+         c_off=dk.col, sA=sP, sB=(Nq * q.ld, hd), sC=(Nk * dk.ld, hd), **bh)
+
+
+# ----------------------------------------------------------------- token kernels --
+def _i32_array(vals: Sequence[int]):
+    return (ctypes.c_int32 * len(vals))(*vals)
+
+
+def mask_sample(samples_per_task: Tensor, task_noise: Tensor, all_noise: Tensor, task_offsets: Sequence[int], n_keep: int):
+    """Deterministic core of generate_random_masks (multimae.py:191-216) on the GPU."""
+    _require_gpu(task_noise, 'mask noise')
+    B, Ntot = all_noise.shape
+    T = len(task_offsets) - 1
+    dev = all_noise.device
+    mask_all = torch.empty((B, Ntot), device=dev, dtype=torch.int64)
+    ids_keep = torch.empty((B, n_keep), device=dev, dtype=torch.int64)
+    ids_restore = torch.empty((B, Ntot), device=dev, dtype=torch.int64)
+    spt = samples_per_task.to(device=dev, dtype=torch.int64).contiguous()
+    check(_lib.load().mmae_mask_sample(spt.data_ptr(), task_noise.contiguous().data_ptr(), all_noise.contiguous().data_ptr(),
+                                       ctypes.cast(_i32_array(task_offsets), ctypes.c_void_p), T, B, Ntot, n_keep,
+                                       mask_all.data_ptr(), ids_keep.data_ptr(), ids_restore.data_ptr(), _stream()),
+          'mask_sample')
+    return mask_all, ids_keep, ids_restore
+
+
+def patch_rows(srcs: Sequence[dict], task_offsets: Sequence[int], sel: Tensor, B: int, n_sel: int, Ktot: int,
+               dtype: torch.dtype) -> Tensor:
+    """srcs: one dict per task: data (tensor), emb (tensor|None), kind, C, H, W, ph, pw, k_off."""
+    T = len(srcs)
+    arr = (PatchSrc * T)()
+    for i, s in enumerate(srcs):
+        _require_gpu(s['data'], 'input image')
+        arr[i].data = s['data'].data_ptr()
+        arr[i].emb = _p(s.get('emb'))
+        arr[i].kind, arr[i].C, arr[i].H, arr[i].W = s['kind'], s['C'], s['H'], s['W']
+        arr[i].ph, arr[i].pw, arr[i].k_off = s['ph'], s['pw'], s['k_off']
+    rows = torch.empty((B * n_sel, Ktot), device=sel.device, dtype=dtype)
+    check(_lib.load().mmae_patch_rows(ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(_i32_array(task_offsets), ctypes.c_void_p),
+                                      T, sel.data_ptr(), rows.data_ptr(), dcode(dtype), B, n_sel, Ktot, _stream()), 'patch_rows')
+    return rows
+
+
+def semseg_emb_bwd(d_rows: Tensor, cls: Tensor, sel: Tensor, d_emb: Tensor, *, B, H, W, E, ph, pw, n_sel, k_off, tok_off,
+                   n_patches, n_cls) -> None:
+    check(_lib.load().mmae_semseg_emb_bwd(d_rows.data_ptr(), dcode(d_rows.dtype), d_rows.stride(0), cls.data_ptr(), sel.data_ptr(),
+                                          d_emb.data_ptr(), B, H, W, E, ph, pw, n_sel, k_off, tok_off, n_patches, n_cls,
+                                          _stream()), 'semseg_emb_bwd')
+
+
+def _ptr_array(ts: Sequence[Tensor]):
+    return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def tokens_assemble(proj: Tensor, biases: Sequence[Tensor], poss: Sequence[Tensor], task_offsets: Sequence[int], sel: Tensor,
+                    global_tok: Optional[Tensor], B: int, n_sel: int, G: int, D: int) -> Tensor:
+    tok = torch.empty((B, n_sel + G, D), device=proj.device, dtype=torch.float32)
+    check(_lib.load().mmae_tokens_assemble(tok.data_ptr(), proj.data_ptr(), ctypes.cast(_ptr_array(biases), ctypes.c_void_p),
+                                           ctypes.cast(_ptr_array(poss), ctypes.c_void_p),
+                                           ctypes.cast(_i32_array(task_offsets), ctypes.c_void_p), len(biases), sel.data_ptr(),
+                                           _p(global_tok), B, n_sel, G, D, _stream()), 'tokens_assemble')
+    return tok
+
+
+def tokens_assemble_bwd(d_tok: Tensor, task_offsets: Sequence[int], sel: Tensor, B: int, n_sel: int, G: int, D: int,
+                        act: torch.dtype):
+    """returns d_proj (act) [B*n_sel, D] and sums f32 [T+G, D] (bias grads per task, then global-token grads)."""
+    lib = _lib.load()
+    T = len(task_offsets) - 1
+    nblk = lib.mmae_tokens_assemble_bwd_nblk(B)
+    part = torch.empty((nblk, T + G, D), device=d_tok.device, dtype=torch.float32)
+    d_proj = torch.empty((B * n_sel, D), device=d_tok.device, dtype=act)
+    check(lib.mmae_tokens_assemble_bwd(d_tok.data_ptr(), d_proj.data_ptr(), dcode(act),
+                                       ctypes.cast(_i32_array(task_offsets), ctypes.c_void_p), T, sel.data_ptr(), part.data_ptr(),
+                                       B, n_sel, G, D, _stream()), 'tokens_assemble_bwd')
+    sums = torch.empty((T + G, D), device=d_tok.device, dtype=torch.float32)
+    reduce_partials(part, sums, False)
+    return d_proj, sums
+
+
+def decoder_build(ctx: Tensor, ids_keep: Tensor, ids_restore: Tensor, mask_token: Tensor, task_emb: Tensor, pos: Tensor,
+                  task_offsets: Sequence[int], q_task: int, B: int, n_keep: int, G: int, D: int, n_q: int):
+    queries = torch.empty((B * n_q, D), device=ctx.device, dtype=torch.float32)
+    context = torch.empty((B * (n_keep + G), D), device=ctx.device, dtype=torch.float32)
+    check(_lib.load().mmae_decoder_build(ctx.data_ptr(), ids_keep.data_ptr(), ids_restore.data_ptr(), mask_token.data_ptr(),
+                                         task_emb.data_ptr(), pos.data_ptr(), ctypes.cast(_i32_array(task_offsets), ctypes.c_void_p),
+                                         len(task_offsets) - 1, q_task, B, n_keep, G, D, n_q, queries.data_ptr(),
+                                         context.data_ptr(), _stream()), 'decoder_build')
+    return queries, context
+
+
+def decoder_build_bwd(d_queries: Tensor, d_context: Tensor, ids_keep: Tensor, ids_restore: Tensor, task_offsets: Sequence[int],
+                      q_task: int, B: int, n_keep: int, G: int, D: int, n_q: int):
+    """returns d_ctx f32 [B*(n_keep+G), D] and sums f32 [T+1, D] (task embeddings, then mask token)."""
+    lib = _lib.load()
+    T = len(task_offsets) - 1
+    nblk = lib.mmae_decoder_build_bwd_nblk(B)
+    part = torch.empty((nblk, T + 1, D), device=d_queries.device, dtype=torch.float32)
+    d_ctx = torch.empty((B * (n_keep + G), D), device=d_queries.device, dtype=torch.float32)
+    check(lib.mmae_decoder_build_bwd(d_queries.data_ptr(), d_context.data_ptr(), ids_keep.data_ptr(), ids_restore.data_ptr(),
+                                     ctypes.cast(_i32_array(task_offsets), ctypes.c_void_p), T, q_task, B, n_keep, G, D, n_q,
+                                     d_ctx.data_ptr(), part.data_ptr(), _stream()), 'decoder_build_bwd')
+    sums = torch.empty((T + 1, D), device=d_queries.device, dtype=torch.float32)
+    reduce_partials(part, sums, False)
+    return d_ctx, sums
+
+
+def unpatchify(pat: Tensor, B: int, C: int, nh: int, nw: int, ph: int, pw: int) -> Tensor:
+    img = torch.empty((B, C, nh * ph, nw * pw), device=pat.device, dtype=torch.float32)
+    check(_lib.load().mmae_unpatchify(pat.data_ptr(), img.data_ptr(), B, C, nh, nw, ph, pw, _stream()), 'unpatchify')
+    return img
+
+
+def patchify(img: Tensor, C: int, nh: int, nw: int, ph: int, pw: int, dtype: torch.dtype) -> Tensor:
+    B = img.shape[0]
+    pat = torch.empty((B * nh * nw, C * ph * pw), device=img.device, dtype=dtype)
+    check(_lib.load().mmae_patchify(img.contiguous().data_ptr(), pat.data_ptr(), dcode(dtype), B, C, nh, nw, ph, pw, _stream()),
+          'patchify')
+    return pat
+
+
+# ----------------------------------------------------------------------- optimiser --
+def sumsq(x: Tensor, out: Tensor, ws: Tensor) -> None:
+    check(_lib.load().mmae_sumsq(x.data_ptr(), x.numel(), out.data_ptr(), ws.data_ptr(), _stream()), 'sumsq')
+
+
+def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, *, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float,
+          step: int, grad_scale: Optional[Tensor] = None, skip_flag: Optional[Tensor] = None, shadow: Optional[Tensor] = None) -> None:
+    check(_lib.load().mmae_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
+                                 weight_decay, step, _p(grad_scale), _p(skip_flag), _p(shadow),
+                                 dcode(shadow.dtype) if shadow is not None else F32, _stream()), 'adamw')

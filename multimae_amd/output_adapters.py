@@ -1,0 +1,161 @@
+"""Output adapters (mirror of the reference's ``multimae/output_adapters.py`` for the
+pre-training path).
+
+Reference: SpatialOutputAdapter output_adapters.py:33-282.  Same constructor, same parameter
+names and registration order (mask_token, pos_emb, task_embeddings, decoder.{q,kv,proj},
+{context,query,out}_norm, mlp, decoder_transformer.*, out_proj, proj_context registered last
+in init()).  forward() is ONE autograd node (functions.SpatialAdapterFn) whose forward and
+backward are fixed HIP kernel sequences; the (B, N_total, D) mask-token tensor of the
+reference is never materialised.
+
+The fine-tuning heads of the reference (Linear / Segmenter / ConvNeXt / DPT adapters) are out
+of scope for the pre-training hot path.
+"""
+from __future__ import annotations
+
+from functools import partial
+from typing import Dict, Optional, Tuple, Union
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import engine
+from .functions import SpatialAdapterFn
+from .multimae_utils import (Block, CrossAttention, LayerNorm, Linear, Mlp, _as_hip_norm, _cfg, block_params,
+                             build_2d_sincos_posemb, pair, trunc_normal_)
+
+
+class SpatialOutputAdapter(nn.Module):
+    """Cross-attention decoder for spatial outputs (output_adapters.py:33-142)."""
+
+    def __init__(self, num_channels: int, stride_level: int, patch_size_full: Union[int, Tuple[int, int]],
+                 dim_tokens_enc: Optional[int] = None, dim_tokens: int = 256, depth: int = 0, learnable_pos_emb: int = False,
+                 image_size: Union[int, Tuple[int]] = 224, mlp_ratio: int = 4.0, num_heads: int = 8, qkv_bias: bool = True,
+                 drop_rate: float = 0.0, attn_drop_rate: float = 0.0, drop_path_rate: float = 0.0,
+                 norm_layer: nn.Module = partial(nn.LayerNorm, eps=1e-6), use_task_queries: bool = True,
+                 task: Optional[str] = None, context_tasks: Optional[list] = None, use_xattn: bool = True):
+        super().__init__()
+        self.num_channels = num_channels
+        self.stride_level = stride_level
+        self.patch_size_full = pair(patch_size_full)
+        self.dim_tokens_enc = dim_tokens_enc
+        self.dim_tokens = dim_tokens
+        self.learnable_pos_emb = learnable_pos_emb
+        self.image_size = pair(image_size)
+        self.use_task_queries = use_task_queries
+        self.task = task
+        self.use_xattn = use_xattn
+        self.num_heads = num_heads
+        self.depth = depth
+        if not use_xattn:
+            raise NotImplementedError('use_xattn=False is not built in the HIP engine (pre-training default is True)')
+        if learnable_pos_emb:
+            raise NotImplementedError('learnable decoder positional embeddings are not built in the HIP engine')
+        if drop_path_rate != 0.0 or drop_rate != 0.0 or attn_drop_rate != 0.0:
+            raise NotImplementedError('decoder dropout / drop-path > 0 is not built in the HIP engine')
+
+        self.P_H = max(1, self.patch_size_full[0] // stride_level)
+        self.P_W = max(1, self.patch_size_full[1] // stride_level)
+
+        if context_tasks is not None:
+            self.task_embeddings = nn.ParameterDict(
+                {t: nn.Parameter(torch.zeros(1, 1, self.dim_tokens)) for t in context_tasks})
+            for embedding in self.task_embeddings.values():
+                trunc_normal_(embedding, std=0.02)
+        else:
+            self.task_embeddings = None
+
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, self.dim_tokens))
+
+        h_posemb = self.image_size[0] // (self.stride_level * self.P_H)
+        w_posemb = self.image_size[1] // (self.stride_level * self.P_W)
+        self.pos_emb = nn.Parameter(build_2d_sincos_posemb(h=h_posemb, w=w_posemb, embed_dim=self.dim_tokens),
+                                    requires_grad=False)
+
+        self.decoder = CrossAttention(dim=self.dim_tokens, num_heads=num_heads, qkv_bias=qkv_bias,
+                                      attn_drop=attn_drop_rate, proj_drop=drop_rate)
+        self.context_norm = _as_hip_norm(norm_layer, self.dim_tokens)
+        self.query_norm = _as_hip_norm(norm_layer, self.dim_tokens)
+        self.out_norm = _as_hip_norm(norm_layer, self.dim_tokens)
+        mlp_hidden_dim = int(self.dim_tokens * mlp_ratio)
+        self.mlp = Mlp(in_features=self.dim_tokens, hidden_features=mlp_hidden_dim)
+
+        if depth > 0:
+            dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+            self.decoder_transformer = nn.Sequential(*[
+                Block(dim=self.dim_tokens, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, drop=drop_rate,
+                      attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer) for i in range(depth)])
+        else:
+            self.decoder_transformer = nn.Identity()
+
+        self.dim_patch = self.num_channels * self.P_H * self.P_W
+        self.out_proj = Linear(self.dim_tokens, self.dim_patch)
+
+        if self.dim_tokens_enc is not None:
+            self.init(dim_tokens_enc=dim_tokens_enc)
+
+    def init(self, dim_tokens_enc: int = 768):
+        self.dim_tokens_enc = dim_tokens_enc
+        self.proj_context = Linear(self.dim_tokens_enc, self.dim_tokens)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_emb', 'mask_token', 'task_embeddings'}
+
+    def _pos_tokens(self, nh: int, nw: int) -> torch.Tensor:
+        """bilinear-resized decoder pos-emb as (nh*nw, D) (output_adapters.py:172-173), cached."""
+        p = self.pos_emb
+        key = (nh, nw, p._version, p.device, p.data_ptr())
+        cache = self.__dict__.setdefault('_pos_cache', {})
+        t = cache.get(key)
+        if t is None:
+            cache.clear()
+            with torch.no_grad():
+                r = F.interpolate(p.detach(), size=(nh, nw), mode='bilinear', align_corners=False)
+                t = r[0].flatten(1).t().contiguous().float()
+            cache[key] = t
+        return t
+
+    def _params(self, in_tasks):
+        te = []
+        for t in in_tasks:
+            if self.task_embeddings is not None and t in self.task_embeddings:
+                te.append(self.task_embeddings[t])
+            else:
+                te.append(None)
+        d = self.decoder
+        ps = [self.mask_token, *te, d.q.weight, d.q.bias, d.kv.weight, d.kv.bias, d.proj.weight, d.proj.bias,
+              self.context_norm.weight, self.context_norm.bias, self.query_norm.weight, self.query_norm.bias,
+              self.out_norm.weight, self.out_norm.bias, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight,
+              self.mlp.fc2.bias]
+        if self.depth > 0:
+            for blk in self.decoder_transformer:
+                ps += block_params(blk)
+        ps += [self.out_proj.weight, self.out_proj.bias, self.proj_context.weight, self.proj_context.bias]
+        return ps
+
+    def forward(self, encoder_tokens: torch.Tensor, input_info: Dict, ids_keep: torch.Tensor, ids_restore: torch.Tensor,
+                act_dtype: Optional[torch.dtype] = None, on_done=None):
+        """(B, n_keep+G, D_enc) encoder tokens -> (B, C, H_t, W_t) prediction (output_adapters.py:236-282)."""
+        assert self.dim_tokens_enc is not None, 'Need to call init(dim_tokens_enc) function first'
+        if self.task_embeddings is None:
+            raise AttributeError('SpatialOutputAdapter built with context_tasks=None has no task_embeddings '
+                                 '(the reference raises here too, output_adapters.py:166)')
+        H, W = input_info['image_size']
+        nh = H // (self.stride_level * self.P_H)
+        nw = W // (self.stride_level * self.P_W)
+        in_tasks = list(input_info['tasks'].keys())
+        if not (self.use_task_queries and self.task in input_info['tasks']):
+            raise NotImplementedError('decoding a task that is not among the encoder inputs (pure mask-token queries) is not built; '
+                                      'pre-training always decodes input tasks')
+        offs = [0]
+        for t in in_tasks:
+            n = input_info['tasks'][t]['num_tokens']
+            assert n == nh * nw, 'all tasks must share the decoder token grid (output_adapters.py:175)'
+            offs.append(offs[-1] + n)
+        G = input_info.get('num_global_tokens', 0)
+        cfg = _cfg(self, act=act_dtype, heads=self.num_heads, eps=self.query_norm.eps, task_offsets=offs,
+                   q_task=in_tasks.index(self.task), G=G, D=self.dim_tokens, pos=self._pos_tokens(nh, nw), depth=self.depth,
+                   C=self.num_channels, nh=nh, nw=nw, ph=self.P_H, pw=self.P_W, on_done=on_done)
+        return SpatialAdapterFn.apply(cfg, encoder_tokens, ids_keep.contiguous(), ids_restore.contiguous(), *self._params(in_tasks))

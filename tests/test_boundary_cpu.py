@@ -1,0 +1,89 @@
+"""CPU: host-side logic of the boundary -- state_dict contract, seeded-init parity with the
+reference, registry, C-ABI export check, no-fallback behaviour."""
+import ctypes
+import os
+
+import pytest
+import torch
+
+from helpers import MINI, build_engine_model, build_mini_engine, load_mini, load_scalars
+
+
+def test_cabi_exports_every_declared_symbol():
+    from multimae_amd import _lib
+    names = _lib.declared_symbols()
+    assert len(names) >= 30
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f'libmmae_hip.so does not export {n}'
+    assert _lib.load().mmae_abi_version() == 1
+
+
+def test_state_dict_contract_and_seeded_init_base():
+    """Appendix A: 351 keys; same RNG call order as the reference => identical initial weights."""
+    gold = load_scalars()['base_rgb_depth_semseg']
+    torch.manual_seed(0)
+    m = build_engine_model(['rgb', 'depth', 'semseg'], 16, 224)
+    sd = m.state_dict()
+    assert len(sd) == gold['num_keys'] == 351
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == gold['num_trainable']
+    assert abs(float(sum(v.double().sum() for v in sd.values())) - gold['state_dict_sum']) < 1e-6
+    assert sd['encoder.0.attn.qkv.weight'].shape == (2304, 768)
+    assert sd['input_adapters.semseg.proj.weight'].shape == (768, 64, 4, 4)
+    assert sd['output_adapters.semseg.out_proj.weight'].shape == (2128, 256)
+    assert sd['output_adapters.rgb.task_embeddings.depth'].shape == (1, 1, 256)
+    assert not m.input_adapters['rgb'].pos_emb.requires_grad
+    keys = list(sd)
+    assert keys[0] == 'global_tokens' and keys[-1] == 'encoder.11.mlp.fc2.bias'
+
+
+def test_seeded_init_tiny_matches_reference_sum():
+    gold = load_scalars()['tiny_rgb']
+    torch.manual_seed(0)
+    m = build_engine_model(['rgb'], 8, 64, enc=(192, 12, 3), posemb_size=224)
+    sd = m.state_dict()
+    assert len(sd) == gold['num_keys']
+    assert abs(float(sum(v.double().sum() for v in sd.values())) - gold['state_dict_sum']) < 1e-6
+
+
+def test_mini_state_dict_loads_golden_weights():
+    g = load_mini()
+    m = build_mini_engine()
+    missing, unexpected = m.load_state_dict(g['sd'], strict=True)
+    assert not missing and not unexpected
+    # same key ORDER as the reference's state_dict (the fixture preserves it)
+    assert list(m.state_dict()) == list(g['sd'])
+
+
+def test_registry_and_factories():
+    import multimae_amd as M
+    from multimae_amd import registry
+    for n in ('pretrain_multimae_base', 'pretrain_multimae_large', 'multivit_base', 'multivit_large'):
+        assert registry.is_model(n)
+    m = M.multivit_base(input_adapters={'rgb': M.PatchedInputAdapter(3, 1, 16)}, output_adapters=None)
+    assert isinstance(m, M.MultiViT) and m.get_num_layers() == 12
+    assert 'global_tokens' in m.state_dict()
+    with pytest.raises(RuntimeError):
+        M.create_model('no_such_model')
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly off-GPU instead of silently computing with torch."""
+    m = build_mini_engine()
+    x = {'rgb': torch.randn(2, 3, 32, 32), 'depth': torch.randn(2, 1, 32, 32), 'semseg': torch.randint(0, 133, (2, 8, 8))}
+    with pytest.raises(RuntimeError, match='no CPU'):
+        m(x, num_encoded_tokens=12)
+    import multimae_amd as M
+    with pytest.raises(RuntimeError, match='no CPU'):
+        M.MaskedMSELoss(8)(torch.randn(2, 3, 32, 32), torch.randn(2, 3, 32, 32), torch.ones(2, 16, dtype=torch.long))
+
+
+def test_input_info_and_sincos_match_oracle():
+    import multimae_oracle as orc
+    from multimae_amd.multimae_utils import build_2d_sincos_posemb
+    for h, w, d in [(14, 14, 768), (4, 4, 128), (28, 28, 192), (3, 5, 16)]:
+        assert torch.equal(build_2d_sincos_posemb(h, w, d), orc.sincos_posemb_2d(h, w, d))
+    m = build_mini_engine()
+    info = m.generate_input_info({'rgb': 16, 'depth': 16, 'semseg': 16}, (32, 32))
+    assert info['tasks']['depth'] == {'num_tokens': 16, 'has_2d_posemb': True, 'start_idx': 16, 'end_idx': 32}
+    assert info['num_task_tokens'] == 48 and info['num_global_tokens'] == 1

@@ -1,0 +1,93 @@
+"""CPU: full host-side control flow of the engine (all Functions, both precisions, both gradient
+routing modes, optimiser, reducer hooks) against a type-checking stub of the C ABI."""
+import pytest
+import torch
+
+from helpers import MINI, build_mini_engine, load_mini
+
+
+@pytest.fixture()
+def stubbed(monkeypatch):
+    from multimae_amd import _lib, ops
+    import dryrun_harness
+    old = (_lib._lib, ops._require_gpu, ops._stream)
+    dryrun_harness.install()
+    yield
+    _lib._lib, ops._require_gpu, ops._stream = old
+
+
+def _step(model, mode, direct, x, fp32_adapters=()):
+    import multimae_amd as M
+    P = MINI['P']
+    fns = {'rgb': M.MaskedMSELoss(P, 1), 'depth': M.MaskedL1Loss(P, 1), 'semseg': M.MaskedCrossEntropyLoss(P, 4),
+           'norm_rgb': M.MaskedMSELoss(P, 1, norm_pix=True)}
+    M.engine.set_direct_grads(direct)
+    try:
+        with M.engine.precision(mode):
+            preds, masks = model(x, num_encoded_tokens=MINI['nvis'], alphas=1.0, fp32_output_adapters=list(fp32_adapters))
+            tgt = dict(x, norm_rgb=x['rgb'])
+            mk = dict(masks, norm_rgb=masks['rgb'])
+            losses = {k: fns[k](preds[k].float(), tgt[k], mask=mk[k]) for k in preds}
+            sum(losses.values()).backward()
+    finally:
+        M.engine.set_direct_grads(False)
+    return preds, masks
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('direct', [False, True])
+def test_full_step_control_flow(stubbed, mode, direct):
+    import multimae_amd as M
+    g = load_mini()
+    model = build_mini_engine()
+    model.load_state_dict(g['sd'])
+    if direct:
+        arena = model.build_arena()
+        assert arena.intact()
+    ready = []
+    model._grad_ready_cb = ready.append
+    preds, masks = _step(model, mode, direct, g['x'], fp32_adapters=('semseg',))
+    assert preds['rgb'].shape == (3, 3, 32, 32) and preds['semseg'].shape == (3, 133, 8, 8)
+    assert masks['depth'].shape == (3, 16) and masks['depth'].dtype == torch.int64
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and p.grad.shape == p.shape, n
+        else:
+            assert p.grad is None, n
+    assert ready[:2] == ['output_adapters.norm_rgb', 'output_adapters.semseg'] or set(ready) >= {'encoder.0', 'encoder.1'}
+    assert ready[-1] == 'encoder.0'
+
+
+def test_optimizer_and_arena_flow(stubbed):
+    import multimae_amd as M
+    from multimae_amd.optim import FusedAdamW
+    g = load_mini()
+    model = build_mini_engine()
+    model.load_state_dict(g['sd'])
+    arena = model.build_arena()
+    sd_after = model.state_dict()
+    for k, v in g['sd'].items():
+        assert torch.equal(sd_after[k], v), k           # the arena move preserves every value and key
+    assert arena.n_trainable <= arena.numel and arena.grad.numel() == arena.n_trainable
+    opt = FusedAdamW(model, lr=1e-3, clip_grad=1.0)
+    opt.zero_grad()
+    _step(model, 'bf16', True, g['x'])
+    gn = opt.step()
+    assert gn.shape == (1,) and opt.step_count == 1
+    assert model.encoder[0].attn.qkv.weight.grad.data_ptr() == arena.grad.data_ptr() + 4 * arena.offsets['encoder.0.attn.qkv.weight']
+
+
+def test_standalone_modules_flow(stubbed):
+    import multimae_amd as M
+    from multimae_amd.multimae_utils import Attention, Block, CrossAttention, LayerNorm, Linear, Mlp
+    x = torch.randn(2, 5, 64, requires_grad=True)
+    for mod in (Linear(64, 32), LayerNorm(64), Mlp(64, 128), Attention(64, 2, qkv_bias=True), Block(64, 2, qkv_bias=True)):
+        y = mod(x)
+        y.sum().backward()
+        assert all(p.grad is not None for p in mod.parameters())
+    ca = CrossAttention(64, 2, qkv_bias=True)
+    ca(x, torch.randn(2, 7, 64)).sum().backward()
+    vit = M.multivit_base({'rgb': M.PatchedInputAdapter(3, 1, 16)}, None)
+    with torch.no_grad():
+        outs = vit(torch.randn(1, 3, 32, 32), return_all_layers=True)
+    assert len(outs) == 12 and outs[0].shape == (1, 5, 768)

@@ -1,0 +1,358 @@
+"""GPU parity tests, kernel level: every HIP kernel (called through the C ABI) against the CPU
+oracle / plain fp32 math on the same seeded inputs.  Integer outputs must be bit-exact; fp
+tolerances are stated per test."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import multimae_oracle as orc
+from helpers import load_masks_base, load_mini, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+# ----------------------------------------------------------------------------------------------
+def test_probe_tr16_semantics():
+    """Pins the ds_read_b64_tr_b16 lane mapping the k-strided GEMM operands rely on: within a
+    16-lane group, lane i supplies the address of 4 contiguous bf16 (row i>>2, cols (i&3)*4..+3 of a
+    [4][16] block) and receives column i (rows 0..3)."""
+    from multimae_amd import _lib, ops
+    img = torch.arange(1024, dtype=torch.int32).to(torch.int16)
+    # 4 groups: group g reads block rows 4g..4g+3 of a [16][64]-element row-major image (row stride 128 B)
+    addr = torch.zeros(64, dtype=torch.int32)
+    for l in range(64):
+        g, i = l >> 4, l & 15
+        row, col = 4 * g + (i >> 2), (i & 3) * 4
+        addr[l] = (row * 64 + col) * 2
+    out = torch.zeros(256, dtype=torch.int16, device=DEV)
+    _lib.check(_lib.load().mmae_probe_tr16(img.to(DEV).data_ptr(), addr.to(DEV).data_ptr(), out.data_ptr(), ops._stream()), 'probe')
+    out = out.cpu().view(64, 4).int()
+    exp = torch.zeros(64, 4, dtype=torch.int32)
+    for l in range(64):
+        g, i = l >> 4, l & 15
+        for j in range(4):
+            exp[l, j] = (4 * g + j) * 64 + i
+    assert torch.equal(out, exp), f'tr16 mapping differs:\n{out[:20]}\nexpected\n{exp[:20]}'
+
+
+# ----------------------------------------------------------------------------------------------
+def _gemm_case(dtype, M, N, K, a_trans, b_trans, *, tile=0, seed=0):
+    from multimae_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g)
+    if dtype == torch.bfloat16:
+        A, B = bf(A).float(), bf(B).float()
+    ref = A.double() @ B.double().t()
+    pad = lambda n: (n + 7) // 8 * 8
+    if a_trans:
+        As = torch.zeros(K, pad(M)); As[:, :M] = A.t(); lda = pad(M)
+    else:
+        As = torch.zeros(M, pad(K)); As[:, :K] = A; lda = pad(K)
+    if b_trans:
+        Bs = torch.zeros(K, pad(N)); Bs[:, :N] = B.t(); ldb = pad(N)
+    else:
+        Bs = torch.zeros(N, pad(K)); Bs[:, :K] = B; ldb = pad(K)
+    C = torch.full((M, pad(N)), float('nan'), device=DEV)
+    ops.gemm(As.to(DEV, dtype), Bs.to(DEV, dtype), C, M, N, K, lda=lda, ldb=ldb, ldc=pad(N), a_trans=a_trans, b_trans=b_trans, tile=tile)
+    torch.cuda.synchronize()
+    out = C[:, :N].cpu().double()
+    assert torch.isfinite(out).all()
+    return float((out - ref).norm() / ref.norm())
+
+
+@pytest.mark.parametrize('a_trans,b_trans', [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize('shape', [(256, 256, 128), (128, 384, 64), (300, 200, 136), (99, 99, 64), (196, 99, 32), (520, 72, 1000)])
+def test_gemm_bf16_layouts(shape, a_trans, b_trans):
+    """bf16 products are exact in fp32, so vs fp64 on the same bf16 inputs only fp32 summation
+    error remains: rel-L2 <= 2e-6."""
+    M, N, K = shape
+    for tile in (1, 2):
+        assert _gemm_case(torch.bfloat16, M, N, K, a_trans, b_trans, tile=tile) < 2e-6, (shape, tile)
+
+
+@pytest.mark.parametrize('a_trans,b_trans', [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize('shape', [(256, 256, 128), (300, 200, 136), (99, 99, 64), (70, 530, 33)])
+def test_gemm_f32_layouts(shape, a_trans, b_trans):
+    """exact-f32 MFMA == fmaf chain: rel-L2 <= 2e-6 vs fp64."""
+    M, N, K = shape
+    assert _gemm_case(torch.float32, M, N, K, a_trans, b_trans) < 2e-6
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_gemm_epilogues(dtype):
+    from multimae_amd import ops
+    from multimae_amd._lib import EPI_DGELU, EPI_GELU
+    torch.manual_seed(1)
+    M, N, K = 200, 264, 128
+    x, w = torch.randn(M, K) * 0.5, torch.randn(N, K) * 0.2
+    if dtype == torch.bfloat16:
+        x, w = bf(x).float(), bf(w).float()
+    bias, resid = torch.randn(N), torch.randn(M, N)
+    xd, wd = x.to(DEV, dtype), w.to(DEV, dtype)
+    lin = x @ w.t() + bias
+    tol = 1e-5 if dtype == torch.float32 else 1e-5
+    # bias + residual, f32 out
+    out = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(xd, wd, bias.to(DEV), out, resid=resid.to(DEV))
+    assert rel_err(out, lin + resid) < tol
+    # GELU epilogue: aux = pre-activation, C = gelu
+    aux = torch.empty(M, N, device=DEV, dtype=dtype)
+    act = torch.empty(M, N, device=DEV, dtype=dtype)
+    ops.linear_fwd(xd, wd, bias.to(DEV), act, aux=aux, epi=EPI_GELU)
+    t2 = 1e-5 if dtype == torch.float32 else 4e-3       # bf16 output rounding 2^-9
+    assert rel_err(aux.float(), lin) < t2
+    assert rel_err(act.float(), orc.gelu_erf(lin)) < t2
+    # dGELU epilogue of the dX product: out = (dy @ W) * gelu'(pre)
+    dy = torch.randn(M, N) * 0.3
+    if dtype == torch.bfloat16:
+        dy = bf(dy).float()
+    pre = torch.randn(M, K)
+    if dtype == torch.bfloat16:
+        pre = bf(pre).float()
+    pre_d = pre.to(DEV, dtype)
+    dxo = torch.empty(M, K, device=DEV, dtype=dtype)
+    ops.linear_dx(dy.to(DEV, dtype), wd, dxo, aux=pre_d, epi=EPI_DGELU)
+    p = pre.clone().requires_grad_(True)
+    orc.gelu_erf(p).backward(dy @ w)
+    assert rel_err(dxo.float(), p.grad) < t2
+    # dW with accumulate
+    dw = torch.ones(N, K, device=DEV)
+    ops.linear_dw(dy.to(DEV, dtype), xd, dw, accumulate=True)
+    assert rel_err(dw, 1.0 + dy.t() @ x) < 1e-5
+    # bf16 C, alpha
+    c16 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(xd, wd, c16, M, N, K, lda=K, ldb=K, ldc=N, alpha=0.5)
+    assert rel_err(c16.float(), 0.5 * (x @ w.t())) < 4e-3
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('geom', [(3, 2, 17, 17, 64), (2, 12, 99, 99, 64), (2, 8, 196, 99, 32), (2, 8, 196, 196, 32), (1, 3, 50, 50, 64)])
+def test_attention_unfused_fwd_bwd(dtype, geom):
+    """batched-GEMM + row-softmax attention (self and cross) vs the oracle formula, fwd and bwd."""
+    from multimae_amd import ops
+    from multimae_amd.ops import AttnView
+    B, H, Nq, Nk, hd = geom
+    D = H * hd
+    torch.manual_seed(2)
+    q, k, v, do = (torch.randn(B, n, D) for n in (Nq, Nk, Nk, Nq))
+    if dtype == torch.bfloat16:
+        q, k, v, do = (bf(t).float() for t in (q, k, v, do))
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    sp = lambda t, n: t.reshape(B, n, H, hd).permute(0, 2, 1, 3)
+    a = ((sp(qr, Nq) @ sp(kr, Nk).transpose(-2, -1)) * hd ** -0.5).softmax(-1)
+    o_ref = (a @ sp(vr, Nk)).transpose(1, 2).reshape(B, Nq, D)
+    o_ref.backward(do)
+    # packed like the engine: q in its own buffer, k|v packed with ld 2D
+    qd = q.reshape(B * Nq, D).to(DEV, dtype)
+    kvd = torch.cat([k, v], -1).reshape(B * Nk, 2 * D).to(DEV, dtype)
+    od = torch.empty(B * Nq, D, device=DEV, dtype=dtype)
+    P = ops.attention_fwd(AttnView(qd, 0, D, Nq), AttnView(kvd, 0, 2 * D, Nk), AttnView(kvd, D, 2 * D, Nk), AttnView(od, 0, D, Nq), B, H, hd,
+                          hd ** -0.5)
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(od.float().view(B, Nq, D), o_ref) < tol
+    dq = torch.empty(B * Nq, D, device=DEV, dtype=dtype)
+    dkv = torch.empty(B * Nk, 2 * D, device=DEV, dtype=dtype)
+    dod = do.reshape(B * Nq, D).to(DEV, dtype)
+    ops.attention_bwd(AttnView(qd, 0, D, Nq), AttnView(kvd, 0, 2 * D, Nk), AttnView(kvd, D, 2 * D, Nk), P, AttnView(dod, 0, D, Nq),
+                      AttnView(dq, 0, D, Nq), AttnView(dkv, 0, 2 * D, Nk), AttnView(dkv, D, 2 * D, Nk), B, H, hd, hd ** -0.5)
+    tol = 5e-5 if dtype == torch.float32 else 2e-2
+    assert rel_err(dq.float().view(B, Nq, D), qr.grad) < tol
+    assert rel_err(dkv.float().view(B, Nk, 2 * D)[..., :D], kr.grad) < tol
+    assert rel_err(dkv.float().view(B, Nk, 2 * D)[..., D:], vr.grad) < tol
+
+
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('D', [64, 128, 192, 256, 768, 1024])
+def test_layernorm_fwd_bwd(D):
+    from multimae_amd import ops
+    torch.manual_seed(3)
+    R = 333
+    x = torch.randn(R, D) * 2 + 0.5
+    w, b = torch.randn(D), torch.randn(D)
+    dy, dxin = torch.randn(R, D), torch.randn(R, D)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = orc.layer_norm(xr, wr, br, 1e-6)
+    y_ref.backward(dy)
+    y, mean, rstd = ops.layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, torch.float32)
+    assert rel_err(y, y_ref) < 2e-6
+    y16, _, _ = ops.layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, torch.bfloat16)
+    assert rel_err(y16.float(), y_ref) < 4e-3
+    dx, dxa, dg, db = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd, dxin.to(DEV), torch.bfloat16)
+    assert rel_err(dx, xr.grad + dxin) < 5e-6
+    assert rel_err(dxa.float(), xr.grad + dxin) < 4e-3
+    assert rel_err(dg, wr.grad) < 1e-5 and rel_err(db, br.grad) < 1e-5
+    dx2, none, _, _ = ops.layernorm_bwd(bf(dy).to(DEV), x.to(DEV), w.to(DEV), mean, rstd, None, None)
+    assert none is None and rel_err(dx2, xr.grad) < 6e-3
+
+
+def test_softmax_colsum_cast_transpose():
+    from multimae_amd import _lib, ops
+    torch.manual_seed(4)
+    rows, n, ld = 500, 99, 104
+    S = torch.randn(rows, ld) * 3
+    P = torch.full((rows, ld), 7.0, device=DEV)
+    ops.softmax_fwd(S.to(DEV), P, rows, n, 0.125)
+    ref = (S[:, :n] * 0.125).softmax(-1)
+    assert rel_err(P[:, :n], ref) < 2e-6 and float(P[:, n:].abs().max()) == 0.0
+    dP = torch.randn(rows, ld)
+    dS = torch.full((rows, ld), 7.0, device=DEV)
+    ops.softmax_bwd(P, dP.to(DEV), dS, rows, n, 0.125)
+    sr = S[:, :n].clone().requires_grad_(True)
+    (sr * 0.125).softmax(-1).backward(dP[:, :n])
+    assert rel_err(dS[:, :n], sr.grad) < 5e-6 and float(dS[:, n:].abs().max()) == 0.0
+    # column sums
+    for dt in (torch.float32, torch.bfloat16):
+        dy = torch.randn(3001, 264)
+        dyd = dy.to(DEV, dt)
+        out = torch.ones(264, device=DEV)
+        ops.colsum(dyd, out, True)
+        assert rel_err(out, 1.0 + dyd.float().cpu().sum(0)) < 1e-5
+    # casts
+    x = torch.randn(100003)
+    assert torch.equal(ops.cast(x.to(DEV), torch.bfloat16).cpu(), x.to(torch.bfloat16))
+    assert torch.equal(ops.cast(bf(x).to(DEV), torch.float32).cpu(), bf(x).float())
+    w = torch.randn(130, 70)
+    wt = torch.empty(70, 130, device=DEV, dtype=torch.bfloat16)
+    _lib.check(_lib.load().mmae_transpose_cast(w.to(DEV).data_ptr(), wt.data_ptr(), 1, 130, 70, ops._stream()), 'transpose')
+    assert torch.equal(wt.cpu(), bf(w.t().contiguous()))
+    y = torch.randn(1001).to(DEV); z = torch.randn(1001).to(DEV); y0 = y.clone()
+    ops.axpy_(y, z, 0.5)
+    assert torch.allclose(y, y0 + 0.5 * z)
+
+
+# ----------------------------------------------------------------------------------------------
+def test_mask_sampler_bit_exact_vs_reference_golden():
+    """integer path: bit-exact against the reference's own sampler output (3x196 tokens, 98 kept)."""
+    from multimae_amd import ops
+    g = load_masks_base()
+    noise = torch.cat([g['noise_rgb'], g['noise_depth'], g['noise_semseg']], 1)
+    m, k, r = ops.mask_sample(g['samples_per_task'], noise.to(DEV), g['noise_all'].to(DEV), [0, 196, 392, 588], 98)
+    assert torch.equal(m.cpu(), g['mask_all'])
+    assert torch.equal(k.cpu(), g['ids_keep'])
+    assert torch.equal(r.cpu(), g['ids_restore'])
+    gm = load_mini()
+    noise = torch.cat([gm['noise'][d] for d in ('rgb', 'depth', 'semseg')], 1)
+    spt = orc.samples_per_task_from_dirichlet(gm['dirichlet'], 12)
+    m, k, r = ops.mask_sample(spt, noise.to(DEV), gm['noise_all'].to(DEV), [0, 16, 32, 48], 12)
+    assert torch.equal(k.cpu(), gm['ids_keep']) and torch.equal(r.cpu(), gm['ids_restore'])
+
+
+def test_mask_sampler_properties_full_batch():
+    """size-independent properties at the bench batch (B=256): permutation, exact count, keep==visible,
+    and equality with the oracle on fresh noise (incl. zero-token tasks and ties)."""
+    from multimae_amd import ops
+    torch.manual_seed(5)
+    B = 256
+    dist, tn, an = orc.draw_mask_randoms(B, [196] * 3, 1.0)
+    spt = orc.samples_per_task_from_dirichlet(dist, 98)
+    spt[0] = torch.tensor([98, 0, 0]); spt[1] = torch.tensor([0, 0, 98]); spt[2] = torch.tensor([40, 40, 40])   # edge rows
+    an[3, 10] = an[3, 11]                                                                                       # forced tie
+    mo, ko, ro = orc.masks_from_noise(spt, tn, an, 98)
+    m, k, r = ops.mask_sample(spt, torch.cat(tn, 1).to(DEV), an.to(DEV), [0, 196, 392, 588], 98)
+    assert torch.equal(m.cpu(), mo) and torch.equal(k.cpu(), ko) and torch.equal(r.cpu(), ro)
+    assert torch.equal(torch.sort(r.cpu(), 1)[0], torch.arange(588).expand(B, -1))
+    assert (m == 0).sum(1).eq(98).all() and torch.gather(m, 1, k).sum() == 0
+
+
+def test_patch_embed_assemble_vs_oracle():
+    """gather-first embedding (patch rows -> K-sliced GEMMs -> assemble) == oracle's embed-all + gather."""
+    from multimae_amd import engine
+    from helpers import MINI, build_mini_engine, mini_oracle_cfg
+    g = load_mini()
+    cfg = mini_oracle_cfg()
+    model = build_mini_engine()
+    model.load_state_dict(g['sd'])
+    model.to(DEV)
+    from multimae_amd.input_adapters import embed_tokens
+    x = {k: v.to(DEV) for k, v in g['x'].items()}
+    with engine.precision('fp32'):
+        tok = embed_tokens(model, model.input_adapters, x, g['ids_keep'].to(DEV), model.global_tokens)
+        assert rel_err(tok, g['enc_in']) < 2e-6
+        # stand-alone adapters produce ALL tokens (reference adapter API)
+        toks = orc.all_input_tokens(g['x'], g['sd'], cfg)
+        for d in MINI['doms']:
+            assert rel_err(model.input_adapters[d](x[d]), toks[d]) < 2e-6, d
+    with engine.precision('bf16'):
+        tok = embed_tokens(model, model.input_adapters, x, g['ids_keep'].to(DEV), model.global_tokens)
+        assert rel_err(tok, g['enc_in']) < 1e-2
+
+
+def test_patchify_roundtrip_and_layout():
+    from multimae_amd import ops
+    torch.manual_seed(6)
+    B, C, nh, nw, ph, pw = 3, 5, 4, 6, 2, 4
+    pat = torch.randn(B * nh * nw, C * ph * pw)
+    img = ops.unpatchify(pat.to(DEV), B, C, nh, nw, ph, pw)
+    ref = pat.reshape(B, nh, nw, C, ph, pw).permute(0, 3, 1, 4, 2, 5).reshape(B, C, nh * ph, nw * pw)
+    assert torch.equal(img.cpu(), ref)
+    back = ops.patchify(img, C, nh, nw, ph, pw, torch.float32)
+    assert torch.equal(back.cpu(), pat)
+
+
+@pytest.mark.parametrize('kind,norm_pix', [(0, False), (0, True), (1, False)])
+def test_masked_pixel_losses(kind, norm_pix):
+    import multimae_amd as M
+    torch.manual_seed(7)
+    B, C, S, P = 5, 3, 32, 8
+    pred, tgt = torch.randn(B, C, S, S), torch.randn(B, C, S, S)
+    mask = (torch.rand(B, 16) < 0.7).long()
+    mask[1] = 0                                           # a sample with no masked token drops out (nanmean)
+    pr = pred.clone().requires_grad_(True)
+    ref = (orc.masked_mse if kind == 0 else orc.masked_l1)(pr, tgt, mask, P, 1, norm_pix=norm_pix)
+    (ref * 1.7).backward()
+    fn = (M.MaskedMSELoss if kind == 0 else M.MaskedL1Loss)(P, 1, norm_pix=norm_pix)
+    pd = pred.to(DEV).requires_grad_(True)
+    out = fn(pd, tgt.to(DEV), mask=mask.to(DEV))
+    (out * 1.7).backward()
+    assert abs(float(out) - float(ref)) < 2e-6 * max(1.0, abs(float(ref)))
+    assert rel_err(pd.grad, pr.grad) < 1e-5
+    # mask=None == plain mean; all-zero mask == 0 with zero grad
+    assert abs(float(fn(pred.to(DEV), tgt.to(DEV))) - float((orc.masked_mse if kind == 0 else orc.masked_l1)(pred, tgt, None, P, 1, norm_pix=norm_pix))) < 5e-6
+    z = fn(pred.to(DEV).requires_grad_(True), tgt.to(DEV), mask=torch.zeros(B, 16, dtype=torch.long, device=DEV))
+    assert float(z) == 0.0
+
+
+def test_masked_cross_entropy():
+    import multimae_amd as M
+    torch.manual_seed(8)
+    B, C, S, P = 4, 133, 8, 2            # semseg map 8x8, patch 2 (stride 4 of an 8-px patch)
+    logits, tgt = torch.randn(B, C, S, S) * 2, torch.randint(0, C, (B, S, S))
+    mask = (torch.rand(B, 16) < 0.6).long()
+    mask[2] = 0
+    lr = logits.clone().requires_grad_(True)
+    ref = orc.masked_ce(lr, tgt, mask, 8, 4)
+    ref.backward()
+    ld = logits.to(DEV).requires_grad_(True)
+    out = M.MaskedCrossEntropyLoss(8, 4)(ld, tgt.to(DEV), mask=mask.to(DEV))
+    out.backward()
+    assert abs(float(out) - float(ref)) < 5e-6
+    assert rel_err(ld.grad, lr.grad) < 1e-5
+
+
+def test_adamw_and_sumsq():
+    from multimae_amd import ops
+    torch.manual_seed(9)
+    n = 100003
+    p, g = torch.randn(n), torch.randn(n)
+    m, v = torch.zeros(n), torch.zeros(n)
+    pd, md, vd = p.to(DEV), m.to(DEV), v.to(DEV)
+    shadow = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    P, Mo, V = {'p': p.clone()}, {'p': m.clone()}, {'p': v.clone()}
+    for step in (1, 2, 3):
+        g = torch.randn(n)
+        ops.adamw(pd, g.to(DEV), md, vd, lr=1e-3, beta1=0.9, beta2=0.95, eps=1e-8, weight_decay=0.05, step=step, shadow=shadow)
+        orc.adamw_step(P, {'p': g}, Mo, V, step, 1e-3, 0.05)
+    assert rel_err(pd, P['p']) < 1e-6 and rel_err(vd, V['p']) < 1e-6
+    assert torch.equal(shadow.cpu(), pd.cpu().to(torch.bfloat16))
+    out, ws = torch.zeros(1, device=DEV), torch.empty(1024, device=DEV)
+    ops.sumsq(g.to(DEV), out, ws)
+    assert abs(float(out) - float((g.double() ** 2).sum())) / float((g.double() ** 2).sum()) < 1e-6

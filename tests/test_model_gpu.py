@@ -1,0 +1,242 @@
+"""GPU parity tests, model level: the HIP engine behind the reference's module API against the
+reference-generated golden fixtures and the CPU oracle.
+
+Tolerances (anchored to SURVEY.md Appendix E, the reference's own numerical noise floor):
+  fp32 parity mode : preds rel-L2 <= 2e-5, losses |d| <= 1e-4, grads rel-L2 <= 2e-4
+  bf16 speed mode  : preds rel-L2 <= 1.5e-2, losses |d| <= 1e-2 abs / 5e-3 rel, grads rel-L2 <= 5e-2
+  integer outputs (masks / ids) bit-exact in both modes.
+"""
+import pytest
+import torch
+
+import multimae_oracle as orc
+from helpers import (MINI, build_engine_model, build_mini_engine, load_mini, load_scalars, make_inputs, mini_oracle_cfg,
+                     rel_err)
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _loss_fns(P):
+    import multimae_amd as M
+    return {'rgb': M.MaskedMSELoss(P, 1), 'depth': M.MaskedL1Loss(P, 1), 'semseg': M.MaskedCrossEntropyLoss(P, 4),
+            'norm_rgb': M.MaskedMSELoss(P, 1, norm_pix=True)}
+
+
+def _run_mini(mode, direct=False, arena=False):
+    import multimae_amd as M
+    g = load_mini()
+    model = build_mini_engine()
+    model.load_state_dict(g['sd'])
+    model.to(DEV)
+    if arena:
+        model.build_arena()
+    x = {k: v.to(DEV) for k, v in g['x'].items()}
+    tm = {d: g['mask'][d].to(DEV) for d in MINI['doms']}
+    ids = (g['ids_keep'].to(DEV), g['ids_restore'].to(DEV))
+    model.generate_random_masks = lambda *a, **k: (tm, ids[0], ids[1])
+    M.engine.set_direct_grads(direct)
+    try:
+        with M.engine.precision(mode):
+            preds, masks = model(x, num_encoded_tokens=MINI['nvis'], alphas=1.0)
+            fns = _loss_fns(MINI['P'])
+            tgt = dict(x, norm_rgb=x['rgb'])
+            mk = dict(masks, norm_rgb=masks['rgb'])
+            losses = {k: fns[k](preds[k].float(), tgt[k], mask=mk[k]) for k in preds}
+            if direct:
+                model._mmae_arena.zero_grad()
+            sum(losses.values()).backward()
+    finally:
+        M.engine.set_direct_grads(False)
+    torch.cuda.synchronize()
+    return g, model, preds, losses
+
+
+@pytest.mark.parametrize('mode,arena,direct', [('fp32', False, False), ('fp32', True, True), ('bf16', False, False), ('bf16', True, True)])
+def test_mini_model_fwd_bwd_vs_reference_golden(mode, arena, direct):
+    g, model, preds, losses = _run_mini(mode, direct=direct, arena=arena)
+    ptol, ltol, gtol = (2e-5, 1e-4, 2e-4) if mode == 'fp32' else (1.5e-2, 1e-2, 5e-2)
+    for k, v in g['pred'].items():
+        assert preds[k].shape == v.shape
+        assert rel_err(preds[k], v) < ptol, (k, rel_err(preds[k], v))
+    for k, v in g['loss'].items():
+        assert abs(float(losses[k]) - v) < ltol, (k, float(losses[k]), v)
+    worst = ('', 0.0)
+    named = dict(model.named_parameters())
+    assert set(g['grad']) == {n for n, p in named.items() if p.requires_grad}
+    for n, gr in g['grad'].items():
+        assert named[n].grad is not None, n
+        e = rel_err(named[n].grad, gr)
+        if e > worst[1]:
+            worst = (n, e)
+    assert worst[1] < gtol, worst
+
+
+def test_mini_model_sampler_in_forward_matches_reference_ids():
+    """End-to-end sampler: same CPU Dirichlet stream as the reference; the device noise is injected
+    from the golden stream (the reference draws it with the device generator)."""
+    import multimae_amd as M
+    g = load_mini()
+    model = build_mini_engine()
+    model.load_state_dict(g['sd'])
+    model.to(DEV)
+    noise = [g['noise'][d].to(DEV) for d in MINI['doms']] + [g['noise_all'].to(DEV)]
+    it = iter(noise)
+    real_rand = torch.rand
+
+    def fake_rand(*size, **kw):
+        if kw.get('device') is not None and torch.device(kw['device']).type == 'cuda':
+            return next(it)
+        return real_rand(*size, **kw)
+    torch.manual_seed(1)
+    torch.rand = fake_rand
+    try:
+        tm, k, r = model.generate_random_masks({d: 16 for d in MINI['doms']}, MINI['nvis'], alphas=1.0, batch_size=MINI['B'], device=DEV)
+    finally:
+        torch.rand = real_rand
+    assert torch.equal(k.cpu(), g['ids_keep']) and torch.equal(r.cpu(), g['ids_restore'])
+    for d in MINI['doms']:
+        assert torch.equal(tm[d].cpu(), g['mask'][d])
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_base_config_known_answers(mode):
+    """ViT-B RGB+D+S at B=4 (BASELINE.json configs[2] geometry): seeded init identical to the reference,
+    masks from the same seeded CPU stream are NOT reproducible on the GPU generator, so the losses are
+    compared through the oracle run on the engine's own masks; the reference's recorded losses for its
+    own masks bound the plausible range."""
+    import multimae_amd as M
+    gold = load_scalars()['base_rgb_depth_semseg']
+    doms = ['rgb', 'depth', 'semseg']
+    torch.manual_seed(0)
+    model = build_engine_model(doms, 16, 224)
+    x = make_inputs(doms, 4, 224)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(DEV)
+    model.build_arena()
+    xd = {k: v.to(DEV) for k, v in x.items()}
+    torch.manual_seed(1)
+    with M.engine.precision(mode):
+        preds, masks = model(xd, num_encoded_tokens=98, alphas=1.0, fp32_output_adapters=['semseg'])
+        fns = _loss_fns(16)
+        tgt = dict(xd, norm_rgb=xd['rgb'])
+        mk = dict(masks, norm_rgb=masks['rgb'])
+        losses = {k: fns[k](preds[k].float(), tgt[k], mask=mk[k]) for k in preds}
+        sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    mask_all = torch.cat([masks[d] for d in doms], 1).cpu()
+    assert (mask_all == 0).sum(1).eq(98).all()
+    # oracle on the same weights/inputs/masks (recover ids from the masks: any order of the kept set is
+    # equivalent up to fp summation order -- Block permutation equivariance)
+    ids_shuffle = torch.argsort(mask_all.float(), dim=1, stable=True)
+    ids_restore = torch.argsort(ids_shuffle, dim=1, stable=True)
+    ids_keep = ids_shuffle[:, :98]
+    cfg = orc.standard_config(doms)
+    with torch.no_grad():
+        po = orc.multimae_forward(x, sd, cfg, ids_keep, ids_restore)
+        lo = orc.pretrain_losses(po, x, mask_all, cfg, {d: 196 for d in doms})
+    ltol = 2e-4 if mode == 'fp32' else 1e-2
+    for k in lo:
+        assert abs(float(losses[k]) - float(lo[k])) < ltol, (k, float(losses[k]), float(lo[k]))
+        # same init + same input distribution => close to the reference's recorded value for ITS masks
+        assert abs(float(losses[k]) - gold['losses'][k]) < 0.35, (k, float(losses[k]), gold['losses'][k])
+    ptol = 5e-5 if mode == 'fp32' else 2e-2
+    for k in po:
+        m = mk[k].cpu()
+        assert rel_err(preds[k], po[k]) < ptol, (k, rel_err(preds[k], po[k]))
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
+    assert 0.5 * gold['grad_norm'] < gn < 2.0 * gold['grad_norm'], (gn, gold['grad_norm'])
+
+
+def test_block_permutation_equivariance_full_size():
+    """size-independent property: a Block commutes with token permutations."""
+    import multimae_amd as M
+    from multimae_amd.multimae_utils import Block
+    from functools import partial
+    from torch import nn
+    torch.manual_seed(11)
+    blk = Block(768, 12, mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6)).to(DEV)
+    x = torch.randn(8, 99, 768, device=DEV)
+    perm = torch.randperm(99, device=DEV)
+    with torch.no_grad(), M.engine.precision('fp32'):
+        a = blk(x)[:, perm]
+        b = blk(x[:, perm].contiguous())
+    assert rel_err(a, b) < 5e-6
+
+
+def test_encoder_only_and_multivit_paths():
+    import multimae_amd as M
+    g = load_mini()
+    cfg = mini_oracle_cfg()
+    m = MINI
+    ins = {'rgb': M.PatchedInputAdapter(3, 1, m['P'], image_size=m['S'])}
+    vit = M.MultiViT(ins, None, num_global_tokens=1, dim_tokens=m['dim'], depth=m['depth'], num_heads=m['heads'])
+    sd = {k: v for k, v in g['sd'].items() if k.startswith(('global_tokens', 'input_adapters.rgb.', 'encoder.'))}
+    vit.load_state_dict(sd)
+    vit.to(DEV).eval()
+    x = g['x']['rgb'].to(DEV)
+    import copy
+    ocfg = orc.standard_config(['rgb'], patch_size=m['P'], image_size=m['S'], dim_tokens=m['dim'], depth=m['depth'], num_heads=m['heads'],
+                               dec_dim=m['dec_dim'], dec_depth=m['dec_depth'], dec_heads=m['dec_heads'])
+    ref = orc.multivit_forward_tokens({'rgb': g['x']['rgb']}, g['sd'], ocfg, return_all_layers=True)
+    with torch.no_grad(), M.engine.precision('fp32'):
+        outs = vit(x, return_all_layers=True)
+        last = vit(x)
+    assert len(outs) == m['depth']
+    for a, b in zip(outs, ref):
+        assert rel_err(a, b) < 2e-5
+    assert rel_err(last, ref[-1]) < 2e-5
+
+
+def test_training_loop_loss_curve_matches_oracle():
+    """10 AdamW steps (fused HIP optimiser on the flat arena, fp32 parity mode) vs the oracle run with
+    torch autograd + the oracle AdamW on the same masks: loss curve within 1e-4 (north_star criterion)."""
+    import multimae_amd as M
+    from multimae_amd.optim import FusedAdamW
+    g = load_mini()
+    cfg = mini_oracle_cfg()
+    doms = MINI['doms']
+    model = build_mini_engine()
+    model.load_state_dict(g['sd'])
+    model.to(DEV)
+    arena = model.build_arena()
+    M.engine.set_direct_grads(True)
+    opt = FusedAdamW(model, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
+    sd = {k: v.clone() for k, v in g['sd'].items()}
+    names = [n for n in g['grad']]
+    mo = {n: torch.zeros_like(sd[n]) for n in names}
+    vo = {n: torch.zeros_like(sd[n]) for n in names}
+    x = g['x']
+    xd = {k: v.to(DEV) for k, v in x.items()}
+    fns = _loss_fns(MINI['P'])
+    curve_e, curve_o = [], []
+    try:
+        with M.engine.precision('fp32'):
+            for step in range(1, 11):
+                torch.manual_seed(100 + step)
+                dist, tn, an = orc.draw_mask_randoms(MINI['B'], [16, 16, 16], 1.0)
+                spt = orc.samples_per_task_from_dirichlet(dist, MINI['nvis'])
+                mask_all, ik, ir = orc.masks_from_noise(spt, tn, an, MINI['nvis'])
+                tm = {d: mask_all[:, 16 * i:16 * i + 16].to(DEV) for i, d in enumerate(doms)}
+                model.generate_random_masks = lambda *a, **k: (tm, ik.to(DEV), ir.to(DEV))
+                opt.zero_grad()
+                preds, masks = model(xd, num_encoded_tokens=MINI['nvis'])
+                mk = dict(masks, norm_rgb=masks['rgb'])
+                tgt = dict(xd, norm_rgb=xd['rgb'])
+                loss = sum(fns[k](preds[k].float(), tgt[k], mask=mk[k]) for k in preds)
+                loss.backward()
+                opt.step()
+                curve_e.append(float(loss))
+                # oracle step
+                sdo = {k: (v.clone().requires_grad_(True) if k in mo else v) for k, v in sd.items()}
+                po = orc.multimae_forward(x, sdo, cfg, ik, ir)
+                lo = sum(orc.pretrain_losses(po, x, mask_all, cfg, {d: 16 for d in doms}).values())
+                lo.backward()
+                curve_o.append(float(lo))
+                with torch.no_grad():
+                    orc.adamw_step({n: sd[n] for n in names}, {n: sdo[n].grad for n in names}, mo, vo, step, 1e-3, 0.05)
+    finally:
+        M.engine.set_direct_grads(False)
+    diffs = [abs(a - b) for a, b in zip(curve_e, curve_o)]
+    assert max(diffs) < 1e-4, (curve_e, curve_o)
+    assert curve_e[-1] < curve_e[0]
