@@ -67,13 +67,22 @@ def loss_fns():
             'norm_rgb': M.MaskedMSELoss(16, 1, norm_pix=True)}
 
 
-def cpu_baseline(cfg: str, sample_B: int, steps: int):
+def log(msg):
+    print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+
+def cpu_baseline(cfg: str, sample_B: int, steps: int, threads: int = 0):
     """The oracle (CPU restatement pinned to the reference, oracle/multimae_oracle.py) timed on the host
     cores: the same step (fwd -> 4 losses -> backward -> AdamW) in fp32."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import multimae_oracle as orc
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = threads or min(avail, 64)
     torch.set_num_threads(cores)
+    log(f'cpu_baseline: {avail} cores available, using {cores} threads, B={sample_B}, {steps}+1 steps')
     model, doms = build_model(cfg)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     train = {n for n, p in model.named_parameters() if p.requires_grad}
@@ -107,6 +116,7 @@ def cpu_baseline(cfg: str, sample_B: int, steps: int):
             for n in train:
                 sd[n].grad = None
         times.append(time.perf_counter() - t0)
+        log(f'cpu_baseline step {step}: {times[-1]:.2f} s')
     times = sorted(times[1:])
     med = times[len(times) // 2]
     return {'value': round(sample_B / med, 3), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
@@ -123,7 +133,8 @@ def main():
     ap.add_argument('--config', default='cfg3', choices=['cfg3', 'cfg2'])
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-batch', type=int, default=16)
+    ap.add_argument('--cpu-sample-batch', type=int, default=8)
+    ap.add_argument('--cpu-threads', type=int, default=0)
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--no-kernel-timing', action='store_true')
     args = ap.parse_args()
@@ -181,9 +192,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log(f'model built on {device}, B={B}, world={world}; warmup {args.warmup}')
     for _ in range(args.warmup):
         step()
     sync()
+    log('warmup done; timing')
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -195,7 +208,8 @@ def main():
         dt = float(t)
     ms_per_step = dt / args.steps * 1e3
     img_s = B * world * args.steps / dt
-    final_loss = float(last['loss'])
+    final_loss = float(last['loss'].detach())
+    log(f'timed region done: {ms_per_step:.2f} ms/step, {img_s:.1f} img/s, loss {final_loss:.4f}')
 
     # per-kernel timing pass (outside the timed region): HIP events around every MFMA GEMM launch
     roof = None
@@ -214,6 +228,7 @@ def main():
         step()
         torch.cuda.synchronize()
         ops.gemm = orig
+        log('kernel timing pass done')
         tot_ms = {torch.bfloat16: 0.0, torch.float32: 0.0}
         tot_fl = {torch.bfloat16: 0.0, torch.float32: 0.0}
         cnt = {torch.bfloat16: 0, torch.float32: 0}
@@ -235,7 +250,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         M.engine.set_direct_grads(False)
-        cpu = cpu_baseline(args.config, args.cpu_sample_batch, args.cpu_steps)
+        cpu = cpu_baseline(args.config, args.cpu_sample_batch, args.cpu_steps, args.cpu_threads)
 
     if rank == 0:
         out = {

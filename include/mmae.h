@@ -82,6 +82,7 @@ typedef struct mmae_gemm_desc {
     int32_t accumulate;          /* C += v (c_dtype must be f32) */
     float alpha;
     int32_t tile;                /* 0 = auto, 1 = 128x128, 2 = 256x128 */
+    int32_t split_k;             /* 0 = auto, 1 = off, n = n K-slices combined by f32 atomics (plain f32 C only) */
 } mmae_gemm_desc;
 
 int mmae_gemm(const mmae_gemm_desc* d, void* stream);
@@ -220,8 +221,9 @@ int mmae_decoder_build_bwd(const float* d_queries, const float* d_context, const
  * b c (nh ph) (nw pw)', output_adapters.py:277-280, and its transpose for autograd.
  * ------------------------------------------------------------------------- */
 int mmae_unpatchify(const float* patches, float* img, int B, int C, int nh, int nw, int ph, int pw, void* stream);
-int mmae_patchify(const float* img, void* patches, int patches_dtype, int B, int C, int nh, int nw, int ph, int pw,
-                  void* stream);
+/* patches act dtype [B*nh*nw][ld], ld >= C*ph*pw (columns beyond C*ph*pw are left untouched) */
+int mmae_patchify(const float* img, void* patches, int patches_dtype, int64_t ld, int B, int C, int nh, int nw, int ph,
+                  int pw, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Masked losses.  Replace MaskedMSELoss / MaskedL1Loss (criterion.py:84-114,

@@ -38,7 +38,7 @@ class GemmDesc(ctypes.Structure):
         ('bias', ctypes.c_void_p), ('resid', ctypes.c_void_p), ('ldr', ctypes.c_int64),
         ('aux', ctypes.c_void_p), ('ldaux', ctypes.c_int64),
         ('aux_dtype', ctypes.c_int32), ('epi', ctypes.c_int32), ('accumulate', ctypes.c_int32),
-        ('alpha', ctypes.c_float), ('tile', ctypes.c_int32),
+        ('alpha', ctypes.c_float), ('tile', ctypes.c_int32), ('split_k', ctypes.c_int32),
     ]
 
 

@@ -156,13 +156,15 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_kernel(const GemmArgs 
         return __builtin_bit_cast(bf16x8, r);
     };
 
-    const int nkt = (g.K + BK - 1) / BK;
-    gload(0);
+    const int nkt_all = (g.K + BK - 1) / BK;
+    const int kt_begin = blockIdx.z * g.kt_per_split;
+    const int nkt = (kt_begin + g.kt_per_split < nkt_all) ? kt_begin + g.kt_per_split : nkt_all;
+    gload(kt_begin);
     lstore(0);
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = kt_begin; kt < nkt; ++kt) {
         if (kt + 1 < nkt) gload(kt + 1);
-        const char* sa = smem + (kt & 1) * STAGE;
+        const char* sa = smem + ((kt - kt_begin) & 1) * STAGE;
         const char* sb = sa + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
@@ -178,7 +180,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_kernel(const GemmArgs 
                 for (int tm = 0; tm < 2; ++tm)
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[tn], af[tm], acc[tn][tm], 0, 0, 0);
         }
-        if (kt + 1 < nkt) lstore((kt + 1) & 1);
+        if (kt + 1 < nkt) lstore((kt + 1 - kt_begin) & 1);
         __syncthreads();
     }
 
@@ -204,7 +206,7 @@ int launch(const GemmArgs& g, int batch, hipStream_t st) {
     const int tiles_m = (g.M + BM - 1) / BM;
     GemmArgs a = g;
     a.tiles_n = (g.N + BN - 1) / BN;
-    dim3 grid(tiles_m * a.tiles_n, batch), block(WM * WN * 64);
+    dim3 grid(tiles_m * a.tiles_n, batch, a.splitk), block(WM * WN * 64);
     const size_t lds = 2 * (BM + BN) * 128;
     static bool attr_done = false;   // benign race: idempotent
     if (!attr_done) {

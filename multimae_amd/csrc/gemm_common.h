@@ -14,6 +14,7 @@ struct GemmArgs {
     int c_f32, aux_f32, epi, accumulate, vec;
     float alpha;
     int tiles_n;
+    int splitk, kt_per_split;     // splitk > 1: each z-slice adds its partial product with f32 atomics
 };
 
 // The kernels compute D[i = n][j = m] (B fragment as the MFMA "A" operand) so that one lane
@@ -25,6 +26,11 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, char* Cz, int 
     float v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = acc[j] * g.alpha;
+    if (g.splitk > 1) {   // split-K partial: C (f32, pre-zeroed or accumulating) += v, no other epilogue work
+        float* c = (float*)Cz + (long long)m * g.ldc + n;
+        for (int j = 0; j < cnt; ++j) atomicAdd(c + j, v[j]);
+        return;
+    }
     const bool full = g.vec && (cnt == 4);
     if (g.bias) {
         if (full) { f32x4 b = ld4(g.bias + n);

@@ -62,11 +62,13 @@ __global__ void __launch_bounds__(NT) gemm_f32_kernel(const GemmArgs g, const lo
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int fr = lane & 31, fk = lane >> 5;
-    const int nkt = (g.K + BK - 1) / BK;
-    gload(0); lstore(0); __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
+    const int nkt_all = (g.K + BK - 1) / BK;
+    const int kt_begin = blockIdx.z * g.kt_per_split;
+    const int nkt = (kt_begin + g.kt_per_split < nkt_all) ? kt_begin + g.kt_per_split : nkt_all;
+    gload(kt_begin); lstore(0); __syncthreads();
+    for (int kt = kt_begin; kt < nkt; ++kt) {
         if (kt + 1 < nkt) gload(kt + 1);
-        const int s = kt & 1;
+        const int s = (kt - kt_begin) & 1;
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             float av[2], bv[2];
@@ -81,7 +83,7 @@ __global__ void __launch_bounds__(NT) gemm_f32_kernel(const GemmArgs g, const lo
                 for (int tm = 0; tm < 2; ++tm)
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[tn], av[tm], acc[tn][tm], 0, 0, 0);
         }
-        if (kt + 1 < nkt) lstore((kt + 1) & 1);
+        if (kt + 1 < nkt) lstore((kt + 1 - kt_begin) & 1);
         __syncthreads();
     }
 #pragma unroll
@@ -106,7 +108,7 @@ int mmae_gemm_f32_impl(const mmae_gemm_desc* d, const GemmArgs& g0, hipStream_t 
     const int tiles_m = (d->M + BM - 1) / BM;
     const long long sa_m = d->a_trans ? 1 : d->lda, sa_k = d->a_trans ? d->lda : 1;
     const long long sb_n = d->b_trans ? 1 : d->ldb, sb_k = d->b_trans ? d->ldb : 1;
-    dim3 grid(tiles_m * g.tiles_n, d->batch), block(NT);
+    dim3 grid(tiles_m * g.tiles_n, d->batch, g.splitk), block(NT);
     hipLaunchKernelGGL(gemm_f32_kernel, grid, block, 0, st, g, sa_m, sa_k, sb_n, sb_k);
     return mmae_check_launch("gemm_f32");
 }

@@ -59,7 +59,8 @@ __global__ void __launch_bounds__(256) pixel_loss_fwd_kernel(const float* __rest
             const float d = pred[a] - t;
             s += kind == 0 ? d * d : fabsf(d);
         }
-        acc += wave_sum(s);
+        s = wave_sum(s);                 // every lane now holds the patch total
+        if (lane == 0) acc += s;
     }
     float dummy = 0.f;
     block_sum2(acc, dummy);

@@ -57,6 +57,34 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     if (d->aux) vec = vec && (d->ldaux % 4 == 0) && ((uintptr_t)d->aux % 16 == 0);
     g.vec = vec ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
+    // split-K: the dW-type products (small M x N, K = all rows of the batch) would otherwise
+    // occupy a handful of the 256 CUs.  Partials are combined with f32 atomics into C.
+    const int bk = d->ab_dtype == MMAE_BF16 ? 64 : 16;
+    const int nkt = (d->K + bk - 1) / bk;
+    const long long tiles = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128) * d->batch;
+    int splitk = 1;
+    if (d->c_dtype == MMAE_F32 && d->epi == MMAE_EPI_NONE && !d->bias && !d->resid && d->split_k != 1) {
+        if (d->split_k > 1) splitk = d->split_k;
+        else if (tiles < 512 && nkt >= 16) {
+            splitk = (int)((1024 + tiles - 1) / tiles);
+            const int max_split = nkt / 8;             // keep >= 8 K tiles per slice
+            if (splitk > max_split) splitk = max_split;
+            if (splitk < 1) splitk = 1;
+        }
+    }
+    if (splitk > nkt) splitk = nkt;
+    g.kt_per_split = (nkt + splitk - 1) / splitk;
+    g.splitk = (nkt + g.kt_per_split - 1) / g.kt_per_split;
+    if (g.splitk > 1 && !d->accumulate) {
+        // atomics need a zeroed target: clear the (possibly strided / batched) C rows first
+        for (int z = 0; z < d->batch; ++z) {
+            char* cz = (char*)d->C + ((long long)(z / d->batch_inner) * d->sC_outer + (long long)(z % d->batch_inner) * d->sC_inner) * 4;
+            if (hipMemset2DAsync(cz, (size_t)d->ldc * 4, 0, (size_t)d->N * 4, (size_t)d->M, st) != hipSuccess) {
+                mmae_set_error("gemm: hipMemset2DAsync failed");
+                return MMAE_ELAUNCH;
+            }
+        }
+    }
     if (d->ab_dtype == MMAE_BF16) return mmae_gemm_bf16_impl(d, g, st);
     return mmae_gemm_f32_impl(d, g, st);
 }

@@ -294,7 +294,7 @@ __global__ void unpatchify_kernel(const float* __restrict__ pat, float* __restri
     img[i] = pat[((b * nh + py) * nw + px) * ((long long)C * ph * pw) + ((long long)c * ph + iy) * pw + ix];
 }
 template <typename PT>
-__global__ void patchify_kernel(const float* __restrict__ img, PT* __restrict__ pat, int C, int nh, int nw, int ph, int pw,
+__global__ void patchify_kernel(const float* __restrict__ img, PT* __restrict__ pat, long long ld, int C, int nh, int nw, int ph, int pw,
                                 long long total) {
     const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over B*N*(C*ph*pw)
     if (o >= total) return;
@@ -304,7 +304,7 @@ __global__ void patchify_kernel(const float* __restrict__ img, PT* __restrict__ 
     const int py = (int)(r % nh); const long long b = r / nh;
     const int c = k / (ph * pw), iy = (k / pw) % ph, ix = k % pw;
     const int W = nw * pw, H = nh * ph;
-    ActT<PT>::st(pat + o, img[((b * C + c) * H + py * ph + iy) * W + px * pw + ix]);
+    ActT<PT>::st(pat + (o / KP) * ld + k, img[((b * C + c) * H + py * ph + iy) * W + px * pw + ix]);
 }
 
 // hardware probe: what does ds_read_b64_tr_b16 return for a given LDS image / lane addresses
@@ -448,12 +448,12 @@ int mmae_unpatchify(const float* patches, float* img, int B, int C, int nh, int 
     return mmae_check_launch("unpatchify");
 }
 
-int mmae_patchify(const float* img, void* patches, int patches_dtype, int B, int C, int nh, int nw, int ph, int pw, void* stream) {
-    MMAE_REQUIRE(patches && img && B > 0 && C > 0, "patchify: bad argument");
+int mmae_patchify(const float* img, void* patches, int patches_dtype, int64_t ld, int B, int C, int nh, int nw, int ph, int pw, void* stream) {
+    MMAE_REQUIRE(patches && img && B > 0 && C > 0 && ld >= (int64_t)C * ph * pw, "patchify: bad argument");
     const long long total = (long long)B * C * nh * ph * nw * pw;
     hipStream_t st = (hipStream_t)stream;
-    if (patches_dtype == MMAE_BF16) hipLaunchKernelGGL((patchify_kernel<uint16_t>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, img, (uint16_t*)patches, C, nh, nw, ph, pw, total);
-    else hipLaunchKernelGGL((patchify_kernel<float>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, img, (float*)patches, C, nh, nw, ph, pw, total);
+    if (patches_dtype == MMAE_BF16) hipLaunchKernelGGL((patchify_kernel<uint16_t>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, img, (uint16_t*)patches, (long long)ld, C, nh, nw, ph, pw, total);
+    else hipLaunchKernelGGL((patchify_kernel<float>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, img, (float*)patches, (long long)ld, C, nh, nw, ph, pw, total);
     return mmae_check_launch("patchify");
 }
 

@@ -37,7 +37,7 @@ class GradSink:
         tgt, acc = self._target(p)
         M, N = dy.shape
         K = K if K is not None else x.shape[1]
-        ops.gemm(dy, x, tgt, N, K, M, lda=N, ldb=ldx if ldx is not None else x.shape[1], ldc=K, a_trans=True, b_trans=True,
+        ops.gemm(dy, x, tgt, N, K, M, lda=dy.stride(0), ldb=ldx if ldx is not None else x.stride(0), ldc=K, a_trans=True, b_trans=True,
                  b_off=x_off, accumulate=acc)
         return None if acc else tgt
 
@@ -195,6 +195,8 @@ class EmbedFn(torch.autograd.Function):
         D, G, act, wc = cfg.D, cfg.G, cfg.act, cfg.wc
         data, ws, bs, embs = tens[0::4], tens[1::4], tens[2::4], tens[3::4]
         Ktot = sum(t['K'] for t in cfg.tasks)
+        if act == torch.bfloat16 and any(t['K'] % 8 for t in cfg.tasks):
+            raise NotImplementedError('bf16 patch embedding needs C*P_H*P_W to be a multiple of 8 for every modality')
         srcs = []
         for t, d, e in zip(cfg.tasks, data, embs):
             ops._require_gpu(d, 'input tensor')

@@ -49,7 +49,7 @@ def gemm(A: Tensor, B: Tensor, C: Tensor, M: int, N: int, K: int, *, lda: int, l
          batch: int = 1, batch_inner: int = 1, sA=(0, 0), sB=(0, 0), sC=(0, 0),
          bias: Optional[Tensor] = None, resid: Optional[Tensor] = None, ldr: int = 0,
          aux: Optional[Tensor] = None, ldaux: int = 0, epi: int = EPI_NONE, accumulate: bool = False,
-         alpha: float = 1.0, tile: int = 0) -> None:
+         alpha: float = 1.0, tile: int = 0, split_k: int = 0) -> None:
     """C[M,N] (+)= alpha * A[M,K] . B[N,K]^T with the fused epilogue of mmae_gemm.
     *_off are element offsets into the tensors' storage views (column offsets into packed qkv etc.)."""
     _require_gpu(A, 'gemm A')
@@ -71,7 +71,7 @@ def gemm(A: Tensor, B: Tensor, C: Tensor, M: int, N: int, K: int, *, lda: int, l
     d.resid, d.ldr = _p(resid), ldr
     d.aux, d.ldaux = _p(aux), ldaux
     d.aux_dtype = dcode(aux.dtype) if aux is not None else F32
-    d.epi, d.accumulate, d.alpha, d.tile = epi, int(accumulate), alpha, tile
+    d.epi, d.accumulate, d.alpha, d.tile, d.split_k = epi, int(accumulate), alpha, tile, split_k
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() >= N
     if resid is not None:
@@ -92,7 +92,7 @@ def linear_dx(dy: Tensor, w: Tensor, out: Tensor, *, aux: Optional[Tensor] = Non
     """out[M,K] = dy[M,N] @ w[N,K]   (w read through the transposing LDS path)."""
     M, N = dy.shape
     K = w.shape[1]
-    gemm(dy, w, out, M, K, N, lda=N, ldb=K, ldc=K, b_trans=True, aux=aux, ldaux=K, epi=epi)
+    gemm(dy, w, out, M, K, N, lda=dy.stride(0), ldb=K, ldc=K, b_trans=True, aux=aux, ldaux=K, epi=epi)
     return out
 
 
@@ -100,7 +100,7 @@ def linear_dw(dy: Tensor, x: Tensor, dw: Tensor, accumulate: bool) -> Tensor:
     """dw[N,K] (+)= dy[M,N]^T @ x[M,K]   (both operands k-strided)."""
     M, N = dy.shape
     K = x.shape[1]
-    gemm(dy, x, dw, N, K, M, lda=N, ldb=K, ldc=K, a_trans=True, b_trans=True, accumulate=accumulate)
+    gemm(dy, x, dw, N, K, M, lda=dy.stride(0), ldb=x.stride(0), ldc=K, a_trans=True, b_trans=True, accumulate=accumulate)
     return dw
 
 
@@ -349,11 +349,16 @@ def unpatchify(pat: Tensor, B: int, C: int, nh: int, nw: int, ph: int, pw: int) 
 
 
 def patchify(img: Tensor, C: int, nh: int, nw: int, ph: int, pw: int, dtype: torch.dtype) -> Tensor:
+    """(B,C,H,W) f32 -> [B*nh*nw, C*ph*pw] act dtype.  The row stride is padded to a multiple of 8 elements
+    (zero-filled) so the result is a legal MFMA GEMM operand for any patch dimension; a [:, :C*ph*pw] view is
+    returned."""
     B = img.shape[0]
-    pat = torch.empty((B * nh * nw, C * ph * pw), device=img.device, dtype=dtype)
-    check(_lib.load().mmae_patchify(img.contiguous().data_ptr(), pat.data_ptr(), dcode(dtype), B, C, nh, nw, ph, pw, _stream()),
-          'patchify')
-    return pat
+    KP = C * ph * pw
+    ld = round_up(KP, 8)
+    img = img.contiguous()
+    buf = (torch.empty if ld == KP else torch.zeros)((B * nh * nw, ld), device=img.device, dtype=dtype)
+    check(_lib.load().mmae_patchify(img.data_ptr(), buf.data_ptr(), dcode(dtype), ld, B, C, nh, nw, ph, pw, _stream()), 'patchify')
+    return buf if ld == KP else buf[:, :KP]
 
 
 # ----------------------------------------------------------------------- optimiser --

@@ -33,7 +33,9 @@ def test_probe_tr16_semantics():
         row, col = 4 * g + (i >> 2), (i & 3) * 4
         addr[l] = (row * 64 + col) * 2
     out = torch.zeros(256, dtype=torch.int16, device=DEV)
-    _lib.check(_lib.load().mmae_probe_tr16(img.to(DEV).data_ptr(), addr.to(DEV).data_ptr(), out.data_ptr(), ops._stream()), 'probe')
+    img_d, addr_d = img.to(DEV), addr.to(DEV)          # keep the device buffers alive across the launch
+    _lib.check(_lib.load().mmae_probe_tr16(img_d.data_ptr(), addr_d.data_ptr(), out.data_ptr(), ops._stream()), 'probe')
+    torch.cuda.synchronize()
     out = out.cpu().view(64, 4).int()
     exp = torch.zeros(64, 4, dtype=torch.int32)
     for l in range(64):
@@ -222,7 +224,8 @@ def test_softmax_colsum_cast_transpose():
     assert torch.equal(ops.cast(bf(x).to(DEV), torch.float32).cpu(), bf(x).float())
     w = torch.randn(130, 70)
     wt = torch.empty(70, 130, device=DEV, dtype=torch.bfloat16)
-    _lib.check(_lib.load().mmae_transpose_cast(w.to(DEV).data_ptr(), wt.data_ptr(), 1, 130, 70, ops._stream()), 'transpose')
+    w_d = w.to(DEV)
+    _lib.check(_lib.load().mmae_transpose_cast(w_d.data_ptr(), wt.data_ptr(), 1, 130, 70, ops._stream()), 'transpose')
     assert torch.equal(wt.cpu(), bf(w.t().contiguous()))
     y = torch.randn(1001).to(DEV); z = torch.randn(1001).to(DEV); y0 = y.clone()
     ops.axpy_(y, z, 0.5)
@@ -314,7 +317,11 @@ def test_masked_pixel_losses(kind, norm_pix):
     out = fn(pd, tgt.to(DEV), mask=mask.to(DEV))
     (out * 1.7).backward()
     assert abs(float(out) - float(ref)) < 2e-6 * max(1.0, abs(float(ref)))
-    assert rel_err(pd.grad, pr.grad) < 1e-5
+    # sample 1 has no masked token: the reference's autograd yields NaN there (0 * inf through sum/count);
+    # the engine yields exact zeros.  Compare the other samples.
+    keep = [0, 2, 3, 4]
+    assert torch.isnan(pr.grad[1]).all() and float(pd.grad[1].abs().max()) == 0.0
+    assert rel_err(pd.grad[keep], pr.grad[keep]) < 1e-5
     # mask=None == plain mean; all-zero mask == 0 with zero grad
     assert abs(float(fn(pred.to(DEV), tgt.to(DEV))) - float((orc.masked_mse if kind == 0 else orc.masked_l1)(pred, tgt, None, P, 1, norm_pix=norm_pix))) < 5e-6
     z = fn(pred.to(DEV).requires_grad_(True), tgt.to(DEV), mask=torch.zeros(B, 16, dtype=torch.long, device=DEV))
@@ -335,7 +342,9 @@ def test_masked_cross_entropy():
     out = M.MaskedCrossEntropyLoss(8, 4)(ld, tgt.to(DEV), mask=mask.to(DEV))
     out.backward()
     assert abs(float(out) - float(ref)) < 5e-6
-    assert rel_err(ld.grad, lr.grad) < 1e-5
+    keep = [0, 1, 3]                                    # sample 2: no masked token (reference grad is NaN, engine 0)
+    assert float(ld.grad[2].abs().max()) == 0.0
+    assert rel_err(ld.grad[keep], lr.grad[keep]) < 1e-5
 
 
 def test_adamw_and_sumsq():
