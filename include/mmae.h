@@ -82,10 +82,16 @@ typedef struct mmae_gemm_desc {
     int32_t accumulate;          /* C += v (c_dtype must be f32) */
     float alpha;
     int32_t tile;                /* 0 = auto, 1 = 128x128, 2 = 256x128 */
-    int32_t split_k;             /* 0 = auto, 1 = off, n = n K-slices combined by f32 atomics (plain f32 C only) */
+    int32_t split_k;             /* <= 1: off; n: n K-slices, each writing a dense f32 [M][N] partial into ws,
+                                    then summed into C in a fixed order (plain unbatched f32 C only).  The library
+                                    never allocates: ask mmae_gemm_auto_splitk() and pass a workspace. */
+    void* ws;                    /* f32 workspace of ws_elems >= split_k * M * N elements (split_k > 1) */
+    int64_t ws_elems;
 } mmae_gemm_desc;
 
 int mmae_gemm(const mmae_gemm_desc* d, void* stream);
+/* suggested number of K slices for an [M,N,K] product on a 256-CU MI355X (1 = do not split) */
+int mmae_gemm_auto_splitk(int M, int N, int K, int ab_dtype);
 
 /* ------------------------------------------------------------------------- *
  * LayerNorm (biased variance, eps inside rsqrt), rows of width D.

@@ -236,12 +236,8 @@ int mmae_gemm_bf16_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t 
     MMAE_REQUIRE(a_rows * d->lda * 2 < 0x7fffffffLL && b_rows * d->ldb * 2 < 0x7fffffffLL, "gemm bf16: operand >= 2 GiB");
     if (d->a_trans) MMAE_REQUIRE(d->M % 8 == 0 || d->lda >= ((d->M + 7) / 8) * 8, "gemm bf16: transposed A row too short");
     if (d->b_trans) MMAE_REQUIRE(d->N % 8 == 0 || d->ldb >= ((d->N + 7) / 8) * 8, "gemm bf16: transposed B row too short");
-    int tile = d->tile;
-    if (tile == 0) {
-        // 256x128 only when it still fills the chip (>= 2 workgroups per CU) and M is large
-        const long long t256 = (long long)((d->M + 255) / 256) * ((d->N + 127) / 128) * d->batch;
-        tile = (d->M >= 1024 && t256 >= 512) ? 2 : 1;
-    }
+    // 128x128 (2 workgroups / CU) measured faster than 256x128 on every shape of the step (profiles/r1)
+    const int tile = d->tile == 2 ? 2 : 1;
     if (tile == 2) return dispatch_layout<4, 2>(g, d->batch, d->a_trans != 0, d->b_trans != 0, st);
     return dispatch_layout<2, 2>(g, d->batch, d->a_trans != 0, d->b_trans != 0, st);
 }

@@ -14,7 +14,8 @@ struct GemmArgs {
     int c_f32, aux_f32, epi, accumulate, vec;
     float alpha;
     int tiles_n;
-    int splitk, kt_per_split;     // splitk > 1: each z-slice adds its partial product with f32 atomics
+    int splitk, kt_per_split;     // splitk > 1: z-slice s writes its partial product to ws[s][M][N] (f32)
+    float* ws;
 };
 
 // The kernels compute D[i = n][j = m] (B fragment as the MFMA "A" operand) so that one lane
@@ -26,9 +27,9 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, char* Cz, int 
     float v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = acc[j] * g.alpha;
-    if (g.splitk > 1) {   // split-K partial: C (f32, pre-zeroed or accumulating) += v, no other epilogue work
-        float* c = (float*)Cz + (long long)m * g.ldc + n;
-        for (int j = 0; j < cnt; ++j) atomicAdd(c + j, v[j]);
+    if (g.splitk > 1) {   // split-K partial slab (dense [M][N] f32); combined by splitk_reduce_kernel
+        float* c = g.ws + ((long long)blockIdx.z * g.M + m) * g.N + n;
+        if (cnt == 4 && (g.N & 3) == 0) { f32x4 t = {v[0], v[1], v[2], v[3]}; st4(c, t); } else for (int j = 0; j < cnt; ++j) c[j] = v[j];
         return;
     }
     const bool full = g.vec && (cnt == 4);

@@ -128,20 +128,50 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const DT* __restrict__ dy, 
     }
 }
 
-// out[c] (+)= sum_r part[r][c].  One thread per column, rows summed in order (deterministic).
-__global__ void colsum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int nrows, int ncols,
-                                       int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncols) return;
+// out[c] (+)= sum_r part[r][c].  Workgroup = 64 columns x 4 row phases (coalesced 256-B rows, 4-way
+// unrolled so 16 loads are in flight per lane), fixed summation order (deterministic).
+__global__ void __launch_bounds__(256) colsum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int nrows,
+                                                              int ncols, int accumulate) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int r = 0;
-    for (; r + 4 <= nrows; r += 4) {
-        s0 += part[(long long)(r + 0) * ncols + c]; s1 += part[(long long)(r + 1) * ncols + c];
-        s2 += part[(long long)(r + 2) * ncols + c]; s3 += part[(long long)(r + 3) * ncols + c];
+    if (c < ncols) {
+        int r = ty;
+        for (; r + 12 < nrows; r += 16) {
+            s0 += part[(long long)(r + 0) * ncols + c]; s1 += part[(long long)(r + 4) * ncols + c];
+            s2 += part[(long long)(r + 8) * ncols + c]; s3 += part[(long long)(r + 12) * ncols + c];
+        }
+        for (; r < nrows; r += 4) s0 += part[(long long)r * ncols + c];
     }
-    for (; r < nrows; ++r) s0 += part[(long long)r * ncols + c];
-    const float s = (s0 + s1) + (s2 + s3);
-    out[c] = accumulate ? out[c] + s : s;
+    red[ty][tx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ty == 0 && c < ncols) {
+        const float s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        out[c] = accumulate ? out[c] + s : s;
+    }
+}
+
+// C[m][n] (+)= sum_s ws[s][m][n]  (split-K combine; ws dense [splits][M][N], C row stride ldc)
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N,
+                                                            long long ldc, int splits, int accumulate) {
+    const long long total4 = ((long long)M * N) >> 2;
+    const long long slab = (long long)M * N;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const long long e = i << 2;
+        f32x4 a = ld4(ws + e);
+        for (int s = 1; s < splits; ++s) { const f32x4 b = ld4(ws + s * slab + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] += b[j];
+        }
+        const int m = (int)(e / N), n = (int)(e % N);
+        float* c = C + (long long)m * ldc + n;
+        if (accumulate) { const f32x4 o = ld4(c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] += o[j];
+        }
+        st4(c, a);
+    }
 }
 
 // column sums of dy [M][ld] (N columns, N % 4 == 0): grid (ceil(N/256), NSPLIT); thread owns 4 columns.
@@ -278,6 +308,14 @@ inline int stream_grid(long long n_vec4) { long long b = (n_vec4 + 255) / 256; r
 
 }  // namespace
 
+int mmae_splitk_reduce(const float* ws, float* C, int M, int N, long long ldc, int splits, int accumulate, hipStream_t st) {
+    MMAE_REQUIRE((N & 3) == 0 && (ldc & 3) == 0 && ((uintptr_t)C % 16) == 0, "gemm: split_k needs N, ldc multiples of 4 and an aligned C");
+    long long nb = ((long long)M * N / 4 + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, ws, C, M, N, ldc, splits, accumulate);
+    return mmae_check_launch("splitk_reduce");
+}
+
 extern "C" {
 
 int mmae_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
@@ -300,7 +338,7 @@ int mmae_layernorm_fwd(const float* x, const float* gamma, const float* beta, vo
     return mmae_check_launch("layernorm_fwd");
 }
 
-int mmae_layernorm_bwd_nblk(int64_t R) { const int64_t b = cdiv64(R, 4); return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }
+int mmae_layernorm_bwd_nblk(int64_t R) { const int64_t b = cdiv64(R, 4); return (int)(b < 1 ? 1 : (b > 512 ? 512 : b)); }
 
 int mmae_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
                        const float* rstd, const float* dx_in, float* dx_out, void* dx_act, int dx_act_dtype, float* part,
@@ -326,12 +364,12 @@ int mmae_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float
 
 int mmae_colsum_partials(const float* part, float* out, int nrows, int ncols, int accumulate, void* stream) {
     MMAE_REQUIRE(part && out && nrows > 0 && ncols > 0, "colsum_partials: bad argument");
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3((ncols + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, out, nrows,
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((ncols + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, out, nrows,
                        ncols, accumulate);
     return mmae_check_launch("colsum_partials");
 }
 
-static int colsum_nsplit(int64_t M) { const int64_t s = cdiv64(M, 64); return (int)(s < 1 ? 1 : (s > 128 ? 128 : s)); }
+static int colsum_nsplit(int64_t M) { const int64_t s = cdiv64(M, 256); return (int)(s < 1 ? 1 : (s > 64 ? 64 : s)); }
 int64_t mmae_colsum_ws_elems(int64_t M, int N) { return (int64_t)colsum_nsplit(M) * N; }
 
 int mmae_colsum(const void* dy, int dtype, int64_t M, int N, int64_t ld, float* out, int accumulate, float* ws,

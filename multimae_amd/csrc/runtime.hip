@@ -22,6 +22,7 @@ int mmae_check_launch(const char* what) {
 
 int mmae_gemm_bf16_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st);
 int mmae_gemm_f32_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st);
+int mmae_splitk_reduce(const float* ws, float* C, int M, int N, long long ldc, int splits, int accumulate, hipStream_t st);
 
 extern "C" {
 
@@ -57,36 +58,37 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     if (d->aux) vec = vec && (d->ldaux % 4 == 0) && ((uintptr_t)d->aux % 16 == 0);
     g.vec = vec ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    // split-K: the dW-type products (small M x N, K = all rows of the batch) would otherwise
-    // occupy a handful of the 256 CUs.  Partials are combined with f32 atomics into C.
+    // split-K: the dW-type products (small M x N, K = all rows of the batch) would otherwise occupy
+    // a handful of the 256 CUs.  Each K slice writes a dense f32 partial slab into the caller's
+    // workspace; a second launch sums the slabs into C in a fixed order (deterministic).
     const int bk = d->ab_dtype == MMAE_BF16 ? 64 : 16;
     const int nkt = (d->K + bk - 1) / bk;
-    const long long tiles = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128) * d->batch;
-    int splitk = 1;
-    if (d->c_dtype == MMAE_F32 && d->epi == MMAE_EPI_NONE && !d->bias && !d->resid && d->split_k != 1) {
-        if (d->split_k > 1) splitk = d->split_k;
-        else if (tiles < 512 && nkt >= 16) {
-            splitk = (int)((1024 + tiles - 1) / tiles);
-            const int max_split = nkt / 8;             // keep >= 8 K tiles per slice
-            if (splitk > max_split) splitk = max_split;
-            if (splitk < 1) splitk = 1;
-        }
+    int splitk = d->split_k > 1 ? d->split_k : 1;
+    if (splitk > 1) {
+        MMAE_REQUIRE(d->c_dtype == MMAE_F32 && d->epi == MMAE_EPI_NONE && !d->bias && !d->resid && d->batch == 1 && d->alpha == 1.0f,
+                     "gemm: split_k needs a plain unbatched f32 C");
+        MMAE_REQUIRE(d->ws && d->ws_elems >= (int64_t)splitk * d->M * d->N, "gemm: split_k workspace too small");
+        MMAE_REQUIRE((uintptr_t)d->ws % 16 == 0, "gemm: split_k workspace unaligned");
     }
     if (splitk > nkt) splitk = nkt;
     g.kt_per_split = (nkt + splitk - 1) / splitk;
     g.splitk = (nkt + g.kt_per_split - 1) / g.kt_per_split;
-    if (g.splitk > 1 && !d->accumulate) {
-        // atomics need a zeroed target: clear the (possibly strided / batched) C rows first
-        for (int z = 0; z < d->batch; ++z) {
-            char* cz = (char*)d->C + ((long long)(z / d->batch_inner) * d->sC_outer + (long long)(z % d->batch_inner) * d->sC_inner) * 4;
-            if (hipMemset2DAsync(cz, (size_t)d->ldc * 4, 0, (size_t)d->N * 4, (size_t)d->M, st) != hipSuccess) {
-                mmae_set_error("gemm: hipMemset2DAsync failed");
-                return MMAE_ELAUNCH;
-            }
-        }
-    }
-    if (d->ab_dtype == MMAE_BF16) return mmae_gemm_bf16_impl(d, g, st);
-    return mmae_gemm_f32_impl(d, g, st);
+    g.ws = (float*)d->ws;
+    int rc = (d->ab_dtype == MMAE_BF16) ? mmae_gemm_bf16_impl(d, g, st) : mmae_gemm_f32_impl(d, g, st);
+    if (rc || g.splitk <= 1) return rc;
+    return mmae_splitk_reduce(g.ws, (float*)d->C, d->M, d->N, d->ldc, g.splitk, d->accumulate, st);
+}
+
+int mmae_gemm_auto_splitk(int M, int N, int K, int ab_dtype) {
+    const int bk = ab_dtype == MMAE_BF16 ? 64 : 16;
+    const int nkt = (K + bk - 1) / bk;
+    const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
+    if (tiles >= 384 || nkt < 32) return 1;
+    int s = (int)((1024 + tiles - 1) / tiles);
+    const int max_split = nkt / 8;                      // keep >= 8 K tiles per slice
+    if (s > max_split) s = max_split;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : s;
 }
 
 }  // extern "C"

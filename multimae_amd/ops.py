@@ -71,12 +71,21 @@ def gemm(A: Tensor, B: Tensor, C: Tensor, M: int, N: int, K: int, *, lda: int, l
     d.resid, d.ldr = _p(resid), ldr
     d.aux, d.ldaux = _p(aux), ldaux
     d.aux_dtype = dcode(aux.dtype) if aux is not None else F32
-    d.epi, d.accumulate, d.alpha, d.tile, d.split_k = epi, int(accumulate), alpha, tile, split_k
+    d.epi, d.accumulate, d.alpha, d.tile = epi, int(accumulate), alpha, tile
+    ws = None
+    lib = _lib.load()
+    if split_k == 0 and batch == 1 and C.dtype == torch.float32 and epi == EPI_NONE and bias is None and resid is None \
+            and alpha == 1.0 and N % 4 == 0 and ldc % 4 == 0:
+        split_k = lib.mmae_gemm_auto_splitk(M, N, K, d.ab_dtype)
+    if split_k > 1:
+        ws = torch.empty((split_k * M * N,), device=A.device, dtype=torch.float32)
+        d.ws, d.ws_elems = ws.data_ptr(), ws.numel()
+    d.split_k = max(split_k, 1)
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() >= N
     if resid is not None:
         assert resid.dtype == torch.float32
-    check(_lib.load().mmae_gemm(ctypes.byref(d), _stream()), 'mmae_gemm')
+    check(lib.mmae_gemm(ctypes.byref(d), _stream()), 'mmae_gemm')
 
 
 def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], out: Tensor, *, resid: Optional[Tensor] = None,
@@ -131,7 +140,7 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
                                  dcode(act_dtype) if act_dtype is not None else F32, part.data_ptr(), R, D, _stream()),
           'layernorm_bwd')
     dgb = torch.empty((2 * D,), device=x.device, dtype=torch.float32)
-    check(lib.mmae_colsum_partials(part.data_ptr(), dgb.data_ptr(), nblk, 2 * D, 0, _stream()), 'colsum_partials')
+    colsum(part.view(nblk, 2 * D), dgb, False)
     return dx, dx_act, dgb[:D], dgb[D:]
 
 

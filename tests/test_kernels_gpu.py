@@ -90,6 +90,29 @@ def test_gemm_f32_layouts(shape, a_trans, b_trans):
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_gemm_splitk_workspace(dtype):
+    """dW-shaped product (tiny M x N, long K): K slices through the workspace + fixed-order reduce; also
+    accumulate-into-C and bit-reproducibility (no atomics)."""
+    from multimae_amd import _lib, ops
+    torch.manual_seed(12)
+    Mr, N, K = 4096, 256, 136                 # dy [Mr, N], x [Mr, K]  ->  dW [N, K]
+    dy, x = torch.randn(Mr, N) * 0.1, torch.randn(Mr, K)
+    if dtype == torch.bfloat16:
+        dy, x = bf(dy).float(), bf(x).float()
+    assert _lib.load().mmae_gemm_auto_splitk(N, K, Mr, ops.dcode(dtype)) > 1
+    ref = dy.double().t() @ x.double()
+    dyd, xd = dy.to(DEV, dtype), x.to(DEV, dtype)
+    dw = torch.full((N, K), 2.0, device=DEV)
+    ops.linear_dw(dyd, xd, dw, accumulate=True)
+    assert rel_err(dw, 2.0 + ref) < 2e-6
+    dw2 = torch.empty((N, K), device=DEV)
+    ops.linear_dw(dyd, xd, dw2, accumulate=False)
+    dw3 = torch.empty((N, K), device=DEV)
+    ops.linear_dw(dyd, xd, dw3, accumulate=False)
+    assert rel_err(dw2, ref) < 2e-6 and torch.equal(dw2, dw3)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
 def test_gemm_epilogues(dtype):
     from multimae_amd import ops
     from multimae_amd._lib import EPI_DGELU, EPI_GELU

@@ -8,11 +8,11 @@ from multimae_amd import ops
 DEV = 'cuda'
 
 
-def bench(name, M, N, K, a_trans, b_trans, tile, dtype=torch.bfloat16, iters=20):
+def bench(name, M, N, K, a_trans, b_trans, tile, dtype=torch.bfloat16, iters=20, split=0):
     A = torch.randn((K, M) if a_trans else (M, K), device=DEV).to(dtype)
     B = torch.randn((K, N) if b_trans else (N, K), device=DEV).to(dtype)
     C = torch.empty(M, N, device=DEV, dtype=torch.float32 if (a_trans and b_trans) else dtype)
-    f = lambda: ops.gemm(A, B, C, M, N, K, lda=A.shape[1], ldb=B.shape[1], ldc=N, a_trans=a_trans, b_trans=b_trans, tile=tile)
+    f = lambda: ops.gemm(A, B, C, M, N, K, lda=A.shape[1], ldb=B.shape[1], ldc=N, a_trans=a_trans, b_trans=b_trans, tile=tile, split_k=split)
     for _ in range(3):
         f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -29,7 +29,7 @@ def bench(name, M, N, K, a_trans, b_trans, tile, dtype=torch.bfloat16, iters=20)
 
 if __name__ == '__main__':
     R, Rd = 25344, 50176
-    for tile in (1, 2):
+    for tile in (1,):
         bench('enc qkv fwd', R, 2304, 768, False, False, tile)
         bench('enc proj fwd', R, 768, 768, False, False, tile)
         bench('enc fc1 fwd', R, 3072, 768, False, False, tile)
@@ -42,6 +42,9 @@ if __name__ == '__main__':
         bench('dec fc1 fwd', Rd, 1024, 256, False, False, tile)
         bench('dec qkv fwd', Rd, 768, 256, False, False, tile)
         bench('dec fc1 dW (TN)', 1024, 256, Rd, True, True, tile)
+        for sp in (1, 4, 16):
+            bench(f'enc fc1 dW split={sp}', 3072, 768, R, True, True, tile, split=sp)
+            bench(f'enc proj dW split={sp}', 768, 768, R, True, True, tile, split=sp)
     bench('square 4096', 4096, 4096, 4096, False, False, 1)
     bench('square 4096', 4096, 4096, 4096, False, False, 2)
     bench('square 8192', 8192, 8192, 8192, False, False, 2)
