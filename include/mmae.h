@@ -131,6 +131,23 @@ int mmae_softmax_bwd(const void* P, int p_dtype, int64_t ldp, const float* dP, i
                      int64_t ldds, int64_t rows, int n, float scale, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Fused attention, bf16, one workgroup per (batch, head); head_dim 32 or 64; 1 <= Nq, Nk <= 256
+ * (the whole K and V of a head live in LDS; scores never reach HBM).  Replaces the
+ * Attention.forward / CrossAttention.forward cores, multimae_utils.py:175-179, 206-210, and their
+ * autograd.  Operands are addressed as base + b*s_b + row*s_r + h*head_dim (elements), so q/k/v
+ * may be column slices of a packed qkv / kv activation.  lse f32 [B][H][Nq] = max + log(sum) of
+ * the scaled scores (saved by fwd, consumed by bwd).  bwd also needs o (fwd output) for
+ * delta = rowsum(dO . O); d_o shares o's strides.
+ * ------------------------------------------------------------------------- */
+int mmae_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
+                  int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb,
+                  int64_t o_sr, float scale, void* stream);
+int mmae_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, void* dq,
+                  void* dk, void* dv, int B, int H, int Nq, int Nk, int hd, int64_t q_sb, int64_t q_sr, int64_t k_sb,
+                  int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr, int64_t dq_sb, int64_t dq_sr,
+                  int64_t dk_sb, int64_t dk_sr, int64_t dv_sb, int64_t dv_sr, float scale, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Casts.  f32 master weights -> act-dtype shadows (optionally transposed so that
  * dX = dY.W is again an "NT" product).
  * ------------------------------------------------------------------------- */

@@ -111,7 +111,7 @@ def block_bwd(dx: Tensor, dx_act: Tensor, saved, P: Sequence[Tensor], wc, sink: 
     g_projb = sink.bias(projb, dx1_act)
     d_qkv = _new((R, 3 * D), dx, act)
     ops.attention_bwd(AttnView(qkv, 0, 3 * D, N), AttnView(qkv, D, 3 * D, N), AttnView(qkv, 2 * D, 3 * D, N), Pm,
-                      AttnView(d_ao, 0, D, N), AttnView(d_qkv, 0, 3 * D, N), AttnView(d_qkv, D, 3 * D, N),
+                      AttnView(ao, 0, D, N), AttnView(d_ao, 0, D, N), AttnView(d_qkv, 0, 3 * D, N), AttnView(d_qkv, D, 3 * D, N),
                       AttnView(d_qkv, 2 * D, 3 * D, N), B, heads, hd, hd ** -0.5)
     d_ln1 = ops.linear_dx(d_qkv, wc(qkvw), _new((R, D), dx, act))
     g_qkvw = sink.weight(qkvw, d_qkv, ln1)
@@ -356,7 +356,7 @@ class SpatialAdapterFn(torch.autograd.Function):
         d_q = torch.empty((B * n_q, D), device=dev, dtype=act)
         d_kv = torch.empty((B * NC, 2 * D), device=dev, dtype=act)
         ops.attention_bwd(AttnView(q, 0, D, n_q), AttnView(kv, 0, 2 * D, NC), AttnView(kv, D, 2 * D, NC), Pm,
-                          AttnView(d_xo, 0, D, n_q), AttnView(d_q, 0, D, n_q), AttnView(d_kv, 0, 2 * D, NC),
+                          AttnView(xo, 0, D, n_q), AttnView(d_xo, 0, D, n_q), AttnView(d_q, 0, D, n_q), AttnView(d_kv, 0, 2 * D, NC),
                           AttnView(d_kv, D, 2 * D, NC), B, heads, hd, hd ** -0.5)
         d_qn = ops.linear_dx(d_q, wc(qw), torch.empty((B * n_q, D), device=dev, dtype=act))
         g_qw, g_qb = sink.weight(qw, d_q, qn), sink.bias(qb, d_q)
@@ -434,19 +434,19 @@ class AttentionCoreFn(torch.autograd.Function):
         o = torch.empty((B * Nq, D), device=q.device, dtype=act)
         Pm = ops.attention_fwd(AttnView(qa, 0, D, Nq), AttnView(ka, 0, D, Nk), AttnView(va, 0, D, Nk), AttnView(o, 0, D, Nq), B, heads,
                                hd, scale)
-        ctx.saved = (qa, ka, va, Pm)
+        ctx.saved = (qa, ka, va, Pm, o)
         ctx.dims = (B, Nq, Nk, D, heads, hd, scale, act)
         return ops.cast(o, torch.float32).view(B, Nq, D)
 
     @staticmethod
     def backward(ctx, d_o: Tensor):
-        qa, ka, va, Pm = ctx.saved
+        qa, ka, va, Pm, o = ctx.saved
         B, Nq, Nk, D, heads, hd, scale, act = ctx.dims
         do = ops.cast(d_o.contiguous().view(-1, D), act)
         dq = torch.empty((B * Nq, D), device=d_o.device, dtype=act)
         dk = torch.empty((B * Nk, D), device=d_o.device, dtype=act)
         dv = torch.empty((B * Nk, D), device=d_o.device, dtype=act)
-        ops.attention_bwd(AttnView(qa, 0, D, Nq), AttnView(ka, 0, D, Nk), AttnView(va, 0, D, Nk), Pm, AttnView(do, 0, D, Nq),
+        ops.attention_bwd(AttnView(qa, 0, D, Nq), AttnView(ka, 0, D, Nk), AttnView(va, 0, D, Nk), Pm, AttnView(o, 0, D, Nq), AttnView(do, 0, D, Nq),
                           AttnView(dq, 0, D, Nq), AttnView(dk, 0, D, Nk), AttnView(dv, 0, D, Nk), B, heads, hd, scale)
         f = torch.float32
         return ops.cast(dq, f).view(B, Nq, D), ops.cast(dk, f).view(B, Nk, D), ops.cast(dv, f).view(B, Nk, D), None, None, None

@@ -208,12 +208,34 @@ class AttnView:
         self.t, self.col, self.ld, self.N = t, col, ld, N
 
 
+_FUSED_ATTN = [True]
+
+
+def set_fused_attention(flag: bool) -> None:
+    """bf16 attention: fused single-kernel path (default) or the batched-GEMM + softmax path."""
+    _FUSED_ATTN[0] = bool(flag)
+
+
+def _ptr(v: AttnView) -> int:
+    return v.t.data_ptr() + v.col * v.t.element_size()
+
+
+def _fusable(q: AttnView, k: AttnView, hd: int) -> bool:
+    return _FUSED_ATTN[0] and q.t.dtype == torch.bfloat16 and hd in (32, 64) and q.N <= 256 and k.N <= 256
+
+
 def attention_fwd(q: AttnView, k: AttnView, v: AttnView, out: AttnView, B: int, H: int, hd: int, scale: float):
-    """softmax(q k^T * scale) v via batched MFMA GEMMs + row softmax.  Returns P (saved for backward).
+    """softmax(q k^T * scale) v.  Returns the state backward needs: ('fused', lse) or ('gemm', P).
     multimae_utils.py:175-179 / 206-210."""
     Nq, Nk = q.N, k.N
-    Np = round_up(Nk, 8)
     dev, act = q.t.device, q.t.dtype
+    if _fusable(q, k, hd):
+        lse = torch.empty((B, H, Nq), device=dev, dtype=torch.float32)
+        check(_lib.load().mmae_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), lse.data_ptr(), B, H, Nq, Nk, hd,
+                                        Nq * q.ld, q.ld, Nk * k.ld, k.ld, Nk * v.ld, v.ld, Nq * out.ld, out.ld, scale, _stream()),
+              'attn_fwd')
+        return ('fused', lse)
+    Np = round_up(Nk, 8)
     S = torch.empty((B, H, Nq, Np), device=dev, dtype=torch.float32)
     gemm(q.t, k.t, S, Nq, Nk, hd, lda=q.ld, ldb=k.ld, ldc=Np, a_off=q.col, b_off=k.col,
          batch=B * H, batch_inner=H, sA=(Nq * q.ld, hd), sB=(Nk * k.ld, hd), sC=(H * Nq * Np, Nq * Np))
@@ -221,12 +243,19 @@ def attention_fwd(q: AttnView, k: AttnView, v: AttnView, out: AttnView, B: int, 
     softmax_fwd(S, P, B * H * Nq, Nk, scale)
     gemm(P, v.t, out.t, Nq, hd, Nk, lda=Np, ldb=v.ld, ldc=out.ld, b_trans=True, b_off=v.col, c_off=out.col,
          batch=B * H, batch_inner=H, sA=(H * Nq * Np, Nq * Np), sB=(Nk * v.ld, hd), sC=(Nq * out.ld, hd))
-    return P
+    return ('gemm', P)
 
 
-def attention_bwd(q: AttnView, k: AttnView, v: AttnView, P: Tensor, d_out: AttnView, dq: AttnView, dk: AttnView,
+def attention_bwd(q: AttnView, k: AttnView, v: AttnView, state, out: AttnView, d_out: AttnView, dq: AttnView, dk: AttnView,
                   dv: AttnView, B: int, H: int, hd: int, scale: float) -> None:
     Nq, Nk = q.N, k.N
+    if state[0] == 'fused':
+        assert d_out.ld == out.ld
+        check(_lib.load().mmae_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(d_out), state[1].data_ptr(), _ptr(dq), _ptr(dk),
+                                        _ptr(dv), B, H, Nq, Nk, hd, Nq * q.ld, q.ld, Nk * k.ld, k.ld, Nk * v.ld, v.ld, Nq * out.ld,
+                                        out.ld, Nq * dq.ld, dq.ld, Nk * dk.ld, dk.ld, Nk * dv.ld, dv.ld, scale, _stream()), 'attn_bwd')
+        return
+    P = state[1]
     Np = P.shape[-1]
     dev, act = q.t.device, q.t.dtype
     bh = dict(batch=B * H, batch_inner=H)

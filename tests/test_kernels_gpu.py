@@ -159,10 +159,23 @@ def test_gemm_epilogues(dtype):
     assert rel_err(c16.float(), 0.5 * (x @ w.t())) < 4e-3
 
 
-@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize('geom', [(3, 2, 17, 17, 64), (2, 12, 99, 99, 64), (2, 8, 196, 99, 32), (2, 8, 196, 196, 32), (1, 3, 50, 50, 64)])
-def test_attention_unfused_fwd_bwd(dtype, geom):
-    """batched-GEMM + row-softmax attention (self and cross) vs the oracle formula, fwd and bwd."""
+@pytest.mark.parametrize('path', ['fused', 'gemm', 'f32'])
+@pytest.mark.parametrize('geom', [(3, 2, 17, 17, 64), (2, 12, 99, 99, 64), (2, 8, 196, 99, 32), (2, 8, 196, 196, 32), (1, 3, 50, 50, 64),
+                                  (2, 16, 197, 197, 64), (1, 2, 256, 256, 32), (2, 3, 1, 33, 64)])
+def test_attention_fwd_bwd(path, geom):
+    """attention (self and cross) vs the oracle formula, fwd and bwd: the fused single-kernel bf16 path,
+    the batched-GEMM + row-softmax bf16 path, and the exact-f32 GEMM path."""
+    from multimae_amd import ops
+    from multimae_amd.ops import AttnView
+    dtype = torch.float32 if path == 'f32' else torch.bfloat16
+    ops.set_fused_attention(path == 'fused')
+    try:
+        _attention_case(dtype, geom, path)
+    finally:
+        ops.set_fused_attention(True)
+
+
+def _attention_case(dtype, geom, path):
     from multimae_amd import ops
     from multimae_amd.ops import AttnView
     B, H, Nq, Nk, hd = geom
@@ -182,12 +195,13 @@ def test_attention_unfused_fwd_bwd(dtype, geom):
     od = torch.empty(B * Nq, D, device=DEV, dtype=dtype)
     P = ops.attention_fwd(AttnView(qd, 0, D, Nq), AttnView(kvd, 0, 2 * D, Nk), AttnView(kvd, D, 2 * D, Nk), AttnView(od, 0, D, Nq), B, H, hd,
                           hd ** -0.5)
+    assert P[0] == ('fused' if path == 'fused' else 'gemm')
     tol = 2e-5 if dtype == torch.float32 else 1e-2
     assert rel_err(od.float().view(B, Nq, D), o_ref) < tol
     dq = torch.empty(B * Nq, D, device=DEV, dtype=dtype)
     dkv = torch.empty(B * Nk, 2 * D, device=DEV, dtype=dtype)
     dod = do.reshape(B * Nq, D).to(DEV, dtype)
-    ops.attention_bwd(AttnView(qd, 0, D, Nq), AttnView(kvd, 0, 2 * D, Nk), AttnView(kvd, D, 2 * D, Nk), P, AttnView(dod, 0, D, Nq),
+    ops.attention_bwd(AttnView(qd, 0, D, Nq), AttnView(kvd, 0, 2 * D, Nk), AttnView(kvd, D, 2 * D, Nk), P, AttnView(od, 0, D, Nq), AttnView(dod, 0, D, Nq),
                       AttnView(dq, 0, D, Nq), AttnView(dkv, 0, 2 * D, Nk), AttnView(dkv, D, 2 * D, Nk), B, H, hd, hd ** -0.5)
     tol = 5e-5 if dtype == torch.float32 else 2e-2
     assert rel_err(dq.float().view(B, Nq, D), qr.grad) < tol
