@@ -30,9 +30,13 @@ __device__ __forceinline__ int lds_ks_off(int krow, int chunk) {
     return krow * (COLS * 2) + ((chunk ^ ((krow & 3) << 2)) << 4);
 }
 
-template <int WM, int WN, bool AKS, bool BKS>
+// DMA = true: operand tiles go HBM -> LDS directly (buffer_load ... lds, 1 KiB per wave instruction,
+// no VGPR staging and none of the slow ds_write_b128 traffic); the XOR swizzle is applied on the
+// SOURCE side: lane p of a wave instruction owns LDS slot p of its 1-KiB segment and fetches the
+// global 16-byte chunk that belongs there.  DMA = false: VGPR-staged loads + ds_write_b128.
+template <int WM, int WN, bool AKS, bool BKS, bool DMA>
 __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_kernel(const GemmArgs g) {
-    constexpr int BM = WM * 64, BN = WN * 64, NT = WM * WN * 64;
+    constexpr int BM = WM * 64, BN = WN * 64, NT = WM * WN * 64, NW = WM * WN;
     constexpr int LA = BM * 8 / NT, LB = BN * 8 / NT;      // 16-byte chunks per thread per tile
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -63,7 +67,12 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_kernel(const GemmArgs 
     int a_lds[LA], b_lds[LB];
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-        const int c = tid + i * NT;
+        int c = tid + i * NT;
+        if (DMA) {   // slot (segment i*NW + wave, lane) -> logical chunk index whose swizzled home is that slot
+            const int seg = i * NW + wave;
+            if (!AKS) { const int b_abs = 4 * seg + (lane >> 4), j = (lane & 15) ^ (b_abs & 15); c = (2 * b_abs + (j >> 3)) * 8 + (j & 7); }
+            else { constexpr int CPR = BM / 8; const int krow = seg * (64 / CPR) + lane / CPR; c = krow * CPR + ((lane % CPR) ^ ((krow & 3) << 2)); }
+        }
         if (!AKS) {
             const int row = c >> 3, kc = c & 7;
             a_kq[i] = kc * 8;
@@ -79,7 +88,12 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_kernel(const GemmArgs 
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
-        const int c = tid + i * NT;
+        int c = tid + i * NT;
+        if (DMA) {
+            const int seg = i * NW + wave;
+            if (!BKS) { const int b_abs = 4 * seg + (lane >> 4), j = (lane & 15) ^ (b_abs & 15); c = (2 * b_abs + (j >> 3)) * 8 + (j & 7); }
+            else { constexpr int CPR = BN / 8; const int krow = seg * (64 / CPR) + lane / CPR; c = krow * CPR + ((lane % CPR) ^ ((krow & 3) << 2)); }
+        }
         if (!BKS) {
             const int row = c >> 3, kc = c & 7;
             b_kq[i] = kc * 8;
@@ -117,6 +131,24 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_kernel(const GemmArgs 
         for (int i = 0; i < LA; ++i) *reinterpret_cast<i32x4*>(sa + a_lds[i]) = ra[i];
 #pragma unroll
         for (int i = 0; i < LB; ++i) *reinterpret_cast<i32x4*>(sb + b_lds[i]) = rb[i];
+    };
+
+    auto dma = [&](int kt, int stage) {
+        const int k0 = kt * BK;
+        char* sa = smem + stage * STAGE;
+        char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const bool ok = (a_off[i] != OOB) && (k0 + a_kq[i] < g.K);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(sa + (i * NW + wave) * 1024), 16,
+                                                     ok ? a_off[i] + (unsigned)kt * a_step : OOB, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const bool ok = (b_off[i] != OOB) && (k0 + b_kq[i] < g.K);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)(sb + (i * NW + wave) * 1024), 16,
+                                                     ok ? b_off[i] + (unsigned)kt * b_step : OOB, 0, 0, 0);
+        }
     };
 
     f32x16 acc[2][2];   // [tn][tm]
@@ -159,11 +191,11 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_kernel(const GemmArgs 
     const int nkt_all = (g.K + BK - 1) / BK;
     const int kt_begin = blockIdx.z * g.kt_per_split;
     const int nkt = (kt_begin + g.kt_per_split < nkt_all) ? kt_begin + g.kt_per_split : nkt_all;
-    gload(kt_begin);
-    lstore(0);
+    if (DMA) { dma(kt_begin, 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    else { gload(kt_begin); lstore(0); }
     __syncthreads();
     for (int kt = kt_begin; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) gload(kt + 1);
+        if (kt + 1 < nkt) { if (DMA) dma(kt + 1, (kt + 1 - kt_begin) & 1); else gload(kt + 1); }
         const char* sa = smem + ((kt - kt_begin) & 1) * STAGE;
         const char* sb = sa + A_BYTES;
 #pragma unroll
@@ -180,7 +212,8 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_kernel(const GemmArgs 
                 for (int tm = 0; tm < 2; ++tm)
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[tn], af[tm], acc[tn][tm], 0, 0, 0);
         }
-        if (kt + 1 < nkt) lstore((kt + 1 - kt_begin) & 1);
+        if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (kt + 1 < nkt) lstore((kt + 1 - kt_begin) & 1);
         __syncthreads();
     }
 
@@ -200,7 +233,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_kernel(const GemmArgs 
     }
 }
 
-template <int WM, int WN, bool AKS, bool BKS>
+template <int WM, int WN, bool AKS, bool BKS, bool DMA>
 int launch(const GemmArgs& g, int batch, hipStream_t st) {
     constexpr int BM = WM * 64, BN = WN * 64;
     const int tiles_m = (g.M + BM - 1) / BM;
@@ -210,19 +243,19 @@ int launch(const GemmArgs& g, int batch, hipStream_t st) {
     const size_t lds = 2 * (BM + BN) * 128;
     static bool attr_done = false;   // benign race: idempotent
     if (!attr_done) {
-        hipFuncSetAttribute((const void*)gemm_bf16_kernel<WM, WN, AKS, BKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)gemm_bf16_kernel<WM, WN, AKS, BKS, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, AKS, BKS>), grid, block, lds, st, a);
+    hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, AKS, BKS, DMA>), grid, block, lds, st, a);
     return mmae_check_launch("gemm_bf16");
 }
 
-template <int WM, int WN>
+template <int WM, int WN, bool DMA>
 int dispatch_layout(const GemmArgs& g, int batch, bool aks, bool bks, hipStream_t st) {
-    if (!aks && !bks) return launch<WM, WN, false, false>(g, batch, st);
-    if (!aks && bks) return launch<WM, WN, false, true>(g, batch, st);
-    if (aks && !bks) return launch<WM, WN, true, false>(g, batch, st);
-    return launch<WM, WN, true, true>(g, batch, st);
+    if (!aks && !bks) return launch<WM, WN, false, false, DMA>(g, batch, st);
+    if (!aks && bks) return launch<WM, WN, false, true, DMA>(g, batch, st);
+    if (aks && !bks) return launch<WM, WN, true, false, DMA>(g, batch, st);
+    return launch<WM, WN, true, true, DMA>(g, batch, st);
 }
 
 }  // namespace
@@ -236,8 +269,11 @@ int mmae_gemm_bf16_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t 
     MMAE_REQUIRE(a_rows * d->lda * 2 < 0x7fffffffLL && b_rows * d->ldb * 2 < 0x7fffffffLL, "gemm bf16: operand >= 2 GiB");
     if (d->a_trans) MMAE_REQUIRE(d->M % 8 == 0 || d->lda >= ((d->M + 7) / 8) * 8, "gemm bf16: transposed A row too short");
     if (d->b_trans) MMAE_REQUIRE(d->N % 8 == 0 || d->ldb >= ((d->N + 7) / 8) * 8, "gemm bf16: transposed B row too short");
-    // 128x128 (2 workgroups / CU) measured faster than 256x128 on every shape of the step (profiles/r1)
-    const int tile = d->tile == 2 ? 2 : 1;
-    if (tile == 2) return dispatch_layout<4, 2>(g, d->batch, d->a_trans != 0, d->b_trans != 0, st);
-    return dispatch_layout<2, 2>(g, d->batch, d->a_trans != 0, d->b_trans != 0, st);
+    // tile codes: 0/1 = 128x128 LDS-DMA (default), 2 = 256x128 LDS-DMA, 3 = 128x128 VGPR-staged, 4 = 256x128 VGPR-staged
+    switch (d->tile) {
+        case 2: return dispatch_layout<4, 2, true>(g, d->batch, d->a_trans != 0, d->b_trans != 0, st);
+        case 3: return dispatch_layout<2, 2, false>(g, d->batch, d->a_trans != 0, d->b_trans != 0, st);
+        case 4: return dispatch_layout<4, 2, false>(g, d->batch, d->a_trans != 0, d->b_trans != 0, st);
+        default: return dispatch_layout<2, 2, true>(g, d->batch, d->a_trans != 0, d->b_trans != 0, st);
+    }
 }

@@ -29,7 +29,7 @@ def bench(name, M, N, K, a_trans, b_trans, tile, dtype=torch.bfloat16, iters=20,
 
 if __name__ == '__main__':
     R, Rd = 25344, 50176
-    for tile in (1,):
+    for tile in (1, 3, 2):
         bench('enc qkv fwd', R, 2304, 768, False, False, tile)
         bench('enc proj fwd', R, 768, 768, False, False, tile)
         bench('enc fc1 fwd', R, 3072, 768, False, False, tile)
