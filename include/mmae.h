@@ -81,7 +81,8 @@ typedef struct mmae_gemm_desc {
     int32_t epi;
     int32_t accumulate;          /* C += v (c_dtype must be f32) */
     float alpha;
-    int32_t tile;                /* bf16 kernel variant: 0/1 = 128x128 LDS-DMA, 2 = 256x128 LDS-DMA, 3/4 = same tiles, VGPR-staged */
+    int32_t tile;                /* bf16 kernel variant: 0/1 = 128x128 LDS-DMA, 2 = 256x128 LDS-DMA, 3/4 = same tiles, VGPR-staged,
+                                    5/6 = same tiles, 4-stage LDS-DMA ring with counted vmcnt (BK = 32) */
     int32_t split_k;             /* <= 1: off; n: n K-slices, each writing a dense f32 [M][N] partial into ws,
                                     then summed into C in a fixed order (plain unbatched f32 C only).  The library
                                     never allocates: ask mmae_gemm_auto_splitk() and pass a workspace. */

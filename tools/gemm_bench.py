@@ -29,7 +29,7 @@ def bench(name, M, N, K, a_trans, b_trans, tile, dtype=torch.bfloat16, iters=20,
 
 if __name__ == '__main__':
     R, Rd = 25344, 50176
-    for tile in (1, 3, 2):
+    for tile in (3, 5, 6):
         bench('enc qkv fwd', R, 2304, 768, False, False, tile)
         bench('enc proj fwd', R, 768, 768, False, False, tile)
         bench('enc fc1 fwd', R, 3072, 768, False, False, tile)
@@ -42,12 +42,9 @@ if __name__ == '__main__':
         bench('dec fc1 fwd', Rd, 1024, 256, False, False, tile)
         bench('dec qkv fwd', Rd, 768, 256, False, False, tile)
         bench('dec fc1 dW (TN)', 1024, 256, Rd, True, True, tile)
-        for sp in (1, 4, 16):
-            bench(f'enc fc1 dW split={sp}', 3072, 768, R, True, True, tile, split=sp)
-            bench(f'enc proj dW split={sp}', 768, 768, R, True, True, tile, split=sp)
-    bench('square 4096', 4096, 4096, 4096, False, False, 1)
-    bench('square 4096', 4096, 4096, 4096, False, False, 2)
-    bench('square 8192', 8192, 8192, 8192, False, False, 2)
+    for t in (3, 5, 6):
+        bench('square 4096', 4096, 4096, 4096, False, False, t)
+        bench('square 8192', 8192, 8192, 8192, False, False, t)
     bench('f32 enc qkv fwd', R, 2304, 768, False, False, 0, torch.float32, 5)
     bench('f32 dec fc1 fwd', Rd, 1024, 256, False, False, 0, torch.float32, 5)
     bench('f32 dec fc1 dW', 1024, 256, Rd, True, True, 0, torch.float32, 5)
