@@ -165,19 +165,8 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_pipe_kernel(const Gemm
         }
     }
 
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-        const int m = m0 + wm * 64 + tm * 32 + (lane & 31);
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int n = n0 + wn * 64 + tn * 32 + rg * 8 + (lane >> 5) * 4;
-                f32x4 v = {acc[tn][tm][rg * 4 + 0], acc[tn][tm][rg * 4 + 1], acc[tn][tm][rg * 4 + 2], acc[tn][tm][rg * 4 + 3]};
-                gemm_epilogue4(g, Cz, m, n, v);
-            }
-        }
-    }
+    __syncthreads();                       // the operand ring is dead: reuse it as per-wave staging
+    gemm_store_tile64(g, Cz, smem + wave * 8192, lane, acc, m0 + wm * 64, n0 + wn * 64);
 }
 
 template <int WM, int WN, bool AKS, bool BKS>

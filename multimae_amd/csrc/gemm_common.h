@@ -85,3 +85,30 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, char* Cz, int 
         if (full) { f32x4 t = {v[0], v[1], v[2], v[3]}; st4(c, t); } else for (int j = 0; j < cnt; ++j) c[j] = f32_to_bf16_bits(v[j]);
     }
 }
+
+// Epilogue of one wave's 64x64 output tile (acc[tn][tm], D[i = n][j = m] MFMA layout), staged through
+// a wave-private 8-KiB LDS region so that every global access of the epilogue (C, residual, aux) is a
+// full 128/256-byte row segment: 16 lanes x 4 consecutive columns per row, 4 rows per instruction.
+// (Direct stores from the MFMA layout touch 32 rows x 8 bytes per instruction: measured 1.2 TB/s.)
+// Caller must have passed a workgroup barrier after the last operand read of the LDS ring.
+__device__ __forceinline__ void gemm_store_tile64(const GemmArgs& g, char* Cz, char* wave_lds, int lane, f32x16 (&acc)[2][2],
+                                                  int m_base, int n_base) {
+    const int hi = lane >> 5, ml = lane & 31;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int c16 = tn * 8 + rg * 2 + hi;
+                f32x4 v = {acc[tn][tm][rg * 4 + 0], acc[tn][tm][rg * 4 + 1], acc[tn][tm][rg * 4 + 2], acc[tn][tm][rg * 4 + 3]};
+                *reinterpret_cast<f32x4*>(wave_lds + ml * 256 + ((c16 ^ (ml & 15)) << 4)) = v;
+            }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = it * 4 + (lane >> 4), c16 = lane & 15;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wave_lds + r * 256 + ((c16 ^ (r & 15)) << 4));
+            gemm_epilogue4(g, Cz, m_base + tm * 32 + r, n_base + c16 * 4, v);
+        }
+    }
+}
