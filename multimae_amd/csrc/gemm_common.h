@@ -86,24 +86,117 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, char* Cz, int 
     }
 }
 
-// Epilogue of one wave's 64x64 output tile (acc[tn][tm], D[i = n][j = m] MFMA layout), staged through
-// a wave-private 8-KiB LDS region so that every global access of the epilogue (C, residual, aux) is a
-// full 128/256-byte row segment: 16 lanes x 4 consecutive columns per row, 4 rows per instruction.
-// (Direct stores from the MFMA layout touch 32 rows x 8 bytes per instruction: measured 1.2 TB/s.)
+// ------------------------------------------------------------------------------------------------
+// Epilogue of one wave's 64x64 output tile (acc[tn][tm], D[i = n][j = m] MFMA layout), staged through a
+// wave-private 8-KiB LDS region so that every global access (C, residual, aux) is a full 128/256-byte
+// row segment: 16 lanes x 4 consecutive columns per row, 4 rows per instruction.  The epilogue flavour
+// is a compile-time parameter of the inner loop (chosen once per wave): with run-time flag tests per
+// 4-element group the epilogue was instruction-bound -- ~13 us per output tile regardless of K
+// (rocprof K-sweep, profiles/r01_gemm_ksweep.txt).
 // Caller must have passed a workgroup barrier after the last operand read of the LDS ring.
-__device__ __forceinline__ void gemm_store_tile64(const GemmArgs& g, char* Cz, char* wave_lds, int lane, f32x16 (&acc)[2][2],
-                                                  int m_base, int n_base) {
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stage_acc_tile(char* wave_lds, int lane, const f32x16 (&acc)[2][2], int tm) {
     const int hi = lane >> 5, ml = lane & 31;
 #pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int c16 = tn * 8 + rg * 2 + hi;
+            f32x4 v = {acc[tn][tm][rg * 4 + 0], acc[tn][tm][rg * 4 + 1], acc[tn][tm][rg * 4 + 2], acc[tn][tm][rg * 4 + 3]};
+            *reinterpret_cast<f32x4*>(wave_lds + ml * 256 + ((c16 ^ (ml & 15)) << 4)) = v;
+        }
+}
+
+__device__ __forceinline__ void st4_bf16_hw(uint16_t* p, f32x4 v) {   // v_cvt_pk_bf16_f32 x2 + one 8-byte store
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+    bf16x4_t b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = (__bf16)v[j];
+    *reinterpret_cast<bf16x4_t*>(p) = b;
+}
+
+// fast paths: alpha == 1, N % 4 == 0, every pointer/ld 4-element aligned (g.vec), aux is bf16
+template <bool BIAS, int EPI, bool RESID, bool C_F32, bool ACC>
+__device__ __forceinline__ void store_tile64_fast(const GemmArgs& g, char* Cbase, long long ldc, char* wave_lds, int lane,
+                                                  const f32x16 (&acc)[2][2], int m_base, int n_base) {
+    const int c16 = lane & 15, rsub = lane >> 4;
+    const int n = n_base + c16 * 4;
+    const bool n_ok = n < g.N;
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (BIAS && n_ok) b4 = ld4(g.bias + n);
+#pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
+        stage_acc_tile(wave_lds, lane, acc, tm);
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
+        for (int it = 0; it < 8; ++it) {
+            const int r = it * 4 + rsub;
+            const int m = m_base + tm * 32 + r;
+            f32x4 v = *reinterpret_cast<const f32x4*>(wave_lds + r * 256 + ((c16 ^ (r & 15)) << 4));
+            if (m < g.M && n_ok) {
+                if (BIAS) {
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int c16 = tn * 8 + rg * 2 + hi;
-                f32x4 v = {acc[tn][tm][rg * 4 + 0], acc[tn][tm][rg * 4 + 1], acc[tn][tm][rg * 4 + 2], acc[tn][tm][rg * 4 + 3]};
-                *reinterpret_cast<f32x4*>(wave_lds + ml * 256 + ((c16 ^ (ml & 15)) << 4)) = v;
+                    for (int j = 0; j < 4; ++j) v[j] += b4[j];
+                }
+                if (EPI == MMAE_EPI_GELU) {
+                    st4_bf16_hw((uint16_t*)g.aux + (long long)m * g.ldaux + n, v);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+                } else if (EPI == MMAE_EPI_DGELU) {
+                    const f32x4 p = ld4((const uint16_t*)g.aux + (long long)m * g.ldaux + n);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(p[j]);
+                }
+                if (RESID) {
+                    const f32x4 t = ld4(g.resid + (long long)m * g.ldr + n);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += t[j];
+                }
+                if (C_F32) {
+                    float* c = (float*)Cbase + (long long)m * ldc + n;
+                    if (ACC) { const f32x4 t = ld4(c);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += t[j];
+                    }
+                    st4(c, v);
+                } else {
+                    st4_bf16_hw((uint16_t*)Cbase + (long long)m * ldc + n, v);
+                }
             }
+        }
+    }
+}
+
+__device__ __forceinline__ void gemm_store_tile64(const GemmArgs& g, char* Cz, char* wave_lds, int lane, f32x16 (&acc)[2][2],
+                                                  int m_base, int n_base) {
+    const bool aligned = g.vec && ((g.N & 3) == 0) && g.alpha == 1.0f;
+    if (g.splitk > 1) {                      // dense f32 partial slab
+        if ((g.N & 3) == 0) {
+            store_tile64_fast<false, 0, false, true, false>(g, (char*)(g.ws + (long long)blockIdx.z * g.M * g.N), g.N, wave_lds, lane, acc, m_base, n_base);
+            return;
+        }
+    } else if (aligned) {
+        const bool bias = g.bias != nullptr, resid = g.resid != nullptr;
+        const bool aux_ok = g.epi == MMAE_EPI_NONE || !g.aux_f32;
+        if (aux_ok) {
+            if (!g.c_f32 && !resid && !g.accumulate) {
+                if (g.epi == MMAE_EPI_NONE) {
+                    if (bias) { store_tile64_fast<true, 0, false, false, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }
+                    store_tile64_fast<false, 0, false, false, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return;
+                }
+                if (g.epi == MMAE_EPI_GELU && bias) { store_tile64_fast<true, MMAE_EPI_GELU, false, false, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }
+                if (g.epi == MMAE_EPI_DGELU && !bias) { store_tile64_fast<false, MMAE_EPI_DGELU, false, false, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }
+            } else if (g.c_f32 && g.epi == MMAE_EPI_NONE) {
+                if (bias && resid && !g.accumulate) { store_tile64_fast<true, 0, true, true, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }
+                if (bias && !resid && !g.accumulate) { store_tile64_fast<true, 0, false, true, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }
+                if (!bias && !resid && !g.accumulate) { store_tile64_fast<false, 0, false, true, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }
+                if (!bias && !resid && g.accumulate) { store_tile64_fast<false, 0, false, true, true>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }
+            }
+        }
+    }
+    // generic path: any flag combination, ragged N, unaligned pointers
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+        stage_acc_tile(wave_lds, lane, acc, tm);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int r = it * 4 + (lane >> 4), c16 = lane & 15;
