@@ -9,6 +9,7 @@
 //    ("k-strided": dW = dY^T X, P.V, ...): its fragments are then fetched with the
 //    gfx950 transposing LDS read ds_read_b64_tr_b16.
 //  * the MFMA is issued as D[n][m] so that a lane owns 4 consecutive n of one row m.
+#include <stdlib.h>
 #include "gemm_common.h"
 
 #define LDS_AS __attribute__((address_space(3)))
@@ -261,7 +262,8 @@ int mmae_gemm_bf16_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t 
     if (d->a_trans) MMAE_REQUIRE(d->M % 8 == 0 || d->lda >= ((d->M + 7) / 8) * 8, "gemm bf16: transposed A row too short");
     if (d->b_trans) MMAE_REQUIRE(d->N % 8 == 0 || d->ldb >= ((d->N + 7) / 8) * 8, "gemm bf16: transposed B row too short");
     // tile codes: 0/1 = 128x128 LDS-DMA (default), 2 = 256x128 LDS-DMA, 3 = 128x128 VGPR-staged, 4 = 256x128 VGPR-staged
-    switch (d->tile) {
+    static const int env_tile = getenv("MMAE_GEMM_TILE") ? atoi(getenv("MMAE_GEMM_TILE")) : 3;   // default: 128x128 VGPR-staged (fastest in the r01 K-sweep)
+    switch (d->tile ? d->tile : env_tile) {
         case 5: case 6: return mmae_gemm_bf16_pipe_impl(d, g, st);     // 4-stage LDS-DMA ring, BK = 32
         case 2: return dispatch_layout<4, 2, true>(g, d->batch, d->a_trans != 0, d->b_trans != 0, st);
         case 3: return dispatch_layout<2, 2, false>(g, d->batch, d->a_trans != 0, d->b_trans != 0, st);
