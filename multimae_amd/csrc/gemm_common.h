@@ -116,7 +116,7 @@ __device__ __forceinline__ void st4_bf16_hw(uint16_t* p, f32x4 v) {   // v_cvt_p
 }
 
 // fast paths: alpha == 1, N % 4 == 0, every pointer/ld 4-element aligned (g.vec), aux is bf16
-template <bool BIAS, int EPI, bool RESID, bool C_F32, bool ACC>
+template <bool BIAS, int EPI, bool RESID, bool C_F32, bool ACC, bool AUX_F32 = false>
 __device__ __forceinline__ void store_tile64_fast(const GemmArgs& g, char* Cbase, long long ldc, char* wave_lds, int lane,
                                                   const f32x16 (&acc)[2][2], int m_base, int n_base) {
     const int c16 = lane & 15, rsub = lane >> 4;
@@ -138,11 +138,13 @@ __device__ __forceinline__ void store_tile64_fast(const GemmArgs& g, char* Cbase
                     for (int j = 0; j < 4; ++j) v[j] += b4[j];
                 }
                 if (EPI == MMAE_EPI_GELU) {
-                    st4_bf16_hw((uint16_t*)g.aux + (long long)m * g.ldaux + n, v);
+                    if (AUX_F32) st4((float*)g.aux + (long long)m * g.ldaux + n, v);
+                    else st4_bf16_hw((uint16_t*)g.aux + (long long)m * g.ldaux + n, v);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
                 } else if (EPI == MMAE_EPI_DGELU) {
-                    const f32x4 p = ld4((const uint16_t*)g.aux + (long long)m * g.ldaux + n);
+                    const f32x4 p = AUX_F32 ? ld4((const float*)g.aux + (long long)m * g.ldaux + n)
+                                            : ld4((const uint16_t*)g.aux + (long long)m * g.ldaux + n);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(p[j]);
                 }
@@ -177,6 +179,10 @@ __device__ __forceinline__ void gemm_store_tile64(const GemmArgs& g, char* Cz, c
     } else if (aligned) {
         const bool bias = g.bias != nullptr, resid = g.resid != nullptr;
         const bool aux_ok = g.epi == MMAE_EPI_NONE || !g.aux_f32;
+        if (!aux_ok && g.c_f32 && !resid && !g.accumulate) {      // exact-f32 mode: f32 C and f32 aux
+            if (g.epi == MMAE_EPI_GELU && bias) { store_tile64_fast<true, MMAE_EPI_GELU, false, true, false, true>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }
+            if (g.epi == MMAE_EPI_DGELU && !bias) { store_tile64_fast<false, MMAE_EPI_DGELU, false, true, false, true>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }
+        }
         if (aux_ok) {
             if (!g.c_f32 && !resid && !g.accumulate) {
                 if (g.epi == MMAE_EPI_NONE) {
