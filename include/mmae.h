@@ -31,6 +31,8 @@ extern "C" {
 
 #define MMAE_F32  0
 #define MMAE_BF16 1
+#define MMAE_F32X3 2   /* GEMM only: f32 operands in memory, multiplied as split bf16 (hi+lo) on the bf16 MFMA:
+                        a.b ~= ah.bh + ah.bl + al.bh, fp32 accumulate (~16 operand mantissa bits, > TF32) */
 
 #define MMAE_EINVAL   (-1)   /* bad argument (shape / alignment / dtype)        */
 #define MMAE_ELAUNCH  (-2)   /* hipLaunchKernel reported an error               */
@@ -65,7 +67,7 @@ const char* mmae_last_error(void);
 
 typedef struct mmae_gemm_desc {
     const void* A; const void* B; void* C;
-    int32_t ab_dtype;            /* MMAE_F32 | MMAE_BF16 */
+    int32_t ab_dtype;            /* MMAE_F32 | MMAE_BF16 | MMAE_F32X3 */
     int32_t c_dtype;             /* MMAE_F32 | MMAE_BF16 */
     int32_t M, N, K;
     int32_t a_trans, b_trans;

@@ -19,7 +19,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_PKG), 'include', 'mmae.h')
 LIB_PATH = os.path.join(_PKG, 'libmmae_hip.so')
 
-F32, BF16 = 0, 1
+F32, BF16, F32X3 = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
 
 

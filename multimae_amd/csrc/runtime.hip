@@ -22,6 +22,7 @@ int mmae_check_launch(const char* what) {
 
 int mmae_gemm_bf16_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st);
 int mmae_gemm_f32_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st);
+int mmae_gemm_f32x3_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st);
 int mmae_splitk_reduce(const float* ws, float* C, int M, int N, long long ldc, int splits, int accumulate, hipStream_t st);
 
 extern "C" {
@@ -33,7 +34,7 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     MMAE_REQUIRE(d && d->A && d->B && d->C, "gemm: null operand");
     MMAE_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: empty problem");
     MMAE_REQUIRE(d->batch >= 1 && d->batch <= 65535 && d->batch_inner >= 1, "gemm: bad batch");
-    MMAE_REQUIRE(d->ab_dtype == MMAE_F32 || d->ab_dtype == MMAE_BF16, "gemm: bad ab_dtype");
+    MMAE_REQUIRE(d->ab_dtype == MMAE_F32 || d->ab_dtype == MMAE_BF16 || d->ab_dtype == MMAE_F32X3, "gemm: bad ab_dtype");
     MMAE_REQUIRE(d->c_dtype == MMAE_F32 || d->c_dtype == MMAE_BF16, "gemm: bad c_dtype");
     MMAE_REQUIRE(!(d->accumulate && d->c_dtype != MMAE_F32), "gemm: accumulate needs f32 C");
     MMAE_REQUIRE(!(d->epi != MMAE_EPI_NONE && !d->aux), "gemm: epilogue needs aux");
@@ -61,7 +62,7 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     // split-K: the dW-type products (small M x N, K = all rows of the batch) would otherwise occupy
     // a handful of the 256 CUs.  Each K slice writes a dense f32 partial slab into the caller's
     // workspace; a second launch sums the slabs into C in a fixed order (deterministic).
-    const int bk = d->ab_dtype == MMAE_BF16 ? 64 : 16;
+    const int bk = d->ab_dtype == MMAE_F32 ? 16 : 64;
     const int nkt = (d->K + bk - 1) / bk;
     int splitk = d->split_k > 1 ? d->split_k : 1;
     if (splitk > 1) {
@@ -74,13 +75,14 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     g.kt_per_split = (nkt + splitk - 1) / splitk;
     g.splitk = (nkt + g.kt_per_split - 1) / g.kt_per_split;
     g.ws = (float*)d->ws;
-    int rc = (d->ab_dtype == MMAE_BF16) ? mmae_gemm_bf16_impl(d, g, st) : mmae_gemm_f32_impl(d, g, st);
+    int rc = (d->ab_dtype == MMAE_BF16) ? mmae_gemm_bf16_impl(d, g, st)
+           : (d->ab_dtype == MMAE_F32X3 ? mmae_gemm_f32x3_impl(d, g, st) : mmae_gemm_f32_impl(d, g, st));
     if (rc || g.splitk <= 1) return rc;
     return mmae_splitk_reduce(g.ws, (float*)d->C, d->M, d->N, d->ldc, g.splitk, d->accumulate, st);
 }
 
 int mmae_gemm_auto_splitk(int M, int N, int K, int ab_dtype) {
-    const int bk = ab_dtype == MMAE_BF16 ? 64 : 16;
+    const int bk = ab_dtype == MMAE_F32 ? 16 : 64;
     const int nkt = (K + bk - 1) / bk;
     const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
     if (tiles >= 384 || nkt < 32) return 1;

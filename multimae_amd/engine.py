@@ -26,6 +26,7 @@ ALIGN = 64  # elements
 _state = {
     'act_dtype': torch.bfloat16,     # bf16 speed mode | float32 exact parity mode
     'direct_grads': False,           # backward accumulates straight into p.grad and returns None
+    'fp32_adapter_gemm': 'x3',       # GEMMs of fp32_output_adapters in bf16 speed mode: 'x3' (split bf16) | 'exact'
 }
 
 
@@ -49,6 +50,17 @@ def precision(mode: str):
         yield
     finally:
         _state['act_dtype'] = old
+
+
+def fp32_adapter_gemm() -> str:
+    return _state['fp32_adapter_gemm']
+
+
+def set_fp32_adapter_gemm(mode: str) -> None:
+    """'x3': f32 operands multiplied as split bf16 (a_hi.b_hi + a_hi.b_lo + a_lo.b_hi, fp32 accumulate; ~16 mantissa bits,
+    above TF32).  'exact': f32-input MFMA (bit-level fmaf chain, 1/16 the bf16 rate)."""
+    assert mode in ('x3', 'exact')
+    _state['fp32_adapter_gemm'] = mode
 
 
 def direct_grads() -> bool:

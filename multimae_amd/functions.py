@@ -266,6 +266,16 @@ class SpatialAdapterFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg: _Cfg, enc: Tensor, ids_keep: Tensor, ids_restore: Tensor, *params):
+        with ops.f32_gemm_mode(getattr(cfg, 'f32_gemm', 'exact')):
+            return SpatialAdapterFn._forward(ctx, cfg, enc, ids_keep, ids_restore, *params)
+
+    @staticmethod
+    def backward(ctx, d_img: Tensor):
+        with ops.f32_gemm_mode(getattr(ctx.cfg, 'f32_gemm', 'exact')):
+            return SpatialAdapterFn._backward(ctx, d_img)
+
+    @staticmethod
+    def _forward(ctx, cfg: _Cfg, enc: Tensor, ids_keep: Tensor, ids_restore: Tensor, *params):
         ops._require_gpu(enc, 'encoder tokens')
         act, wc, D, G, heads, eps = cfg.act, cfg.wc, cfg.D, cfg.G, cfg.heads, cfg.eps
         T = len(cfg.task_offsets) - 1
@@ -317,7 +327,7 @@ class SpatialAdapterFn(torch.autograd.Function):
         return img
 
     @staticmethod
-    def backward(ctx, d_img: Tensor):
+    def _backward(ctx, d_img: Tensor):
         cfg, params = ctx.cfg, ctx.params
         ids_keep, ids_restore = ctx.ids
         B, NC, Denc, n_keep, n_q, T = ctx.dims

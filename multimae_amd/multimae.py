@@ -242,10 +242,16 @@ class MultiMAE(nn.Module):
         for domain in self.output_adapters:
             # reference: adapters listed in fp32_output_adapters run with autocast disabled (:367-377);
             # here they run on the exact-f32 MFMA path
-            act = torch.float32 if domain in fp32_output_adapters else None
+            # here: f32 activations; in bf16 speed mode their GEMMs run as split-bf16 ("x3", >= TF32 precision -- what
+            # the reference's fp32 adapters got on A100 with torch 1.10's allow_tf32 default), in the fp32 parity mode
+            # on the exact-f32 MFMA path
+            fp32 = domain in fp32_output_adapters
+            speed = engine.act_dtype() == torch.bfloat16
             preds[domain] = self.output_adapters[domain](encoder_tokens=encoder_tokens, input_info=input_info,
-                                                         ids_keep=ids_keep, ids_restore=ids_restore, act_dtype=act,
-                                                         on_done=self._adapter_done_cb(domain))
+                                                         ids_keep=ids_keep, ids_restore=ids_restore,
+                                                         act_dtype=torch.float32 if fp32 else None,
+                                                         on_done=self._adapter_done_cb(domain),
+                                                         f32_gemm='x3' if (fp32 and speed and engine.fp32_adapter_gemm() == 'x3') else 'exact')
         return preds, task_masks
 
     # hooks used by dist.GradAllReducer to launch bucketed all-reduces while backward is still running

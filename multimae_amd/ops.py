@@ -12,7 +12,9 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, EPI_NONE, EPI_GELU, EPI_DGELU, GemmDesc, PatchSrc, check
+import contextlib
+
+from ._lib import BF16, F32, F32X3, EPI_NONE, EPI_GELU, EPI_DGELU, GemmDesc, PatchSrc, check
 
 Tensor = torch.Tensor
 
@@ -44,6 +46,24 @@ def round_up(x: int, m: int) -> int:
 
 
 # --------------------------------------------------------------------------- GEMM --
+_F32_GEMM = ['exact']
+
+
+@contextlib.contextmanager
+def f32_gemm_mode(mode: str):
+    """How GEMMs with f32 operands are multiplied inside the block: 'exact' (f32-input MFMA, the parity mode)
+    or 'x3' (split-bf16 on the bf16 MFMA: >= TF32 precision at ~4x the speed; used for fp32_output_adapters
+    in bf16 speed mode)."""
+    assert mode in ('exact', 'x3')
+    old = _F32_GEMM[0]
+    _F32_GEMM[0] = mode
+    try:
+        yield
+    finally:
+        _F32_GEMM[0] = old
+
+
+
 def gemm(A: Tensor, B: Tensor, C: Tensor, M: int, N: int, K: int, *, lda: int, ldb: int, ldc: int,
          a_trans: bool = False, b_trans: bool = False, a_off: int = 0, b_off: int = 0, c_off: int = 0,
          batch: int = 1, batch_inner: int = 1, sA=(0, 0), sB=(0, 0), sC=(0, 0),
@@ -60,6 +80,8 @@ def gemm(A: Tensor, B: Tensor, C: Tensor, M: int, N: int, K: int, *, lda: int, l
     d.B = B.data_ptr() + b_off * esz_ab
     d.C = C.data_ptr() + c_off * esz_c
     d.ab_dtype, d.c_dtype = dcode(A.dtype), dcode(C.dtype)
+    if d.ab_dtype == F32 and _F32_GEMM[0] == 'x3' and lda % 4 == 0 and ldb % 4 == 0:
+        d.ab_dtype = F32X3
     d.M, d.N, d.K = M, N, K
     d.a_trans, d.b_trans = int(a_trans), int(b_trans)
     d.lda, d.ldb, d.ldc = lda, ldb, ldc
