@@ -87,3 +87,56 @@ def test_input_info_and_sincos_match_oracle():
     info = m.generate_input_info({'rgb': 16, 'depth': 16, 'semseg': 16}, (32, 32))
     assert info['tasks']['depth'] == {'num_tokens': 16, 'has_2d_posemb': True, 'start_idx': 16, 'end_idx': 32}
     assert info['num_task_tokens'] == 48 and info['num_global_tokens'] == 1
+
+
+def test_dropin_package_import_surface(tmp_path):
+    """dropin/ makes the engine importable as `multimae` with the reference's import lines
+    (run_pretraining_multimae.py:36-40) and registers the factories in a live utils.registry."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # a stand-in for the reference's utils.registry (same private dict name as utils/registry.py:22)
+    (tmp_path / 'utils').mkdir()
+    (tmp_path / 'utils' / '__init__.py').write_text('')
+    (tmp_path / 'utils' / 'registry.py').write_text('_model_entrypoints = {}\n')
+    code = (
+        'import utils.registry\n'
+        'from multimae import multimae\n'
+        'from multimae.criterion import MaskedCrossEntropyLoss, MaskedL1Loss, MaskedMSELoss\n'
+        'from multimae.input_adapters import PatchedInputAdapter, SemSegInputAdapter\n'
+        'from multimae.output_adapters import SpatialOutputAdapter\n'
+        'from multimae.multimae import pretrain_multimae_base, MultiViT\n'
+        'assert set(utils.registry._model_entrypoints) >= {"pretrain_multimae_base", "pretrain_multimae_large", "multivit_base", "multivit_large"}\n'
+        'm = utils.registry._model_entrypoints["pretrain_multimae_base"](input_adapters={"rgb": PatchedInputAdapter(3, 1, 16)}, output_adapters=None)\n'
+        'assert type(m).__module__ == "multimae_amd.multimae" and len(m.encoder) == 12\n'
+        'print("ok")\n')
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, 'dropin'), str(tmp_path)]))
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/utils'), reason='reference checkout not present (GPU box)')
+def test_reference_create_model_resolves_to_engine():
+    """The reference's OWN utils.model_builder.create_model / utils.registry (unmodified files, imported through the
+    Appendix-B stub so utils/__init__.py's torchvision import never runs) builds the engine's MultiMAE when
+    dropin/ is first on sys.path -- the call run_pretraining_multimae.py:285-291 makes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        'import sys, types\n'
+        'pkg = types.ModuleType("utils"); pkg.__path__ = ["/root/reference/utils"]; sys.modules["utils"] = pkg\n'
+        'from multimae import multimae\n'
+        'from multimae.input_adapters import PatchedInputAdapter, SemSegInputAdapter\n'
+        'from multimae.output_adapters import SpatialOutputAdapter\n'
+        'from utils.model_builder import create_model\n'
+        'ins = {"rgb": PatchedInputAdapter(num_channels=3, stride_level=1, patch_size_full=16)}\n'
+        'outs = {"rgb": SpatialOutputAdapter(num_channels=3, stride_level=1, patch_size_full=16, dim_tokens=256, depth=2, num_heads=8,\n'
+        '                                   use_task_queries=True, task="rgb", context_tasks=["rgb"], use_xattn=True)}\n'
+        'm = create_model("pretrain_multimae_base", input_adapters=ins, output_adapters=outs, num_global_tokens=1, drop_path_rate=0.0)\n'
+        'assert type(m).__module__ == "multimae_amd.multimae", type(m)\n'
+        'assert m.get_num_layers() == 12 and "global_tokens" in m.no_weight_decay()\n'
+        'print("ok")\n')
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, 'dropin'), PYTHONDONTWRITEBYTECODE='1')
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-2000:]
