@@ -24,6 +24,14 @@ def register_model(fn: Callable) -> Callable:
         elif fn.__name__ not in names:
             names.append(fn.__name__)
     ext = sys.modules.get('utils.registry')
+    if ext is None:
+        # deployed next to the reference tree: its registry is importable as utils.registry (the reference's own
+        # multimae/multimae.py:28 imports it at this point too)
+        try:
+            import importlib
+            ext = importlib.import_module('utils.registry')
+        except Exception:
+            ext = None
     if ext is not None and hasattr(ext, '_model_entrypoints'):
         ext._model_entrypoints[fn.__name__] = fn        # live reference registry: take over the name
     return fn
