@@ -90,6 +90,8 @@ typedef struct mmae_gemm_desc {
                                     never allocates: ask mmae_gemm_auto_splitk() and pass a workspace. */
     void* ws;                    /* f32 workspace of ws_elems >= split_k * M * N elements (split_k > 1) */
     int64_t ws_elems;
+    float* colsum_part;          /* optional f32 [ceil(M/64)][N]: per-64-row-block column sums of the epilogue output
+                                    (bias gradient of the next Linear for free); dGELU epilogue only, else must be NULL */
 } mmae_gemm_desc;
 
 int mmae_gemm(const mmae_gemm_desc* d, void* stream);
@@ -102,9 +104,10 @@ int mmae_gemm_auto_splitk(int M, int N, int K, int ab_dtype);
  * output_adapters.py:120-122,265-266.
  *   fwd:  y = (x-mean)*rstd*gamma+beta;   x f32 [R][D]; y act dtype; saves mean,rstd
  *   bwd:  dx_out = (dx_in ? dx_in : 0) + LN'(dy);  also writes an act-dtype copy
- *         dx_act (may be NULL); accumulates per-block partial dgamma/dbeta into
- *         part[nblk][2][D] (nblk = mmae_layernorm_bwd_nblk(R)), reduced by
- *         mmae_colsum_partials.
+ *         dx_act (may be NULL); writes per-block partial sums part[nblk][3][D]
+ *         (nblk = mmae_layernorm_bwd_nblk(R)): dgamma, dbeta and the column sums of dx_out
+ *         (= bias gradient of the Linear that produced this residual-stream value),
+ *         reduced by mmae_colsum / mmae_colsum_partials.
  * ------------------------------------------------------------------------- */
 int mmae_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype,
                        float* mean, float* rstd, int64_t R, int D, float eps, void* stream);

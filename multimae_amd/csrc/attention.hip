@@ -39,10 +39,10 @@ template <> __device__ __forceinline__ int tile_off<32>(int row, int c) {
 
 // rows [0, nrows) of a [.., HD] slice (row stride `sr` elements) -> LDS tile of nrows_pad rows (zero padded)
 template <int HD>
-__device__ __forceinline__ void load_tile(char* lds, const uint16_t* base, long long sr, int nrows, int nrows_pad, int tid) {
+__device__ __forceinline__ void load_tile(char* lds, const uint16_t* base, long long sr, int nrows, int nrows_pad, int tid, int nthr = 256) {
     const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x80000000, 0x00020000);
     constexpr int CPR = HD / 8;
-    for (int c = tid; c < nrows_pad * CPR; c += 256) {
+    for (int c = tid; c < nrows_pad * CPR; c += nthr) {
         const int row = c / CPR, ch = c % CPR;
         const unsigned off = row < nrows ? (unsigned)((row * sr + ch * 8) * 2) : OOB;
         *reinterpret_cast<i32x4*>(lds + tile_off<HD>(row, ch)) = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
@@ -165,8 +165,10 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// 512 threads: after the shared prologue (tiles -> LDS, delta), waves 0-3 run pass 1 and waves 4-7 run
+// pass 2 concurrently (the passes only read LDS and write disjoint outputs).
 template <int HD>
-__global__ void __launch_bounds__(256) attn_bwd_kernel(const AttnArgs a) {
+__global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -180,17 +182,17 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const AttnArgs a) {
     const uint16_t* qg = a.q + b * a.q_sb + h * HD;
     const uint16_t* og = a.o + b * a.o_sb + h * HD;
     const uint16_t* dog = a.d_o + b * a.o_sb + h * HD;
-    load_tile<HD>(Qs, qg, a.q_sr, a.Nq, a.nqp, tid);
-    load_tile<HD>(dOs, dog, a.o_sr, a.Nq, a.nqp, tid);
-    load_tile<HD>(Ks, a.k + b * a.k_sb + h * HD, a.k_sr, a.Nk, a.nkp, tid);
-    load_tile<HD>(Vs, a.v + b * a.v_sb + h * HD, a.v_sr, a.Nk, a.nkp, tid);
-    for (int q = tid; q < a.nqp; q += 256) lse_s[q] = q < a.Nq ? a.lse[((long long)b * a.H + h) * a.Nq + q] : 0.f;
+    load_tile<HD>(Qs, qg, a.q_sr, a.Nq, a.nqp, tid, 512);
+    load_tile<HD>(dOs, dog, a.o_sr, a.Nq, a.nqp, tid, 512);
+    load_tile<HD>(Ks, a.k + b * a.k_sb + h * HD, a.k_sr, a.Nk, a.nkp, tid, 512);
+    load_tile<HD>(Vs, a.v + b * a.v_sb + h * HD, a.v_sr, a.Nk, a.nkp, tid, 512);
+    for (int q = tid; q < a.nqp; q += 512) lse_s[q] = q < a.Nq ? a.lse[((long long)b * a.H + h) * a.Nq + q] : 0.f;
     const int nt = a.nkp >> 5, nqb = a.nqp >> 5;
     const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)qg, 0, 0x80000000, 0x00020000);
     const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void*)og, 0, 0x80000000, 0x00020000);
     const auto rsdO = __builtin_amdgcn_make_buffer_rsrc((void*)dog, 0, 0x80000000, 0x00020000);
     // delta[q] = sum_d dO[q][d] * O[q][d]
-    for (int qblk = wave; qblk < nqb; qblk += 4) {
+    for (int qblk = wave; qblk < nqb; qblk += 8) {
         const int q = qblk * 32 + (lane & 31);
         const bool qok = q < a.Nq;
         float d = 0.f;
@@ -205,8 +207,8 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const AttnArgs a) {
     }
     __syncthreads();
 
-    // ---- pass 1: lane = query row -> dQ
-    for (int qblk = wave; qblk < nqb; qblk += 4) {
+    // ---- pass 1 (waves 0-3): lane = query row -> dQ
+    for (int qblk = wave; wave < 4 && qblk < nqb; qblk += 4) {
         const int q = qblk * 32 + (lane & 31);
         const bool qok = q < a.Nq;
         bf16x8 qf[HD / 16], dof[HD / 16];
@@ -250,8 +252,8 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const AttnArgs a) {
         }
     }
 
-    // ---- pass 2: lane = key row -> dK, dV
-    for (int kblk = wave; kblk < nt; kblk += 4) {
+    // ---- pass 2 (waves 4-7): lane = key row -> dK, dV
+    for (int kblk = wave - 4; wave >= 4 && kblk < nt; kblk += 4) {
         const int key = kblk * 32 + (lane & 31);
         bf16x8 kf[HD / 16], vf[HD / 16];
 #pragma unroll
@@ -357,7 +359,7 @@ int mmae_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
     a.scale = scale;
     const size_t lds = (size_t)2 * (a.nqp + a.nkp) * hd * 2 + (size_t)2 * a.nqp * 4;
     hipStream_t st_ = (hipStream_t)stream;
-    dim3 grid(B * H), block(256);
+    dim3 grid(B * H), block(512);
     if (hd == 64) {
         hipFuncSetAttribute((const void*)attn_bwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((attn_bwd_kernel<64>), grid, block, lds, st_, a);

@@ -16,6 +16,7 @@ struct GemmArgs {
     int tiles_n;
     int splitk, kt_per_split;     // splitk > 1: z-slice s writes its partial product to ws[s][M][N] (f32)
     float* ws;
+    float* colpart;               // optional [ceil(M/64)][N] column sums of the epilogue output (dGELU flavour)
 };
 
 // The kernels compute D[i = n][j = m] (B fragment as the MFMA "A" operand) so that one lane
@@ -116,13 +117,14 @@ __device__ __forceinline__ void st4_bf16_hw(uint16_t* p, f32x4 v) {   // v_cvt_p
 }
 
 // fast paths: alpha == 1, N % 4 == 0, every pointer/ld 4-element aligned (g.vec), aux is bf16
-template <bool BIAS, int EPI, bool RESID, bool C_F32, bool ACC, bool AUX_F32 = false>
+template <bool BIAS, int EPI, bool RESID, bool C_F32, bool ACC, bool AUX_F32 = false, bool COLSUM = false>
 __device__ __forceinline__ void store_tile64_fast(const GemmArgs& g, char* Cbase, long long ldc, char* wave_lds, int lane,
                                                   const f32x16 (&acc)[2][2], int m_base, int n_base) {
     const int c16 = lane & 15, rsub = lane >> 4;
     const int n = n_base + c16 * 4;
     const bool n_ok = n < g.N;
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
     if (BIAS && n_ok) b4 = ld4(g.bias + n);
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
@@ -153,6 +155,10 @@ __device__ __forceinline__ void store_tile64_fast(const GemmArgs& g, char* Cbase
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] += t[j];
                 }
+                if (COLSUM) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cs[j] += v[j];
+                }
                 if (C_F32) {
                     float* c = (float*)Cbase + (long long)m * ldc + n;
                     if (ACC) { const f32x4 t = ld4(c);
@@ -165,6 +171,11 @@ __device__ __forceinline__ void store_tile64_fast(const GemmArgs& g, char* Cbase
                 }
             }
         }
+    }
+    if (COLSUM) {       // the 4 lanes that share a column group (rsub = 0..3) -> one 64-row partial per column
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { cs[j] += __shfl_xor(cs[j], 16, 64); cs[j] += __shfl_xor(cs[j], 32, 64); }
+        if (rsub == 0 && n_ok && m_base < g.M) st4(g.colpart + (long long)(m_base >> 6) * g.N + n, cs);
     }
 }
 
@@ -181,7 +192,11 @@ __device__ __forceinline__ void gemm_store_tile64(const GemmArgs& g, char* Cz, c
         const bool aux_ok = g.epi == MMAE_EPI_NONE || !g.aux_f32;
         if (!aux_ok && g.c_f32 && !resid && !g.accumulate) {      // exact-f32 mode: f32 C and f32 aux
             if (g.epi == MMAE_EPI_GELU && bias) { store_tile64_fast<true, MMAE_EPI_GELU, false, true, false, true>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }
-            if (g.epi == MMAE_EPI_DGELU && !bias) { store_tile64_fast<false, MMAE_EPI_DGELU, false, true, false, true>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }
+            if (g.epi == MMAE_EPI_DGELU && !bias) {
+                if (g.colpart) store_tile64_fast<false, MMAE_EPI_DGELU, false, true, false, true, true>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base);
+                else store_tile64_fast<false, MMAE_EPI_DGELU, false, true, false, true>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base);
+                return;
+            }
         }
         if (aux_ok) {
             if (!g.c_f32 && !resid && !g.accumulate) {
@@ -190,7 +205,11 @@ __device__ __forceinline__ void gemm_store_tile64(const GemmArgs& g, char* Cz, c
                     store_tile64_fast<false, 0, false, false, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return;
                 }
                 if (g.epi == MMAE_EPI_GELU && bias) { store_tile64_fast<true, MMAE_EPI_GELU, false, false, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }
-                if (g.epi == MMAE_EPI_DGELU && !bias) { store_tile64_fast<false, MMAE_EPI_DGELU, false, false, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }
+                if (g.epi == MMAE_EPI_DGELU && !bias) {
+                    if (g.colpart) store_tile64_fast<false, MMAE_EPI_DGELU, false, false, false, false, true>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base);
+                    else store_tile64_fast<false, MMAE_EPI_DGELU, false, false, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base);
+                    return;
+                }
             } else if (g.c_f32 && g.epi == MMAE_EPI_NONE) {
                 if (bias && resid && !g.accumulate) { store_tile64_fast<true, 0, true, true, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }
                 if (bias && !resid && !g.accumulate) { store_tile64_fast<true, 0, false, true, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }

@@ -56,7 +56,8 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x
 // ------------------------------------------------------------------------------------------
 // LayerNorm backward.  Each block walks rows block-stride; each wave keeps dgamma/dbeta
 // partial sums for its column chunks in registers; the 4 waves are combined through LDS and
-// the block writes part[blk][0][D] (dgamma) and part[blk][1][D] (dbeta).
+// the block writes part[blk][0][D] (dgamma), part[blk][1][D] (dbeta) and part[blk][2][D] (column sums of
+// dx_out = the bias gradient of the Linear whose output this residual-stream gradient is).
 // ------------------------------------------------------------------------------------------
 template <int NV, typename DT, typename AT>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const DT* __restrict__ dy, const float* __restrict__ x,
@@ -64,15 +65,16 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const DT* __restrict__ dy, 
                                                      const float* __restrict__ rstd, const float* __restrict__ dx_in,
                                                      float* __restrict__ dx_out, AT* __restrict__ dx_act,
                                                      float* __restrict__ part, long long R, int D) {
-    __shared__ float red[4][2][1024];
+    __shared__ float red[4][3][1024];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    f32x4 g[NV], dg[NV], db[NV];
+    f32x4 g[NV], dg[NV], db[NV], dxs[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 4;
         g[i] = (c < D) ? ld4(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dxs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (long long row = (long long)blockIdx.x * 4 + w; row < R; row += (long long)gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
@@ -110,6 +112,8 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const DT* __restrict__ dy, 
                 }
                 st4(dx_out + row * D + c, o);
                 if (dx_act) st4(dx_act + row * D + c, o);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dxs[i][j] += o[j];
             }
         }
     }
@@ -118,13 +122,13 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const DT* __restrict__ dy, 
         const int c = (lane + 64 * i) * 4;
         if (c < D) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { red[w][0][c + j] = dg[i][j]; red[w][1][c + j] = db[i][j]; }
+            for (int j = 0; j < 4; ++j) { red[w][0][c + j] = dg[i][j]; red[w][1][c + j] = db[i][j]; red[w][2][c + j] = dxs[i][j]; }
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * D; c += 256) {
+    for (int c = threadIdx.x; c < 3 * D; c += 256) {
         const int k = c / D, cc = c % D;
-        part[((long long)blockIdx.x * 2 + k) * D + cc] = (red[0][k][cc] + red[1][k][cc]) + (red[2][k][cc] + red[3][k][cc]);
+        part[((long long)blockIdx.x * 3 + k) * D + cc] = (red[0][k][cc] + red[1][k][cc]) + (red[2][k][cc] + red[3][k][cc]);
     }
 }
 

@@ -51,6 +51,10 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     g.c_f32 = d->c_dtype == MMAE_F32; g.aux_f32 = d->aux_dtype == MMAE_F32;
     g.epi = d->epi; g.accumulate = d->accumulate; g.alpha = d->alpha;
     g.tiles_n = 0;
+    g.colpart = d->colsum_part;
+    MMAE_REQUIRE(!d->colsum_part || (d->epi == MMAE_EPI_DGELU && !d->bias && !d->resid && !d->accumulate && d->batch == 1 && d->split_k <= 1 &&
+                                     d->alpha == 1.0f && d->N % 4 == 0) ,
+                 "gemm: colsum_part is only supported with the plain dGELU epilogue");
     // vector (4-element) epilogue accesses need every touched row start 4-element aligned
     bool vec = (d->ldc % 4 == 0) && (d->sC_outer % 4 == 0) && (d->sC_inner % 4 == 0) &&
                ((uintptr_t)d->C % 16 == 0);
@@ -58,6 +62,7 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     if (d->resid) vec = vec && (d->ldr % 4 == 0) && ((uintptr_t)d->resid % 16 == 0);
     if (d->aux) vec = vec && (d->ldaux % 4 == 0) && ((uintptr_t)d->aux % 16 == 0);
     g.vec = vec ? 1 : 0;
+    MMAE_REQUIRE(!d->colsum_part || (vec && ((uintptr_t)d->colsum_part % 16 == 0)), "gemm: colsum_part needs 4-element aligned C/aux");
     hipStream_t st = (hipStream_t)stream;
     // split-K: the dW-type products (small M x N, K = all rows of the batch) would otherwise occupy
     // a handful of the 256 CUs.  Each K slice writes a dense f32 partial slab into the caller's

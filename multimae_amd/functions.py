@@ -88,27 +88,30 @@ def block_fwd(x: Tensor, P: Sequence[Tensor], wc, heads: int, eps: float, act, B
     return x2, saved
 
 
-def block_bwd(dx: Tensor, dx_act: Tensor, saved, P: Sequence[Tensor], wc, sink: GradSink, heads: int, act, B: int, N: int):
-    """dx f32 [R,D] (+ its act-dtype copy) -> (dx0, dx0_act, 12 parameter grads)."""
+def block_bwd(dx: Tensor, dx_act: Tensor, dx_cs: Optional[Tensor], saved, P: Sequence[Tensor], wc, sink: GradSink, heads: int, act,
+              B: int, N: int):
+    """dx f32 [R,D] (+ its act-dtype copy, + its column sums if the producer already has them)
+    -> (dx0, dx0_act, colsum(dx0), 12 parameter grads)."""
     n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b = P
     x0, ln1, mean1, rstd1, qkv, Pm, ao, x1, ln2, mean2, rstd2, hpre, hact = saved
     R, D = x0.shape
     hd = D // heads
     lnact = None if act == torch.float32 else act
     # MLP
-    d_hpre = ops.linear_dx(dx_act, wc(fc2w), _new(hpre.shape, dx, act), aux=hpre, epi=EPI_DGELU)
+    cs_hpre = _new((fc1w.shape[0],), dx, torch.float32) if fc1b.requires_grad else None
+    d_hpre = ops.linear_dx(dx_act, wc(fc2w), _new(hpre.shape, dx, act), aux=hpre, epi=EPI_DGELU, colsum_out=cs_hpre)
     g_fc2w = sink.weight(fc2w, dx_act, hact)
-    g_fc2b = sink.bias(fc2b, dx_act)
+    g_fc2b = sink.vec(fc2b, dx_cs) if dx_cs is not None else sink.bias(fc2b, dx_act)
     d_ln2 = ops.linear_dx(d_hpre, wc(fc1w), _new((R, D), dx, act))
     g_fc1w = sink.weight(fc1w, d_hpre, ln2)
-    g_fc1b = sink.bias(fc1b, d_hpre)
-    dx1, dx1_act, dg2, db2 = ops.layernorm_bwd(d_ln2, x1, n2w, mean2, rstd2, dx, lnact)
+    g_fc1b = sink.vec(fc1b, cs_hpre) if cs_hpre is not None else None
+    dx1, dx1_act, dg2, db2, cs_dx1 = ops.layernorm_bwd(d_ln2, x1, n2w, mean2, rstd2, dx, lnact)
     if dx1_act is None:
         dx1_act = dx1
     # attention
     d_ao = ops.linear_dx(dx1_act, wc(projw), _new((R, D), dx, act))
     g_projw = sink.weight(projw, dx1_act, ao)
-    g_projb = sink.bias(projb, dx1_act)
+    g_projb = sink.vec(projb, cs_dx1)
     d_qkv = _new((R, 3 * D), dx, act)
     ops.attention_bwd(AttnView(qkv, 0, 3 * D, N), AttnView(qkv, D, 3 * D, N), AttnView(qkv, 2 * D, 3 * D, N), Pm,
                       AttnView(ao, 0, D, N), AttnView(d_ao, 0, D, N), AttnView(d_qkv, 0, 3 * D, N), AttnView(d_qkv, D, 3 * D, N),
@@ -116,12 +119,12 @@ def block_bwd(dx: Tensor, dx_act: Tensor, saved, P: Sequence[Tensor], wc, sink: 
     d_ln1 = ops.linear_dx(d_qkv, wc(qkvw), _new((R, D), dx, act))
     g_qkvw = sink.weight(qkvw, d_qkv, ln1)
     g_qkvb = sink.bias(qkvb, d_qkv)
-    dx0, dx0_act, dg1, db1 = ops.layernorm_bwd(d_ln1, x0, n1w, mean1, rstd1, dx1, lnact)
+    dx0, dx0_act, dg1, db1, cs_dx0 = ops.layernorm_bwd(d_ln1, x0, n1w, mean1, rstd1, dx1, lnact)
     if dx0_act is None:
         dx0_act = dx0
     grads = (sink.vec(n1w, dg1), sink.vec(n1b, db1), g_qkvw, g_qkvb, g_projw, g_projb, sink.vec(n2w, dg2), sink.vec(n2b, db2),
              g_fc1w, g_fc1b, g_fc2w, g_fc2b)
-    return dx0, dx0_act, grads
+    return dx0, dx0_act, cs_dx0, grads
 
 
 class _Cfg:
@@ -159,18 +162,19 @@ class EncoderStackFn(torch.autograd.Function):
         L = len(params) // 12
         sink = GradSink(engine.direct_grads())
         grads: List[Optional[Tensor]] = [None] * (12 * L)
-        dx, dx_act = None, None
+        dx, dx_act, dx_cs = None, None, None
         for l in reversed(range(L)):
             dl = douts[l] if cfg.all_layers else (douts[0] if l == L - 1 else None)
             if dl is not None:
                 dl = dl.contiguous().view(B * N, D)
                 dx = dl if dx is None else ops.axpy_(dx, dl, 1.0)
-                dx_act = None
+                dx_act, dx_cs = None, None
             if dx is None:
                 continue
             if dx_act is None:
                 dx_act = ops.cast(dx, cfg.act)
-            dx, dx_act, g = block_bwd(dx, dx_act, ctx.saved[l], params[12 * l:12 * l + 12], cfg.wc, sink, cfg.heads, cfg.act, B, N)
+            dx, dx_act, dx_cs, g = block_bwd(dx, dx_act, dx_cs, ctx.saved[l], params[12 * l:12 * l + 12], cfg.wc, sink, cfg.heads, cfg.act,
+                                             B, N)
             grads[12 * l:12 * l + 12] = g
             ctx.saved[l] = None
             if cfg.on_layer_done is not None:
@@ -349,20 +353,23 @@ class SpatialAdapterFn(torch.autograd.Function):
         dh_act = ops.linear_dx(d_pat, wc(ow), torch.empty((B * n_q, D), device=dev, dtype=act))
         dh = ops.cast(dh_act, torch.float32)
         bgrads: List[Optional[Tensor]] = [None] * (12 * cfg.depth)
+        dh_cs = None
         for l in reversed(range(cfg.depth)):
-            dh, dh_act, g = block_bwd(dh, dh_act, bsaved[l], blocks[12 * l:12 * l + 12], wc, sink, heads, act, B, n_q)
+            dh, dh_act, dh_cs, g = block_bwd(dh, dh_act, dh_cs, bsaved[l], blocks[12 * l:12 * l + 12], wc, sink, heads, act, B, n_q)
             bgrads[12 * l:12 * l + 12] = g
         # x1 = x + mlp(out_norm(x))
-        d_hpre = ops.linear_dx(dh_act, wc(f2w), torch.empty(hpre.shape, device=dev, dtype=act), aux=hpre, epi=EPI_DGELU)
-        g_f2w, g_f2b = sink.weight(f2w, dh_act, hact), sink.bias(f2b, dh_act)
+        cs_hpre = torch.empty((f1w.shape[0],), device=dev, dtype=torch.float32)
+        d_hpre = ops.linear_dx(dh_act, wc(f2w), torch.empty(hpre.shape, device=dev, dtype=act), aux=hpre, epi=EPI_DGELU, colsum_out=cs_hpre)
+        g_f2w = sink.weight(f2w, dh_act, hact)
+        g_f2b = sink.vec(f2b, dh_cs) if dh_cs is not None else sink.bias(f2b, dh_act)
         d_on = ops.linear_dx(d_hpre, wc(f1w), torch.empty((B * n_q, D), device=dev, dtype=act))
-        g_f1w, g_f1b = sink.weight(f1w, d_hpre, on), sink.bias(f1b, d_hpre)
-        dx, dx_act, g_onw, g_onb = ops.layernorm_bwd(d_on, x, onw, omean, orstd, dh, lnact)
+        g_f1w, g_f1b = sink.weight(f1w, d_hpre, on), sink.vec(f1b, cs_hpre)
+        dx, dx_act, g_onw, g_onb, cs_dx = ops.layernorm_bwd(d_on, x, onw, omean, orstd, dh, lnact)
         if dx_act is None:
             dx_act = dx
         # x = proj(attn(q, k, v))
         d_xo = ops.linear_dx(dx_act, wc(pw_), torch.empty((B * n_q, D), device=dev, dtype=act))
-        g_pw, g_pb = sink.weight(pw_, dx_act, xo), sink.bias(pb, dx_act)
+        g_pw, g_pb = sink.weight(pw_, dx_act, xo), sink.vec(pb, cs_dx)
         d_q = torch.empty((B * n_q, D), device=dev, dtype=act)
         d_kv = torch.empty((B * NC, 2 * D), device=dev, dtype=act)
         ops.attention_bwd(AttnView(q, 0, D, n_q), AttnView(kv, 0, 2 * D, NC), AttnView(kv, D, 2 * D, NC), Pm,
@@ -372,8 +379,8 @@ class SpatialAdapterFn(torch.autograd.Function):
         g_qw, g_qb = sink.weight(qw, d_q, qn), sink.bias(qb, d_q)
         d_cn = ops.linear_dx(d_kv, wc(kvw), torch.empty((B * NC, D), device=dev, dtype=act))
         g_kvw, g_kvb = sink.weight(kvw, d_kv, cn), sink.bias(kvb, d_kv)
-        d_queries, _, g_qnw, g_qnb = ops.layernorm_bwd(d_qn, queries, qnw, qmean, qrstd, None, None)
-        d_context, _, g_cnw, g_cnb = ops.layernorm_bwd(d_cn, context, cnw, cmean, crstd, None, None)
+        d_queries, _, g_qnw, g_qnb, _ = ops.layernorm_bwd(d_qn, queries, qnw, qmean, qrstd, None, None)
+        d_context, _, g_cnw, g_cnb, _ = ops.layernorm_bwd(d_cn, context, cnw, cmean, crstd, None, None)
         d_ctx, sums = ops.decoder_build_bwd(d_queries, d_context, ids_keep, ids_restore, cfg.task_offsets, cfg.q_task, B, n_keep, G, D,
                                             n_q)
         d_ctx_act = ops.cast(d_ctx, act)
@@ -428,7 +435,7 @@ class LayerNormFn(torch.autograd.Function):
     def backward(ctx, dy: Tensor):
         x2, w, mean, rstd = ctx.saved_tensors
         sink = GradSink(engine.direct_grads())
-        dx, _, dg, db = ops.layernorm_bwd(dy.contiguous().view(x2.shape).float(), x2, w.detach(), mean, rstd, None, None)
+        dx, _, dg, db, _ = ops.layernorm_bwd(dy.contiguous().view(x2.shape).float(), x2, w.detach(), mean, rstd, None, None)
         return dx.view(ctx.shp), sink.vec(ctx.wb[0], dg), sink.vec(ctx.wb[1], db), None
 
 

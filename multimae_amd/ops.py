@@ -69,7 +69,7 @@ def gemm(A: Tensor, B: Tensor, C: Tensor, M: int, N: int, K: int, *, lda: int, l
          batch: int = 1, batch_inner: int = 1, sA=(0, 0), sB=(0, 0), sC=(0, 0),
          bias: Optional[Tensor] = None, resid: Optional[Tensor] = None, ldr: int = 0,
          aux: Optional[Tensor] = None, ldaux: int = 0, epi: int = EPI_NONE, accumulate: bool = False,
-         alpha: float = 1.0, tile: int = 0, split_k: int = 0) -> None:
+         alpha: float = 1.0, tile: int = 0, split_k: int = 0, colsum_part: Optional[Tensor] = None) -> None:
     """C[M,N] (+)= alpha * A[M,K] . B[N,K]^T with the fused epilogue of mmae_gemm.
     *_off are element offsets into the tensors' storage views (column offsets into packed qkv etc.)."""
     _require_gpu(A, 'gemm A')
@@ -103,6 +103,7 @@ def gemm(A: Tensor, B: Tensor, C: Tensor, M: int, N: int, K: int, *, lda: int, l
         ws = torch.empty((split_k * M * N,), device=A.device, dtype=torch.float32)
         d.ws, d.ws_elems = ws.data_ptr(), ws.numel()
     d.split_k = max(split_k, 1)
+    d.colsum_part = _p(colsum_part)
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() >= N
     if resid is not None:
@@ -119,11 +120,19 @@ def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], out: Tensor, *, res
     return out
 
 
-def linear_dx(dy: Tensor, w: Tensor, out: Tensor, *, aux: Optional[Tensor] = None, epi: int = EPI_NONE) -> Tensor:
-    """out[M,K] = dy[M,N] @ w[N,K]   (w read through the transposing LDS path)."""
+def linear_dx(dy: Tensor, w: Tensor, out: Tensor, *, aux: Optional[Tensor] = None, epi: int = EPI_NONE,
+              colsum_out: Optional[Tensor] = None) -> Tensor:
+    """out[M,K] = dy[M,N] @ w[N,K]   (w read through the transposing LDS path).
+    colsum_out (f32 [K], dGELU epilogue only): receives the column sums of `out` -- the bias gradient of the Linear
+    whose pre-activation gradient `out` is -- accumulated in the GEMM epilogue instead of a separate pass over out."""
     M, N = dy.shape
     K = w.shape[1]
-    gemm(dy, w, out, M, K, N, lda=dy.stride(0), ldb=K, ldc=K, b_trans=True, aux=aux, ldaux=K, epi=epi)
+    part = None
+    if colsum_out is not None:
+        part = torch.empty(((M + 63) // 64, K), device=dy.device, dtype=torch.float32)
+    gemm(dy, w, out, M, K, N, lda=dy.stride(0), ldb=K, ldc=K, b_trans=True, aux=aux, ldaux=K, epi=epi, colsum_part=part)
+    if part is not None:
+        colsum(part, colsum_out, False)
     return out
 
 
@@ -150,20 +159,20 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out_dtype:
 
 def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dx_in: Optional[Tensor],
                   act_dtype: Optional[torch.dtype]):
-    """returns dx (f32, = dx_in + LN'(dy)), dx_act (act copy or None), dgamma, dbeta (f32 [D])."""
+    """returns dx (f32, = dx_in + LN'(dy)), dx_act (act copy or None), dgamma, dbeta, colsum(dx) (f32 [D] each)."""
     R, D = x.shape
     lib = _lib.load()
     nblk = lib.mmae_layernorm_bwd_nblk(R)
-    part = torch.empty((nblk, 2, D), device=x.device, dtype=torch.float32)
+    part = torch.empty((nblk, 3, D), device=x.device, dtype=torch.float32)
     dx = torch.empty_like(x)
     dx_act = torch.empty((R, D), device=x.device, dtype=act_dtype) if act_dtype is not None else None
     check(lib.mmae_layernorm_bwd(dy.data_ptr(), dcode(dy.dtype), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                  rstd.data_ptr(), _p(dx_in), dx.data_ptr(), _p(dx_act),
                                  dcode(act_dtype) if act_dtype is not None else F32, part.data_ptr(), R, D, _stream()),
           'layernorm_bwd')
-    dgb = torch.empty((2 * D,), device=x.device, dtype=torch.float32)
-    colsum(part.view(nblk, 2 * D), dgb, False)
-    return dx, dx_act, dgb[:D], dgb[D:]
+    dgb = torch.empty((3 * D,), device=x.device, dtype=torch.float32)
+    colsum(part.view(nblk, 3 * D), dgb, False)
+    return dx, dx_act, dgb[:D], dgb[D:2 * D], dgb[2 * D:]
 
 
 def colsum(dy: Tensor, out: Tensor, accumulate: bool) -> Tensor:

@@ -158,10 +158,12 @@ def test_gemm_epilogues(dtype):
         pre = bf(pre).float()
     pre_d = pre.to(DEV, dtype)
     dxo = torch.empty(M, K, device=DEV, dtype=dtype)
-    ops.linear_dx(dy.to(DEV, dtype), wd, dxo, aux=pre_d, epi=EPI_DGELU)
+    cs = torch.empty(K, device=DEV)
+    ops.linear_dx(dy.to(DEV, dtype), wd, dxo, aux=pre_d, epi=EPI_DGELU, colsum_out=cs)
     p = pre.clone().requires_grad_(True)
     orc.gelu_erf(p).backward(dy @ w)
     assert rel_err(dxo.float(), p.grad) < t2
+    assert rel_err(cs, p.grad.sum(0)) < 1e-4            # bias gradient accumulated in the epilogue
     # dW with accumulate
     dw = torch.ones(N, K, device=DEV)
     ops.linear_dw(dy.to(DEV, dtype), xd, dw, accumulate=True)
@@ -238,11 +240,12 @@ def test_layernorm_fwd_bwd(D):
     assert rel_err(y, y_ref) < 2e-6
     y16, _, _ = ops.layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, torch.bfloat16)
     assert rel_err(y16.float(), y_ref) < 4e-3
-    dx, dxa, dg, db = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd, dxin.to(DEV), torch.bfloat16)
+    dx, dxa, dg, db, cs = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd, dxin.to(DEV), torch.bfloat16)
     assert rel_err(dx, xr.grad + dxin) < 5e-6
+    assert rel_err(cs, (xr.grad + dxin).sum(0)) < 1e-5
     assert rel_err(dxa.float(), xr.grad + dxin) < 4e-3
     assert rel_err(dg, wr.grad) < 1e-5 and rel_err(db, br.grad) < 1e-5
-    dx2, none, _, _ = ops.layernorm_bwd(bf(dy).to(DEV), x.to(DEV), w.to(DEV), mean, rstd, None, None)
+    dx2, none, _, _, _ = ops.layernorm_bwd(bf(dy).to(DEV), x.to(DEV), w.to(DEV), mean, rstd, None, None)
     assert none is None and rel_err(dx2, xr.grad) < 6e-3
 
 
