@@ -250,7 +250,7 @@ int dispatch_layout(const GemmArgs& g, int batch, bool aks, bool bks, hipStream_
 
 }  // namespace
 
-int mmae_gemm_bf16_pipe_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st);
+int mmae_gemm_bf16_pipe_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hipStream_t st);
 
 int mmae_gemm_bf16_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st) {
     MMAE_REQUIRE(d->lda % 8 == 0 && d->ldb % 8 == 0, "gemm bf16: lda/ldb must be multiples of 8");
@@ -263,8 +263,9 @@ int mmae_gemm_bf16_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t 
     if (d->b_trans) MMAE_REQUIRE(d->N % 8 == 0 || d->ldb >= ((d->N + 7) / 8) * 8, "gemm bf16: transposed B row too short");
     // tile codes: 0/1 = 128x128 LDS-DMA (default), 2 = 256x128 LDS-DMA, 3 = 128x128 VGPR-staged, 4 = 256x128 VGPR-staged
     static const int env_tile = getenv("MMAE_GEMM_TILE") ? atoi(getenv("MMAE_GEMM_TILE")) : 3;   // default: 128x128 VGPR-staged (fastest in the r01 K-sweep)
-    switch (d->tile ? d->tile : env_tile) {
-        case 5: case 6: return mmae_gemm_bf16_pipe_impl(d, g, st);     // 4-stage LDS-DMA ring, BK = 32
+    const int code = d->tile ? d->tile : env_tile;
+    switch (code) {
+        case 5: case 6: case 7: case 8: return mmae_gemm_bf16_pipe_impl(d, g, code, st);     // LDS-DMA ring, BK = 32
         case 2: return dispatch_layout<4, 2, true>(g, d->batch, d->a_trans != 0, d->b_trans != 0, st);
         case 3: return dispatch_layout<2, 2, false>(g, d->batch, d->a_trans != 0, d->b_trans != 0, st);
         case 4: return dispatch_layout<4, 2, false>(g, d->batch, d->a_trans != 0, d->b_trans != 0, st);

@@ -13,7 +13,7 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 
 namespace {
 
-constexpr int BK = 32, NSTAGE = 4;
+constexpr int BK = 32;
 constexpr unsigned OOB = 0x80000000u;
 
 // k-contiguous tile, rows of 64 B (4 chunks); 4 rows share a 256-B bank row
@@ -33,7 +33,7 @@ template <> __device__ __forceinline__ void wait_vm<4>() { asm volatile("s_waitc
 template <> __device__ __forceinline__ void wait_vm<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vm<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 
-template <int WM, int WN, bool AKS, bool BKS>
+template <int WM, int WN, bool AKS, bool BKS, int NSTAGE>
 __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_pipe_kernel(const GemmArgs g) {
     constexpr int BM = WM * 64, BN = WN * 64, NW = WM * WN;
     constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_pipe_kernel(const Gemm
     for (int kt = kt_begin; kt < nkt; ++kt) {
         // tile kt has landed once at most the tiles issued after it (<= 2) are still outstanding
         const int rem = nkt - 1 - kt;
-        if (rem >= 2) wait_vm<2 * IPT>(); else if (rem == 1) wait_vm<IPT>(); else wait_vm<0>();
+        if (NSTAGE >= 4 && rem >= 2) wait_vm<2 * IPT>(); else if (NSTAGE >= 3 && rem >= 1) wait_vm<IPT>(); else wait_vm<0>();
         __builtin_amdgcn_s_barrier();          // everyone's share of tile kt landed; everyone left tile kt-1
         asm volatile("" ::: "memory");
         if (kt + NSTAGE - 1 < nkt) dma(kt + NSTAGE - 1, (kt + NSTAGE - 1 - kt_begin) % NSTAGE);   // refills the slot of tile kt-1
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_pipe_kernel(const Gemm
     gemm_store_tile64(g, Cz, smem + wave * 8192, lane, acc, m0 + wm * 64, n0 + wn * 64);
 }
 
-template <int WM, int WN, bool AKS, bool BKS>
+template <int WM, int WN, bool AKS, bool BKS, int NSTAGE>
 int launch(const GemmArgs& g, int batch, hipStream_t st) {
     constexpr int BM = WM * 64, BN = WN * 64;
     const int tiles_m = (g.M + BM - 1) / BM;
@@ -181,25 +181,31 @@ int launch(const GemmArgs& g, int batch, hipStream_t st) {
     const size_t lds = (size_t)NSTAGE * (BM + BN) * 64;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_pipe_kernel<WM, WN, AKS, BKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pipe_kernel<WM, WN, AKS, BKS, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_pipe_kernel<WM, WN, AKS, BKS>), grid, block, lds, st, a);
+    hipLaunchKernelGGL((gemm_bf16_pipe_kernel<WM, WN, AKS, BKS, NSTAGE>), grid, block, lds, st, a);
     return mmae_check_launch("gemm_bf16_pipe");
+}
+
+template <int WM, int WN, int NSTAGE>
+int dispatch(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st) {
+    const bool aks = d->a_trans != 0, bks = d->b_trans != 0;
+    if (!aks && !bks) return launch<WM, WN, false, false, NSTAGE>(g, d->batch, st);
+    if (!aks && bks) return launch<WM, WN, false, true, NSTAGE>(g, d->batch, st);
+    if (aks && !bks) return launch<WM, WN, true, false, NSTAGE>(g, d->batch, st);
+    return launch<WM, WN, true, true, NSTAGE>(g, d->batch, st);
 }
 
 }  // namespace
 
-int mmae_gemm_bf16_pipe_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st) {
-    const bool aks = d->a_trans != 0, bks = d->b_trans != 0;
-    if (d->tile == 6) {
-        if (!aks && !bks) return launch<4, 2, false, false>(g, d->batch, st);
-        if (!aks && bks) return launch<4, 2, false, true>(g, d->batch, st);
-        if (aks && !bks) return launch<4, 2, true, false>(g, d->batch, st);
-        return launch<4, 2, true, true>(g, d->batch, st);
+// tile codes: 5 = 128x128 4-stage, 6 = 256x128 4-stage, 7 = 128x128 2-stage (32 KiB LDS, 3+ workgroups / CU),
+//             8 = 128x128 3-stage
+int mmae_gemm_bf16_pipe_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hipStream_t st) {
+    switch (code) {
+        case 6: return dispatch<4, 2, 4>(d, g, st);
+        case 7: return dispatch<2, 2, 2>(d, g, st);
+        case 8: return dispatch<2, 2, 3>(d, g, st);
+        default: return dispatch<2, 2, 4>(d, g, st);
     }
-    if (!aks && !bks) return launch<2, 2, false, false>(g, d->batch, st);
-    if (!aks && bks) return launch<2, 2, false, true>(g, d->batch, st);
-    if (aks && !bks) return launch<2, 2, true, false>(g, d->batch, st);
-    return launch<2, 2, true, true>(g, d->batch, st);
 }

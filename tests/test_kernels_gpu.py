@@ -77,7 +77,7 @@ def test_gemm_bf16_layouts(shape, a_trans, b_trans):
     """bf16 products are exact in fp32, so vs fp64 on the same bf16 inputs only fp32 summation
     error remains: rel-L2 <= 2e-6."""
     M, N, K = shape
-    for tile in (1, 2, 3, 4, 5, 6):
+    for tile in (1, 2, 3, 4, 5, 6, 7, 8):
         assert _gemm_case(torch.bfloat16, M, N, K, a_trans, b_trans, tile=tile) < 2e-6, (shape, tile)
 
 
