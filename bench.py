@@ -137,6 +137,7 @@ def main():
     ap.add_argument('--cpu-threads', type=int, default=0)
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--adapter-streams', type=int, default=1, help='1: output adapters on separate HIP streams')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -166,6 +167,7 @@ def main():
         attach(model, reducer)
     M.engine.set_precision(args.precision)
     M.engine.set_direct_grads(True)
+    M.engine.set_adapter_streams(bool(args.adapter_streams))
     B = args.batch
     lr = 1e-4 * B * world / 256                                   # blr * global_bs / 256 (:372-373)
     opt = FusedAdamW(model, lr=lr, betas=(0.9, 0.95), weight_decay=0.05)

@@ -26,6 +26,7 @@ ALIGN = 64  # elements
 _state = {
     'act_dtype': torch.bfloat16,     # bf16 speed mode | float32 exact parity mode
     'direct_grads': False,           # backward accumulates straight into p.grad and returns None
+    'adapter_streams': False,        # run the independent output adapters on separate HIP streams
     'fp32_adapter_gemm': 'x3',       # GEMMs of fp32_output_adapters in bf16 speed mode: 'x3' (split bf16) | 'exact'
 }
 
@@ -50,6 +51,15 @@ def precision(mode: str):
         yield
     finally:
         _state['act_dtype'] = old
+
+
+def adapter_streams() -> bool:
+    return _state['adapter_streams']
+
+
+def set_adapter_streams(flag: bool) -> None:
+    """Run each output adapter (forward and, through autograd's stream replay, backward) on its own HIP stream."""
+    _state['adapter_streams'] = bool(flag)
 
 
 def fp32_adapter_gemm() -> str:

@@ -239,7 +239,12 @@ class MultiMAE(nn.Module):
             return encoder_tokens, task_masks
 
         preds = {}
-        for domain in self.output_adapters:
+        # The output adapters are independent: run each on its own HIP stream so their many small kernels
+        # (K = 256 GEMMs, 2048-head attention, LayerNorms) fill each other's fill/drain bubbles.  autograd
+        # replays each node's backward on its forward stream, so the backward passes overlap the same way.
+        streams = self._adapter_streams(len(self.output_adapters)) if engine.adapter_streams() else None
+        main = torch.cuda.current_stream() if streams is not None else None
+        for i, domain in enumerate(self.output_adapters):
             # reference: adapters listed in fp32_output_adapters run with autocast disabled (:367-377);
             # here they run on the exact-f32 MFMA path
             # here: f32 activations; in bf16 speed mode their GEMMs run as split-bf16 ("x3", >= TF32 precision -- what
@@ -247,12 +252,28 @@ class MultiMAE(nn.Module):
             # on the exact-f32 MFMA path
             fp32 = domain in fp32_output_adapters
             speed = engine.act_dtype() == torch.bfloat16
-            preds[domain] = self.output_adapters[domain](encoder_tokens=encoder_tokens, input_info=input_info,
-                                                         ids_keep=ids_keep, ids_restore=ids_restore,
-                                                         act_dtype=torch.float32 if fp32 else None,
-                                                         on_done=self._adapter_done_cb(domain),
-                                                         f32_gemm='x3' if (fp32 and speed and engine.fp32_adapter_gemm() == 'x3') else 'exact')
+            kw = dict(encoder_tokens=encoder_tokens, input_info=input_info, ids_keep=ids_keep, ids_restore=ids_restore,
+                      act_dtype=torch.float32 if fp32 else None, on_done=self._adapter_done_cb(domain),
+                      f32_gemm='x3' if (fp32 and speed and engine.fp32_adapter_gemm() == 'x3') else 'exact')
+            if streams is None:
+                preds[domain] = self.output_adapters[domain](**kw)
+            else:
+                st = streams[i]
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    preds[domain] = self.output_adapters[domain](**kw)
+                encoder_tokens.record_stream(st)
+                preds[domain].record_stream(main)
+        if streams is not None:
+            for st in streams:
+                main.wait_stream(st)
         return preds, task_masks
+
+    def _adapter_streams(self, n):
+        ss = self.__dict__.setdefault('_mmae_streams', [])
+        while len(ss) < n:
+            ss.append(torch.cuda.Stream())
+        return ss[:n]
 
     # hooks used by dist.GradAllReducer to launch bucketed all-reduces while backward is still running
     def _layer_done_cb(self):
