@@ -138,6 +138,7 @@ def main():
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--adapter-streams', type=int, default=1, help='1: output adapters on separate HIP streams')
+    ap.add_argument('--wgrad-stream', type=int, default=1, help='1: weight-gradient GEMMs on a side stream')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -168,6 +169,7 @@ def main():
     M.engine.set_precision(args.precision)
     M.engine.set_direct_grads(True)
     M.engine.set_adapter_streams(bool(args.adapter_streams))
+    M.engine.set_wgrad_stream(bool(args.wgrad_stream))
     B = args.batch
     lr = 1e-4 * B * world / 256                                   # blr * global_bs / 256 (:372-373)
     opt = FusedAdamW(model, lr=lr, betas=(0.9, 0.95), weight_decay=0.05)

@@ -45,6 +45,7 @@ class GradAllReducer:
                  group: Optional[dist.ProcessGroup] = None):
         self.grad = grad
         self.group = group
+        self.join = None
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets = plan_buckets(sizes, int(bucket_mb * 1024 * 1024 / 4))
         self._bucket_of: Dict[str, int] = {}
@@ -61,7 +62,10 @@ class GradAllReducer:
     def for_arena(cls, arena, **kw) -> 'GradAllReducer':
         from .engine import ALIGN
         sizes = [(n, arena.offsets[n], (arena.sizes[n] + ALIGN - 1) // ALIGN * ALIGN) for n in arena.names if arena.trainable[n]]
-        return cls(arena.grad, sizes, **kw)
+        r = cls(arena.grad, sizes, **kw)
+        from . import engine
+        r.join = engine.join_wgrad_streams
+        return r
 
     def reset(self) -> None:
         self._remaining = [len(names) for _, _, names in self.buckets]
@@ -74,6 +78,8 @@ class GradAllReducer:
             return
         s, e, _ = self.buckets[i]
         view = self.grad[s:e]
+        if self.join is not None:
+            self.join()                      # weight-gradient side streams -> current stream
         view.mul_(1.0 / self.world)
         self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self._launched[i] = True

@@ -26,7 +26,8 @@ ALIGN = 64  # elements
 _state = {
     'act_dtype': torch.bfloat16,     # bf16 speed mode | float32 exact parity mode
     'direct_grads': False,           # backward accumulates straight into p.grad and returns None
-    'adapter_streams': False,        # run the independent output adapters on separate HIP streams
+    'adapter_streams': False,
+    'wgrad_stream': False,           # direct-grad mode: weight-gradient GEMMs / bias column sums on a side stream per compute stream        # run the independent output adapters on separate HIP streams
     'fp32_adapter_gemm': 'x3',       # GEMMs of fp32_output_adapters in bf16 speed mode: 'x3' (split bf16) | 'exact'
 }
 
@@ -60,6 +61,37 @@ def adapter_streams() -> bool:
 def set_adapter_streams(flag: bool) -> None:
     """Run each output adapter (forward and, through autograd's stream replay, backward) on its own HIP stream."""
     _state['adapter_streams'] = bool(flag)
+
+
+def wgrad_stream() -> bool:
+    return _state['wgrad_stream']
+
+
+def set_wgrad_stream(flag: bool) -> None:
+    """Direct-grad mode only: launch dW = dY^T X GEMMs (and bias column sums) on a side stream so they fill the bubbles of
+    the latency-bound dX chain.  Every consumer of .grad (FusedAdamW.step, GradAllReducer) calls join_wgrad_streams()."""
+    _state['wgrad_stream'] = bool(flag)
+
+
+_side_streams = {}
+
+
+def side_stream_of(stream: 'torch.cuda.Stream') -> 'torch.cuda.Stream':
+    key = (stream.device, stream.cuda_stream)
+    s = _side_streams.get(key)
+    if s is None:
+        s = torch.cuda.Stream(device=stream.device)
+        _side_streams[key] = s
+    return s
+
+
+def join_wgrad_streams() -> None:
+    """Make the current stream wait for every weight-gradient side stream."""
+    if not _side_streams:
+        return
+    cur = torch.cuda.current_stream()
+    for s in _side_streams.values():
+        cur.wait_stream(s)
 
 
 def fp32_adapter_gemm() -> str:

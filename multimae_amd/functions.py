@@ -24,6 +24,18 @@ class GradSink:
 
     def __init__(self, direct: bool):
         self.direct = direct
+        self.side = None
+        if direct and engine.wgrad_stream():
+            self.main = torch.cuda.current_stream()
+            self.side = engine.side_stream_of(self.main)
+
+    def _on_side(self, fn, *tensors):
+        """run fn() on the weight-gradient side stream, ordered after everything enqueued so far on the compute stream"""
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            fn()
+        for t in tensors:
+            t.record_stream(self.side)          # keep the operands alive until the side stream is done with them
 
     def _target(self, p: Tensor):
         if self.direct and p.grad is not None:
@@ -37,15 +49,24 @@ class GradSink:
         tgt, acc = self._target(p)
         M, N = dy.shape
         K = K if K is not None else x.shape[1]
-        ops.gemm(dy, x, tgt, N, K, M, lda=dy.stride(0), ldb=ldx if ldx is not None else x.stride(0), ldc=K, a_trans=True, b_trans=True,
-                 b_off=x_off, accumulate=acc)
+
+        def run():
+            ops.gemm(dy, x, tgt, N, K, M, lda=dy.stride(0), ldb=ldx if ldx is not None else x.stride(0), ldc=K, a_trans=True,
+                     b_trans=True, b_off=x_off, accumulate=acc)
+        if self.side is not None and acc:
+            self._on_side(run, dy, x)
+        else:
+            run()
         return None if acc else tgt
 
     def bias(self, p: Tensor, dy: Tensor):
         if not p.requires_grad:
             return None
         tgt, acc = self._target(p)
-        ops.colsum(dy, tgt, acc)
+        if self.side is not None and acc:
+            self._on_side(lambda: ops.colsum(dy, tgt, acc), dy)
+        else:
+            ops.colsum(dy, tgt, acc)
         return None if acc else tgt
 
     def vec(self, p: Tensor, g: Tensor):
@@ -53,7 +74,11 @@ class GradSink:
         if not p.requires_grad:
             return None
         if self.direct and p.grad is not None:
-            ops.axpy_(p.grad, g.contiguous(), 1.0)
+            g = g.contiguous()
+            if self.side is not None:       # same stream as the GEMM accumulations into the arena (no cross-stream races on .grad)
+                self._on_side(lambda: ops.axpy_(p.grad, g, 1.0), g)
+            else:
+                ops.axpy_(p.grad, g, 1.0)
             return None
         return g.reshape(p.shape)
 

@@ -37,6 +37,7 @@ class FusedAdamW:
         self.grad_norm = torch.zeros(1, device=a.device, dtype=torch.float32)
 
     def zero_grad(self, set_to_none: bool = False) -> None:
+        engine.join_wgrad_streams()
         self.arena.zero_grad()
         self.arena.rebind_grads()
 
@@ -45,6 +46,7 @@ class FusedAdamW:
         """One AdamW update; returns the (device) gradient 2-norm, as the reference's loss_scaler does."""
         a, g = self.arena, self.param_groups[0]
         n = a.n_trainable
+        engine.join_wgrad_streams()
         ops.sumsq(a.grad, self._sumsq, self._ws)
         # scalar bookkeeping on 1-element device tensors (no host sync)
         torch.sqrt(self._sumsq, out=self.grad_norm)

@@ -36,6 +36,8 @@ def _run_mini(mode, direct=False, arena=False):
     ids = (g['ids_keep'].to(DEV), g['ids_restore'].to(DEV))
     model.generate_random_masks = lambda *a, **k: (tm, ids[0], ids[1])
     M.engine.set_direct_grads(direct)
+    M.engine.set_adapter_streams(direct)          # the direct/arena variants also exercise the multi-stream schedule
+    M.engine.set_wgrad_stream(direct)
     try:
         with M.engine.precision(mode):
             preds, masks = model(x, num_encoded_tokens=MINI['nvis'], alphas=1.0)
@@ -46,8 +48,12 @@ def _run_mini(mode, direct=False, arena=False):
             if direct:
                 model._mmae_arena.zero_grad()
             sum(losses.values()).backward()
+            if direct:
+                M.engine.join_wgrad_streams()
     finally:
         M.engine.set_direct_grads(False)
+        M.engine.set_adapter_streams(False)
+        M.engine.set_wgrad_stream(False)
     torch.cuda.synchronize()
     return g, model, preds, losses
 
