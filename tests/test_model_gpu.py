@@ -246,3 +246,82 @@ def test_training_loop_loss_curve_matches_oracle():
     diffs = [abs(a - b) for a, b in zip(curve_e, curve_o)]
     assert max(diffs) < 1e-4, (curve_e, curve_o)
     assert curve_e[-1] < curve_e[0]
+
+
+def _known_answer_case(name, doms, P, S, nvis, enc, posemb, mode, fp32_adapters=()):
+    """Reproduce the reference's recorded step (tests/golden/scalars.json, SURVEY Appendix B recipe): same seeded init
+    (bit-identical weights), same inputs (seed stream), same masks (the reference drew them on the CPU generator after
+    torch.manual_seed(1); replayed here with the oracle's sampler), then compare losses and the gradient norm with the
+    numbers the REFERENCE produced."""
+    import multimae_amd as M
+    gold = load_scalars()[name]
+    torch.manual_seed(0)
+    model = build_engine_model(doms, P, S, enc=enc, posemb_size=posemb)
+    x = make_inputs(doms, 4, S)
+    ntok = (S // P) ** 2
+    torch.manual_seed(1)
+    dist, tn, an = orc.draw_mask_randoms(4, [ntok] * len(doms), 1.0)
+    spt = orc.samples_per_task_from_dirichlet(dist, nvis)
+    mask_all, ik, ir = orc.masks_from_noise(spt, tn, an, nvis)
+    assert int(ik.sum()) == gold['ids_keep_checksum']
+    model.to(DEV)
+    model.build_arena()
+    tm = {d: mask_all[:, i * ntok:(i + 1) * ntok].to(DEV) for i, d in enumerate(doms)}
+    model.generate_random_masks = lambda *a, **k: (tm, ik.to(DEV), ir.to(DEV))
+    xd = {k: v.to(DEV) for k, v in x.items()}
+    with M.engine.precision(mode):
+        preds, masks = model(xd, num_encoded_tokens=nvis, alphas=1.0, fp32_output_adapters=list(fp32_adapters))
+        fns = _loss_fns(P)
+        tgt = dict(xd, norm_rgb=xd['rgb'])
+        mk = dict(masks, norm_rgb=masks['rgb'])
+        losses = {k: fns[k](preds[k].float(), tgt[k], mask=mk[k]) for k in preds}
+        sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    ltol, gtol = (2e-4, 2e-3) if mode == 'fp32' else (1.5e-2, 3e-2)
+    for k, v in gold['losses'].items():
+        assert abs(float(losses[k]) - v) < ltol, (k, float(losses[k]), v)
+    gn = float(torch.norm(torch.stack([p.grad.norm() for p in model.parameters() if p.grad is not None])))
+    assert abs(gn - gold['grad_norm']) / gold['grad_norm'] < gtol, (gn, gold['grad_norm'])
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_reference_known_answers_tiny_cfg1(mode):
+    """BASELINE.json configs[0]: ViT-Tiny, RGB 64x64, patch 8, 49 visible tokens, B=4 (28x28 pos-emb grid interpolated
+    to 8x8: bicubic in the input adapter, bilinear in the decoders)."""
+    _known_answer_case('tiny_rgb', ['rgb'], 8, 64, 49, (192, 12, 3), 224, mode)
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_reference_known_answers_base_cfg3(mode):
+    """BASELINE.json configs[2] geometry at B=4: ViT-B, RGB+depth+semseg, 98 visible tokens, 4 decoders, semseg adapter
+    in fp32 (x3 GEMMs in bf16 mode, exact in fp32 mode)."""
+    _known_answer_case('base_rgb_depth_semseg', ['rgb', 'depth', 'semseg'], 16, 224, 98, None, None, mode, fp32_adapters=('semseg',))
+
+
+def test_vit_large_geometry_cfg5():
+    """BASELINE.json configs[4] geometry (ViT-L: D=1024, 24 layers, 16 heads, 196 visible + 1 global tokens, decoders with a
+    197-token context) at B=2 against the oracle, fp32 parity mode."""
+    import multimae_amd as M
+    doms = ['rgb', 'depth', 'semseg']
+    torch.manual_seed(3)
+    model = build_engine_model(doms, 16, 224, factory='pretrain_multimae_large')
+    x = make_inputs(doms, 2, 224)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    torch.manual_seed(4)
+    dist, tn, an = orc.draw_mask_randoms(2, [196] * 3, 1.0)
+    spt = orc.samples_per_task_from_dirichlet(dist, 196)
+    mask_all, ik, ir = orc.masks_from_noise(spt, tn, an, 196)
+    model.to(DEV)
+    tm = {d: mask_all[:, i * 196:(i + 1) * 196].to(DEV) for i, d in enumerate(doms)}
+    model.generate_random_masks = lambda *a, **k: (tm, ik.to(DEV), ir.to(DEV))
+    xd = {k: v.to(DEV) for k, v in x.items()}
+    cfg = orc.standard_config(doms, dim_tokens=1024, depth=24, num_heads=16)
+    with torch.no_grad():
+        po = orc.multimae_forward(x, sd, cfg, ik, ir)
+        with M.engine.precision('fp32'):
+            preds, _ = model(xd, num_encoded_tokens=196)
+        with M.engine.precision('bf16'):
+            preds16, _ = model(xd, num_encoded_tokens=196)
+    for k in po:
+        assert rel_err(preds[k], po[k]) < 5e-5, (k, rel_err(preds[k], po[k]))
+        assert rel_err(preds16[k], po[k]) < 3e-2, (k, rel_err(preds16[k], po[k]))
