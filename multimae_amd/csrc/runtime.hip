@@ -91,8 +91,7 @@ int mmae_gemm_auto_splitk(int M, int N, int K, int ab_dtype) {
     const int nkt = (K + bk - 1) / bk;
     const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
     if (tiles >= 384 || nkt < 32) return 1;
-    // one full round of workgroups: 256 CUs x 3 resident 128x128 workgroups = 768 slots
-    int s = (int)(768 / tiles);
+    int s = (int)((1024 + tiles - 1) / tiles);
     const int max_split = nkt / 8;                      // keep >= 8 K tiles per slice
     if (s > max_split) s = max_split;
     if (s > 64) s = 64;
