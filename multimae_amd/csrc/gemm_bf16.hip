@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_kernel(const GemmArgs 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    const int tile = blockIdx.x;
+    const int tile = g.xcd_swizzle ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
     const int m0 = (tile / g.tiles_n) * BM;
     const int n0 = (tile % g.tiles_n) * BN;
     const int z = blockIdx.y;

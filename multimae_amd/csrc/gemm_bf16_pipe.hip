@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_pipe_kernel(const Gemm
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int tile = blockIdx.x;
+    const int tile = g.xcd_swizzle ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
     const int m0 = (tile / g.tiles_n) * BM, n0 = (tile % g.tiles_n) * BN;
     const int z = blockIdx.y, zo = z / g.nb_inner, zi = z % g.nb_inner;
     const uint16_t* Az = (const uint16_t*)g.A + zo * g.sAo + zi * g.sAi;

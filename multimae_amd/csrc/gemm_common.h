@@ -16,8 +16,18 @@ struct GemmArgs {
     int tiles_n;
     int splitk, kt_per_split;     // splitk > 1: z-slice s writes its partial product to ws[s][M][N] (f32)
     float* ws;
+    int xcd_swizzle;
     float* colpart;               // optional [ceil(M/64)][N] column sums of the epilogue output (dGELU flavour)
 };
+
+// XCD-aware tile order (MI355X: workgroup b runs on XCD b % 8, each XCD has its own 4 MiB L2): hand every XCD a
+// contiguous range of the row-major tile list, so the workgroups resident on one XCD share A row-panels (and walk B
+// in step) instead of each XCD streaming every A panel through its own L2.  Bijective for any tile count.
+__device__ __forceinline__ int xcd_tile(int bid, int ntiles) {
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int xcd = bid & 7, local = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
 
 // The kernels compute D[i = n][j = m] (B fragment as the MFMA "A" operand) so that one lane
 // owns 4 consecutive n for a fixed m: a row-per-lane epilogue with 8/16-byte accesses.

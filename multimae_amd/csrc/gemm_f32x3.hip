@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256) gemm_f32x3_kernel(const GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile = blockIdx.x;
+    const int tile = g.xcd_swizzle ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
     const int m0 = (tile / g.tiles_n) * BM, n0 = (tile % g.tiles_n) * BN;
     const int z = blockIdx.y, zo = z / g.nb_inner, zi = z % g.nb_inner;
     const float* Az = (const float*)g.A + zo * g.sAo + zi * g.sAi;

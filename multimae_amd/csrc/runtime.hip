@@ -1,6 +1,7 @@
 // ABI bookkeeping (version, per-thread error string) and the GEMM entry point's argument
 // validation / dtype dispatch.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "gemm_common.h"
 
@@ -52,6 +53,8 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     g.epi = d->epi; g.accumulate = d->accumulate; g.alpha = d->alpha;
     g.tiles_n = 0;
     g.colpart = d->colsum_part;
+    static const int env_swz = getenv("MMAE_GEMM_XCD") ? atoi(getenv("MMAE_GEMM_XCD")) : 1;
+    g.xcd_swizzle = env_swz;
     MMAE_REQUIRE(!d->colsum_part || (d->epi == MMAE_EPI_DGELU && !d->bias && !d->resid && !d->accumulate && d->batch == 1 && d->split_k <= 1 &&
                                      d->alpha == 1.0f && d->N % 4 == 0) ,
                  "gemm: colsum_part is only supported with the plain dGELU epilogue");
