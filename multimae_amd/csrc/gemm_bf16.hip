@@ -251,6 +251,7 @@ int dispatch_layout(const GemmArgs& g, int batch, bool aks, bool bks, hipStream_
 }  // namespace
 
 int mmae_gemm_bf16_pipe_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hipStream_t st);
+int mmae_gemm_bf16_pp_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hipStream_t st);
 
 int mmae_gemm_bf16_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st) {
     MMAE_REQUIRE(d->lda % 8 == 0 && d->ldb % 8 == 0, "gemm bf16: lda/ldb must be multiples of 8");
@@ -266,6 +267,7 @@ int mmae_gemm_bf16_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t 
     const int code = d->tile ? d->tile : env_tile;
     switch (code) {
         case 5: case 6: case 7: case 8: return mmae_gemm_bf16_pipe_impl(d, g, code, st);     // LDS-DMA ring, BK = 32
+        case 9: case 10: return mmae_gemm_bf16_pp_impl(d, g, code, st);                     // 8-wave ping-pong, 256/320 x 256
         case 2: return dispatch_layout<4, 2, true>(g, d->batch, d->a_trans != 0, d->b_trans != 0, st);
         case 3: return dispatch_layout<2, 2, false>(g, d->batch, d->a_trans != 0, d->b_trans != 0, st);
         case 4: return dispatch_layout<4, 2, false>(g, d->batch, d->a_trans != 0, d->b_trans != 0, st);

@@ -129,7 +129,7 @@ __device__ __forceinline__ void st4_bf16_hw(uint16_t* p, f32x4 v) {   // v_cvt_p
 // fast paths: alpha == 1, N % 4 == 0, every pointer/ld 4-element aligned (g.vec), aux is bf16
 template <bool BIAS, int EPI, bool RESID, bool C_F32, bool ACC, bool AUX_F32 = false, bool COLSUM = false>
 __device__ __forceinline__ void store_tile64_fast(const GemmArgs& g, char* Cbase, long long ldc, char* wave_lds, int lane,
-                                                  const f32x16 (&acc)[2][2], int m_base, int n_base) {
+                                                  const f32x16 (&acc)[2][2], int m_base, int n_base, int ntm = 2) {
     const int c16 = lane & 15, rsub = lane >> 4;
     const int n = n_base + c16 * 4;
     const bool n_ok = n < g.N;
@@ -138,6 +138,7 @@ __device__ __forceinline__ void store_tile64_fast(const GemmArgs& g, char* Cbase
     if (BIAS && n_ok) b4 = ld4(g.bias + n);
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
+        if (tm >= ntm) break;            // ntm = 1: only the first 32-row half of the tile exists (odd MFMA-tile counts)
         stage_acc_tile(wave_lds, lane, acc, tm);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -190,47 +191,48 @@ __device__ __forceinline__ void store_tile64_fast(const GemmArgs& g, char* Cbase
 }
 
 __device__ __forceinline__ void gemm_store_tile64(const GemmArgs& g, char* Cz, char* wave_lds, int lane, f32x16 (&acc)[2][2],
-                                                  int m_base, int n_base) {
+                                                  int m_base, int n_base, int ntm = 2) {
     const bool aligned = g.vec && ((g.N & 3) == 0) && g.alpha == 1.0f;
     if (g.splitk > 1) {                      // dense f32 partial slab
         if ((g.N & 3) == 0) {
-            store_tile64_fast<false, 0, false, true, false>(g, (char*)(g.ws + (long long)blockIdx.z * g.M * g.N), g.N, wave_lds, lane, acc, m_base, n_base);
+            store_tile64_fast<false, 0, false, true, false>(g, (char*)(g.ws + (long long)blockIdx.z * g.M * g.N), g.N, wave_lds, lane, acc, m_base, n_base, ntm);
             return;
         }
     } else if (aligned) {
         const bool bias = g.bias != nullptr, resid = g.resid != nullptr;
         const bool aux_ok = g.epi == MMAE_EPI_NONE || !g.aux_f32;
         if (!aux_ok && g.c_f32 && !resid && !g.accumulate) {      // exact-f32 mode: f32 C and f32 aux
-            if (g.epi == MMAE_EPI_GELU && bias) { store_tile64_fast<true, MMAE_EPI_GELU, false, true, false, true>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }
+            if (g.epi == MMAE_EPI_GELU && bias) { store_tile64_fast<true, MMAE_EPI_GELU, false, true, false, true>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm); return; }
             if (g.epi == MMAE_EPI_DGELU && !bias) {
-                if (g.colpart) store_tile64_fast<false, MMAE_EPI_DGELU, false, true, false, true, true>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base);
-                else store_tile64_fast<false, MMAE_EPI_DGELU, false, true, false, true>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base);
+                if (g.colpart) store_tile64_fast<false, MMAE_EPI_DGELU, false, true, false, true, true>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm);
+                else store_tile64_fast<false, MMAE_EPI_DGELU, false, true, false, true>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm);
                 return;
             }
         }
         if (aux_ok) {
             if (!g.c_f32 && !resid && !g.accumulate) {
                 if (g.epi == MMAE_EPI_NONE) {
-                    if (bias) { store_tile64_fast<true, 0, false, false, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }
-                    store_tile64_fast<false, 0, false, false, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return;
+                    if (bias) { store_tile64_fast<true, 0, false, false, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm); return; }
+                    store_tile64_fast<false, 0, false, false, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm); return;
                 }
-                if (g.epi == MMAE_EPI_GELU && bias) { store_tile64_fast<true, MMAE_EPI_GELU, false, false, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }
+                if (g.epi == MMAE_EPI_GELU && bias) { store_tile64_fast<true, MMAE_EPI_GELU, false, false, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm); return; }
                 if (g.epi == MMAE_EPI_DGELU && !bias) {
-                    if (g.colpart) store_tile64_fast<false, MMAE_EPI_DGELU, false, false, false, false, true>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base);
-                    else store_tile64_fast<false, MMAE_EPI_DGELU, false, false, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base);
+                    if (g.colpart) store_tile64_fast<false, MMAE_EPI_DGELU, false, false, false, false, true>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm);
+                    else store_tile64_fast<false, MMAE_EPI_DGELU, false, false, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm);
                     return;
                 }
             } else if (g.c_f32 && g.epi == MMAE_EPI_NONE) {
-                if (bias && resid && !g.accumulate) { store_tile64_fast<true, 0, true, true, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }
-                if (bias && !resid && !g.accumulate) { store_tile64_fast<true, 0, false, true, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }
-                if (!bias && !resid && !g.accumulate) { store_tile64_fast<false, 0, false, true, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }
-                if (!bias && !resid && g.accumulate) { store_tile64_fast<false, 0, false, true, true>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base); return; }
+                if (bias && resid && !g.accumulate) { store_tile64_fast<true, 0, true, true, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm); return; }
+                if (bias && !resid && !g.accumulate) { store_tile64_fast<true, 0, false, true, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm); return; }
+                if (!bias && !resid && !g.accumulate) { store_tile64_fast<false, 0, false, true, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm); return; }
+                if (!bias && !resid && g.accumulate) { store_tile64_fast<false, 0, false, true, true>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm); return; }
             }
         }
     }
     // generic path: any flag combination, ragged N, unaligned pointers
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
+        if (tm >= ntm) break;
         stage_acc_tile(wave_lds, lane, acc, tm);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {

@@ -77,8 +77,19 @@ def test_gemm_bf16_layouts(shape, a_trans, b_trans):
     """bf16 products are exact in fp32, so vs fp64 on the same bf16 inputs only fp32 summation
     error remains: rel-L2 <= 2e-6."""
     M, N, K = shape
-    for tile in (1, 2, 3, 4, 5, 6, 7, 8):
+    for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
         assert _gemm_case(torch.bfloat16, M, N, K, a_trans, b_trans, tile=tile) < 2e-6, (shape, tile)
+
+
+@pytest.mark.parametrize('a_trans,b_trans', [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize('tile', [9, 10])
+@pytest.mark.parametrize('shape', [(1000, 520, 32), (1000, 520, 96), (700, 300, 1336), (2048, 768, 776)])
+def test_gemm_bf16_pingpong_ring(shape, tile, a_trans, b_trans):
+    """8-wave ping-pong kernel (tile codes 9 / 10): several 256/320-row tiles with ragged edges, K from one 32-wide tile
+    (shorter than the 4-deep DMA ring) to 42 tiles (ring wraps ten times); repeated to catch ring races."""
+    M, N, K = shape
+    for seed in range(3):
+        assert _gemm_case(torch.bfloat16, M, N, K, a_trans, b_trans, tile=tile, seed=seed) < 2e-6, (shape, tile, seed)
 
 
 @pytest.mark.parametrize('a_trans,b_trans', [(False, False), (False, True), (True, False), (True, True)])

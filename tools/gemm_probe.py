@@ -4,7 +4,7 @@ kernels from event timing, so run under rocprofv3 and read true kernel durations
     python tools/gemm_probe.py --parse out"""
 import sys, os, glob, csv
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-CONFIGS = [(tile, M, N, K) for tile in (3, 7, 8) for (M, N) in ((25344, 768), (25344, 2304), (50176, 1024)) for K in (64, 256, 768, 3072)]
+CONFIGS = [(tile, M, N, K) for tile in (3, 9, 10) for (M, N) in ((25344, 768), (25344, 2304), (25344, 3072), (50176, 1024)) for K in (256, 768, 3072)]
 REP = 6
 if len(sys.argv) > 2 and sys.argv[1] == '--parse':
     f = glob.glob(os.path.join(sys.argv[2], '**', '*kernel_trace.csv'), recursive=True)[0]
