@@ -83,8 +83,9 @@ typedef struct mmae_gemm_desc {
     int32_t epi;
     int32_t accumulate;          /* C += v (c_dtype must be f32) */
     float alpha;
-    int32_t tile;                /* bf16 kernel variant: 0/1 = 128x128 LDS-DMA, 2 = 256x128 LDS-DMA, 3/4 = same tiles, VGPR-staged,
-                                    5/6 = same tiles, 4-stage LDS-DMA ring with counted vmcnt (BK = 32) */
+    int32_t tile;                /* bf16 kernel variant.  0 = let the library choose (mmae_gemm_plan; env MMAE_GEMM_TILE overrides);
+                                    1/2 = 128x128 / 256x128 2-stage LDS-DMA, 3/4 = same tiles, VGPR-staged, 5..8 = LDS-DMA ring
+                                    with counted vmcnt (BK = 32), 9/10 = 8-wave ping-pong on 256x256 / 320x256 tiles */
     int32_t split_k;             /* <= 1: off; n: n K-slices, each writing a dense f32 [M][N] partial into ws,
                                     then summed into C in a fixed order (plain unbatched f32 C only).  The library
                                     never allocates: ask mmae_gemm_auto_splitk() and pass a workspace. */
@@ -95,7 +96,11 @@ typedef struct mmae_gemm_desc {
 } mmae_gemm_desc;
 
 int mmae_gemm(const mmae_gemm_desc* d, void* stream);
-/* suggested number of K slices for an [M,N,K] product on a 256-CU MI355X (1 = do not split) */
+/* What mmae_gemm would pick for this descriptor on a 256-CU MI355X: *tile = bf16 kernel variant (as mmae_gemm_desc.tile;
+ * d->tile / env MMAE_GEMM_TILE honoured), *split_k = number of K slices worth using (1 = do not split; > 1 only for
+ * products the split path supports).  The caller sizes the workspace from *split_k and passes both back in the desc. */
+int mmae_gemm_plan(const mmae_gemm_desc* d, int* tile, int* split_k);
+/* suggested number of K slices for a dW-shaped (both operands k-strided) [M,N,K] product (1 = do not split) */
 int mmae_gemm_auto_splitk(int M, int N, int K, int ab_dtype);
 
 /* ------------------------------------------------------------------------- *

@@ -253,7 +253,7 @@ int dispatch_layout(const GemmArgs& g, int batch, bool aks, bool bks, hipStream_
 int mmae_gemm_bf16_pipe_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hipStream_t st);
 int mmae_gemm_bf16_pp_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hipStream_t st);
 
-int mmae_gemm_bf16_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st) {
+int mmae_gemm_bf16_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hipStream_t st) {
     MMAE_REQUIRE(d->lda % 8 == 0 && d->ldb % 8 == 0, "gemm bf16: lda/ldb must be multiples of 8");
     MMAE_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0, "gemm bf16: A/B must be 16-byte aligned");
     MMAE_REQUIRE(d->sA_outer % 8 == 0 && d->sA_inner % 8 == 0 && d->sB_outer % 8 == 0 && d->sB_inner % 8 == 0,
@@ -262,9 +262,7 @@ int mmae_gemm_bf16_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t 
     MMAE_REQUIRE(a_rows * d->lda * 2 < 0x7fffffffLL && b_rows * d->ldb * 2 < 0x7fffffffLL, "gemm bf16: operand >= 2 GiB");
     if (d->a_trans) MMAE_REQUIRE(d->M % 8 == 0 || d->lda >= ((d->M + 7) / 8) * 8, "gemm bf16: transposed A row too short");
     if (d->b_trans) MMAE_REQUIRE(d->N % 8 == 0 || d->ldb >= ((d->N + 7) / 8) * 8, "gemm bf16: transposed B row too short");
-    // tile codes: 0/1 = 128x128 LDS-DMA (default), 2 = 256x128 LDS-DMA, 3 = 128x128 VGPR-staged, 4 = 256x128 VGPR-staged
-    static const int env_tile = getenv("MMAE_GEMM_TILE") ? atoi(getenv("MMAE_GEMM_TILE")) : 3;   // default: 128x128 VGPR-staged (fastest in the r01 K-sweep)
-    const int code = d->tile ? d->tile : env_tile;
+    // tile codes (chosen by runtime.hip's gemm_plan): 1 = 128x128 LDS-DMA, 2 = 256x128 LDS-DMA, 3 = 128x128 VGPR-staged, 4 = 256x128 VGPR-staged
     switch (code) {
         case 5: case 6: case 7: case 8: return mmae_gemm_bf16_pipe_impl(d, g, code, st);     // LDS-DMA ring, BK = 32
         case 9: case 10: return mmae_gemm_bf16_pp_impl(d, g, code, st);                     // 8-wave ping-pong, 256/320 x 256

@@ -21,10 +21,59 @@ int mmae_check_launch(const char* what) {
     return 0;
 }
 
-int mmae_gemm_bf16_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st);
+int mmae_gemm_bf16_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hipStream_t st);
 int mmae_gemm_f32_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st);
 int mmae_gemm_f32x3_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st);
 int mmae_splitk_reduce(const float* ws, float* C, int M, int N, long long ldc, int splits, int accumulate, hipStream_t st);
+
+namespace {
+
+bool split_eligible(const mmae_gemm_desc* d) {
+    return d->c_dtype == MMAE_F32 && d->epi == MMAE_EPI_NONE && !d->bias && !d->resid && d->batch == 1 && d->alpha == 1.0f &&
+           d->N % 4 == 0 && d->ldc % 4 == 0 && !d->colsum_part;
+}
+
+// Kernel variant + split-K choice for one product (256 CUs; the ping-pong kernel holds one workgroup per CU, the
+// 128 x 128 kernels about three).
+void gemm_plan(const mmae_gemm_desc* d, int* tile_out, int* split_out) {
+    static const int env_tile = getenv("MMAE_GEMM_TILE") ? atoi(getenv("MMAE_GEMM_TILE")) : 0;
+    const int bk = d->ab_dtype == MMAE_F32 ? 16 : 64;
+    const int nkt = (d->K + bk - 1) / bk;
+    const bool can_split = split_eligible(d) && nkt >= 32;
+    int tile = d->tile ? d->tile : env_tile;
+    const long long nt256 = (d->N + 255) / 256;
+    if (tile == 0) {
+        tile = 3;
+        if (d->ab_dtype == MMAE_BF16 && d->batch == 1) {
+            const long long t4 = ((d->M + 255) / 256) * nt256, t5 = ((d->M + 319) / 320) * nt256;
+            if (d->M >= 2048 && d->N >= 192 && d->K >= 128) {
+                // whole rounds of 256 workgroups x rows per tile: 320-row tiles when they waste less of the last round
+                const long long c4 = ((t4 + 255) / 256) * 256, c5 = ((t5 + 255) / 256) * 320;
+                tile = (c5 <= c4 && !d->a_trans && !d->colsum_part) ? 10 : 9;
+            } else if (t4 >= 4 && can_split && d->K >= 4096) {
+                tile = 9;                                   // dW-shaped: few tiles, split along K below
+            }
+        }
+    }
+    int s = 1;
+    if (can_split) {
+        if (tile == 9 || tile == 10) {
+            const long long t = ((d->M + (tile == 9 ? 255 : 319)) / (tile == 9 ? 256 : 320)) * nt256;
+            if (t < 128) s = (int)(256 / t);
+        } else {
+            const long long t = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128);
+            if (t < 384) s = (int)((1024 + t - 1) / t);
+        }
+        const int max_split = nkt / 8;                      // keep >= 8 K tiles per slice
+        if (s > max_split) s = max_split;
+        if (s > 64) s = 64;
+        if (s < 1) s = 1;
+    }
+    *tile_out = tile;
+    *split_out = s;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -83,22 +132,30 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     g.kt_per_split = (nkt + splitk - 1) / splitk;
     g.splitk = (nkt + g.kt_per_split - 1) / g.kt_per_split;
     g.ws = (float*)d->ws;
-    int rc = (d->ab_dtype == MMAE_BF16) ? mmae_gemm_bf16_impl(d, g, st)
+    int code = 0, unused = 0;
+    gemm_plan(d, &code, &unused);
+    int rc = (d->ab_dtype == MMAE_BF16) ? mmae_gemm_bf16_impl(d, g, code, st)
            : (d->ab_dtype == MMAE_F32X3 ? mmae_gemm_f32x3_impl(d, g, st) : mmae_gemm_f32_impl(d, g, st));
     if (rc || g.splitk <= 1) return rc;
     return mmae_splitk_reduce(g.ws, (float*)d->C, d->M, d->N, d->ldc, g.splitk, d->accumulate, st);
 }
 
+int mmae_gemm_plan(const mmae_gemm_desc* d, int* tile, int* split_k) {
+    MMAE_REQUIRE(d && tile && split_k, "gemm_plan: null argument");
+    MMAE_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm_plan: empty problem");
+    gemm_plan(d, tile, split_k);
+    return 0;
+}
+
 int mmae_gemm_auto_splitk(int M, int N, int K, int ab_dtype) {
-    const int bk = ab_dtype == MMAE_F32 ? 16 : 64;
-    const int nkt = (K + bk - 1) / bk;
-    const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
-    if (tiles >= 384 || nkt < 32) return 1;
-    int s = (int)((1024 + tiles - 1) / tiles);
-    const int max_split = nkt / 8;                      // keep >= 8 K tiles per slice
-    if (s > max_split) s = max_split;
-    if (s > 64) s = 64;
-    return s < 1 ? 1 : s;
+    mmae_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.M = M; d.N = N; d.K = K; d.ab_dtype = ab_dtype; d.c_dtype = MMAE_F32;
+    d.a_trans = d.b_trans = 1; d.batch = d.batch_inner = 1; d.alpha = 1.0f;
+    d.ldc = (N + 3) / 4 * 4;
+    int tile = 0, s = 1;
+    gemm_plan(&d, &tile, &s);
+    return (N % 4 == 0) ? s : 1;
 }
 
 }  // extern "C"

@@ -96,9 +96,11 @@ def gemm(A: Tensor, B: Tensor, C: Tensor, M: int, N: int, K: int, *, lda: int, l
     d.epi, d.accumulate, d.alpha, d.tile = epi, int(accumulate), alpha, tile
     ws = None
     lib = _lib.load()
-    if split_k == 0 and batch == 1 and C.dtype == torch.float32 and epi == EPI_NONE and bias is None and resid is None \
-            and alpha == 1.0 and N % 4 == 0 and ldc % 4 == 0:
-        split_k = lib.mmae_gemm_auto_splitk(M, N, K, d.ab_dtype)
+    d.colsum_part = _p(colsum_part)
+    if split_k == 0:
+        t_, s_ = ctypes.c_int(0), ctypes.c_int(1)
+        check(lib.mmae_gemm_plan(ctypes.byref(d), ctypes.byref(t_), ctypes.byref(s_)), 'mmae_gemm_plan')
+        d.tile, split_k = t_.value, s_.value
     if split_k > 1:
         ws = torch.empty((split_k * M * N,), device=A.device, dtype=torch.float32)
         d.ws, d.ws_elems = ws.data_ptr(), ws.numel()
