@@ -20,6 +20,7 @@
 // Read-after-DMA: every wave waits (counted) for its pieces of tile t before b_4t-1; the first read of tile t is
 // after b_4t-1.  Write-after-read: the ring slot of tile t is re-targeted (tile t+4) in MEM(2t+3) / MEM(2t+4),
 // which every wave reaches after b_4t+4, when the last reader (group 1, MEM(2t+1)) has drained its lgkmcnt.
+#include <stdlib.h>
 #include "gemm_common.h"
 
 #define LDS_AS __attribute__((address_space(3)))
@@ -187,6 +188,13 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
         __builtin_amdgcn_s_setprio(0);
     };
 
+    // De-phase the CUs (multi-round launches only): all 256 first-round workgroups would otherwise reach their epilogues
+    // together, every round -- an HBM write burst with the MFMA pipes idle, then a compute phase with HBM idle.  A
+    // one-off start delay of 0..3 quarter-tiles per CU makes the epilogue of one CU overlap the main loops of others.
+    if (g.stagger > 0 && blockIdx.x < 256 && gridDim.z == 1) {
+        const int n = ((blockIdx.x >> 3) & 3) * g.stagger;          // units of 64 x 127 cycles
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     // prologue: tiles 0, 1 and the first half of tile 2
     dma_first(0); dma_second(0);
     dma_first(1); dma_second(1);
@@ -245,6 +253,8 @@ int launch(const GemmArgs& g, int batch, hipStream_t st) {
     GemmArgs a = g;
     a.tiles_n = (g.N + BN - 1) / BN;
     a.kt_per_split = g.kt_per_split * 2;                 // runtime.hip counts 64-wide K tiles; this kernel steps by 32
+    static const int env_stagger = getenv("MMAE_GEMM_STAGGER") ? atoi(getenv("MMAE_GEMM_STAGGER")) : 0;   // quarter-tile delay in 8128-cycle units per 1024 of K
+    a.stagger = (tiles_m * a.tiles_n > 300) ? (int)((long long)env_stagger * g.K / 1024) : 0;
     dim3 grid(tiles_m * a.tiles_n, batch, a.splitk), block(512);
     const size_t lds = (size_t)4 * (BM + BN) * 64 + 1024;
     static bool attr_done = false;

@@ -17,6 +17,7 @@ struct GemmArgs {
     int splitk, kt_per_split;     // splitk > 1: z-slice s writes its partial product to ws[s][M][N] (f32)
     float* ws;
     int xcd_swizzle;
+    int stagger;                  // ping-pong kernel: start-delay unit (x 8128 cycles) used to de-phase the CUs
     float* colpart;               // optional [ceil(M/64)][N] column sums of the epilogue output (dGELU flavour)
 };
 
@@ -126,59 +127,115 @@ __device__ __forceinline__ void st4_bf16_hw(uint16_t* p, f32x4 v) {   // v_cvt_p
     *reinterpret_cast<bf16x4_t*>(p) = b;
 }
 
-// fast paths: alpha == 1, N % 4 == 0, every pointer/ld 4-element aligned (g.vec), aux is bf16
+// fast paths: alpha == 1, N % 4 == 0, every pointer/ld 4-element aligned (g.vec), aux is bf16 (or f32 with AUX_F32).
+// All global traffic goes through raw buffer instructions on descriptors based at the tile's first row: masked lanes use
+// the out-of-range offset (loads return 0, stores are dropped), so the loop has no branches, and the epilogue's INPUT
+// streams (dGELU pre-activations, residual) are prefetched one 32-row round ahead -- with the loads inside a bounds
+// branch every 4-row step of the dGELU / residual epilogues exposed a full HBM round trip (~30 us per 256 x 256 tile).
+__device__ __forceinline__ i32x2 pack4_bf16(f32x4 v) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+    bf16x4_t b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = (__bf16)v[j];
+    return __builtin_bit_cast(i32x2, b);
+}
+__device__ __forceinline__ f32x4 unpack4_bf16(i32x2 r) {
+    f32x4 o;
+    o[0] = __uint_as_float(((uint32_t)r[0]) << 16); o[1] = __uint_as_float(((uint32_t)r[0]) & 0xffff0000u);
+    o[2] = __uint_as_float(((uint32_t)r[1]) << 16); o[3] = __uint_as_float(((uint32_t)r[1]) & 0xffff0000u);
+    return o;
+}
+template <typename T>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(T* base, long long row, long long ld) {
+    const unsigned long long v = (unsigned long long)(base + row * ld);       // wave-uniform: keep it in SGPRs
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x80000000, 0x00020000);
+}
+
 template <bool BIAS, int EPI, bool RESID, bool C_F32, bool ACC, bool AUX_F32 = false, bool COLSUM = false>
 __device__ __forceinline__ void store_tile64_fast(const GemmArgs& g, char* Cbase, long long ldc, char* wave_lds, int lane,
                                                   const f32x16 (&acc)[2][2], int m_base, int n_base, int ntm = 2) {
+    constexpr unsigned OOB_OFF = 0x80000000u;
     const int c16 = lane & 15, rsub = lane >> 4;
     const int n = n_base + c16 * 4;
     const bool n_ok = n < g.N;
+    const int rows_left = g.M - m_base;                  // rows r (tile-relative) < rows_left exist
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 cs = {0.f, 0.f, 0.f, 0.f};
     if (BIAS && n_ok) b4 = ld4(g.bias + n);
+    constexpr int C_ESZ = C_F32 ? 4 : 2, AUX_ESZ = AUX_F32 ? 4 : 2;
+    const auto rsC = C_F32 ? row_rsrc((float*)Cbase, m_base, ldc) : row_rsrc((uint16_t*)Cbase, m_base, ldc);
+    const auto rsAux = (EPI != MMAE_EPI_NONE) ? (AUX_F32 ? row_rsrc((float*)g.aux, m_base, g.ldaux) : row_rsrc((uint16_t*)g.aux, m_base, g.ldaux)) : rsC;
+    const auto rsRes = RESID ? row_rsrc((float*)g.resid, m_base, g.ldr) : rsC;
+    auto voff = [&](int tm, int it, long long ld, int esz) -> int {
+        const int r = tm * 32 + it * 4 + rsub;
+        return (n_ok && r < rows_left) ? (int)((r * ld + n) * esz) : (int)OOB_OFF;
+    };
+    // input prefetch ring: slot gi % PD holds the inputs of global 4-row step gi = tm * 8 + it; refilled for step gi + PD
+    // right after use (f32 streams: 4 steps = 16 VGPRs; the bf16 aux stream affords 8)
+    constexpr int PD = (RESID || AUX_F32) ? 4 : 8;
+    i32x4 pre_res[PD];
+    i32x4 pre_aux[PD];                                   // bf16 aux uses the low two dwords
+    auto prefetch = [&](int gi) {
+        const int tm = gi >> 3, it = gi & 7, sl = gi % PD;
+        if (tm >= ntm) return;
+        if (RESID) pre_res[sl] = __builtin_amdgcn_raw_buffer_load_b128(rsRes, voff(tm, it, g.ldr, 4), 0, 0);
+        if (EPI == MMAE_EPI_DGELU) {
+            if (AUX_F32) pre_aux[sl] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, voff(tm, it, g.ldaux, 4), 0, 0);
+            else {
+                const i32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rsAux, voff(tm, it, g.ldaux, 2), 0, 0);
+                pre_aux[sl][0] = t[0]; pre_aux[sl][1] = t[1];
+            }
+        }
+    };
+    if (RESID || EPI == MMAE_EPI_DGELU) {
+#pragma unroll
+        for (int gi = 0; gi < PD; ++gi) prefetch(gi);
+    }
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
-        if (tm >= ntm) break;            // ntm = 1: only the first 32-row half of the tile exists (odd MFMA-tile counts)
-        stage_acc_tile(wave_lds, lane, acc, tm);
+        if (tm < ntm) {                  // ntm = 1: only the first 32-row half of the tile exists (odd MFMA-tile counts)
+            stage_acc_tile(wave_lds, lane, acc, tm);
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int r = it * 4 + rsub;
-            const int m = m_base + tm * 32 + r;
-            f32x4 v = *reinterpret_cast<const f32x4*>(wave_lds + r * 256 + ((c16 ^ (r & 15)) << 4));
-            if (m < g.M && n_ok) {
+            for (int it = 0; it < 8; ++it) {
+                const int r = it * 4 + rsub;
+                f32x4 v = *reinterpret_cast<const f32x4*>(wave_lds + r * 256 + ((c16 ^ (r & 15)) << 4));
+                const bool ok = n_ok && (tm * 32 + r) < rows_left;
                 if (BIAS) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] += b4[j];
                 }
                 if (EPI == MMAE_EPI_GELU) {
-                    if (AUX_F32) st4((float*)g.aux + (long long)m * g.ldaux + n, v);
-                    else st4_bf16_hw((uint16_t*)g.aux + (long long)m * g.ldaux + n, v);
+                    if (AUX_F32) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rsAux, voff(tm, it, g.ldaux, 4), 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b64(pack4_bf16(v), rsAux, voff(tm, it, g.ldaux, 2), 0, 0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
                 } else if (EPI == MMAE_EPI_DGELU) {
-                    const f32x4 p = AUX_F32 ? ld4((const float*)g.aux + (long long)m * g.ldaux + n)
-                                            : ld4((const uint16_t*)g.aux + (long long)m * g.ldaux + n);
+                    i32x2 lo2; lo2[0] = pre_aux[(tm * 8 + it) % PD][0]; lo2[1] = pre_aux[(tm * 8 + it) % PD][1];
+                    const f32x4 p = AUX_F32 ? __builtin_bit_cast(f32x4, pre_aux[(tm * 8 + it) % PD]) : unpack4_bf16(lo2);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(p[j]);
                 }
                 if (RESID) {
-                    const f32x4 t = ld4(g.resid + (long long)m * g.ldr + n);
+                    const f32x4 t = __builtin_bit_cast(f32x4, pre_res[(tm * 8 + it) % PD]);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] += t[j];
                 }
+                if ((RESID || EPI == MMAE_EPI_DGELU) && tm * 8 + it + PD < 16) prefetch(tm * 8 + it + PD);   // refill this slot
                 if (COLSUM) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) cs[j] += v[j];
+                    for (int j = 0; j < 4; ++j) cs[j] += ok ? v[j] : 0.f;
                 }
                 if (C_F32) {
-                    float* c = (float*)Cbase + (long long)m * ldc + n;
-                    if (ACC) { const f32x4 t = ld4(c);
+                    const int o = voff(tm, it, ldc, 4);
+                    if (ACC) {
+                        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsC, o, 0, 0));
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] += t[j];
                     }
-                    st4(c, v);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rsC, o, 0, 0);
                 } else {
-                    st4_bf16_hw((uint16_t*)Cbase + (long long)m * ldc + n, v);
+                    __builtin_amdgcn_raw_buffer_store_b64(pack4_bf16(v), rsC, voff(tm, it, ldc, C_ESZ), 0, 0);
                 }
             }
         }
