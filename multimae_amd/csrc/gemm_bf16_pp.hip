@@ -20,7 +20,6 @@
 // Read-after-DMA: every wave waits (counted) for its pieces of tile t before b_4t-1; the first read of tile t is
 // after b_4t-1.  Write-after-read: the ring slot of tile t is re-targeted (tile t+4) in MEM(2t+3) / MEM(2t+4),
 // which every wave reaches after b_4t+4, when the last reader (group 1, MEM(2t+1)) has drained its lgkmcnt.
-#include <stdlib.h>
 #include "gemm_common.h"
 
 #define LDS_AS __attribute__((address_space(3)))
@@ -178,6 +177,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
         for (int t = 0; t < TM; ++t) af[t] = AKS ? frag_ks(sa, wm * WMR + t * 32, kk) : frag_kc(sa, wm * WMR + t * 32, kk);
         if (kk == 0) dma_second(u + 2); else dma_first(u + 3);
     };
+    // (Issuing the DMA pieces between the MFMAs instead -- an LDS-DMA issue stalls its wave 60-180 cycles -- measured 1-10 %
+    // slower than keeping them in the memory half-phase.)
     auto mfma_phase = [&]() {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -188,13 +189,6 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
         __builtin_amdgcn_s_setprio(0);
     };
 
-    // De-phase the CUs (multi-round launches only): all 256 first-round workgroups would otherwise reach their epilogues
-    // together, every round -- an HBM write burst with the MFMA pipes idle, then a compute phase with HBM idle.  A
-    // one-off start delay of 0..3 quarter-tiles per CU makes the epilogue of one CU overlap the main loops of others.
-    if (g.stagger > 0 && blockIdx.x < 256 && gridDim.z == 1) {
-        const int n = ((blockIdx.x >> 3) & 3) * g.stagger;          // units of 64 x 127 cycles
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     // prologue: tiles 0, 1 and the first half of tile 2
     dma_first(0); dma_second(0);
     dma_first(1); dma_second(1);
@@ -211,7 +205,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
             mem_phase(u, 1);
             wg_barrier();
             mfma_phase();
-            wait_vm<W>();                                // tile u + 1
+            wait_vm<W>();                               // tile u + 1
             wg_barrier();
         }
     } else {
@@ -222,7 +216,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
             mfma_phase();
             wg_barrier();
             mem_phase(u, 1);
-            wait_vm<W>();                                // tile u + 1
+            wait_vm<W>();                               // tile u + 1
             wg_barrier();
             mfma_phase();
         }
@@ -253,8 +247,6 @@ int launch(const GemmArgs& g, int batch, hipStream_t st) {
     GemmArgs a = g;
     a.tiles_n = (g.N + BN - 1) / BN;
     a.kt_per_split = g.kt_per_split * 2;                 // runtime.hip counts 64-wide K tiles; this kernel steps by 32
-    static const int env_stagger = getenv("MMAE_GEMM_STAGGER") ? atoi(getenv("MMAE_GEMM_STAGGER")) : 0;   // quarter-tile delay in 8128-cycle units per 1024 of K
-    a.stagger = (tiles_m * a.tiles_n > 300) ? (int)((long long)env_stagger * g.K / 1024) : 0;
     dim3 grid(tiles_m * a.tiles_n, batch, a.splitk), block(512);
     const size_t lds = (size_t)4 * (BM + BN) * 64 + 1024;
     static bool attr_done = false;

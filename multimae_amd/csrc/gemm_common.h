@@ -17,7 +17,6 @@ struct GemmArgs {
     int splitk, kt_per_split;     // splitk > 1: z-slice s writes its partial product to ws[s][M][N] (f32)
     float* ws;
     int xcd_swizzle;
-    int stagger;                  // ping-pong kernel: start-delay unit (x 8128 cycles) used to de-phase the CUs
     float* colpart;               // optional [ceil(M/64)][N] column sums of the epilogue output (dGELU flavour)
 };
 

@@ -104,7 +104,6 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     g.colpart = d->colsum_part;
     static const int env_swz = getenv("MMAE_GEMM_XCD") ? atoi(getenv("MMAE_GEMM_XCD")) : 1;
     g.xcd_swizzle = env_swz;
-    g.stagger = 0;
     MMAE_REQUIRE(!d->colsum_part || (d->epi == MMAE_EPI_DGELU && !d->bias && !d->resid && !d->accumulate && d->batch == 1 && d->split_k <= 1 &&
                                      d->alpha == 1.0f && d->N % 4 == 0) ,
                  "gemm: colsum_part is only supported with the plain dGELU epilogue");

@@ -6,7 +6,7 @@ from multimae_amd import ops
 M, N, K = 25344, 2304, 3072
 A = torch.randn(M, K, device='cuda').to(torch.bfloat16); B = torch.randn(N, K, device='cuda').to(torch.bfloat16)
 C = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
-for tile in (3, 8, 5):
+for tile in (3, 9, 10):
     for _ in range(3):
         ops.gemm(A, B, C, M, N, K, lda=K, ldb=K, ldc=N, tile=tile)
 torch.cuda.synchronize()
