@@ -93,6 +93,11 @@ typedef struct mmae_gemm_desc {
     int64_t ws_elems;
     float* colsum_part;          /* optional f32 [ceil(M/64)][N]: per-64-row-block column sums of the epilogue output
                                     (bias gradient of the next Linear for free); dGELU epilogue only, else must be NULL */
+    float* a_colsum;             /* optional f32 [M]: receives sum_k A[k][m] -- for a dW product (A = dy, k-strided) that is the
+                                    bias gradient, taken from the operand tiles already in LDS instead of a second pass over dy.
+                                    Only for bf16, a_trans = 1, batch = 1 products that mmae_gemm_plan maps to tile 9; needs
+                                    max(split_k, 1) * M extra workspace floats after the split-K slabs. */
+    int32_t a_colsum_acc;        /* a_colsum += (else =) */
 } mmae_gemm_desc;
 
 int mmae_gemm(const mmae_gemm_desc* d, void* stream);

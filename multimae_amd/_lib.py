@@ -40,6 +40,7 @@ class GemmDesc(ctypes.Structure):
         ('aux_dtype', ctypes.c_int32), ('epi', ctypes.c_int32), ('accumulate', ctypes.c_int32),
         ('alpha', ctypes.c_float), ('tile', ctypes.c_int32), ('split_k', ctypes.c_int32),
         ('ws', ctypes.c_void_p), ('ws_elems', ctypes.c_int64), ('colsum_part', ctypes.c_void_p),
+        ('a_colsum', ctypes.c_void_p), ('a_colsum_acc', ctypes.c_int32),
     ]
 
 

@@ -168,6 +168,12 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
     };
 
     bf16x8 af[TM], bf[2];
+    // optional column sums of the k-strided A operand (bias gradient of a dW product): the wn = 0 waves of the n-tile-0
+    // workgroups add up the A fragments they hold anyway (v_dot2c with a vector of ones, in the shadow of the MFMAs)
+    const bool do_acs = AKS && g.acs != nullptr && n0 == 0 && wn == 0;
+    float acs[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) acs[t] = 0.f;
     auto mem_phase = [&](int u, int kk) {
         const char* sa = smem + (u & (NST - 1)) * STAGE;
         const char* sb = sa + A_BYTES;
@@ -187,6 +193,14 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
             for (int tm = 0; tm < TM; ++tm)
                 acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[tn], af[tm], acc[tn][tm], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+        if (AKS && do_acs) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const i32x4 w = __builtin_bit_cast(i32x4, af[tm]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acs[tm]) : "v"(w[j]), "v"(0x3f803f80));
+            }
+        }
     };
 
     // prologue: tiles 0, 1 and the first half of tile 2
@@ -219,6 +233,14 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
             wait_vm<W>();                               // tile u + 1
             wg_barrier();
             mfma_phase();
+        }
+    }
+    if (AKS && do_acs) {                                 // lanes l and l + 32 hold the two k-halves of row l
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const float v = acs[tm] + __shfl_xor(acs[tm], 32, 64);
+            const int m = m0 + wm * WMR + tm * 32 + (lane & 31);
+            if (lane < 32 && m < g.M) g.acs[(long long)blockIdx.z * g.M + m] = v;
         }
     }
     wait_vm<0>();                                        // the zero-fill tail pieces must not land on the staging area

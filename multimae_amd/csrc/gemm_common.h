@@ -17,6 +17,7 @@ struct GemmArgs {
     int splitk, kt_per_split;     // splitk > 1: z-slice s writes its partial product to ws[s][M][N] (f32)
     float* ws;
     int xcd_swizzle;
+    float* acs;                   // optional [splitk][M] partial column sums of the k-strided A operand (ping-pong kernel)
     float* colpart;               // optional [ceil(M/64)][N] column sums of the epilogue output (dGELU flavour)
 };
 

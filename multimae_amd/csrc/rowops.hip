@@ -310,7 +310,21 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
 
 inline int stream_grid(long long n_vec4) { long long b = (n_vec4 + 255) / 256; return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); }
 
+// out[m] (+)= sum_s part[s][m]   (fixed order)
+__global__ void __launch_bounds__(256) acs_reduce_kernel(const float* __restrict__ part, int splits, int M, float* __restrict__ out, int accumulate) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float a = accumulate ? out[m] : 0.f;
+    for (int s = 0; s < splits; ++s) a += part[(long long)s * M + m];
+    out[m] = a;
+}
+
 }  // namespace
+
+int mmae_acs_reduce(const float* part, int splits, int M, float* out, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(acs_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, part, splits, M, out, accumulate);
+    return mmae_check_launch("acs_reduce");
+}
 
 int mmae_splitk_reduce(const float* ws, float* C, int M, int N, long long ldc, int splits, int accumulate, hipStream_t st) {
     MMAE_REQUIRE((N & 3) == 0 && (ldc & 3) == 0 && ((uintptr_t)C % 16) == 0, "gemm: split_k needs N, ldc multiples of 4 and an aligned C");

@@ -25,6 +25,7 @@ int mmae_gemm_bf16_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hi
 int mmae_gemm_f32_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st);
 int mmae_gemm_f32x3_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st);
 int mmae_splitk_reduce(const float* ws, float* C, int M, int N, long long ldc, int splits, int accumulate, hipStream_t st);
+int mmae_acs_reduce(const float* part, int splits, int M, float* out, int accumulate, hipStream_t st);
 
 namespace {
 
@@ -134,9 +135,22 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     g.ws = (float*)d->ws;
     int code = 0, unused = 0;
     gemm_plan(d, &code, &unused);
+    g.acs = nullptr;
+    if (d->a_colsum) {
+        MMAE_REQUIRE(d->ab_dtype == MMAE_BF16 && d->a_trans && d->batch == 1 && code == 9,
+                     "gemm: a_colsum needs a bf16, a_trans, unbatched product on the 256x256 ping-pong kernel (see mmae_gemm_plan)");
+        const int64_t slab = g.splitk > 1 ? (int64_t)g.splitk * d->M * d->N : 0;
+        MMAE_REQUIRE(d->ws && d->ws_elems >= slab + (int64_t)g.splitk * d->M, "gemm: a_colsum workspace too small");
+        g.acs = (float*)d->ws + slab;
+    }
     int rc = (d->ab_dtype == MMAE_BF16) ? mmae_gemm_bf16_impl(d, g, code, st)
            : (d->ab_dtype == MMAE_F32X3 ? mmae_gemm_f32x3_impl(d, g, st) : mmae_gemm_f32_impl(d, g, st));
-    if (rc || g.splitk <= 1) return rc;
+    if (rc) return rc;
+    if (g.acs) {
+        rc = mmae_acs_reduce(g.acs, g.splitk, d->M, d->a_colsum, d->a_colsum_acc, st);
+        if (rc) return rc;
+    }
+    if (g.splitk <= 1) return 0;
     return mmae_splitk_reduce(g.ws, (float*)d->C, d->M, d->N, d->ldc, g.splitk, d->accumulate, st);
 }
 

@@ -51,13 +51,27 @@ class GradSink:
         K = K if K is not None else x.shape[1]
 
         def run():
-            ops.gemm(dy, x, tgt, N, K, M, lda=dy.stride(0), ldb=ldx if ldx is not None else x.stride(0), ldc=K, a_trans=True,
-                     b_trans=True, b_off=x_off, accumulate=acc)
+            ops.linear_dw(dy, x, tgt, acc, x_off=x_off, ldx=ldx, K=K)
         if self.side is not None and acc:
             self._on_side(run, dy, x)
         else:
             run()
         return None if acc else tgt
+
+    def linear(self, w: Tensor, b: Optional[Tensor], dy: Tensor, x: Tensor):
+        """(dW, db) of y = x W^T + b in ONE launch where the GEMM kernel can also sum dy's columns."""
+        if b is None or not b.requires_grad or not w.requires_grad:
+            return self.weight(w, dy, x), (self.bias(b, dy) if b is not None else None)
+        wt, wacc = self._target(w)
+        bt, bacc = self._target(b)
+
+        def run():
+            ops.linear_dw(dy, x, wt, wacc, db=bt.view(-1), db_accumulate=bacc)
+        if self.side is not None and wacc and bacc:
+            self._on_side(run, dy, x)
+        else:
+            run()
+        return (None if wacc else wt), (None if bacc else bt)
 
     def bias(self, p: Tensor, dy: Tensor):
         if not p.requires_grad:
@@ -125,8 +139,10 @@ def block_bwd(dx: Tensor, dx_act: Tensor, dx_cs: Optional[Tensor], saved, P: Seq
     # MLP
     cs_hpre = _new((fc1w.shape[0],), dx, torch.float32) if fc1b.requires_grad else None
     d_hpre = ops.linear_dx(dx_act, wc(fc2w), _new(hpre.shape, dx, act), aux=hpre, epi=EPI_DGELU, colsum_out=cs_hpre)
-    g_fc2w = sink.weight(fc2w, dx_act, hact)
-    g_fc2b = sink.vec(fc2b, dx_cs) if dx_cs is not None else sink.bias(fc2b, dx_act)
+    if dx_cs is not None:
+        g_fc2w, g_fc2b = sink.weight(fc2w, dx_act, hact), sink.vec(fc2b, dx_cs)
+    else:
+        g_fc2w, g_fc2b = sink.linear(fc2w, fc2b, dx_act, hact)
     d_ln2 = ops.linear_dx(d_hpre, wc(fc1w), _new((R, D), dx, act))
     g_fc1w = sink.weight(fc1w, d_hpre, ln2)
     g_fc1b = sink.vec(fc1b, cs_hpre) if cs_hpre is not None else None
@@ -142,8 +158,7 @@ def block_bwd(dx: Tensor, dx_act: Tensor, dx_cs: Optional[Tensor], saved, P: Seq
                       AttnView(ao, 0, D, N), AttnView(d_ao, 0, D, N), AttnView(d_qkv, 0, 3 * D, N), AttnView(d_qkv, D, 3 * D, N),
                       AttnView(d_qkv, 2 * D, 3 * D, N), B, heads, hd, hd ** -0.5)
     d_ln1 = ops.linear_dx(d_qkv, wc(qkvw), _new((R, D), dx, act))
-    g_qkvw = sink.weight(qkvw, d_qkv, ln1)
-    g_qkvb = sink.bias(qkvb, d_qkv)
+    g_qkvw, g_qkvb = sink.linear(qkvw, qkvb, d_qkv, ln1)
     dx0, dx0_act, dg1, db1, cs_dx0 = ops.layernorm_bwd(d_ln1, x0, n1w, mean1, rstd1, dx1, lnact)
     if dx0_act is None:
         dx0_act = dx0
@@ -374,7 +389,7 @@ class SpatialAdapterFn(torch.autograd.Function):
         hd = D // heads
 
         d_pat = ops.patchify(d_img, cfg.C, cfg.nh, cfg.nw, cfg.ph, cfg.pw, act)         # [B*n_q, C*ph*pw]
-        g_ow, g_ob = sink.weight(ow, d_pat, h_act), sink.bias(ob, d_pat)
+        g_ow, g_ob = sink.linear(ow, ob, d_pat, h_act)
         dh_act = ops.linear_dx(d_pat, wc(ow), torch.empty((B * n_q, D), device=dev, dtype=act))
         dh = ops.cast(dh_act, torch.float32)
         bgrads: List[Optional[Tensor]] = [None] * (12 * cfg.depth)
@@ -385,8 +400,10 @@ class SpatialAdapterFn(torch.autograd.Function):
         # x1 = x + mlp(out_norm(x))
         cs_hpre = torch.empty((f1w.shape[0],), device=dev, dtype=torch.float32)
         d_hpre = ops.linear_dx(dh_act, wc(f2w), torch.empty(hpre.shape, device=dev, dtype=act), aux=hpre, epi=EPI_DGELU, colsum_out=cs_hpre)
-        g_f2w = sink.weight(f2w, dh_act, hact)
-        g_f2b = sink.vec(f2b, dh_cs) if dh_cs is not None else sink.bias(f2b, dh_act)
+        if dh_cs is not None:
+            g_f2w, g_f2b = sink.weight(f2w, dh_act, hact), sink.vec(f2b, dh_cs)
+        else:
+            g_f2w, g_f2b = sink.linear(f2w, f2b, dh_act, hact)
         d_on = ops.linear_dx(d_hpre, wc(f1w), torch.empty((B * n_q, D), device=dev, dtype=act))
         g_f1w, g_f1b = sink.weight(f1w, d_hpre, on), sink.vec(f1b, cs_hpre)
         dx, dx_act, g_onw, g_onb, cs_dx = ops.layernorm_bwd(d_on, x, onw, omean, orstd, dh, lnact)
@@ -401,15 +418,15 @@ class SpatialAdapterFn(torch.autograd.Function):
                           AttnView(xo, 0, D, n_q), AttnView(d_xo, 0, D, n_q), AttnView(d_q, 0, D, n_q), AttnView(d_kv, 0, 2 * D, NC),
                           AttnView(d_kv, D, 2 * D, NC), B, heads, hd, hd ** -0.5)
         d_qn = ops.linear_dx(d_q, wc(qw), torch.empty((B * n_q, D), device=dev, dtype=act))
-        g_qw, g_qb = sink.weight(qw, d_q, qn), sink.bias(qb, d_q)
+        g_qw, g_qb = sink.linear(qw, qb, d_q, qn)
         d_cn = ops.linear_dx(d_kv, wc(kvw), torch.empty((B * NC, D), device=dev, dtype=act))
-        g_kvw, g_kvb = sink.weight(kvw, d_kv, cn), sink.bias(kvb, d_kv)
+        g_kvw, g_kvb = sink.linear(kvw, kvb, d_kv, cn)
         d_queries, _, g_qnw, g_qnb, _ = ops.layernorm_bwd(d_qn, queries, qnw, qmean, qrstd, None, None)
         d_context, _, g_cnw, g_cnb, _ = ops.layernorm_bwd(d_cn, context, cnw, cmean, crstd, None, None)
         d_ctx, sums = ops.decoder_build_bwd(d_queries, d_context, ids_keep, ids_restore, cfg.task_offsets, cfg.q_task, B, n_keep, G, D,
                                             n_q)
         d_ctx_act = ops.cast(d_ctx, act)
-        g_pcw, g_pcb = sink.weight(pcw, d_ctx_act, enc_act), sink.bias(pcb, d_ctx_act)
+        g_pcw, g_pcb = sink.linear(pcw, pcb, d_ctx_act, enc_act)
         d_enc = ops.linear_dx(d_ctx_act, wc(pcw), torch.empty((B * NC, Denc), device=dev, dtype=torch.float32))
         g_mask = sink.vec(mask_token, sums[T])
         g_temb = [sink.vec(t, sums[i]) if t is not None else None for i, t in enumerate(temb)]
@@ -442,7 +459,8 @@ class LinearFn(torch.autograd.Function):
         sink = GradSink(engine.direct_grads())
         dy2 = ops.cast(dy.contiguous().view(-1, w.shape[0]), cfg.act)
         dx = ops.linear_dx(dy2, cfg.wc(w), torch.empty((dy2.shape[0], w.shape[1]), device=dy.device, dtype=torch.float32))
-        return None, dx.view(ctx.shp), sink.weight(w, dy2, x2), (sink.bias(b, dy2) if b is not None else None)
+        gw, gb = sink.linear(w, b, dy2, x2)
+        return None, dx.view(ctx.shp), gw, gb
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -517,8 +535,9 @@ class MlpFn(torch.autograd.Function):
         dy2 = ops.cast(dy.contiguous().view(-1, f2w.shape[0]), cfg.act)
         d_hpre = ops.linear_dx(dy2, cfg.wc(f2w), torch.empty(hpre.shape, device=dy.device, dtype=cfg.act), aux=hpre, epi=EPI_DGELU)
         dx = ops.linear_dx(d_hpre, cfg.wc(f1w), torch.empty((dy2.shape[0], f1w.shape[1]), device=dy.device, dtype=torch.float32))
-        return (None, dx.view(ctx.shp), sink.weight(f1w, d_hpre, x2), sink.bias(f1b, d_hpre), sink.weight(f2w, dy2, hact),
-                sink.bias(f2b, dy2))
+        g1w, g1b = sink.linear(f1w, f1b, d_hpre, x2)
+        g2w, g2b = sink.linear(f2w, f2b, dy2, hact)
+        return None, dx.view(ctx.shp), g1w, g1b, g2w, g2b
 
 
 # ------------------------------------------------------------------------------------------

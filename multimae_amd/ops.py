@@ -64,12 +64,17 @@ def f32_gemm_mode(mode: str):
 
 
 
+import os as _os
+_FUSED_DB = _os.environ.get('MMAE_FUSED_DB', '1') != '0'
+
+
 def gemm(A: Tensor, B: Tensor, C: Tensor, M: int, N: int, K: int, *, lda: int, ldb: int, ldc: int,
          a_trans: bool = False, b_trans: bool = False, a_off: int = 0, b_off: int = 0, c_off: int = 0,
          batch: int = 1, batch_inner: int = 1, sA=(0, 0), sB=(0, 0), sC=(0, 0),
          bias: Optional[Tensor] = None, resid: Optional[Tensor] = None, ldr: int = 0,
          aux: Optional[Tensor] = None, ldaux: int = 0, epi: int = EPI_NONE, accumulate: bool = False,
-         alpha: float = 1.0, tile: int = 0, split_k: int = 0, colsum_part: Optional[Tensor] = None) -> None:
+         alpha: float = 1.0, tile: int = 0, split_k: int = 0, colsum_part: Optional[Tensor] = None,
+         a_colsum: Optional[Tensor] = None, a_colsum_acc: bool = False) -> bool:
     """C[M,N] (+)= alpha * A[M,K] . B[N,K]^T with the fused epilogue of mmae_gemm.
     *_off are element offsets into the tensors' storage views (column offsets into packed qkv etc.)."""
     _require_gpu(A, 'gemm A')
@@ -101,16 +106,23 @@ def gemm(A: Tensor, B: Tensor, C: Tensor, M: int, N: int, K: int, *, lda: int, l
         t_, s_ = ctypes.c_int(0), ctypes.c_int(1)
         check(lib.mmae_gemm_plan(ctypes.byref(d), ctypes.byref(t_), ctypes.byref(s_)), 'mmae_gemm_plan')
         d.tile, split_k = t_.value, s_.value
-    if split_k > 1:
-        ws = torch.empty((split_k * M * N,), device=A.device, dtype=torch.float32)
+    # a_colsum (sum over k of the k-strided A operand = bias gradient of a dW product) rides along only on the kernel that
+    # implements it; otherwise the caller gets False back and runs its own column sum
+    fused_cs = _FUSED_DB and a_colsum is not None and d.tile == 9 and a_trans and d.ab_dtype == BF16 and batch == 1
+    n_ws = (split_k * M * N if split_k > 1 else 0) + (max(split_k, 1) * M if fused_cs else 0)
+    if n_ws:
+        ws = torch.empty((n_ws,), device=A.device, dtype=torch.float32)
         d.ws, d.ws_elems = ws.data_ptr(), ws.numel()
     d.split_k = max(split_k, 1)
-    d.colsum_part = _p(colsum_part)
+    if fused_cs:
+        assert a_colsum.dtype == torch.float32 and a_colsum.numel() >= M
+        d.a_colsum, d.a_colsum_acc = a_colsum.data_ptr(), int(a_colsum_acc)
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() >= N
     if resid is not None:
         assert resid.dtype == torch.float32
     check(lib.mmae_gemm(ctypes.byref(d), _stream()), 'mmae_gemm')
+    return fused_cs
 
 
 def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], out: Tensor, *, resid: Optional[Tensor] = None,
@@ -138,11 +150,17 @@ def linear_dx(dy: Tensor, w: Tensor, out: Tensor, *, aux: Optional[Tensor] = Non
     return out
 
 
-def linear_dw(dy: Tensor, x: Tensor, dw: Tensor, accumulate: bool) -> Tensor:
-    """dw[N,K] (+)= dy[M,N]^T @ x[M,K]   (both operands k-strided)."""
+def linear_dw(dy: Tensor, x: Tensor, dw: Tensor, accumulate: bool, *, db: Optional[Tensor] = None, db_accumulate: bool = False,
+              x_off: int = 0, ldx: Optional[int] = None, K: Optional[int] = None) -> Tensor:
+    """dw[N,K] (+)= dy[M,N]^T @ x[M,K]   (both operands k-strided).
+    db (f32 [N]): also the bias gradient  db (+)= column sums of dy  -- inside the GEMM when the kernel supports it (it
+    reads dy's tiles anyway), else by a separate column-sum launch."""
     M, N = dy.shape
-    K = x.shape[1]
-    gemm(dy, x, dw, N, K, M, lda=dy.stride(0), ldb=x.stride(0), ldc=K, a_trans=True, b_trans=True, accumulate=accumulate)
+    K = K if K is not None else x.shape[1]
+    fused = gemm(dy, x, dw, N, K, M, lda=dy.stride(0), ldb=ldx if ldx is not None else x.stride(0), ldc=K, a_trans=True, b_trans=True,
+                 b_off=x_off, accumulate=accumulate, a_colsum=db, a_colsum_acc=db_accumulate)
+    if db is not None and not fused:
+        colsum(dy, db, db_accumulate)
     return dw
 
 

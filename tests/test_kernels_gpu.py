@@ -429,3 +429,28 @@ def test_adamw_and_sumsq():
     out, ws = torch.zeros(1, device=DEV), torch.empty(1024, device=DEV)
     ops.sumsq(g.to(DEV), out, ws)
     assert abs(float(out) - float((g.double() ** 2).sum())) / float((g.double() ** 2).sum()) < 1e-6
+
+
+@pytest.mark.parametrize('shape', [(4096, 512, 264), (25344, 768, 768), (5000, 1024, 256)])
+@pytest.mark.parametrize('acc', [False, True])
+def test_linear_dw_fused_bias_grad(shape, acc):
+    """dW product with the bias gradient taken from the dy tiles inside the GEMM (mmae_gemm_desc.a_colsum): the column sums
+    are exact bf16 -> f32 additions, so vs fp64 only f32 summation error remains (rel 2e-6); also split-K + accumulate."""
+    from multimae_amd import _lib, ops
+    import ctypes
+    Mr, N, K = shape
+    torch.manual_seed(3)
+    dy, x = bf(torch.randn(Mr, N) * 0.1 + 0.03).float(), bf(torch.randn(Mr, K)).float()
+    dyd, xd = dy.to(DEV, torch.bfloat16), x.to(DEV, torch.bfloat16)
+    dw = torch.full((N, K), 1.5 if acc else float('nan'), device=DEV)
+    db = torch.full((N,), 0.25 if acc else float('nan'), device=DEV)
+    # (the planner must actually put these shapes on the kernel that implements the fused sum)
+    d = _lib.GemmDesc(); d.M, d.N, d.K, d.ab_dtype, d.c_dtype, d.a_trans, d.b_trans, d.batch, d.batch_inner, d.alpha = N, K, Mr, 1, 0, 1, 1, 1, 1, 1.0
+    d.ldc = K
+    t_, s_ = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.load().mmae_gemm_plan(ctypes.byref(d), ctypes.byref(t_), ctypes.byref(s_))
+    assert t_.value == 9, t_.value
+    ops.linear_dw(dyd, xd, dw, acc, db=db, db_accumulate=acc)
+    base_w, base_b = (1.5, 0.25) if acc else (0.0, 0.0)
+    assert rel_err(dw, base_w + dy.double().t() @ x.double()) < 2e-6
+    assert rel_err(db, base_b + dy.double().sum(0)) < 2e-6
