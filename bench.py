@@ -67,6 +67,19 @@ def loss_fns():
             'norm_rgb': M.MaskedMSELoss(16, 1, norm_pix=True)}
 
 
+def pmc_traffic(dom):
+    """HBM bytes per bf16-GEMM launch (average over the launches of one step) from the committed rocprofv3 PMC passes of this
+    same command (tools/pmc_traffic.py -> profiles/r01_pmc_traffic.json; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).
+    Counters cannot be read from inside the process, so this is the recorded figure, or None if no PMC pass is committed."""
+    if dom != torch.bfloat16:
+        return None
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+    try:
+        return json.load(open(f)).get('gemm_bf16_traffic_per_launch')
+    except (OSError, ValueError):
+        return None
+
+
 def log(msg):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
@@ -204,6 +217,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_ms = (time.perf_counter() - t0) / args.steps * 1e3        # launch-side time per step (before the final sync)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -213,7 +227,7 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     img_s = B * world * args.steps / dt
     final_loss = float(last['loss'].detach())
-    log(f'timed region done: {ms_per_step:.2f} ms/step, {img_s:.1f} img/s, loss {final_loss:.4f}')
+    log(f'timed region done: {ms_per_step:.2f} ms/step, {img_s:.1f} img/s, loss {final_loss:.4f} (host enqueue {host_ms:.2f} ms/step)')
 
     # per-kernel timing pass (outside the timed region): HIP events around every MFMA GEMM launch
     roof = None
@@ -243,8 +257,8 @@ def main():
         dom = torch.bfloat16 if args.precision == 'bf16' else torch.float32
         peak = PEAK_BF16_TFLOPS if dom == torch.bfloat16 else 157.3
         ach = tot_fl[dom] / (tot_ms[dom] * 1e-3) / 1e12 if tot_ms[dom] > 0 else 0.0
-        roof = {'bound': 'mfma', 'kernel': 'gemm_bf16_kernel (all MFMA GEMM launches of one step)' if dom == torch.bfloat16 else 'gemm_f32_kernel',
-                'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
+        roof = {'bound': 'mfma', 'kernel': 'gemm_bf16_pp_kernel / gemm_bf16_kernel (all bf16 MFMA GEMM launches of one step)' if dom == torch.bfloat16 else 'gemm_f32_kernel',
+                'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': pmc_traffic(dom),
                 'launches_per_step': cnt[dom], 'gemm_ms_per_step': round(tot_ms[dom], 3),
                 'gemm_gflop_per_step': round(tot_fl[dom] / 1e9, 1),
                 'f32_adapter_gemm_ms_per_step': round(tot_ms[torch.float32], 3) if dom == torch.bfloat16 else None,

@@ -342,7 +342,13 @@ def mask_sample(samples_per_task: Tensor, task_noise: Tensor, all_noise: Tensor,
     mask_all = torch.empty((B, Ntot), device=dev, dtype=torch.int64)
     ids_keep = torch.empty((B, n_keep), device=dev, dtype=torch.int64)
     ids_restore = torch.empty((B, Ntot), device=dev, dtype=torch.int64)
-    spt = samples_per_task.to(device=dev, dtype=torch.int64).contiguous()
+    # pinned + non_blocking: a pageable H2D copy blocks the host until the stream has drained, i.e. once per step the host
+    # would lose its whole launch lead (measured: ~1.2 ms of GPU idle at every step start behind the CPU Dirichlet draw)
+    spt = samples_per_task.to(dtype=torch.int64).contiguous()
+    if spt.device.type == 'cpu' and dev.type == 'cuda':
+        spt = spt.pin_memory().to(dev, non_blocking=True)
+    else:
+        spt = spt.to(dev)
     check(_lib.load().mmae_mask_sample(spt.data_ptr(), task_noise.contiguous().data_ptr(), all_noise.contiguous().data_ptr(),
                                        ctypes.cast(_i32_array(task_offsets), ctypes.c_void_p), T, B, Ntot, n_keep,
                                        mask_all.data_ptr(), ids_keep.data_ptr(), ids_restore.data_ptr(), _stream()),
