@@ -11,7 +11,7 @@ def load(d, name):
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] != name:
             continue
-        k = r['Kernel_Name'].split('(')[0].replace('void (anonymous namespace)::', '')
+        k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
         per[k][0] += float(r['Counter_Value']); per[k][1] += 1
     return per
 fe, wr = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
