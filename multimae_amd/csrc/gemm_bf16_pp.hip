@@ -20,6 +20,7 @@
 // Read-after-DMA: every wave waits (counted) for its pieces of tile t before b_4t-1; the first read of tile t is
 // after b_4t-1.  Write-after-read: the ring slot of tile t is re-targeted (tile t+4) in MEM(2t+3) / MEM(2t+4),
 // which every wave reaches after b_4t+4, when the last reader (group 1, MEM(2t+1)) has drained its lgkmcnt.
+#include <stdlib.h>
 #include "gemm_common.h"
 
 #define LDS_AS __attribute__((address_space(3)))
@@ -73,14 +74,13 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
     static_assert(LB == 2 && LA >= 2 && LA <= 3, "piece schedule below assumes 2 + (2|3) pieces per wave and tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
+    // `lane` is laundered through an empty asm at the top of every output tile: everything derived from it (fragment and
+    // DMA addresses) is then recomputed per tile instead of being hoisted out of the persistent loop, where ~70 address
+    // VGPRs would stay live across the epilogue (on top of the 128-160 accumulators: 100-190 spilled registers)
+    int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int tile = g.xcd_swizzle ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
-    // integer division runs on the VALU: pin the (wave-uniform) results back into SGPRs, or the buffer descriptors
-    // below end up in VGPRs and every DMA instruction gets a waterfall loop
-    const int tile_m = __builtin_amdgcn_readfirstlane(tile / g.tiles_n);
-    const int m0 = tile_m * BM, n0 = (tile - tile_m * g.tiles_n) * BN;
     const int z = blockIdx.y, zo = __builtin_amdgcn_readfirstlane(z / g.nb_inner), zi = z - zo * g.nb_inner;
     const uint16_t* Az = sgpr_ptr((const uint16_t*)g.A + zo * g.sAo + zi * g.sAi);
     const uint16_t* Bz = sgpr_ptr((const uint16_t*)g.B + zo * g.sBo + zi * g.sBi);
@@ -88,39 +88,48 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Az, 0, 0x80000000, 0x00020000);
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bz, 0, 0x80000000, 0x00020000);
 
-    // lane p of DMA piece s fills LDS slot p of that 1-KiB segment: find the chunk living there
+    // lane p of DMA piece s fills LDS slot p of that 1-KiB segment: find the chunk living there.
+    // Persistent workgroups: blockIdx.x walks the tile list in steps of gridDim.x; set_tile() re-targets the DMA offsets.
     unsigned a_off[LA], b_off[LB];
     int a_kq[LA], b_kq[LB];
+    int m0 = 0, n0 = 0;
+    auto set_tile = [&](int v, int& tm0, int& tn0) {
+        const int tile = g.xcd_swizzle ? xcd_tile(v, g.tiles_total) : v;
+        // integer division runs on the VALU: pin the (wave-uniform) result back into an SGPR
+        const int tile_m = __builtin_amdgcn_readfirstlane(tile / g.tiles_n);
+        tm0 = tile_m * BM; tn0 = (tile - tile_m * g.tiles_n) * BN;
 #pragma unroll
-    for (int i = 0; i < LA; ++i) {
-        const int seg = i * NW + wave;
-        if (!AKS) {
-            const int b_abs = 4 * seg + (lane >> 4), j = (lane & 15) ^ (b_abs & 15);
-            const int row = 4 * b_abs + (j >> 2), c = j & 3;
-            a_kq[i] = c * 8;
-            a_off[i] = (seg < PA && m0 + row < g.M) ? (unsigned)((((long long)(m0 + row)) * g.lda + c * 8) * 2) : OOB;
-        } else {
-            constexpr int CPR = BM / 8;
-            const int krow = seg * (64 / CPR) + lane / CPR, ch = (lane % CPR) ^ ((krow & 3) << 2);
-            a_kq[i] = krow;
-            a_off[i] = (seg < PA && m0 + ch * 8 < g.M) ? (unsigned)((((long long)krow) * g.lda + m0 + ch * 8) * 2) : OOB;
+        for (int i = 0; i < LA; ++i) {
+            const int seg = i * NW + wave;
+            if (!AKS) {
+                const int b_abs = 4 * seg + (lane >> 4), j = (lane & 15) ^ (b_abs & 15);
+                const int row = 4 * b_abs + (j >> 2), c = j & 3;
+                a_kq[i] = c * 8;
+                a_off[i] = (seg < PA && tm0 + row < g.M) ? (unsigned)((((long long)(tm0 + row)) * g.lda + c * 8) * 2) : OOB;
+            } else {
+                constexpr int CPR = BM / 8;
+                const int krow = seg * (64 / CPR) + lane / CPR, ch = (lane % CPR) ^ ((krow & 3) << 2);
+                a_kq[i] = krow;
+                a_off[i] = (seg < PA && tm0 + ch * 8 < g.M) ? (unsigned)((((long long)krow) * g.lda + tm0 + ch * 8) * 2) : OOB;
+            }
         }
-    }
 #pragma unroll
-    for (int i = 0; i < LB; ++i) {
-        const int seg = i * NW + wave;
-        if (!BKS) {
-            const int b_abs = 4 * seg + (lane >> 4), j = (lane & 15) ^ (b_abs & 15);
-            const int row = 4 * b_abs + (j >> 2), c = j & 3;
-            b_kq[i] = c * 8;
-            b_off[i] = (n0 + row < g.N) ? (unsigned)((((long long)(n0 + row)) * g.ldb + c * 8) * 2) : OOB;
-        } else {
-            constexpr int CPR = BN / 8;
-            const int krow = seg * (64 / CPR) + lane / CPR, ch = (lane % CPR) ^ ((krow & 3) << 2);
-            b_kq[i] = krow;
-            b_off[i] = (n0 + ch * 8 < g.N) ? (unsigned)((((long long)krow) * g.ldb + n0 + ch * 8) * 2) : OOB;
+        for (int i = 0; i < LB; ++i) {
+            const int seg = i * NW + wave;
+            if (!BKS) {
+                const int b_abs = 4 * seg + (lane >> 4), j = (lane & 15) ^ (b_abs & 15);
+                const int row = 4 * b_abs + (j >> 2), c = j & 3;
+                b_kq[i] = c * 8;
+                b_off[i] = (tn0 + row < g.N) ? (unsigned)((((long long)(tn0 + row)) * g.ldb + c * 8) * 2) : OOB;
+            } else {
+                constexpr int CPR = BN / 8;
+                const int krow = seg * (64 / CPR) + lane / CPR, ch = (lane % CPR) ^ ((krow & 3) << 2);
+                b_kq[i] = krow;
+                b_off[i] = (tn0 + ch * 8 < g.N) ? (unsigned)((((long long)krow) * g.ldb + tn0 + ch * 8) * 2) : OOB;
+            }
         }
-    }
+    };
+    set_tile(blockIdx.x, m0, n0);
     const unsigned a_step = AKS ? (unsigned)(g.lda * BK * 2) : (unsigned)(BK * 2);
     const unsigned b_step = BKS ? (unsigned)(g.ldb * BK * 2) : (unsigned)(BK * 2);
 
@@ -147,16 +156,14 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
     auto dma_second = [&](int u) { dma_b(u, 0); dma_b(u, 1); if (LA == 3) dma_a(u, 2); };       // LA + LB - 2 pieces
 
     f32x16 acc[2][TM];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < TM; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int fr = lane & 31, fk = lane >> 5;
-    const int tg = lane >> 4, tp = lane & 15;
-    const int t_i0 = (tg & 1) * 16, t_kh = (tg >> 1) * 8;
+    int fr = 0, fk = 0, tp = 0, t_i0 = 0, t_kh = 0;
+    auto derive = [&]() {
+        fr = lane & 31; fk = lane >> 5;
+        const int tg = lane >> 4;
+        tp = lane & 15; t_i0 = (tg & 1) * 16; t_kh = (tg >> 1) * 8;
+    };
+    derive();
     auto frag_kc = [&](const char* base, int row0, int kk) -> bf16x8 {
         return *reinterpret_cast<const bf16x8*>(base + kc_off(row0 + fr, kk * 2 + fk));
     };
@@ -170,10 +177,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
     bf16x8 af[TM], bf[2];
     // optional column sums of the k-strided A operand (bias gradient of a dW product): the wn = 0 waves of the n-tile-0
     // workgroups add up the A fragments they hold anyway (v_dot2c with a vector of ones, in the shadow of the MFMAs)
-    const bool do_acs = AKS && g.acs != nullptr && n0 == 0 && wn == 0;
+    bool do_acs = false;
     float acs[TM];
-#pragma unroll
-    for (int t = 0; t < TM; ++t) acs[t] = 0.f;
     auto mem_phase = [&](int u, int kk) {
         const char* sa = smem + (u & (NST - 1)) * STAGE;
         const char* sb = sa + A_BYTES;
@@ -183,8 +188,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
         for (int t = 0; t < TM; ++t) af[t] = AKS ? frag_ks(sa, wm * WMR + t * 32, kk) : frag_kc(sa, wm * WMR + t * 32, kk);
         if (kk == 0) dma_second(u + 2); else dma_first(u + 3);
     };
-    // (Issuing the DMA pieces between the MFMAs instead -- an LDS-DMA issue stalls its wave 60-180 cycles -- measured 1-10 %
-    // slower than keeping them in the memory half-phase.)
+    // (Issuing all, or one, of the phase's DMA pieces between the MFMAs instead -- an LDS-DMA issue stalls its wave 60-180
+    // cycles -- measured 0-10 % slower than keeping them in the memory half-phase.)
     auto mfma_phase = [&]() {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -203,62 +208,94 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
         }
     };
 
-    // prologue: tiles 0, 1 and the first half of tile 2
+    // prologue of the first tile: K tiles 0, 1 and the first half of K tile 2
     dma_first(0); dma_second(0);
     dma_first(1); dma_second(1);
     dma_first(2);
-    wait_vm<W>();                                        // tile 0 has landed (this wave's share)
+    wait_vm<W>();                                        // K tile 0 has landed (this wave's share)
     wg_barrier();
 
-    if (wm == 0) {
-        for (int u = 0; u < T; ++u) {
-            mem_phase(u, 0);
-            wg_barrier();
-            mfma_phase();
-            wg_barrier();
-            mem_phase(u, 1);
-            wg_barrier();
-            mfma_phase();
-            wait_vm<W>();                               // tile u + 1
-            wg_barrier();
-        }
-    } else {
-        for (int u = 0; u < T; ++u) {
-            wg_barrier();
-            mem_phase(u, 0);
-            wg_barrier();
-            mfma_phase();
-            wg_barrier();
-            mem_phase(u, 1);
-            wait_vm<W>();                               // tile u + 1
-            wg_barrier();
-            mfma_phase();
-        }
-    }
-    if (AKS && do_acs) {                                 // lanes l and l + 32 hold the two k-halves of row l
+    // epilogue staging lives in ring slots 2-3 so that slots 0-1 can already receive the NEXT output tile's first two K
+    // tiles while this tile's results are written out (the DMA latency and most of the prologue hide under the epilogue)
+    char* stage = smem + 2 * STAGE + wave * 8192;
+    static_assert(2 * STAGE >= 8 * 8192, "staging must fit in ring slots 2-3");
+    for (int v = blockIdx.x; v < g.tiles_total; v += gridDim.x) {
+        asm volatile("" : "+v"(lane));
+        derive();
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const float v = acs[tm] + __shfl_xor(acs[tm], 32, 64);
-            const int m = m0 + wm * WMR + tm * 32 + (lane & 31);
-            if (lane < 32 && m < g.M) g.acs[(long long)blockIdx.z * g.M + m] = v;
-        }
-    }
-    wait_vm<0>();                                        // the zero-fill tail pieces must not land on the staging area
-    __syncthreads();                                     // the operand ring is dead: reuse it as per-wave staging
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        do_acs = AKS && g.acs != nullptr && n0 == 0 && wn == 0;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) acs[t] = 0.f;
 
-    char* stage = smem + wave * 8192;
-    const int mw = m0 + wm * WMR, nw = n0 + wn * 64;
-    {
-        f32x16 sub[2][2] = {{acc[0][0], acc[0][1]}, {acc[1][0], acc[1][1]}};
-        gemm_store_tile64(g, Cz, stage, lane, sub, mw, nw);
-    }
-    {
-        f32x16 sub[2][2] = {{acc[0][2], acc[0][3]}, {acc[1][2], acc[1][3]}};
-        gemm_store_tile64(g, Cz, stage, lane, sub, mw + 64, nw);
-    }
-    if (TM & 1) {
-        f32x16 sub[2][2] = {{acc[0][TM - 1], acc[0][TM - 1]}, {acc[1][TM - 1], acc[1][TM - 1]}};
-        gemm_store_tile64(g, Cz, stage, lane, sub, mw + (TM - 1) * 32, nw, 1);
+        if (wm == 0) {
+            for (int u = 0; u < T; ++u) {
+                mem_phase(u, 0);
+                wg_barrier();
+                mfma_phase();
+                wg_barrier();
+                mem_phase(u, 1);
+                wg_barrier();
+                mfma_phase();
+                wait_vm<W>();                                // K tile u + 1
+                wg_barrier();
+            }
+        } else {
+            for (int u = 0; u < T; ++u) {
+                wg_barrier();
+                mem_phase(u, 0);
+                wg_barrier();
+                mfma_phase();
+                wg_barrier();
+                mem_phase(u, 1);
+                wait_vm<W>();                                // K tile u + 1
+                wg_barrier();
+                mfma_phase();
+            }
+        }
+        if (AKS && do_acs) {                                 // lanes l and l + 32 hold the two k-halves of row l
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const float sv = acs[tm] + __shfl_xor(acs[tm], 32, 64);
+                const int m = m0 + wm * WMR + tm * 32 + (lane & 31);
+                if (lane < 32 && m < g.M) g.acs[(long long)blockIdx.z * g.M + m] = sv;
+            }
+        }
+        wait_vm<0>();                                        // the zero-fill tail pieces must not land on live data
+        __syncthreads();                                     // every wave is out of the ring
+
+        const int mw = m0 + wm * WMR, nw = n0 + wn * 64;
+        const bool has_next = v + (int)gridDim.x < g.tiles_total;
+        if (has_next) {                                      // next tile: K tiles 0, 1 -> slots 0, 1 (in flight during the epilogue)
+            asm volatile("" : "+v"(lane));
+            set_tile(v + gridDim.x, m0, n0);
+            dma_first(0); dma_second(0);
+            dma_first(1); dma_second(1);
+        }
+        {
+            f32x16 sub[2][2] = {{acc[0][0], acc[0][1]}, {acc[1][0], acc[1][1]}};
+            gemm_store_tile64(g, Cz, stage, lane, sub, mw, nw);
+        }
+        {
+            f32x16 sub[2][2] = {{acc[0][2], acc[0][3]}, {acc[1][2], acc[1][3]}};
+            gemm_store_tile64(g, Cz, stage, lane, sub, mw + 64, nw);
+        }
+        if (TM & 1) {
+            f32x16 sub[2][2] = {{acc[0][TM - 1], acc[0][TM - 1]}, {acc[1][TM - 1], acc[1][TM - 1]}};
+            gemm_store_tile64(g, Cz, stage, lane, sub, mw + (TM - 1) * 32, nw, 1);
+        }
+        if (has_next) {
+            // loads and stores share vmcnt and may retire out of order with respect to each other: drain everything (the
+            // prefetched K tiles landed long ago; this waits for the last store acknowledgements only), then hand ring
+            // slots 2-3 back to the DMA ring
+            wait_vm<0>();
+            __syncthreads();
+            dma_first(2);
+        }
     }
 }
 
@@ -269,7 +306,11 @@ int launch(const GemmArgs& g, int batch, hipStream_t st) {
     GemmArgs a = g;
     a.tiles_n = (g.N + BN - 1) / BN;
     a.kt_per_split = g.kt_per_split * 2;                 // runtime.hip counts 64-wide K tiles; this kernel steps by 32
-    dim3 grid(tiles_m * a.tiles_n, batch, a.splitk), block(512);
+    a.tiles_total = tiles_m * a.tiles_n;
+    static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    static const int env_persist = getenv("MMAE_PP_PERSIST") ? atoi(getenv("MMAE_PP_PERSIST")) : 1;
+    const int gx = (env_persist && a.tiles_total > n_cu) ? n_cu : a.tiles_total;      // one resident workgroup per CU walks the tile list
+    dim3 grid(gx, batch, a.splitk), block(512);
     const size_t lds = (size_t)4 * (BM + BN) * 64 + 1024;
     static bool attr_done = false;
     if (!attr_done) {

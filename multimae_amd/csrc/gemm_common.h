@@ -13,7 +13,7 @@ struct GemmArgs {
     void* aux; long long ldaux;
     int c_f32, aux_f32, epi, accumulate, vec;
     float alpha;
-    int tiles_n;
+    int tiles_n, tiles_total;
     int splitk, kt_per_split;     // splitk > 1: z-slice s writes its partial product to ws[s][M][N] (f32)
     float* ws;
     int xcd_swizzle;
