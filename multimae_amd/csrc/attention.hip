@@ -37,17 +37,32 @@ template <> __device__ __forceinline__ int tile_off<32>(int row, int c) {
     return (row >> 2) * 256 + (((((row & 3) << 2) | c) ^ ((row >> 2) & 15)) << 4);
 }
 
-// rows [0, nrows) of a [.., HD] slice (row stride `sr` elements) -> LDS tile of nrows_pad rows (zero padded)
-template <int HD>
-__device__ __forceinline__ void load_tile(char* lds, const uint16_t* base, long long sr, int nrows, int nrows_pad, int tid, int nthr = 256) {
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x80000000, 0x00020000);
-    constexpr int CPR = HD / 8;
-    for (int c = tid; c < nrows_pad * CPR; c += nthr) {
-        const int row = c / CPR, ch = c % CPR;
-        const unsigned off = row < nrows ? (unsigned)((row * sr + ch * 8) * 2) : OOB;
-        *reinterpret_cast<i32x4*>(lds + tile_off<HD>(row, ch)) = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+// rows [0, nrows) of a [.., HD] slice (row stride `sr` elements) -> LDS tile of nrows_pad rows (zero padded).
+// Two-phase so that a kernel can put ALL its tile loads in flight before the first LDS write: with load -> ds_write per
+// chunk (and one loop per tile) every chunk exposed a full HBM round trip -- 8 in a row in the backward prologue.
+template <int HD, int NTHR>
+struct TileLoader {
+    static constexpr int CPR = HD / 8;
+    static constexpr int MAXIT = (256 * CPR + NTHR - 1) / NTHR;       // nrows_pad <= 256
+    i32x4 r[MAXIT];
+    __device__ __forceinline__ void issue(const uint16_t* base, long long sr, int nrows, int nrows_pad, int tid) {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x80000000, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < MAXIT; ++i) {
+            const int c = tid + i * NTHR;
+            const int row = c / CPR, ch = c % CPR;
+            const unsigned off = (c < nrows_pad * CPR && row < nrows) ? (unsigned)((row * sr + ch * 8) * 2) : OOB;
+            r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+        }
     }
-}
+    __device__ __forceinline__ void commit(char* lds, int nrows_pad, int tid) {
+#pragma unroll
+        for (int i = 0; i < MAXIT; ++i) {
+            const int c = tid + i * NTHR;
+            if (c < nrows_pad * CPR) *reinterpret_cast<i32x4*>(lds + tile_off<HD>(c / CPR, c % CPR)) = r[i];
+        }
+    }
+};
 
 // MFMA operand "row fragment": lane supplies row (row0 + lane&31), k = 16*ks + 8*(lane>>5) + 0..7
 template <int HD>
@@ -86,15 +101,20 @@ __device__ __forceinline__ void store4(uint16_t* p, float a, float b, float c, f
 
 // -------------------------------------------------------------------------------------------------
 template <int HD, int NT>
-__global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs a) {
+__global__ void __launch_bounds__(256, NT == 4 ? 3 : 1) attn_fwd_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     char* Ks = smem;
     char* Vs = smem + a.nkp * HD * 2;
-    load_tile<HD>(Ks, a.k + b * a.k_sb + h * HD, a.k_sr, a.Nk, a.nkp, tid);
-    load_tile<HD>(Vs, a.v + b * a.v_sb + h * HD, a.v_sr, a.Nk, a.nkp, tid);
+    {
+        TileLoader<HD, 256> lk, lv;
+        lk.issue(a.k + b * a.k_sb + h * HD, a.k_sr, a.Nk, a.nkp, tid);
+        lv.issue(a.v + b * a.v_sb + h * HD, a.v_sr, a.Nk, a.nkp, tid);
+        lk.commit(Ks, a.nkp, tid);
+        lv.commit(Vs, a.nkp, tid);
+    }
     __syncthreads();
     const int nt = a.nkp >> 5, nqb = (a.Nq + 31) >> 5;
     const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(a.q + b * a.q_sb + h * HD), 0, 0x80000000, 0x00020000);
@@ -182,11 +202,18 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs a) {
     const uint16_t* qg = a.q + b * a.q_sb + h * HD;
     const uint16_t* og = a.o + b * a.o_sb + h * HD;
     const uint16_t* dog = a.d_o + b * a.o_sb + h * HD;
-    load_tile<HD>(Qs, qg, a.q_sr, a.Nq, a.nqp, tid, 512);
-    load_tile<HD>(dOs, dog, a.o_sr, a.Nq, a.nqp, tid, 512);
-    load_tile<HD>(Ks, a.k + b * a.k_sb + h * HD, a.k_sr, a.Nk, a.nkp, tid, 512);
-    load_tile<HD>(Vs, a.v + b * a.v_sb + h * HD, a.v_sr, a.Nk, a.nkp, tid, 512);
-    for (int q = tid; q < a.nqp; q += 512) lse_s[q] = q < a.Nq ? a.lse[((long long)b * a.H + h) * a.Nq + q] : 0.f;
+    {
+        TileLoader<HD, 512> lq, ld, lk, lv;
+        lq.issue(qg, a.q_sr, a.Nq, a.nqp, tid);
+        ld.issue(dog, a.o_sr, a.Nq, a.nqp, tid);
+        lk.issue(a.k + b * a.k_sb + h * HD, a.k_sr, a.Nk, a.nkp, tid);
+        lv.issue(a.v + b * a.v_sb + h * HD, a.v_sr, a.Nk, a.nkp, tid);
+        for (int q = tid; q < a.nqp; q += 512) lse_s[q] = q < a.Nq ? a.lse[((long long)b * a.H + h) * a.Nq + q] : 0.f;
+        lq.commit(Qs, a.nqp, tid);
+        ld.commit(dOs, a.nqp, tid);
+        lk.commit(Ks, a.nkp, tid);
+        lv.commit(Vs, a.nkp, tid);
+    }
     const int nt = a.nkp >> 5, nqb = a.nqp >> 5;
     const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)qg, 0, 0x80000000, 0x00020000);
     const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void*)og, 0, 0x80000000, 0x00020000);
