@@ -134,6 +134,12 @@ int mmae_colsum_partials(const float* part, float* out, int nrows, int ncols, in
 int64_t mmae_colsum_ws_elems(int64_t M, int N);
 int mmae_colsum(const void* dy, int dtype, int64_t M, int N, int64_t ld, float* out, int accumulate,
                 float* ws, void* stream);
+/* same reduction, scattered: column c is delivered to dsts_host[c / seg_w][c % seg_w] (host array of nseg <= 8
+ * device pointers, NULL = drop that segment).  One pass over a partial block feeds several parameter
+ * gradients, e.g. LayerNorm's [dgamma | dbeta | bias gradient of the producing Linear]
+ * (autograd's three AccumulateGrad nodes of multimae_utils.py:222-232). */
+int mmae_colsum_scatter(const void* dy, int dtype, int64_t M, int N, int64_t ld, int seg_w, const void* dsts_host,
+                        int nseg, int accumulate, float* ws, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Row softmax over materialised attention scores (unfused attention path and the
@@ -303,6 +309,12 @@ int mmae_sumsq(const float* x, int64_t n, float* out, float* ws, void* stream);
 int mmae_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                float eps, float weight_decay, int step, const float* grad_scale_dev, const int32_t* skip_flag,
                void* shadow, int shadow_dtype, void* stream);
+/* same update with the step-dependent scalars read from device memory: hyper_dev f32[4] =
+ * { lr, weight_decay, 1 - beta1^step, sqrt(1 - beta2^step) }.  A captured hipGraph of the training step replays
+ * with the schedule's current values (the host refreshes the 16 bytes before every replay). */
+int mmae_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev, float beta1,
+                   float beta2, float eps, const float* grad_scale_dev, const int32_t* skip_flag, void* shadow,
+                   int shadow_dtype, void* stream);
 
 /* hardware probes used by tests/ to pin instruction semantics the kernels rely on */
 int mmae_probe_tr16(const uint16_t* lds_image_1024, const uint32_t* lane_byte_addr_64, uint16_t* out_64x4,

@@ -171,8 +171,10 @@ template <typename ST>
 __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
                                                     float wd, float bc1, float bc2_sqrt, const float* __restrict__ grad_scale,
-                                                    const int* __restrict__ skip, ST* __restrict__ shadow) {
+                                                    const int* __restrict__ skip, ST* __restrict__ shadow,
+                                                    const float* __restrict__ hyper) {
     if (skip && *skip) return;
+    if (hyper) { lr = hyper[0]; wd = hyper[1]; bc1 = hyper[2]; bc2_sqrt = hyper[3]; }   // step-dependent scalars from HBM (hipGraph replay)
     const float gs = grad_scale ? *grad_scale : 1.f;
     for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
         if (i + 4 <= n) {
@@ -281,10 +283,24 @@ int mmae_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr
     if (nb > 8192) nb = 8192;
     hipStream_t st = (hipStream_t)stream;
     if (shadow && shadow_dtype == MMAE_BF16)
-        hipLaunchKernelGGL((adamw_kernel<uint16_t>), dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale_dev, (const int*)skip_flag, (uint16_t*)shadow);
+        hipLaunchKernelGGL((adamw_kernel<uint16_t>), dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale_dev, (const int*)skip_flag, (uint16_t*)shadow, (const float*)nullptr);
     else
-        hipLaunchKernelGGL((adamw_kernel<float>), dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale_dev, (const int*)skip_flag, (float*)shadow);
+        hipLaunchKernelGGL((adamw_kernel<float>), dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale_dev, (const int*)skip_flag, (float*)shadow, (const float*)nullptr);
     return mmae_check_launch("adamw");
+}
+
+int mmae_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev, float beta1, float beta2, float eps,
+                   const float* grad_scale_dev, const int32_t* skip_flag, void* shadow, int shadow_dtype, void* stream) {
+    MMAE_REQUIRE(p && g && m && v && n > 0 && hyper_dev, "adamw_dev: bad argument");
+    MMAE_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0), "adamw_dev: unaligned");
+    long long nb = cdiv64(n, 1024);
+    if (nb > 8192) nb = 8192;
+    hipStream_t st = (hipStream_t)stream;
+    if (shadow && shadow_dtype == MMAE_BF16)
+        hipLaunchKernelGGL((adamw_kernel<uint16_t>), dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, (long long)n, 0.f, beta1, beta2, eps, 0.f, 1.f, 1.f, grad_scale_dev, (const int*)skip_flag, (uint16_t*)shadow, hyper_dev);
+    else
+        hipLaunchKernelGGL((adamw_kernel<float>), dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, (long long)n, 0.f, beta1, beta2, eps, 0.f, 1.f, 1.f, grad_scale_dev, (const int*)skip_flag, (float*)shadow, hyper_dev);
+    return mmae_check_launch("adamw_dev");
 }
 
 }  // extern "C"

@@ -132,9 +132,13 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const DT* __restrict__ dy, 
     }
 }
 
+// Up to 8 destination segments for a column-sum result: column c goes to dst[c / seg_w][c % seg_w] (a null segment is
+// dropped).  Lets ONE reduction feed several parameter gradients (LayerNorm dgamma | dbeta | the bias gradient riding along).
+struct ColDst { float* dst[8]; int seg_w; };
+
 // out[c] (+)= sum_r part[r][c].  Workgroup = 64 columns x 4 row phases (coalesced 256-B rows, 4-way
 // unrolled so 16 loads are in flight per lane), fixed summation order (deterministic).
-__global__ void __launch_bounds__(256) colsum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int nrows,
+__global__ void __launch_bounds__(256) colsum_partials_kernel(const float* __restrict__ part, const ColDst out, int nrows,
                                                               int ncols, int accumulate) {
     __shared__ float red[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -152,7 +156,9 @@ __global__ void __launch_bounds__(256) colsum_partials_kernel(const float* __res
     __syncthreads();
     if (ty == 0 && c < ncols) {
         const float s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
-        out[c] = accumulate ? out[c] + s : s;
+        const int seg = c / out.seg_w;
+        float* o = out.dst[seg];
+        if (o) { o += c - seg * out.seg_w; *o = accumulate ? *o + s : s; }
     }
 }
 
@@ -178,21 +184,34 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
     }
 }
 
-// column sums of dy [M][ld] (N columns, N % 4 == 0): grid (ceil(N/256), NSPLIT); thread owns 4 columns.
+// column sums of dy [M][ld] (N columns, N % 4 == 0): grid (ceil(N/256), NSPLIT); thread owns 4 columns.  The row walk is
+// 4-way unrolled (4 independent 16-byte loads in flight per lane): with a single dependent load per iteration and only a
+// handful of workgroups this kernel was pure latency -- 66 us to reduce a 512 x 2304 LayerNorm partial block.
 template <typename DT>
 __global__ void __launch_bounds__(256) colsum_kernel(const DT* __restrict__ dy, long long M, int N, long long ld,
                                                      float* __restrict__ ws) {
     __shared__ f32x4 red[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = (blockIdx.x * 64 + lane) * 4;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     if (c < N) {
-        for (long long r = (long long)blockIdx.y * 4 + w; r < M; r += (long long)gridDim.y * 4) {
+        const long long step = (long long)gridDim.y * 4;
+        long long r = (long long)blockIdx.y * 4 + w;
+        for (; r + 3 * step < M; r += 4 * step) {
+            const f32x4 v0 = ld4(dy + r * ld + c), v1 = ld4(dy + (r + step) * ld + c), v2 = ld4(dy + (r + 2 * step) * ld + c),
+                        v3 = ld4(dy + (r + 3 * step) * ld + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s0[j] += v0[j]; s1[j] += v1[j]; s2[j] += v2[j]; s3[j] += v3[j]; }
+        }
+        for (; r < M; r += step) {
             const f32x4 v = ld4(dy + r * ld + c);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s[j] += v[j];
+            for (int j = 0; j < 4; ++j) s0[j] += v[j];
         }
     }
+    f32x4 s;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = (s0[j] + s1[j]) + (s2[j] + s3[j]);
     red[w][lane] = s;
     __syncthreads();
     if (w == 0 && c < N) {
@@ -380,28 +399,55 @@ int mmae_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float
     return mmae_check_launch("layernorm_bwd");
 }
 
-int mmae_colsum_partials(const float* part, float* out, int nrows, int ncols, int accumulate, void* stream) {
-    MMAE_REQUIRE(part && out && nrows > 0 && ncols > 0, "colsum_partials: bad argument");
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3((ncols + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, out, nrows,
-                       ncols, accumulate);
+static int launch_partials(const float* part, const ColDst& d, int nrows, int ncols, int accumulate, void* stream) {
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((ncols + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, d, nrows, ncols,
+                       accumulate);
     return mmae_check_launch("colsum_partials");
 }
 
-static int colsum_nsplit(int64_t M) { const int64_t s = cdiv64(M, 256); return (int)(s < 1 ? 1 : (s > 64 ? 64 : s)); }
+int mmae_colsum_partials(const float* part, float* out, int nrows, int ncols, int accumulate, void* stream) {
+    MMAE_REQUIRE(part && out && nrows > 0 && ncols > 0, "colsum_partials: bad argument");
+    ColDst d = {};
+    d.dst[0] = out; d.seg_w = ncols;
+    return launch_partials(part, d, nrows, ncols, accumulate, stream);
+}
+
+// Row-split factor: enough workgroups to cover the load latency even for the short, wide partial blocks the backward pass
+// reduces (LayerNorm: 512 x 3D, dGELU: ceil(M/64) x 4D), <= 256 slabs for the long activations.
+static int colsum_nsplit(int64_t M) { const int64_t s = cdiv64(M, 16); return (int)(s < 1 ? 1 : (s > 256 ? 256 : s)); }
 int64_t mmae_colsum_ws_elems(int64_t M, int N) { return (int64_t)colsum_nsplit(M) * N; }
 
-int mmae_colsum(const void* dy, int dtype, int64_t M, int N, int64_t ld, float* out, int accumulate, float* ws,
-                void* stream) {
-    MMAE_REQUIRE(dy && out && ws && M > 0 && N > 0, "colsum: bad argument");
-    MMAE_REQUIRE(N % 4 == 0 && ld % 4 == 0, "colsum: N and ld must be multiples of 4");
+static int colsum_impl(const void* dy, int dtype, int64_t M, int N, int64_t ld, const ColDst& d, int accumulate, float* ws,
+                       void* stream) {
     const int ns = colsum_nsplit(M);
+    if (ns == 1 && dtype == MMAE_F32 && ld == N) return launch_partials((const float*)dy, d, (int)M, N, accumulate, stream);
     dim3 grid((N + 255) / 256, ns), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MMAE_BF16) hipLaunchKernelGGL((colsum_kernel<uint16_t>), grid, block, 0, st, (const uint16_t*)dy, (long long)M, N, (long long)ld, ws);
     else hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, st, (const float*)dy, (long long)M, N, (long long)ld, ws);
     int rc = mmae_check_launch("colsum");
     if (rc) return rc;
-    return mmae_colsum_partials(ws, out, ns, N, accumulate, stream);
+    return launch_partials(ws, d, ns, N, accumulate, stream);
+}
+
+int mmae_colsum(const void* dy, int dtype, int64_t M, int N, int64_t ld, float* out, int accumulate, float* ws,
+                void* stream) {
+    MMAE_REQUIRE(dy && out && ws && M > 0 && N > 0, "colsum: bad argument");
+    MMAE_REQUIRE(N % 4 == 0 && ld % 4 == 0, "colsum: N and ld must be multiples of 4");
+    ColDst d = {};
+    d.dst[0] = out; d.seg_w = N;
+    return colsum_impl(dy, dtype, M, N, ld, d, accumulate, ws, stream);
+}
+
+int mmae_colsum_scatter(const void* dy, int dtype, int64_t M, int N, int64_t ld, int seg_w, const void* dsts, int nseg,
+                        int accumulate, float* ws, void* stream) {
+    MMAE_REQUIRE(dy && dsts && ws && M > 0 && N > 0, "colsum_scatter: bad argument");
+    MMAE_REQUIRE(N % 4 == 0 && ld % 4 == 0, "colsum_scatter: N and ld must be multiples of 4");
+    MMAE_REQUIRE(seg_w > 0 && nseg >= 1 && nseg <= 8 && (int64_t)seg_w * nseg >= N, "colsum_scatter: need 1..8 segments covering N columns");
+    ColDst d = {};
+    for (int i = 0; i < nseg; ++i) d.dst[i] = ((float* const*)dsts)[i];
+    d.seg_w = seg_w;
+    return colsum_impl(dy, dtype, M, N, ld, d, accumulate, ws, stream);
 }
 
 int mmae_softmax_fwd(const float* S, int64_t lds_, void* P, int p_dtype, int64_t ldp, int64_t rows, int n, float scale,

@@ -74,6 +74,7 @@ def set_wgrad_stream(flag: bool) -> None:
 
 
 _side_streams = {}
+_dirty_sides = set()          # side streams that received work since the last join
 
 
 def side_stream_of(stream: 'torch.cuda.Stream') -> 'torch.cuda.Stream':
@@ -85,13 +86,82 @@ def side_stream_of(stream: 'torch.cuda.Stream') -> 'torch.cuda.Stream':
     return s
 
 
+def mark_side_dirty(side: 'torch.cuda.Stream') -> None:
+    _dirty_sides.add(side)
+
+
 def join_wgrad_streams() -> None:
-    """Make the current stream wait for every weight-gradient side stream."""
-    if not _side_streams:
+    """Make the current stream wait for every weight-gradient side stream that was handed work since the last join.
+    (Only those: inside a hipGraph capture a wait on a stream that is not part of the capture is an error.)"""
+    if not _dirty_sides:
         return
     cur = torch.cuda.current_stream()
-    for s in _side_streams.values():
+    for s in list(_dirty_sides):
         cur.wait_stream(s)
+    _dirty_sides.clear()
+
+
+# ---------------------------------------------------------------------------------------------
+# hipGraph capture of a whole training step (graph.StepGraph).  The few values a step takes from the HOST every
+# iteration -- the Dirichlet token budget of the mask sampler (CPU generator, multimae.py:185-189) and AdamW's
+# step-dependent scalars -- enter the graph through static device tensors that are refreshed before every replay.
+# ---------------------------------------------------------------------------------------------
+class HostInputs:
+    """(static device tensor, host thunk) pairs registered while a step is being captured.
+
+    The device tensors are carved out of a slab allocated BEFORE the capture starts: a tensor allocated inside the
+    capture comes from the graph's private pool, where it may alias a temporary that was freed earlier in the same step --
+    whose kernels would then overwrite the refreshed value during every replay (seen: AdamW reading garbage scalars)."""
+
+    def __init__(self, device=None, slab_bytes: int = 1 << 20):
+        self.items = []          # [device tensor, thunk, pending host value]
+        self.slab = torch.empty(slab_bytes, dtype=torch.uint8, device=device) if device is not None else None
+        self.used = 0
+
+    def _carve(self, shape, dtype, device) -> torch.Tensor:
+        if self.slab is None:
+            return torch.empty(shape, dtype=dtype, device=device)
+        nbytes = torch.empty((), dtype=dtype).element_size()
+        for d in shape:
+            nbytes *= d
+        off = (self.used + 255) // 256 * 256
+        if off + nbytes > self.slab.numel():
+            raise RuntimeError('HostInputs: static slab exhausted (raise slab_bytes)')
+        self.used = off + nbytes
+        return self.slab[off:off + nbytes].view(dtype).view(shape)
+
+    def add(self, thunk, device) -> torch.Tensor:
+        val = thunk()
+        dev = self._carve(tuple(val.shape), val.dtype, device)
+        self.items.append([dev, thunk, val])
+        return dev
+
+    def refresh(self) -> None:
+        """Draw / compute this step's host values and enqueue their H2D copies (stream-ordered before the replay)."""
+        for it in self.items:
+            dev, thunk, pending = it
+            val = pending if pending is not None else thunk()
+            it[2] = None
+            dev.copy_(val.pin_memory() if dev.is_cuda else val, non_blocking=True)
+
+
+_capture: Optional[HostInputs] = None
+
+
+def capturing() -> Optional[HostInputs]:
+    return _capture
+
+
+def host_input(thunk, device) -> torch.Tensor:
+    """Per-step host-computed tensor on the device.  Eager: pinned + non-blocking H2D (a pageable copy would block the
+    host until the stream drains, losing the whole launch lead).  While a step graph is being captured: a static device
+    tensor that StepGraph refreshes from `thunk` before every replay."""
+    if _capture is not None:
+        return _capture.add(thunk, device)
+    val = thunk()
+    if val.device.type == 'cpu' and torch.device(device).type == 'cuda':
+        return val.pin_memory().to(device, non_blocking=True)
+    return val.to(device)
 
 
 def fp32_adapter_gemm() -> str:

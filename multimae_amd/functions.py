@@ -32,6 +32,7 @@ class GradSink:
     def _on_side(self, fn, *tensors):
         """run fn() on the weight-gradient side stream, ordered after everything enqueued so far on the compute stream"""
         self.side.wait_stream(self.main)
+        engine.mark_side_dirty(self.side)
         with torch.cuda.stream(self.side):
             fn()
         for t in tensors:
@@ -83,6 +84,56 @@ class GradSink:
             ops.colsum(dy, tgt, acc)
         return None if acc else tgt
 
+    def colsums(self, part: Tensor, seg_w: int, params: Sequence):
+        """Column sums of part [rows, len(params) * seg_w] -> segment i is (added to) the gradient of params[i].
+        An entry is a Parameter (seg_w == numel), a (Parameter, k) pair (slice k of a gradient of several segments) or None
+        (dropped).  Direct mode: ONE reduction scatters straight into the arena-backed .grad views -- on the weight-gradient
+        side stream when there is one, so the parameter-gradient reductions leave the dX critical path; returns None per
+        entry.  Otherwise returns the gradient tensors (one per distinct Parameter, at its first entry)."""
+        dsts: List[Optional[Tensor]] = []
+        accs: List[bool] = []
+        outs: List[Optional[Tensor]] = [None] * len(params)
+        fresh = {}
+        for i, e in enumerate(params):
+            p, k = (e if isinstance(e, tuple) else (e, None))
+            if p is None or not p.requires_grad:
+                dsts.append(None)
+                accs.append(False)
+                continue
+            if self.direct and p.grad is not None:
+                flat, acc = p.grad.view(-1), True
+            else:
+                acc = False
+                flat = fresh.get(id(p))
+                if flat is None:
+                    flat = (torch.zeros if k is not None else torch.empty)((p.numel(),), device=part.device, dtype=torch.float32)
+                    fresh[id(p)] = flat
+                    outs[i] = flat.view(p.shape)
+            accs.append(acc)
+            dsts.append(flat if k is None else flat[k * seg_w:(k + 1) * seg_w])
+        live = [a for a, d in zip(accs, dsts) if d is not None]
+        if not live:
+            return outs
+        if all(live) or not any(live):
+            acc = live[0]
+            if self.side is not None and acc:
+                self._on_side(lambda: ops.colsum_scatter(part, seg_w, dsts, True), part)
+            else:
+                ops.colsum_scatter(part, seg_w, dsts, acc)
+            return outs
+        # mixed bound / unbound gradients (some .grad views missing): reduce once, hand out per parameter
+        tmp = torch.empty((part.shape[1],), device=part.device, dtype=torch.float32)
+        ops.colsum(part, tmp, False)
+        for i, (d, a) in enumerate(zip(dsts, accs)):
+            if d is None:
+                continue
+            seg = tmp[i * seg_w:i * seg_w + d.numel()]
+            if a:
+                ops.axpy_(d, seg.contiguous(), 1.0)
+            else:
+                d.copy_(seg)
+        return outs
+
     def vec(self, p: Tensor, g: Tensor):
         """g already holds the f32 gradient (any shape with p.numel() elements)."""
         if not p.requires_grad:
@@ -127,44 +178,47 @@ def block_fwd(x: Tensor, P: Sequence[Tensor], wc, heads: int, eps: float, act, B
     return x2, saved
 
 
-def block_bwd(dx: Tensor, dx_act: Tensor, dx_cs: Optional[Tensor], saved, P: Sequence[Tensor], wc, sink: GradSink, heads: int, act,
-              B: int, N: int):
-    """dx f32 [R,D] (+ its act-dtype copy, + its column sums if the producer already has them)
-    -> (dx0, dx0_act, colsum(dx0), 12 parameter grads)."""
+def block_bwd(dx: Tensor, dx_act: Tensor, fc2b_done: bool, saved, P: Sequence[Tensor], wc, sink: GradSink, heads: int, act,
+              B: int, N: int, cs_param: Optional[Tensor] = None):
+    """dx f32 [R,D] (+ its act-dtype copy) -> (dx0, dx0_act, g_cs, 12 parameter grads).
+    fc2b_done: the bias gradient of fc2 (column sums of dx) was already delivered by the producer of dx.
+    cs_param: the parameter whose gradient is colsum(dx0) -- the bias of the Linear that produced this block's input
+    (the previous block's fc2); its gradient rides along with the LayerNorm-1 reduction and comes back as g_cs."""
     n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b = P
     x0, ln1, mean1, rstd1, qkv, Pm, ao, x1, ln2, mean2, rstd2, hpre, hact = saved
     R, D = x0.shape
     hd = D // heads
+    Hd = fc1w.shape[0]
     lnact = None if act == torch.float32 else act
     # MLP
-    cs_hpre = _new((fc1w.shape[0],), dx, torch.float32) if fc1b.requires_grad else None
-    d_hpre = ops.linear_dx(dx_act, wc(fc2w), _new(hpre.shape, dx, act), aux=hpre, epi=EPI_DGELU, colsum_out=cs_hpre)
-    if dx_cs is not None:
-        g_fc2w, g_fc2b = sink.weight(fc2w, dx_act, hact), sink.vec(fc2b, dx_cs)
+    part_h = _new(ops.dx_colsum_part_shape(R, Hd), dx, torch.float32) if fc1b.requires_grad else None
+    d_hpre = ops.linear_dx(dx_act, wc(fc2w), _new(hpre.shape, dx, act), aux=hpre, epi=EPI_DGELU, colsum_part=part_h)
+    if fc2b_done:
+        g_fc2w, g_fc2b = sink.weight(fc2w, dx_act, hact), None
     else:
         g_fc2w, g_fc2b = sink.linear(fc2w, fc2b, dx_act, hact)
     d_ln2 = ops.linear_dx(d_hpre, wc(fc1w), _new((R, D), dx, act))
     g_fc1w = sink.weight(fc1w, d_hpre, ln2)
-    g_fc1b = sink.vec(fc1b, cs_hpre) if cs_hpre is not None else None
-    dx1, dx1_act, dg2, db2, cs_dx1 = ops.layernorm_bwd(d_ln2, x1, n2w, mean2, rstd2, dx, lnact)
+    g_fc1b = sink.colsums(part_h, Hd, [fc1b])[0] if part_h is not None else None
+    dx1, dx1_act, part2 = ops.layernorm_bwd_part(d_ln2, x1, n2w, mean2, rstd2, dx, lnact)
     if dx1_act is None:
         dx1_act = dx1
+    g_n2w, g_n2b, g_projb = sink.colsums(part2, D, [n2w, n2b, projb])
     # attention
     d_ao = ops.linear_dx(dx1_act, wc(projw), _new((R, D), dx, act))
     g_projw = sink.weight(projw, dx1_act, ao)
-    g_projb = sink.vec(projb, cs_dx1)
     d_qkv = _new((R, 3 * D), dx, act)
     ops.attention_bwd(AttnView(qkv, 0, 3 * D, N), AttnView(qkv, D, 3 * D, N), AttnView(qkv, 2 * D, 3 * D, N), Pm,
                       AttnView(ao, 0, D, N), AttnView(d_ao, 0, D, N), AttnView(d_qkv, 0, 3 * D, N), AttnView(d_qkv, D, 3 * D, N),
                       AttnView(d_qkv, 2 * D, 3 * D, N), B, heads, hd, hd ** -0.5)
     d_ln1 = ops.linear_dx(d_qkv, wc(qkvw), _new((R, D), dx, act))
     g_qkvw, g_qkvb = sink.linear(qkvw, qkvb, d_qkv, ln1)
-    dx0, dx0_act, dg1, db1, cs_dx0 = ops.layernorm_bwd(d_ln1, x0, n1w, mean1, rstd1, dx1, lnact)
+    dx0, dx0_act, part1 = ops.layernorm_bwd_part(d_ln1, x0, n1w, mean1, rstd1, dx1, lnact)
     if dx0_act is None:
         dx0_act = dx0
-    grads = (sink.vec(n1w, dg1), sink.vec(n1b, db1), g_qkvw, g_qkvb, g_projw, g_projb, sink.vec(n2w, dg2), sink.vec(n2b, db2),
-             g_fc1w, g_fc1b, g_fc2w, g_fc2b)
-    return dx0, dx0_act, cs_dx0, grads
+    g_n1w, g_n1b, g_cs = sink.colsums(part1, D, [n1w, n1b, cs_param])
+    grads = (g_n1w, g_n1b, g_qkvw, g_qkvb, g_projw, g_projb, g_n2w, g_n2b, g_fc1w, g_fc1b, g_fc2w, g_fc2b)
+    return dx0, dx0_act, g_cs, grads
 
 
 class _Cfg:
@@ -202,20 +256,27 @@ class EncoderStackFn(torch.autograd.Function):
         L = len(params) // 12
         sink = GradSink(engine.direct_grads())
         grads: List[Optional[Tensor]] = [None] * (12 * L)
-        dx, dx_act, dx_cs = None, None, None
+        dx, dx_act = None, None
+        fc2b_done, g_cs = False, None
         for l in reversed(range(L)):
             dl = douts[l] if cfg.all_layers else (douts[0] if l == L - 1 else None)
             if dl is not None:
                 dl = dl.contiguous().view(B * N, D)
                 dx = dl if dx is None else ops.axpy_(dx, dl, 1.0)
-                dx_act, dx_cs = None, None
+                dx_act = None
             if dx is None:
                 continue
             if dx_act is None:
                 dx_act = ops.cast(dx, cfg.act)
-            dx, dx_act, dx_cs, g = block_bwd(dx, dx_act, dx_cs, ctx.saved[l], params[12 * l:12 * l + 12], cfg.wc, sink, cfg.heads, cfg.act,
-                                             B, N)
+            # the bias gradient of block l-1's fc2 (column sums of this block's input gradient) rides along with this
+            # block's LayerNorm-1 reduction -- unless more gradient is added to dx before block l-1 sees it (all_layers)
+            cs_param = params[12 * (l - 1) + 11] if (l > 0 and not cfg.all_layers) else None
+            dx, dx_act, g_cs_next, g = block_bwd(dx, dx_act, fc2b_done, ctx.saved[l], params[12 * l:12 * l + 12], cfg.wc, sink,
+                                                 cfg.heads, cfg.act, B, N, cs_param)
             grads[12 * l:12 * l + 12] = g
+            if fc2b_done:
+                grads[12 * l + 11] = g_cs
+            fc2b_done, g_cs = cs_param is not None and cs_param.requires_grad, g_cs_next
             ctx.saved[l] = None
             if cfg.on_layer_done is not None:
                 cfg.on_layer_done(l)
@@ -268,14 +329,17 @@ class EmbedFn(torch.autograd.Function):
         D, G, act, wc = cfg.D, cfg.G, cfg.act, cfg.wc
         Ktot = rows.shape[1]
         sink = GradSink(engine.direct_grads())
-        d_proj, sums = ops.tokens_assemble_bwd(d_tok.contiguous(), cfg.task_offsets, sel, B, n_sel, G, D, act)
+        d_proj, part = ops.tokens_assemble_bwd(d_tok.contiguous(), cfg.task_offsets, sel, B, n_sel, G, D, act, raw=True)
+        # one reduction of the per-workgroup partials feeds every projection bias and the global tokens
+        gt_p = ctx.gt if (G > 0 and ctx.gt is not None) else None
+        g_small = sink.colsums(part, D, [tens[4 * i + 2] for i in range(T)] + [(gt_p, g) for g in range(G)])
         out: List[Optional[Tensor]] = []
         for i, t in enumerate(cfg.tasks):
             w, b, emb = tens[4 * i + 1], tens[4 * i + 2], tens[4 * i + 3]
             gw = sink.weight(w, d_proj, rows, x_off=t['k_off'], ldx=Ktot, K=t['K'])
             if gw is not None:
                 gw = gw.view(w.shape)
-            gb = sink.vec(b, sums[i])
+            gb = g_small[i]
             ge = None
             if emb is not None and emb.requires_grad:
                 d_rows = ops.linear_dx(d_proj, wc(w).view(D, t['K']), torch.empty((B * n_sel, t['K']), device=sel.device, dtype=act))
@@ -285,9 +349,7 @@ class EmbedFn(torch.autograd.Function):
                                    n_sel=n_sel, k_off=0, tok_off=cfg.task_offsets[i], n_patches=t['n_patches'], n_cls=emb.shape[0])
                 ge = sink.vec(emb, ge_buf)
             out += [None, gw, gb, ge]
-        g_glob = None
-        if G > 0 and ctx.gt is not None and ctx.gt.requires_grad:
-            g_glob = sink.vec(ctx.gt, sums[T:T + G].reshape(ctx.gt.shape))
+        g_glob = g_small[T] if G > 0 else None
         return (None, None, g_glob, *out)
 
 
@@ -393,25 +455,32 @@ class SpatialAdapterFn(torch.autograd.Function):
         dh_act = ops.linear_dx(d_pat, wc(ow), torch.empty((B * n_q, D), device=dev, dtype=act))
         dh = ops.cast(dh_act, torch.float32)
         bgrads: List[Optional[Tensor]] = [None] * (12 * cfg.depth)
-        dh_cs = None
+        fc2b_done, g_cs = False, None
         for l in reversed(range(cfg.depth)):
-            dh, dh_act, dh_cs, g = block_bwd(dh, dh_act, dh_cs, bsaved[l], blocks[12 * l:12 * l + 12], wc, sink, heads, act, B, n_q)
+            cs_param = blocks[12 * (l - 1) + 11] if l > 0 else f2b
+            dh, dh_act, g_cs_next, g = block_bwd(dh, dh_act, fc2b_done, bsaved[l], blocks[12 * l:12 * l + 12], wc, sink, heads, act, B,
+                                                 n_q, cs_param)
             bgrads[12 * l:12 * l + 12] = g
+            if fc2b_done:
+                bgrads[12 * l + 11] = g_cs
+            fc2b_done, g_cs = cs_param.requires_grad, g_cs_next
         # x1 = x + mlp(out_norm(x))
-        cs_hpre = torch.empty((f1w.shape[0],), device=dev, dtype=torch.float32)
-        d_hpre = ops.linear_dx(dh_act, wc(f2w), torch.empty(hpre.shape, device=dev, dtype=act), aux=hpre, epi=EPI_DGELU, colsum_out=cs_hpre)
-        if dh_cs is not None:
-            g_f2w, g_f2b = sink.weight(f2w, dh_act, hact), sink.vec(f2b, dh_cs)
+        Hd = f1w.shape[0]
+        part_h = torch.empty(ops.dx_colsum_part_shape(B * n_q, Hd), device=dev, dtype=torch.float32)
+        d_hpre = ops.linear_dx(dh_act, wc(f2w), torch.empty(hpre.shape, device=dev, dtype=act), aux=hpre, epi=EPI_DGELU, colsum_part=part_h)
+        if fc2b_done:
+            g_f2w, g_f2b = sink.weight(f2w, dh_act, hact), g_cs
         else:
             g_f2w, g_f2b = sink.linear(f2w, f2b, dh_act, hact)
         d_on = ops.linear_dx(d_hpre, wc(f1w), torch.empty((B * n_q, D), device=dev, dtype=act))
-        g_f1w, g_f1b = sink.weight(f1w, d_hpre, on), sink.vec(f1b, cs_hpre)
-        dx, dx_act, g_onw, g_onb, cs_dx = ops.layernorm_bwd(d_on, x, onw, omean, orstd, dh, lnact)
+        g_f1w, g_f1b = sink.weight(f1w, d_hpre, on), sink.colsums(part_h, Hd, [f1b])[0]
+        dx, dx_act, part_o = ops.layernorm_bwd_part(d_on, x, onw, omean, orstd, dh, lnact)
         if dx_act is None:
             dx_act = dx
+        g_onw, g_onb, g_pb = sink.colsums(part_o, D, [onw, onb, pb])
         # x = proj(attn(q, k, v))
         d_xo = ops.linear_dx(dx_act, wc(pw_), torch.empty((B * n_q, D), device=dev, dtype=act))
-        g_pw, g_pb = sink.weight(pw_, dx_act, xo), sink.vec(pb, cs_dx)
+        g_pw = sink.weight(pw_, dx_act, xo)
         d_q = torch.empty((B * n_q, D), device=dev, dtype=act)
         d_kv = torch.empty((B * NC, 2 * D), device=dev, dtype=act)
         ops.attention_bwd(AttnView(q, 0, D, n_q), AttnView(kv, 0, 2 * D, NC), AttnView(kv, D, 2 * D, NC), Pm,
@@ -421,18 +490,21 @@ class SpatialAdapterFn(torch.autograd.Function):
         g_qw, g_qb = sink.linear(qw, qb, d_q, qn)
         d_cn = ops.linear_dx(d_kv, wc(kvw), torch.empty((B * NC, D), device=dev, dtype=act))
         g_kvw, g_kvb = sink.linear(kvw, kvb, d_kv, cn)
-        d_queries, _, g_qnw, g_qnb, _ = ops.layernorm_bwd(d_qn, queries, qnw, qmean, qrstd, None, None)
-        d_context, _, g_cnw, g_cnb, _ = ops.layernorm_bwd(d_cn, context, cnw, cmean, crstd, None, None)
-        d_ctx, sums = ops.decoder_build_bwd(d_queries, d_context, ids_keep, ids_restore, cfg.task_offsets, cfg.q_task, B, n_keep, G, D,
-                                            n_q)
+        d_queries, _, part_q = ops.layernorm_bwd_part(d_qn, queries, qnw, qmean, qrstd, None, None)
+        g_qnw, g_qnb, _ = sink.colsums(part_q, D, [qnw, qnb, None])
+        d_context, _, part_c = ops.layernorm_bwd_part(d_cn, context, cnw, cmean, crstd, None, None)
+        g_cnw, g_cnb, _ = sink.colsums(part_c, D, [cnw, cnb, None])
+        d_ctx, part_b = ops.decoder_build_bwd(d_queries, d_context, ids_keep, ids_restore, cfg.task_offsets, cfg.q_task, B, n_keep, G, D,
+                                              n_q, raw=True)
+        g_build = sink.colsums(part_b, D, list(temb) + [mask_token])
         d_ctx_act = ops.cast(d_ctx, act)
         g_pcw, g_pcb = sink.linear(pcw, pcb, d_ctx_act, enc_act)
         d_enc = ops.linear_dx(d_ctx_act, wc(pcw), torch.empty((B * NC, Denc), device=dev, dtype=torch.float32))
-        g_mask = sink.vec(mask_token, sums[T])
-        g_temb = [sink.vec(t, sums[i]) if t is not None else None for i, t in enumerate(temb)]
+        g_mask = g_build[T]
+        g_temb = g_build[:T]
         ctx.saved = None
-        grads = [g_mask, *g_temb, g_qw, g_qb, g_kvw, g_kvb, g_pw, g_pb, sink.vec(cnw, g_cnw), sink.vec(cnb, g_cnb),
-                 sink.vec(qnw, g_qnw), sink.vec(qnb, g_qnb), sink.vec(onw, g_onw), sink.vec(onb, g_onb), g_f1w, g_f1b, g_f2w, g_f2b,
+        grads = [g_mask, *g_temb, g_qw, g_qb, g_kvw, g_kvb, g_pw, g_pb, g_cnw, g_cnb,
+                 g_qnw, g_qnb, g_onw, g_onb, g_f1w, g_f1b, g_f2w, g_f2b,
                  *bgrads, g_ow, g_ob, g_pcw, g_pcb]
         if cfg.on_done is not None:
             cfg.on_done()

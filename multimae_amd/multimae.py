@@ -132,11 +132,14 @@ class MultiMAE(nn.Module):
         else:
             B, counts = batch_size, [int(v) for v in vals]
         alphas = [alphas] * len(counts) if isinstance(alphas, float) else alphas
-        if sample_tasks_uniformly:
-            dist = Dirichlet(self.sample_alphas(B, len(counts), alphas=alphas)).sample()
-        else:
-            dist = Dirichlet(torch.Tensor(alphas)).sample((B,))
-        samples_per_task = (dist * num_encoded_tokens).round().long()            # :189
+
+        def draw():                     # host side of the sampler: Dirichlet on the CPU generator -> tokens per task
+            if sample_tasks_uniformly:
+                dist = Dirichlet(self.sample_alphas(B, len(counts), alphas=alphas)).sample()
+            else:
+                dist = Dirichlet(torch.Tensor(alphas)).sample((B,))
+            return (dist * num_encoded_tokens).round().long().contiguous()       # :189
+        samples_per_task = engine.host_input(draw, device)
         task_noise = torch.cat([torch.rand(B, n, device=device) for n in counts], dim=1)   # :195
         all_noise = torch.rand(B, sum(counts), device=device)                    # :204
         offs = [0]

@@ -135,19 +135,25 @@ def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], out: Tensor, *, res
 
 
 def linear_dx(dy: Tensor, w: Tensor, out: Tensor, *, aux: Optional[Tensor] = None, epi: int = EPI_NONE,
-              colsum_out: Optional[Tensor] = None) -> Tensor:
+              colsum_out: Optional[Tensor] = None, colsum_part: Optional[Tensor] = None) -> Tensor:
     """out[M,K] = dy[M,N] @ w[N,K]   (w read through the transposing LDS path).
-    colsum_out (f32 [K], dGELU epilogue only): receives the column sums of `out` -- the bias gradient of the Linear
-    whose pre-activation gradient `out` is -- accumulated in the GEMM epilogue instead of a separate pass over out."""
+    dGELU epilogue only -- the column sums of `out` (= the bias gradient of the Linear whose pre-activation gradient `out`
+    is) collected in the GEMM epilogue instead of a separate pass over out:
+      colsum_part (f32 [ceil(M/64), K]): receives the per-64-row partial sums (caller reduces them, see GradSink.colsums);
+      colsum_out  (f32 [K]): receives the reduced sums."""
     M, N = dy.shape
     K = w.shape[1]
-    part = None
-    if colsum_out is not None:
-        part = torch.empty(((M + 63) // 64, K), device=dy.device, dtype=torch.float32)
+    part = colsum_part
+    if colsum_out is not None and part is None:
+        part = torch.empty(dx_colsum_part_shape(M, K), device=dy.device, dtype=torch.float32)
     gemm(dy, w, out, M, K, N, lda=dy.stride(0), ldb=K, ldc=K, b_trans=True, aux=aux, ldaux=K, epi=epi, colsum_part=part)
-    if part is not None:
+    if colsum_out is not None:
         colsum(part, colsum_out, False)
     return out
+
+
+def dx_colsum_part_shape(M: int, K: int):
+    return ((M + 63) // 64, K)
 
 
 def linear_dw(dy: Tensor, x: Tensor, dw: Tensor, accumulate: bool, *, db: Optional[Tensor] = None, db_accumulate: bool = False,
@@ -177,21 +183,30 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out_dtype:
     return y, mean, rstd
 
 
-def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dx_in: Optional[Tensor],
-                  act_dtype: Optional[torch.dtype]):
-    """returns dx (f32, = dx_in + LN'(dy)), dx_act (act copy or None), dgamma, dbeta, colsum(dx) (f32 [D] each)."""
+def layernorm_bwd_part(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dx_in: Optional[Tensor],
+                       act_dtype: Optional[torch.dtype]):
+    """returns dx (f32, = dx_in + LN'(dy)), dx_act (act copy or None) and the UNREDUCED per-workgroup partial sums
+    part f32 [nblk, 3*D] = [dgamma | dbeta | colsum(dx)] (reduce with colsum / colsum_scatter, off the critical path)."""
     R, D = x.shape
     lib = _lib.load()
     nblk = lib.mmae_layernorm_bwd_nblk(R)
-    part = torch.empty((nblk, 3, D), device=x.device, dtype=torch.float32)
+    part = torch.empty((nblk, 3 * D), device=x.device, dtype=torch.float32)
     dx = torch.empty_like(x)
     dx_act = torch.empty((R, D), device=x.device, dtype=act_dtype) if act_dtype is not None else None
     check(lib.mmae_layernorm_bwd(dy.data_ptr(), dcode(dy.dtype), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                  rstd.data_ptr(), _p(dx_in), dx.data_ptr(), _p(dx_act),
                                  dcode(act_dtype) if act_dtype is not None else F32, part.data_ptr(), R, D, _stream()),
           'layernorm_bwd')
+    return dx, dx_act, part
+
+
+def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dx_in: Optional[Tensor],
+                  act_dtype: Optional[torch.dtype]):
+    """returns dx (f32, = dx_in + LN'(dy)), dx_act (act copy or None), dgamma, dbeta, colsum(dx) (f32 [D] each)."""
+    D = x.shape[1]
+    dx, dx_act, part = layernorm_bwd_part(dy, x, gamma, mean, rstd, dx_in, act_dtype)
     dgb = torch.empty((3 * D,), device=x.device, dtype=torch.float32)
-    colsum(part.view(nblk, 3 * D), dgb, False)
+    colsum(part, dgb, False)
     return dx, dx_act, dgb[:D], dgb[D:2 * D], dgb[2 * D:]
 
 
@@ -203,6 +218,20 @@ def colsum(dy: Tensor, out: Tensor, accumulate: bool) -> Tensor:
     check(lib.mmae_colsum(dy.data_ptr(), dcode(dy.dtype), M, N, dy.stride(0), out.data_ptr(), int(accumulate),
                           ws.data_ptr(), _stream()), 'colsum')
     return out
+
+
+def colsum_scatter(dy: Tensor, seg_w: int, dsts: Sequence[Optional[Tensor]], accumulate: bool) -> None:
+    """column sums of dy [M, len(dsts)*seg_w]; segment i (columns i*seg_w .. (i+1)*seg_w) (+)= into dsts[i] (f32, seg_w
+    elements, contiguous); None drops the segment."""
+    M, N = dy.shape
+    assert 1 <= len(dsts) <= 8 and seg_w * len(dsts) >= N, (N, seg_w, len(dsts))
+    for d in dsts:
+        assert d is None or (d.dtype == torch.float32 and d.numel() >= min(seg_w, N) and d.is_contiguous())
+    lib = _lib.load()
+    ws = torch.empty((lib.mmae_colsum_ws_elems(M, N),), device=dy.device, dtype=torch.float32)
+    arr = (ctypes.c_void_p * len(dsts))(*[_p(d) for d in dsts])
+    check(lib.mmae_colsum_scatter(dy.data_ptr(), dcode(dy.dtype), M, N, dy.stride(0), seg_w, ctypes.cast(arr, ctypes.c_void_p),
+                                  len(dsts), int(accumulate), ws.data_ptr(), _stream()), 'colsum_scatter')
 
 
 def reduce_partials(part: Tensor, out: Tensor, accumulate: bool) -> Tensor:
@@ -347,7 +376,7 @@ def mask_sample(samples_per_task: Tensor, task_noise: Tensor, all_noise: Tensor,
     spt = samples_per_task.to(dtype=torch.int64).contiguous()
     if spt.device.type == 'cpu' and dev.type == 'cuda':
         spt = spt.pin_memory().to(dev, non_blocking=True)
-    else:
+    elif spt.device != dev:
         spt = spt.to(dev)
     check(_lib.load().mmae_mask_sample(spt.data_ptr(), task_noise.contiguous().data_ptr(), all_noise.contiguous().data_ptr(),
                                        ctypes.cast(_i32_array(task_offsets), ctypes.c_void_p), T, B, Ntot, n_keep,
@@ -395,8 +424,9 @@ def tokens_assemble(proj: Tensor, biases: Sequence[Tensor], poss: Sequence[Tenso
 
 
 def tokens_assemble_bwd(d_tok: Tensor, task_offsets: Sequence[int], sel: Tensor, B: int, n_sel: int, G: int, D: int,
-                        act: torch.dtype):
-    """returns d_proj (act) [B*n_sel, D] and sums f32 [T+G, D] (bias grads per task, then global-token grads)."""
+                        act: torch.dtype, raw: bool = False):
+    """returns d_proj (act) [B*n_sel, D] and sums f32 [T+G, D] (bias grads per task, then global-token grads);
+    raw=True: the unreduced partials [nblk, (T+G)*D] instead of the sums."""
     lib = _lib.load()
     T = len(task_offsets) - 1
     nblk = lib.mmae_tokens_assemble_bwd_nblk(B)
@@ -405,6 +435,8 @@ def tokens_assemble_bwd(d_tok: Tensor, task_offsets: Sequence[int], sel: Tensor,
     check(lib.mmae_tokens_assemble_bwd(d_tok.data_ptr(), d_proj.data_ptr(), dcode(act),
                                        ctypes.cast(_i32_array(task_offsets), ctypes.c_void_p), T, sel.data_ptr(), part.data_ptr(),
                                        B, n_sel, G, D, _stream()), 'tokens_assemble_bwd')
+    if raw:
+        return d_proj, part.view(nblk, (T + G) * D)
     sums = torch.empty((T + G, D), device=d_tok.device, dtype=torch.float32)
     reduce_partials(part, sums, False)
     return d_proj, sums
@@ -422,8 +454,9 @@ def decoder_build(ctx: Tensor, ids_keep: Tensor, ids_restore: Tensor, mask_token
 
 
 def decoder_build_bwd(d_queries: Tensor, d_context: Tensor, ids_keep: Tensor, ids_restore: Tensor, task_offsets: Sequence[int],
-                      q_task: int, B: int, n_keep: int, G: int, D: int, n_q: int):
-    """returns d_ctx f32 [B*(n_keep+G), D] and sums f32 [T+1, D] (task embeddings, then mask token)."""
+                      q_task: int, B: int, n_keep: int, G: int, D: int, n_q: int, raw: bool = False):
+    """returns d_ctx f32 [B*(n_keep+G), D] and sums f32 [T+1, D] (task embeddings, then mask token);
+    raw=True: the unreduced partials [nblk, (T+1)*D] instead of the sums."""
     lib = _lib.load()
     T = len(task_offsets) - 1
     nblk = lib.mmae_decoder_build_bwd_nblk(B)
@@ -432,6 +465,8 @@ def decoder_build_bwd(d_queries: Tensor, d_context: Tensor, ids_keep: Tensor, id
     check(lib.mmae_decoder_build_bwd(d_queries.data_ptr(), d_context.data_ptr(), ids_keep.data_ptr(), ids_restore.data_ptr(),
                                      ctypes.cast(_i32_array(task_offsets), ctypes.c_void_p), T, q_task, B, n_keep, G, D, n_q,
                                      d_ctx.data_ptr(), part.data_ptr(), _stream()), 'decoder_build_bwd')
+    if raw:
+        return d_ctx, part.view(nblk, (T + 1) * D)
     sums = torch.empty((T + 1, D), device=d_queries.device, dtype=torch.float32)
     reduce_partials(part, sums, False)
     return d_ctx, sums
@@ -459,6 +494,15 @@ def patchify(img: Tensor, C: int, nh: int, nw: int, ph: int, pw: int, dtype: tor
 # ----------------------------------------------------------------------- optimiser --
 def sumsq(x: Tensor, out: Tensor, ws: Tensor) -> None:
     check(_lib.load().mmae_sumsq(x.data_ptr(), x.numel(), out.data_ptr(), ws.data_ptr(), _stream()), 'sumsq')
+
+
+def adamw_dev(p: Tensor, g: Tensor, m: Tensor, v: Tensor, hyper: Tensor, *, beta1: float, beta2: float, eps: float,
+              grad_scale: Optional[Tensor] = None, skip_flag: Optional[Tensor] = None, shadow: Optional[Tensor] = None) -> None:
+    """AdamW with {lr, weight_decay, 1 - beta1^t, sqrt(1 - beta2^t)} read from the device tensor `hyper` (f32 [4])."""
+    assert hyper.dtype == torch.float32 and hyper.numel() >= 4 and hyper.is_cuda
+    check(_lib.load().mmae_adamw_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), hyper.data_ptr(), beta1, beta2,
+                                     eps, _p(grad_scale), _p(skip_flag), _p(shadow),
+                                     dcode(shadow.dtype) if shadow is not None else F32, _stream()), 'adamw_dev')
 
 
 def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, *, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float,

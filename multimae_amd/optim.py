@@ -11,6 +11,7 @@ reference's per-iteration cosine tables (run_pretraining_multimae.py:474-480) pl
 """
 from __future__ import annotations
 
+import math
 from typing import Optional, Tuple
 
 import torch
@@ -56,12 +57,23 @@ class FusedAdamW:
             self._skip.add_((self.grad_norm >= self.skip_grad).to(torch.int32))
         if self.clip_grad is not None:
             torch.clamp(self.clip_grad / (self.grad_norm + 1e-6), max=1.0, out=self._scale)
-        self.step_count += 1
         b1, b2 = g['betas']
         shadow = a.shadow[:n] if a.shadow is not None else None
-        ops.adamw(a.param[:n], a.grad, self.m, self.v, lr=g['lr'] * g.get('lr_scale', 1.0), beta1=b1, beta2=b2, eps=g['eps'],
-                  weight_decay=g['weight_decay'], step=self.step_count,
-                  grad_scale=self._scale if self.clip_grad is not None else None, skip_flag=self._skip, shadow=shadow)
+        cap = engine.capturing()
+        if cap is not None:
+            # hipGraph capture: the step-dependent scalars come from HBM, refreshed by the host before every replay
+            def hyper():
+                self.step_count += 1
+                gg = self.param_groups[0]
+                return torch.tensor([gg['lr'] * gg.get('lr_scale', 1.0), gg['weight_decay'], 1.0 - b1 ** self.step_count,
+                                     math.sqrt(1.0 - b2 ** self.step_count)], dtype=torch.float32)
+            ops.adamw_dev(a.param[:n], a.grad, self.m, self.v, cap.add(hyper, a.device), beta1=b1, beta2=b2, eps=g['eps'],
+                          grad_scale=self._scale if self.clip_grad is not None else None, skip_flag=self._skip, shadow=shadow)
+        else:
+            self.step_count += 1
+            ops.adamw(a.param[:n], a.grad, self.m, self.v, lr=g['lr'] * g.get('lr_scale', 1.0), beta1=b1, beta2=b2, eps=g['eps'],
+                      weight_decay=g['weight_decay'], step=self.step_count,
+                      grad_scale=self._scale if self.clip_grad is not None else None, skip_flag=self._skip, shadow=shadow)
         if shadow is not None:
             a.mark_shadow_fresh()
         return self.grad_norm

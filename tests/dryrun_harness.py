@@ -31,7 +31,7 @@ class FakeLib:
             if name in ('mmae_tokens_assemble_bwd_nblk', 'mmae_decoder_build_bwd_nblk'):
                 return min(args[0], 256)
             if name == 'mmae_colsum_ws_elems':
-                return 128 * args[1]
+                return 256 * args[1]
             if name == 'mmae_last_error':
                 return b'stub'
             return 0

@@ -140,3 +140,27 @@ def test_reference_create_model_resolves_to_engine():
     env = dict(os.environ, PYTHONPATH=os.path.join(root, 'dropin'), PYTHONDONTWRITEBYTECODE='1')
     out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-2000:]
+
+
+def test_host_inputs_refresh_protocol():
+    """engine.HostInputs (the per-step host values of a captured step graph): the value drawn at capture time serves the
+    first replay, later replays call the thunk again, in registration order."""
+    from multimae_amd import engine
+    calls = []
+
+    def make(tag):
+        def thunk():
+            calls.append(tag)
+            return torch.tensor([float(len(calls))])
+        return thunk
+    hi = engine.HostInputs()
+    a = hi.add(make('a'), 'cpu')
+    b = hi.add(make('b'), 'cpu')
+    assert calls == ['a', 'b']
+    hi.refresh()                                   # first replay: pending capture-time values, no new draw
+    assert calls == ['a', 'b'] and float(a) == 1.0 and float(b) == 2.0
+    hi.refresh()
+    assert calls == ['a', 'b', 'a', 'b'] and float(a) == 3.0 and float(b) == 4.0
+    # eager mode: host_input just evaluates the thunk
+    assert engine.capturing() is None
+    assert float(engine.host_input(make('c'), 'cpu')) == 5.0

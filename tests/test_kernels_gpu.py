@@ -282,6 +282,18 @@ def test_softmax_colsum_cast_transpose():
         out = torch.ones(264, device=DEV)
         ops.colsum(dyd, out, True)
         assert rel_err(out, 1.0 + dyd.float().cpu().sum(0)) < 1e-5
+    # scattered column sums: short/wide partial blocks (the LayerNorm / dGELU reductions), segments to separate
+    # destinations, a dropped segment, accumulate on and off
+    for M_, seg, nseg in ((512, 768, 3), (396, 3072, 1), (7, 64, 5), (25344, 256, 2)):
+        dy = torch.randn(M_, seg * nseg).to(DEV)
+        ref = dy.double().sum(0).cpu()
+        for acc in (False, True):
+            dsts = [torch.full((seg,), 2.0, device=DEV) if i != 1 or nseg == 1 else None for i in range(nseg)]
+            ops.colsum_scatter(dy, seg, dsts, acc)
+            for i, d in enumerate(dsts):
+                if d is not None:
+                    exp = ref[i * seg:(i + 1) * seg] + (2.0 if acc else 0.0)
+                    assert float((d.double().cpu() - exp).abs().max()) < 1e-3 * max(1.0, M_ ** 0.5 / 8), (M_, seg, nseg, acc, i)
     # casts
     x = torch.randn(100003)
     assert torch.equal(ops.cast(x.to(DEV), torch.bfloat16).cpu(), x.to(torch.bfloat16))

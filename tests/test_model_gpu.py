@@ -248,6 +248,76 @@ def test_training_loop_loss_curve_matches_oracle():
     assert curve_e[-1] < curve_e[0]
 
 
+def _train_steps(n_steps, use_graph, fixed_masks):
+    """n AdamW steps of the mini model in bf16 speed mode with every stream option on (the bench configuration),
+    eagerly or through graph.StepGraph; returns (losses, final parameter arena copy, mask history)."""
+    import multimae_amd as M
+    from multimae_amd.graph import StepGraph
+    from multimae_amd.optim import FusedAdamW
+    g = load_mini()
+    model = build_mini_engine()
+    model.load_state_dict(g['sd'])
+    model.to(DEV)
+    arena = model.build_arena()
+    opt = FusedAdamW(model, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
+    xd = {k: v.to(DEV) for k, v in g['x'].items()}
+    tgt = dict(xd, norm_rgb=xd['rgb'])
+    fns = _loss_fns(MINI['P'])
+    if fixed_masks:
+        tm = {d: g['mask'][d].to(DEV) for d in MINI['doms']}
+        ids = (g['ids_keep'].to(DEV), g['ids_restore'].to(DEV))
+        model.generate_random_masks = lambda *a, **k: (tm, ids[0], ids[1])
+    out = {}
+
+    def step():
+        opt.zero_grad()
+        preds, masks = model(xd, num_encoded_tokens=MINI['nvis'], alphas=1.0, fp32_output_adapters=['semseg'])
+        mk = dict(masks, norm_rgb=masks['rgb'])
+        loss = sum(fns[k](preds[k].float(), tgt[k], mask=mk[k]) for k in preds)
+        loss.backward()
+        opt.step()
+        out['loss'], out['mask'] = loss, masks['rgb']
+        return loss
+
+    M.engine.set_direct_grads(True)
+    M.engine.set_adapter_streams(True)
+    M.engine.set_wgrad_stream(True)
+    losses, masks = [], []
+    try:
+        torch.manual_seed(7)
+        step()                                     # one eager step first (lazy streams / kernel attributes), as bench.py does
+        losses.append(float(out['loss'])); masks.append(out['mask'].clone())
+        run = StepGraph(step) if use_graph else step
+        for _ in range(n_steps - 1):
+            run()
+            torch.cuda.synchronize()
+            losses.append(float(out['loss'])); masks.append(out['mask'].clone())
+    finally:
+        M.engine.set_direct_grads(False)
+        M.engine.set_adapter_streams(False)
+        M.engine.set_wgrad_stream(False)
+    assert opt.step_count == n_steps
+    return losses, arena.param.clone(), masks
+
+
+def test_step_graph_replay_matches_eager_steps():
+    """The whole step captured as ONE hipGraph (all adapter / weight-gradient streams as graph branches, AdamW scalars
+    through HBM) and replayed 4x == 5 eager steps on the same masks: same loss curve and same final parameters (up to
+    the float-atomic class-embedding gradient)."""
+    le, pe, _ = _train_steps(5, False, True)
+    lg, pg, _ = _train_steps(5, True, True)
+    assert max(abs(a - b) for a, b in zip(le, lg)) < 2e-4, (le, lg)
+    assert le[-1] < le[0]
+    assert rel_err(pg, pe) < 1e-5
+
+
+def test_step_graph_resamples_masks_every_replay():
+    """Replays draw fresh masks: the Dirichlet budgets come from the host before each replay, the noise from the graph-safe
+    device generator; every sample keeps exactly nvis tokens."""
+    _, _, masks = _train_steps(4, True, False)
+    assert not torch.equal(masks[1], masks[2]) and not torch.equal(masks[2], masks[3])
+
+
 def _known_answer_case(name, doms, P, S, nvis, enc, posemb, mode, fp32_adapters=()):
     """Reproduce the reference's recorded step (tests/golden/scalars.json, SURVEY Appendix B recipe): same seeded init
     (bit-identical weights), same inputs (seed stream), same masks (the reference drew them on the CPU generator after
