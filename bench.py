@@ -242,9 +242,17 @@ def main():
     final_loss = float(last['loss'].detach())
     log(f'timed region done: {ms_per_step:.2f} ms/step, {img_s:.1f} img/s, loss {final_loss:.4f} (host enqueue {host_ms:.2f} ms/step)')
 
-    # per-kernel timing pass (outside the timed region): HIP events around every MFMA GEMM launch
+    # per-kernel timing pass (outside the timed region): HIP events around every MFMA GEMM launch.  The pass runs with the
+    # multi-stream options OFF, so every launch is alone on the GPU and on the stream the events are recorded on: a launch's
+    # event-bracketed time is then that kernel's own duration (with the adapters / weight-gradient GEMMs on other streams a
+    # bracketed launch also counts the time it shares the CUs with them).  rocprofv3 of
+    # `bench.py --adapter-streams 0 --wgrad-stream 0` gives the same per-kernel averages (profiles/*_serialized_*).
     roof = None
     if not args.no_kernel_timing:
+        M.engine.set_adapter_streams(False)
+        M.engine.set_wgrad_stream(False)
+        step()
+        torch.cuda.synchronize()
         rec = []
         orig = ops.gemm
 
@@ -255,10 +263,19 @@ def main():
             e1.record()
             rec.append((e0, e1, 2.0 * Mm * N * K * kw.get('batch', 1), A.dtype))
         ops.gemm = timed_gemm
-        import multimae_amd.functions as F_
+        # park the GPU for ~80 ms first, so the whole step is already queued when it starts executing: the events then
+        # bracket back-to-back kernels (with the GPU waiting for the host, a launch's bracket would include ~20 us of Python)
+        try:
+            torch.cuda._sleep(int(0.08 * 2.0e9))
+        except Exception:                      # noqa: BLE001 -- no spin kernel in this torch build: fill memory instead
+            junk = torch.empty(1 << 30, device=device, dtype=torch.uint8)
+            for _ in range(40):
+                junk.zero_()
         step()
         torch.cuda.synchronize()
         ops.gemm = orig
+        M.engine.set_adapter_streams(bool(args.adapter_streams))
+        M.engine.set_wgrad_stream(bool(args.wgrad_stream))
         log('kernel timing pass done')
         tot_ms = {torch.bfloat16: 0.0, torch.float32: 0.0}
         tot_fl = {torch.bfloat16: 0.0, torch.float32: 0.0}
@@ -270,7 +287,7 @@ def main():
         dom = torch.bfloat16 if args.precision == 'bf16' else torch.float32
         peak = PEAK_BF16_TFLOPS if dom == torch.bfloat16 else 157.3
         ach = tot_fl[dom] / (tot_ms[dom] * 1e-3) / 1e12 if tot_ms[dom] > 0 else 0.0
-        roof = {'bound': 'mfma', 'kernel': 'gemm_bf16_pp_kernel / gemm_bf16_kernel (all bf16 MFMA GEMM launches of one step)' if dom == torch.bfloat16 else 'gemm_f32_kernel',
+        roof = {'bound': 'mfma', 'kernel': 'gemm_bf16_pp_kernel / gemm_bf16_kernel (all bf16 MFMA GEMM launches of one step, each timed alone on its stream)' if dom == torch.bfloat16 else 'gemm_f32_kernel',
                 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': pmc_traffic(dom),
                 'launches_per_step': cnt[dom], 'gemm_ms_per_step': round(tot_ms[dom], 3),
                 'gemm_gflop_per_step': round(tot_fl[dom] / 1e9, 1),

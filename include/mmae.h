@@ -168,6 +168,17 @@ int mmae_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
                   void* dk, void* dv, int B, int H, int Nq, int Nk, int hd, int64_t q_sb, int64_t q_sr, int64_t k_sb,
                   int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr, int64_t dq_sb, int64_t dq_sr,
                   int64_t dk_sb, int64_t dk_sr, int64_t dv_sb, int64_t dv_sr, float scale, void* stream);
+/* The same two kernels for f32 q/k/v/o/dO/dq/dk/dv (fp32_output_adapters in speed mode): operands split into bf16 hi + lo
+ * on the fly, every product as a_hi.b_hi + a_hi.b_lo + a_lo.b_hi with fp32 accumulation (the MMAE_F32X3 precision).
+ * Strides in f32 elements.  backward needs 4 * (Nq_pad + Nk_pad) * head_dim * 2 bytes of LDS <= 160 KB, else MMAE_ESUPPORT. */
+int mmae_attn_fwd_f32x3(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
+                  int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb,
+                  int64_t o_sr, float scale, void* stream);
+int mmae_attn_bwd_f32x3(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, void* dq,
+                  void* dk, void* dv, int B, int H, int Nq, int Nk, int hd, int64_t q_sb, int64_t q_sr, int64_t k_sb,
+                  int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr, int64_t dq_sb, int64_t dq_sr,
+                  int64_t dk_sb, int64_t dk_sr, int64_t dv_sb, int64_t dv_sr, float scale, void* stream);
+
 
 /* ------------------------------------------------------------------------- *
  * Casts.  f32 master weights -> act-dtype shadows (optionally transposed so that

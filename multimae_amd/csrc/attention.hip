@@ -9,6 +9,12 @@
 //             produces dK and dV; delta = rowsum(dO . O).  7 small MFMA products instead of 5, no atomics,
 //             no HBM traffic beyond Q, K, V, O, dO in and dQ, dK, dV out.
 //
+// X3 = true: the same kernels for f32 activations (fp32_output_adapters in speed mode).  Operands are split on the fly
+// into bf16 hi + lo parts (tiles: when they are written to LDS; register operands: right before the MFMA) and every
+// product runs as  a.b ~= a_hi.b_hi + a_hi.b_lo + a_lo.b_hi  with fp32 accumulation -- the precision of the split-bf16
+// ("x3") GEMMs those adapters use, ~16 operand mantissa bits.  Replaces, for them, 2-5 batched x3 GEMM launches plus a
+// softmax pass over materialised (B, H, Nq, Nk) f32 scores per attention.
+//
 // Replaces Attention.forward / CrossAttention.forward cores (multimae_utils.py:175-179, 206-210) + autograd.
 #include "common.h"
 
@@ -20,8 +26,8 @@ namespace {
 constexpr unsigned OOB = 0x80000000u;
 
 struct AttnArgs {
-    const uint16_t *q, *k, *v, *o, *d_o;
-    uint16_t *out, *dq, *dk, *dv;
+    const void *q, *k, *v, *o, *d_o;          // bf16 (uint16_t) or, in the X3 kernels, f32
+    void *out, *dq, *dk, *dv;
     float* lse;
     int B, H, Nq, Nk, nqp, nkp;
     long long q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, dq_sb, dq_sr, dk_sb, dk_sr, dv_sb, dv_sr;
@@ -64,6 +70,47 @@ struct TileLoader {
     }
 };
 
+__device__ __forceinline__ void split8(const i32x4& a, const i32x4& b, bf16x8& hi, bf16x8& lo) {
+    const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        hi[j] = (__bf16)fa[j]; lo[j] = (__bf16)(fa[j] - (float)hi[j]);
+        hi[4 + j] = (__bf16)fb[j]; lo[4 + j] = (__bf16)(fb[j] - (float)hi[4 + j]);
+    }
+}
+// f32 rows -> a hi tile and a lo tile (same swizzled layout, `lo_off` bytes apart)
+template <int HD, int NTHR>
+struct TileLoaderF32 {
+    static constexpr int CPR = HD / 8;
+    static constexpr int MAXIT = (256 * CPR + NTHR - 1) / NTHR;
+    i32x4 r0[MAXIT], r1[MAXIT];
+    __device__ __forceinline__ void issue(const float* base, long long sr, int nrows, int nrows_pad, int tid) {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x80000000, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < MAXIT; ++i) {
+            const int c = tid + i * NTHR;
+            const int row = c / CPR, ch = c % CPR;
+            const bool ok = c < nrows_pad * CPR && row < nrows;
+            const unsigned off = (unsigned)((row * sr + ch * 8) * 4);
+            r0[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0);
+            r1[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : OOB, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void commit(char* lds, int lo_off, int nrows_pad, int tid) {
+#pragma unroll
+        for (int i = 0; i < MAXIT; ++i) {
+            const int c = tid + i * NTHR;
+            if (c < nrows_pad * CPR) {
+                bf16x8 hi, lo;
+                split8(r0[i], r1[i], hi, lo);
+                char* p = lds + tile_off<HD>(c / CPR, c % CPR);
+                *reinterpret_cast<bf16x8*>(p) = hi;
+                *reinterpret_cast<bf16x8*>(p + lo_off) = lo;
+            }
+        }
+    }
+};
+
 // MFMA operand "row fragment": lane supplies row (row0 + lane&31), k = 16*ks + 8*(lane>>5) + 0..7
 template <int HD>
 __device__ __forceinline__ bf16x8 frag_rows(const char* tile, int row0, int ks, int lane) {
@@ -89,42 +136,84 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
     for (int j = 0; j < 8; ++j) r[j] = (__bf16)v[8 * s + j];
     return r;
 }
+__device__ __forceinline__ bf16x8 pack8_lo(const f32x16& v, int s) {     // residual of pack8: v - float(bf16(v))
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (__bf16)(v[8 * s + j] - (float)(__bf16)v[8 * s + j]);
+    return r;
+}
 __device__ __forceinline__ bf16x8 load_frag_global(const __amdgpu_buffer_rsrc_t rs, bool ok, long long row, long long sr, int ks, int hi) {
     const unsigned off = ok ? (unsigned)((row * sr + ks * 16 + hi * 8) * 2) : OOB;
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+}
+__device__ __forceinline__ void load_frag_global_f32(const __amdgpu_buffer_rsrc_t rs, bool ok, long long row, long long sr, int ks, int hi,
+                                                     bf16x8& h, bf16x8& l) {
+    const unsigned off = (unsigned)((row * sr + ks * 16 + hi * 8) * 4);
+    const i32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0);
+    const i32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : OOB, 0, 0);
+    split8(a, b, h, l);
+}
+// c += a . b for operands given as (hi, lo) pairs; X3 = false ignores the lo parts
+template <bool X3>
+__device__ __forceinline__ f32x16 mma(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x16 c) {
+    if (X3) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
 }
 // store 4 consecutive head-dim values of one row
 __device__ __forceinline__ void store4(uint16_t* p, float a, float b, float c, float d) {
     f32x4 t = {a, b, c, d};
     st4(p, t);
 }
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+    f32x4 t = {a, b, c, d};
+    st4(p, t);
+}
+template <bool X3> struct ActOf { typedef uint16_t T; };
+template <> struct ActOf<true> { typedef float T; };
 
 // -------------------------------------------------------------------------------------------------
-template <int HD, int NT>
-__global__ void __launch_bounds__(256, NT == 4 ? 3 : 1) attn_fwd_kernel(const AttnArgs a) {
+template <int HD, int NT, bool X3>
+__global__ void __launch_bounds__(256, (NT == 4 && !X3) ? 3 : (NT <= 7 ? 2 : 1)) attn_fwd_kernel(const AttnArgs a) {
+    typedef typename ActOf<X3>::T AT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const int tile_b = a.nkp * HD * 2;
+    const int lo = 2 * tile_b;                          // X3: [K hi | V hi | K lo | V lo]
     char* Ks = smem;
-    char* Vs = smem + a.nkp * HD * 2;
-    {
+    char* Vs = smem + tile_b;
+    const AT* kg = (const AT*)a.k + b * a.k_sb + h * HD;
+    const AT* vg = (const AT*)a.v + b * a.v_sb + h * HD;
+    if constexpr (X3) {
+        TileLoaderF32<HD, 256> lk, lv;
+        lk.issue(kg, a.k_sr, a.Nk, a.nkp, tid);
+        lv.issue(vg, a.v_sr, a.Nk, a.nkp, tid);
+        lk.commit(Ks, lo, a.nkp, tid);
+        lv.commit(Vs, lo, a.nkp, tid);
+    } else {
         TileLoader<HD, 256> lk, lv;
-        lk.issue(a.k + b * a.k_sb + h * HD, a.k_sr, a.Nk, a.nkp, tid);
-        lv.issue(a.v + b * a.v_sb + h * HD, a.v_sr, a.Nk, a.nkp, tid);
+        lk.issue(kg, a.k_sr, a.Nk, a.nkp, tid);
+        lv.issue(vg, a.v_sr, a.Nk, a.nkp, tid);
         lk.commit(Ks, a.nkp, tid);
         lv.commit(Vs, a.nkp, tid);
     }
     __syncthreads();
     const int nt = a.nkp >> 5, nqb = (a.Nq + 31) >> 5;
-    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(a.q + b * a.q_sb + h * HD), 0, 0x80000000, 0x00020000);
-    uint16_t* ob = a.out + b * a.o_sb + h * HD;
+    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)((const AT*)a.q + b * a.q_sb + h * HD), 0, 0x80000000, 0x00020000);
+    AT* ob = (AT*)a.out + b * a.o_sb + h * HD;
     for (int qblk = wave; qblk < nqb; qblk += 4) {
         const int q = qblk * 32 + (lane & 31);
         const bool qok = q < a.Nq;
-        bf16x8 qf[HD / 16];
+        bf16x8 qf[HD / 16], ql[HD / 16];
 #pragma unroll
-        for (int ks = 0; ks < HD / 16; ++ks) qf[ks] = load_frag_global(rsQ, qok, q, a.q_sr, ks, hi);
+        for (int ks = 0; ks < HD / 16; ++ks) {
+            if constexpr (X3) load_frag_global_f32(rsQ, qok, q, a.q_sr, ks, hi, qf[ks], ql[ks]);
+            else { qf[ks] = load_frag_global(rsQ, qok, q, a.q_sr, ks, hi); ql[ks] = qf[ks]; }
+        }
         f32x16 s[NT];
         float m = -INFINITY;
 #pragma unroll
@@ -133,8 +222,11 @@ __global__ void __launch_bounds__(256, NT == 4 ? 3 : 1) attn_fwd_kernel(const At
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < HD / 16; ++ks)
-                    s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Ks, t * 32, ks, lane), qf[ks], s[t], 0, 0, 0);
+                for (int ks = 0; ks < HD / 16; ++ks) {
+                    const bf16x8 kh = frag_rows<HD>(Ks, t * 32, ks, lane);
+                    const bf16x8 kl = X3 ? frag_rows<HD>(Ks + lo, t * 32, ks, lane) : kh;
+                    s[t] = mma<X3>(kh, kl, qf[ks], ql[ks], s[t]);
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -165,9 +257,13 @@ __global__ void __launch_bounds__(256, NT == 4 ? 3 : 1) attn_fwd_kernel(const At
 #pragma unroll
                 for (int sI = 0; sI < 2; ++sI) {
                     const bf16x8 pf = pack8(s[t], sI);
+                    const bf16x8 pl = X3 ? pack8_lo(s[t], sI) : pf;
 #pragma unroll
-                    for (int dt = 0; dt < HD / 32; ++dt)
-                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<HD>(Vs, dt * 32, t * 32 + 16 * sI, lane), pf, o[dt], 0, 0, 0);
+                    for (int dt = 0; dt < HD / 32; ++dt) {
+                        const bf16x8 vh = frag_cols<HD>(Vs, dt * 32, t * 32 + 16 * sI, lane);
+                        const bf16x8 vl = X3 ? frag_cols<HD>(Vs + lo, dt * 32, t * 32 + 16 * sI, lane) : vh;
+                        o[dt] = mma<X3>(vh, vl, pf, pl, o[dt]);
+                    }
                 }
             }
         }
@@ -187,8 +283,9 @@ __global__ void __launch_bounds__(256, NT == 4 ? 3 : 1) attn_fwd_kernel(const At
 // -------------------------------------------------------------------------------------------------
 // 512 threads: after the shared prologue (tiles -> LDS, delta), waves 0-3 run pass 1 and waves 4-7 run
 // pass 2 concurrently (the passes only read LDS and write disjoint outputs).
-template <int HD>
+template <int HD, bool X3>
 __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs a) {
+    typedef typename ActOf<X3>::T AT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -197,17 +294,36 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs a) {
     char* dOs = Qs + a.nqp * HD * 2;
     char* Ks = dOs + a.nqp * HD * 2;
     char* Vs = Ks + a.nkp * HD * 2;
-    float* lse_s = (float*)(Vs + a.nkp * HD * 2);
+    const int lo = 2 * (a.nqp + a.nkp) * HD * 2;        // X3: the four lo tiles follow the four hi tiles
+    float* lse_s = (float*)(Vs + a.nkp * HD * 2 + (X3 ? lo : 0));
     float* delta_s = lse_s + a.nqp;
-    const uint16_t* qg = a.q + b * a.q_sb + h * HD;
-    const uint16_t* og = a.o + b * a.o_sb + h * HD;
-    const uint16_t* dog = a.d_o + b * a.o_sb + h * HD;
-    {
+    const AT* qg = (const AT*)a.q + b * a.q_sb + h * HD;
+    const AT* og = (const AT*)a.o + b * a.o_sb + h * HD;
+    const AT* dog = (const AT*)a.d_o + b * a.o_sb + h * HD;
+    const AT* kg = (const AT*)a.k + b * a.k_sb + h * HD;
+    const AT* vg = (const AT*)a.v + b * a.v_sb + h * HD;
+    if constexpr (X3) {
+        {
+            TileLoaderF32<HD, 512> lq, ld;
+            lq.issue(qg, a.q_sr, a.Nq, a.nqp, tid);
+            ld.issue(dog, a.o_sr, a.Nq, a.nqp, tid);
+            for (int q = tid; q < a.nqp; q += 512) lse_s[q] = q < a.Nq ? a.lse[((long long)b * a.H + h) * a.Nq + q] : 0.f;
+            lq.commit(Qs, lo, a.nqp, tid);
+            ld.commit(dOs, lo, a.nqp, tid);
+        }
+        {
+            TileLoaderF32<HD, 512> lk, lv;
+            lk.issue(kg, a.k_sr, a.Nk, a.nkp, tid);
+            lv.issue(vg, a.v_sr, a.Nk, a.nkp, tid);
+            lk.commit(Ks, lo, a.nkp, tid);
+            lv.commit(Vs, lo, a.nkp, tid);
+        }
+    } else {
         TileLoader<HD, 512> lq, ld, lk, lv;
         lq.issue(qg, a.q_sr, a.Nq, a.nqp, tid);
         ld.issue(dog, a.o_sr, a.Nq, a.nqp, tid);
-        lk.issue(a.k + b * a.k_sb + h * HD, a.k_sr, a.Nk, a.nkp, tid);
-        lv.issue(a.v + b * a.v_sb + h * HD, a.v_sr, a.Nk, a.nkp, tid);
+        lk.issue(kg, a.k_sr, a.Nk, a.nkp, tid);
+        lv.issue(vg, a.v_sr, a.Nk, a.nkp, tid);
         for (int q = tid; q < a.nqp; q += 512) lse_s[q] = q < a.Nq ? a.lse[((long long)b * a.H + h) * a.Nq + q] : 0.f;
         lq.commit(Qs, a.nqp, tid);
         ld.commit(dOs, a.nqp, tid);
@@ -215,7 +331,6 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs a) {
         lv.commit(Vs, a.nkp, tid);
     }
     const int nt = a.nkp >> 5, nqb = a.nqp >> 5;
-    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)qg, 0, 0x80000000, 0x00020000);
     const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void*)og, 0, 0x80000000, 0x00020000);
     const auto rsdO = __builtin_amdgcn_make_buffer_rsrc((void*)dog, 0, 0x80000000, 0x00020000);
     // delta[q] = sum_d dO[q][d] * O[q][d]
@@ -225,9 +340,20 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs a) {
         float d = 0.f;
 #pragma unroll
         for (int ks = 0; ks < HD / 16; ++ks) {
-            const bf16x8 of = load_frag_global(rsO, qok, q, a.o_sr, ks, hi), df = load_frag_global(rsdO, qok, q, a.o_sr, ks, hi);
+            if constexpr (X3) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d += (float)of[j] * (float)df[j];
+                for (int half = 0; half < 2; ++half) {
+                    const unsigned off = qok ? (unsigned)((q * a.o_sr + ks * 16 + hi * 8 + half * 4) * 4) : OOB;
+                    const f32x4 of = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsO, off, 0, 0));
+                    const f32x4 df = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsdO, off, 0, 0));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d += of[j] * df[j];
+                }
+            } else {
+                const bf16x8 of = load_frag_global(rsO, qok, q, a.o_sr, ks, hi), df = load_frag_global(rsdO, qok, q, a.o_sr, ks, hi);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d += (float)of[j] * (float)df[j];
+            }
         }
         d += __shfl_xor(d, 32, 64);
         if (hi == 0) delta_s[q] = d;
@@ -238,9 +364,13 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs a) {
     for (int qblk = wave; wave < 4 && qblk < nqb; qblk += 4) {
         const int q = qblk * 32 + (lane & 31);
         const bool qok = q < a.Nq;
-        bf16x8 qf[HD / 16], dof[HD / 16];
+        bf16x8 qf[HD / 16], dof[HD / 16], ql[HD / 16], dol[HD / 16];
 #pragma unroll
-        for (int ks = 0; ks < HD / 16; ++ks) { qf[ks] = frag_rows<HD>(Qs, qblk * 32, ks, lane); dof[ks] = frag_rows<HD>(dOs, qblk * 32, ks, lane); }
+        for (int ks = 0; ks < HD / 16; ++ks) {
+            qf[ks] = frag_rows<HD>(Qs, qblk * 32, ks, lane); dof[ks] = frag_rows<HD>(dOs, qblk * 32, ks, lane);
+            ql[ks] = X3 ? frag_rows<HD>(Qs + lo, qblk * 32, ks, lane) : qf[ks];
+            dol[ks] = X3 ? frag_rows<HD>(dOs + lo, qblk * 32, ks, lane) : dof[ks];
+        }
         const float lse_q = lse_s[q], delta_q = delta_s[q];
         f32x16 dq[HD / 32];
 #pragma unroll
@@ -253,8 +383,10 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs a) {
             for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < HD / 16; ++ks) {
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Ks, t * 32, ks, lane), qf[ks], st, 0, 0, 0);
-                dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Vs, t * 32, ks, lane), dof[ks], dpt, 0, 0, 0);
+                const bf16x8 kh = frag_rows<HD>(Ks, t * 32, ks, lane), vh = frag_rows<HD>(Vs, t * 32, ks, lane);
+                const bf16x8 kl = X3 ? frag_rows<HD>(Ks + lo, t * 32, ks, lane) : kh, vl = X3 ? frag_rows<HD>(Vs + lo, t * 32, ks, lane) : vh;
+                st = mma<X3>(kh, kl, qf[ks], ql[ks], st);
+                dpt = mma<X3>(vh, vl, dof[ks], dol[ks], dpt);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -264,13 +396,17 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs a) {
 #pragma unroll
             for (int sI = 0; sI < 2; ++sI) {
                 const bf16x8 dsf = pack8(st, sI);
+                const bf16x8 dsl = X3 ? pack8_lo(st, sI) : dsf;
 #pragma unroll
-                for (int dt = 0; dt < HD / 32; ++dt)
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<HD>(Ks, dt * 32, t * 32 + 16 * sI, lane), dsf, dq[dt], 0, 0, 0);
+                for (int dt = 0; dt < HD / 32; ++dt) {
+                    const bf16x8 kh = frag_cols<HD>(Ks, dt * 32, t * 32 + 16 * sI, lane);
+                    const bf16x8 kl = X3 ? frag_cols<HD>(Ks + lo, dt * 32, t * 32 + 16 * sI, lane) : kh;
+                    dq[dt] = mma<X3>(kh, kl, dsf, dsl, dq[dt]);
+                }
             }
         }
         if (qok) {
-            uint16_t* dst = a.dq + b * a.dq_sb + h * HD + q * a.dq_sr;
+            AT* dst = (AT*)a.dq + b * a.dq_sb + h * HD + q * a.dq_sr;
 #pragma unroll
             for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
@@ -282,9 +418,13 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs a) {
     // ---- pass 2 (waves 4-7): lane = key row -> dK, dV
     for (int kblk = wave - 4; wave >= 4 && kblk < nt; kblk += 4) {
         const int key = kblk * 32 + (lane & 31);
-        bf16x8 kf[HD / 16], vf[HD / 16];
+        bf16x8 kf[HD / 16], vf[HD / 16], kl[HD / 16], vl[HD / 16];
 #pragma unroll
-        for (int ks = 0; ks < HD / 16; ++ks) { kf[ks] = frag_rows<HD>(Ks, kblk * 32, ks, lane); vf[ks] = frag_rows<HD>(Vs, kblk * 32, ks, lane); }
+        for (int ks = 0; ks < HD / 16; ++ks) {
+            kf[ks] = frag_rows<HD>(Ks, kblk * 32, ks, lane); vf[ks] = frag_rows<HD>(Vs, kblk * 32, ks, lane);
+            kl[ks] = X3 ? frag_rows<HD>(Ks + lo, kblk * 32, ks, lane) : kf[ks];
+            vl[ks] = X3 ? frag_rows<HD>(Vs + lo, kblk * 32, ks, lane) : vf[ks];
+        }
         f32x16 dk[HD / 32], dv[HD / 32];
 #pragma unroll
         for (int dt = 0; dt < HD / 32; ++dt)
@@ -296,8 +436,10 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs a) {
             for (int r = 0; r < 16; ++r) { sm[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < HD / 16; ++ks) {
-                sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Qs, qt * 32, ks, lane), kf[ks], sm, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(dOs, qt * 32, ks, lane), vf[ks], dp, 0, 0, 0);
+                const bf16x8 qh = frag_rows<HD>(Qs, qt * 32, ks, lane), doh = frag_rows<HD>(dOs, qt * 32, ks, lane);
+                const bf16x8 qlo = X3 ? frag_rows<HD>(Qs + lo, qt * 32, ks, lane) : qh, dolo = X3 ? frag_rows<HD>(dOs + lo, qt * 32, ks, lane) : doh;
+                sm = mma<X3>(qh, qlo, kf[ks], kl[ks], sm);
+                dp = mma<X3>(doh, dolo, vf[ks], vl[ks], dp);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -309,16 +451,20 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs a) {
 #pragma unroll
             for (int sI = 0; sI < 2; ++sI) {
                 const bf16x8 pf = pack8(sm, sI), dsf = pack8(dp, sI);
+                const bf16x8 pl = X3 ? pack8_lo(sm, sI) : pf, dsl = X3 ? pack8_lo(dp, sI) : dsf;
 #pragma unroll
                 for (int dt = 0; dt < HD / 32; ++dt) {
-                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<HD>(dOs, dt * 32, qt * 32 + 16 * sI, lane), pf, dv[dt], 0, 0, 0);
-                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<HD>(Qs, dt * 32, qt * 32 + 16 * sI, lane), dsf, dk[dt], 0, 0, 0);
+                    const bf16x8 doh = frag_cols<HD>(dOs, dt * 32, qt * 32 + 16 * sI, lane), qh = frag_cols<HD>(Qs, dt * 32, qt * 32 + 16 * sI, lane);
+                    const bf16x8 dolo = X3 ? frag_cols<HD>(dOs + lo, dt * 32, qt * 32 + 16 * sI, lane) : doh;
+                    const bf16x8 qlo = X3 ? frag_cols<HD>(Qs + lo, dt * 32, qt * 32 + 16 * sI, lane) : qh;
+                    dv[dt] = mma<X3>(doh, dolo, pf, pl, dv[dt]);
+                    dk[dt] = mma<X3>(qh, qlo, dsf, dsl, dk[dt]);
                 }
             }
         }
         if (key < a.Nk) {
-            uint16_t* dkd = a.dk + b * a.dk_sb + h * HD + key * a.dk_sr;
-            uint16_t* dvd = a.dv + b * a.dv_sb + h * HD + key * a.dv_sr;
+            AT* dkd = (AT*)a.dk + b * a.dk_sb + h * HD + key * a.dk_sr;
+            AT* dvd = (AT*)a.dv + b * a.dv_sb + h * HD + key * a.dv_sr;
 #pragma unroll
             for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
@@ -341,60 +487,95 @@ int check_common(int B, int H, int Nq, int Nk, int hd, const long long* strides,
 
 extern "C" {
 
-int mmae_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
-                  int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr,
-                  float scale, void* stream) {
+static int attn_fwd_impl(bool x3, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
+                         int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr,
+                         float scale, void* stream) {
     MMAE_REQUIRE(q && k && v && o && lse, "attn_fwd: null pointer");
     const long long st[] = {q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr};
     const int rc = check_common(B, H, Nq, Nk, hd, st, 8);
     MMAE_REQUIRE(rc == 0, rc == -2 ? "attn: head_dim must be 32 or 64" : (rc == -3 ? "attn: strides must be multiples of 8" : "attn: need 1 <= Nq, Nk <= 256"));
-    MMAE_REQUIRE(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)o % 8 == 0), "attn_fwd: unaligned pointer");
+    MMAE_REQUIRE(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)o % (x3 ? 16 : 8) == 0), "attn_fwd: unaligned pointer");
     AttnArgs a = {};
-    a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = (const uint16_t*)v; a.out = (uint16_t*)o; a.lse = lse;
+    a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.nqp = (Nq + 31) / 32 * 32; a.nkp = (Nk + 31) / 32 * 32;
     a.q_sb = q_sb; a.q_sr = q_sr; a.k_sb = k_sb; a.k_sr = k_sr; a.v_sb = v_sb; a.v_sr = v_sr; a.o_sb = o_sb; a.o_sr = o_sr;
     a.scale = scale;
-    const size_t lds = (size_t)2 * a.nkp * hd * 2;
+    const size_t lds = (size_t)2 * a.nkp * hd * 2 * (x3 ? 2 : 1);
     hipStream_t st_ = (hipStream_t)stream;
     dim3 grid(B * H), block(256);
-#define LAUNCH_FWD(HD, NT)                                                                                                  \
+#define LAUNCH_FWD(HD, NT, X3)                                                                                               \
     do {                                                                                                                     \
-        hipFuncSetAttribute((const void*)attn_fwd_kernel<HD, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
-        hipLaunchKernelGGL((attn_fwd_kernel<HD, NT>), grid, block, lds, st_, a);                                             \
+        hipFuncSetAttribute((const void*)attn_fwd_kernel<HD, NT, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((attn_fwd_kernel<HD, NT, X3>), grid, block, lds, st_, a);                                         \
     } while (0)
-    const bool small = a.nkp <= 128;
-    if (hd == 64) { if (small) LAUNCH_FWD(64, 4); else LAUNCH_FWD(64, 8); }
-    else { if (small) LAUNCH_FWD(32, 4); else LAUNCH_FWD(32, 8); }
+    // NT = key tiles held in registers per query block: 4 (<= 128 keys), 7 (<= 224: the 196-token decoder grids; one 16-register
+    // score tile less than NT = 8 is what lets two waves per SIMD fit) or 8
+    const bool small = a.nkp <= 128, mid = a.nkp <= 224;
+    if (x3) {
+        if (hd == 64) { if (small) LAUNCH_FWD(64, 4, true); else if (mid) LAUNCH_FWD(64, 7, true); else LAUNCH_FWD(64, 8, true); }
+        else { if (small) LAUNCH_FWD(32, 4, true); else if (mid) LAUNCH_FWD(32, 7, true); else LAUNCH_FWD(32, 8, true); }
+    } else {
+        if (hd == 64) { if (small) LAUNCH_FWD(64, 4, false); else if (mid) LAUNCH_FWD(64, 7, false); else LAUNCH_FWD(64, 8, false); }
+        else { if (small) LAUNCH_FWD(32, 4, false); else if (mid) LAUNCH_FWD(32, 7, false); else LAUNCH_FWD(32, 8, false); }
+    }
 #undef LAUNCH_FWD
     return mmae_check_launch("attn_fwd");
+}
+
+static int attn_bwd_impl(bool x3, const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, void* dq,
+                         void* dk, void* dv, int B, int H, int Nq, int Nk, int hd, int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr,
+                         int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr, int64_t dq_sb, int64_t dq_sr, int64_t dk_sb, int64_t dk_sr,
+                         int64_t dv_sb, int64_t dv_sr, float scale, void* stream) {
+    MMAE_REQUIRE(q && k && v && o && d_o && lse && dq && dk && dv, "attn_bwd: null pointer");
+    const long long st[] = {q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, dq_sb, dq_sr, dk_sb, dk_sr, dv_sb, dv_sr};
+    const int rc = check_common(B, H, Nq, Nk, hd, st, 14);
+    MMAE_REQUIRE(rc == 0, rc == -2 ? "attn: head_dim must be 32 or 64" : (rc == -3 ? "attn: strides must be multiples of 8" : "attn: need 1 <= Nq, Nk <= 256"));
+    AttnArgs a = {};
+    a.q = q; a.k = k; a.v = v; a.o = o; a.d_o = d_o;
+    a.dq = dq; a.dk = dk; a.dv = dv; a.lse = (float*)lse;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.nqp = (Nq + 31) / 32 * 32; a.nkp = (Nk + 31) / 32 * 32;
+    a.q_sb = q_sb; a.q_sr = q_sr; a.k_sb = k_sb; a.k_sr = k_sr; a.v_sb = v_sb; a.v_sr = v_sr; a.o_sb = o_sb; a.o_sr = o_sr;
+    a.dq_sb = dq_sb; a.dq_sr = dq_sr; a.dk_sb = dk_sb; a.dk_sr = dk_sr; a.dv_sb = dv_sb; a.dv_sr = dv_sr;
+    a.scale = scale;
+    const size_t lds = (size_t)2 * (a.nqp + a.nkp) * hd * 2 * (x3 ? 2 : 1) + (size_t)2 * a.nqp * 4;
+    if (lds > 160 * 1024) { mmae_set_error("attn_bwd: tiles exceed the 160 KB LDS (f32 split path: (Nq + Nk) * head_dim too large)"); return MMAE_ESUPPORT; }
+    hipStream_t st_ = (hipStream_t)stream;
+    dim3 grid(B * H), block(512);
+#define LAUNCH_BWD(HD, X3)                                                                                                   \
+    do {                                                                                                                     \
+        hipFuncSetAttribute((const void*)attn_bwd_kernel<HD, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+        hipLaunchKernelGGL((attn_bwd_kernel<HD, X3>), grid, block, lds, st_, a);                                             \
+    } while (0)
+    if (x3) { if (hd == 64) LAUNCH_BWD(64, true); else LAUNCH_BWD(32, true); }
+    else { if (hd == 64) LAUNCH_BWD(64, false); else LAUNCH_BWD(32, false); }
+#undef LAUNCH_BWD
+    return mmae_check_launch("attn_bwd");
+}
+
+int mmae_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
+                  int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr,
+                  float scale, void* stream) {
+    return attn_fwd_impl(false, q, k, v, o, lse, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, scale, stream);
+}
+int mmae_attn_fwd_f32x3(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
+                        int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr,
+                        float scale, void* stream) {
+    return attn_fwd_impl(true, q, k, v, o, lse, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, scale, stream);
 }
 
 int mmae_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, void* dq, void* dk,
                   void* dv, int B, int H, int Nq, int Nk, int hd, int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb,
                   int64_t v_sr, int64_t o_sb, int64_t o_sr, int64_t dq_sb, int64_t dq_sr, int64_t dk_sb, int64_t dk_sr, int64_t dv_sb,
                   int64_t dv_sr, float scale, void* stream) {
-    MMAE_REQUIRE(q && k && v && o && d_o && lse && dq && dk && dv, "attn_bwd: null pointer");
-    const long long st[] = {q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, dq_sb, dq_sr, dk_sb, dk_sr, dv_sb, dv_sr};
-    const int rc = check_common(B, H, Nq, Nk, hd, st, 14);
-    MMAE_REQUIRE(rc == 0, rc == -2 ? "attn: head_dim must be 32 or 64" : (rc == -3 ? "attn: strides must be multiples of 8" : "attn: need 1 <= Nq, Nk <= 256"));
-    AttnArgs a = {};
-    a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = (const uint16_t*)v; a.o = (const uint16_t*)o; a.d_o = (const uint16_t*)d_o;
-    a.dq = (uint16_t*)dq; a.dk = (uint16_t*)dk; a.dv = (uint16_t*)dv; a.lse = (float*)lse;
-    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.nqp = (Nq + 31) / 32 * 32; a.nkp = (Nk + 31) / 32 * 32;
-    a.q_sb = q_sb; a.q_sr = q_sr; a.k_sb = k_sb; a.k_sr = k_sr; a.v_sb = v_sb; a.v_sr = v_sr; a.o_sb = o_sb; a.o_sr = o_sr;
-    a.dq_sb = dq_sb; a.dq_sr = dq_sr; a.dk_sb = dk_sb; a.dk_sr = dk_sr; a.dv_sb = dv_sb; a.dv_sr = dv_sr;
-    a.scale = scale;
-    const size_t lds = (size_t)2 * (a.nqp + a.nkp) * hd * 2 + (size_t)2 * a.nqp * 4;
-    hipStream_t st_ = (hipStream_t)stream;
-    dim3 grid(B * H), block(512);
-    if (hd == 64) {
-        hipFuncSetAttribute((const void*)attn_bwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((attn_bwd_kernel<64>), grid, block, lds, st_, a);
-    } else {
-        hipFuncSetAttribute((const void*)attn_bwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((attn_bwd_kernel<32>), grid, block, lds, st_, a);
-    }
-    return mmae_check_launch("attn_bwd");
+    return attn_bwd_impl(false, q, k, v, o, d_o, lse, dq, dk, dv, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, dq_sb,
+                         dq_sr, dk_sb, dk_sr, dv_sb, dv_sr, scale, stream);
+}
+int mmae_attn_bwd_f32x3(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, void* dq, void* dk,
+                        void* dv, int B, int H, int Nq, int Nk, int hd, int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb,
+                        int64_t v_sr, int64_t o_sb, int64_t o_sr, int64_t dq_sb, int64_t dq_sr, int64_t dk_sb, int64_t dk_sr, int64_t dv_sb,
+                        int64_t dv_sr, float scale, void* stream) {
+    return attn_bwd_impl(true, q, k, v, o, d_o, lse, dq, dk, dv, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, dq_sb,
+                         dq_sr, dk_sb, dk_sr, dv_sb, dv_sr, scale, stream);
 }
 
 }  // extern "C"

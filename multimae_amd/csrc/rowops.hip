@@ -76,17 +76,39 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const DT* __restrict__ dy, 
         db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         dxs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (long long row = (long long)blockIdx.x * 4 + w; row < R; row += (long long)gridDim.x * 4) {
-        const float mu = mean[row], rs = rstd[row];
-        const DT* dyr = dy + row * D;
-        const float* xr = x + row * D;
+    // Software-pipelined row walk: the loads of the wave's NEXT row are issued before the two wave reductions of the current
+    // one, so every wave keeps two rows of HBM traffic in flight (with one row per iteration and ~8 waves per CU the kernel
+    // sat at ~60 % of the HBM rate).
+    const long long step = (long long)gridDim.x * 4;
+    long long row = (long long)blockIdx.x * 4 + w;
+    f32x4 nd[NV], nx[NV], na[NV];
+    float nmu = 0.f, nrs = 0.f;
+    auto fetch = [&](long long r) {
+        nmu = mean[r]; nrs = rstd[r];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < D) {
+                nd[i] = ld4(dy + r * D + c);
+                nx[i] = ld4(x + r * D + c);
+                if (dx_in) na[i] = ld4(dx_in + r * D + c);
+            }
+        }
+    };
+    if (row < R) fetch(row);
+    for (; row < R; row += step) {
+        const float mu = nmu, rs = nrs;
+        f32x4 d_[NV], xv_[NV], a_[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { d_[i] = nd[i]; xv_[i] = nx[i]; a_[i] = na[i]; }
+        if (row + step < R) fetch(row + step);
         f32x4 xh[NV], dh[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (lane + 64 * i) * 4;
             if (c < D) {
-                const f32x4 d = ld4(dyr + c), xv = ld4(xr + c);
+                const f32x4 d = d_[i], xv = xv_[i];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     xh[i][j] = (xv[j] - mu) * rs;
@@ -106,9 +128,9 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const DT* __restrict__ dy, 
                 f32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = rs * (dh[i][j] - c1 - xh[i][j] * c2);
-                if (dx_in) { const f32x4 a = ld4(dx_in + row * D + c);
+                if (dx_in) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] += a[j];
+                    for (int j = 0; j < 4; ++j) o[j] += a_[i][j];
                 }
                 st4(dx_out + row * D + c, o);
                 if (dx_act) st4(dx_act + row * D + c, o);
@@ -375,7 +397,7 @@ int mmae_layernorm_fwd(const float* x, const float* gamma, const float* beta, vo
     return mmae_check_launch("layernorm_fwd");
 }
 
-int mmae_layernorm_bwd_nblk(int64_t R) { const int64_t b = cdiv64(R, 4); return (int)(b < 1 ? 1 : (b > 512 ? 512 : b)); }
+int mmae_layernorm_bwd_nblk(int64_t R) { const int64_t b = cdiv64(R, 4); return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }
 
 int mmae_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
                        const float* rstd, const float* dx_in, float* dx_out, void* dx_act, int dx_act_dtype, float* part,

@@ -57,10 +57,13 @@ void gemm_plan(const mmae_gemm_desc* d, int* tile_out, int* split_out) {
         }
     }
     int s = 1;
+    // workgroups a split product should reach (ping-pong kernel: one per CU).  Below 256 the dW launches leave CUs to the dX
+    // chain they run beside, write fewer partial slabs and run longer K loops; tunable for experiments.
+    static const int env_wgs = getenv("MMAE_SPLITK_WGS") ? atoi(getenv("MMAE_SPLITK_WGS")) : 256;
     if (can_split) {
         if (tile == 9 || tile == 10) {
             const long long t = ((d->M + (tile == 9 ? 255 : 319)) / (tile == 9 ? 256 : 320)) * nt256;
-            if (t < 128) s = (int)(256 / t);
+            if (t * 2 <= env_wgs) s = (int)(env_wgs / t);
         } else {
             const long long t = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128);
             if (t < 384) s = (int)((1024 + t - 1) / t);

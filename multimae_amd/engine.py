@@ -216,6 +216,7 @@ class ParamArena:
         self.grad = torch.zeros(self.n_trainable, device=device, dtype=torch.float32)
         self.shadow: Optional[torch.Tensor] = None
         self._shadow_token = False
+        self._scope = 0
         self._views: Dict[int, torch.Tensor] = {}
         self._shadow_views: Dict[int, torch.Tensor] = {}
         self._params: Dict[str, nn.Parameter] = {}
@@ -253,6 +254,8 @@ class ParamArena:
     # -- shadows -------------------------------------------------------------------
     def refresh_shadow(self) -> None:
         """bf16 copy of the whole parameter arena (one cast launch)."""
+        if self._scope > 0 and self.shadow is not None:
+            return                      # inside a model forward: refreshed once when the scope was entered
         if self.shadow is None:
             self.shadow = torch.empty(self.numel, device=self.device, dtype=torch.bfloat16)
         if self._shadow_token:          # produced by the fused optimiser for exactly these values
@@ -262,6 +265,19 @@ class ParamArena:
 
     def mark_shadow_fresh(self) -> None:
         self._shadow_token = True
+
+    @contextlib.contextmanager
+    def forward_scope(self):
+        """One model forward: the shadow is brought up to date once on entry and every WeightCache created inside (embed,
+        encoder stack, each output adapter) reuses it -- without the scope each of them re-cast the whole 98 M-element
+        arena, 5 full passes per step."""
+        if self._scope == 0:
+            self.refresh_shadow()
+        self._scope += 1
+        try:
+            yield
+        finally:
+            self._scope -= 1
 
     def weight(self, p: nn.Parameter, dtype: torch.dtype) -> torch.Tensor:
         """act-dtype view of parameter p (the f32 master itself in fp32 mode)."""
@@ -277,6 +293,17 @@ class ParamArena:
 
     def _off_of(self, p: nn.Parameter) -> int:
         return (p.data_ptr() - self.param.data_ptr()) // 4
+
+
+@contextlib.contextmanager
+def forward_scope(module: nn.Module):
+    """Shadow-refresh scope of one forward pass of `module` (no-op without an arena or outside bf16 mode)."""
+    a = arena_of(module)
+    if a is None or act_dtype() != torch.bfloat16:
+        yield
+        return
+    with a.forward_scope():
+        yield
 
 
 def arena_of(module: nn.Module) -> Optional[ParamArena]:

@@ -397,7 +397,9 @@ class SpatialAdapterFn(torch.autograd.Function):
         save = any(ctx.needs_input_grad)
 
         enc2 = enc.contiguous().view(B * NC, Denc)
-        enc_act = ops.cast(enc2, act)
+        enc_act = getattr(cfg, 'enc_act', None)      # act-dtype copy shared by all adapters of one forward (MultiMAE.forward)
+        if enc_act is None or enc_act.dtype != act or enc_act.shape != enc2.shape:
+            enc_act = ops.cast(enc2, act)
         ctx_tok = _lin_fwd(enc_act, pcw, pcb, wc, torch.float32)                        # :258
         te = torch.zeros((T, D), device=dev, dtype=torch.float32)
         for i, t in enumerate(temb):

@@ -207,6 +207,10 @@ class MultiMAE(nn.Module):
                 fp32_output_adapters: List[str] = []):
         """(preds: {task: (B,C,H,W)}, task_masks: {task: (B,N) int64, 0 = visible}); without output
         adapters (encoder_tokens, task_masks).  Signature and semantics: multimae.py:271-379."""
+        with engine.forward_scope(self):
+            return self._forward(x, mask_inputs, task_masks, num_encoded_tokens, alphas, sample_tasks_uniformly, fp32_output_adapters)
+
+    def _forward(self, x, mask_inputs, task_masks, num_encoded_tokens, alphas, sample_tasks_uniformly, fp32_output_adapters):
         x = {'rgb': x} if isinstance(x, torch.Tensor) else x
         B, H, W = self._image_size(x)
         counts = self._token_counts(x)
@@ -247,6 +251,11 @@ class MultiMAE(nn.Module):
         # replays each node's backward on its forward stream, so the backward passes overlap the same way.
         streams = self._adapter_streams(len(self.output_adapters)) if engine.adapter_streams() else None
         main = torch.cuda.current_stream() if streams is not None else None
+        # every bf16 adapter starts from the same bf16 copy of the encoder output: cast it once, before the streams fork
+        enc_bf16 = None
+        if engine.act_dtype() == torch.bfloat16 and any(d not in fp32_output_adapters for d in self.output_adapters):
+            Be, Ne, De = encoder_tokens.shape
+            enc_bf16 = ops.cast(encoder_tokens.detach().contiguous().view(Be * Ne, De), torch.bfloat16)
         for i, domain in enumerate(self.output_adapters):
             # reference: adapters listed in fp32_output_adapters run with autocast disabled (:367-377);
             # here they run on the exact-f32 MFMA path
@@ -257,6 +266,7 @@ class MultiMAE(nn.Module):
             speed = engine.act_dtype() == torch.bfloat16
             kw = dict(encoder_tokens=encoder_tokens, input_info=input_info, ids_keep=ids_keep, ids_restore=ids_restore,
                       act_dtype=torch.float32 if fp32 else None, on_done=self._adapter_done_cb(domain),
+                      encoder_tokens_act=None if fp32 else enc_bf16,
                       f32_gemm='x3' if (fp32 and speed and engine.fp32_adapter_gemm() == 'x3') else 'exact')
             if streams is None:
                 preds[domain] = self.output_adapters[domain](**kw)
@@ -266,6 +276,8 @@ class MultiMAE(nn.Module):
                 with torch.cuda.stream(st):
                     preds[domain] = self.output_adapters[domain](**kw)
                 encoder_tokens.record_stream(st)
+                if enc_bf16 is not None:
+                    enc_bf16.record_stream(st)
                 preds[domain].record_stream(main)
         if streams is not None:
             for st in streams:
@@ -316,6 +328,10 @@ class MultiViT(MultiMAE):
         return tokens, input_info
 
     def forward(self, x: Union[Dict[str, torch.Tensor], torch.Tensor], return_all_layers=False, **kwargs):
+        with engine.forward_scope(self):
+            return self._forward_vit(x, return_all_layers)
+
+    def _forward_vit(self, x, return_all_layers):
         input_tokens, input_info = self.process_input(x)
         encoder_tokens = run_blocks(self.encoder, input_tokens, root=self, all_layers=return_all_layers)
         if self.output_adapters is None:

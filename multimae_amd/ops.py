@@ -301,7 +301,14 @@ def _ptr(v: AttnView) -> int:
 
 
 def _fusable(q: AttnView, k: AttnView, hd: int) -> bool:
-    return _FUSED_ATTN[0] and q.t.dtype == torch.bfloat16 and hd in (32, 64) and q.N <= 256 and k.N <= 256
+    if not (_FUSED_ATTN[0] and hd in (32, 64) and q.N <= 256 and k.N <= 256):
+        return False
+    if q.t.dtype == torch.bfloat16:
+        return True
+    # f32 activations: only where the surrounding GEMMs are split-bf16 too (fp32 adapters in speed mode); the backward's
+    # eight hi/lo tiles must fit the 160 KB LDS
+    lds_bwd = 4 * (round_up(q.N, 32) + round_up(k.N, 32)) * hd * 2 + 8 * round_up(q.N, 32)
+    return q.t.dtype == torch.float32 and _F32_GEMM[0] == 'x3' and lds_bwd <= 160 * 1024
 
 
 def attention_fwd(q: AttnView, k: AttnView, v: AttnView, out: AttnView, B: int, H: int, hd: int, scale: float):
@@ -311,7 +318,8 @@ def attention_fwd(q: AttnView, k: AttnView, v: AttnView, out: AttnView, B: int, 
     dev, act = q.t.device, q.t.dtype
     if _fusable(q, k, hd):
         lse = torch.empty((B, H, Nq), device=dev, dtype=torch.float32)
-        check(_lib.load().mmae_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), lse.data_ptr(), B, H, Nq, Nk, hd,
+        fwd = _lib.load().mmae_attn_fwd if act == torch.bfloat16 else _lib.load().mmae_attn_fwd_f32x3
+        check(fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), lse.data_ptr(), B, H, Nq, Nk, hd,
                                         Nq * q.ld, q.ld, Nk * k.ld, k.ld, Nk * v.ld, v.ld, Nq * out.ld, out.ld, scale, _stream()),
               'attn_fwd')
         return ('fused', lse)
@@ -331,7 +339,8 @@ def attention_bwd(q: AttnView, k: AttnView, v: AttnView, state, out: AttnView, d
     Nq, Nk = q.N, k.N
     if state[0] == 'fused':
         assert d_out.ld == out.ld
-        check(_lib.load().mmae_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(d_out), state[1].data_ptr(), _ptr(dq), _ptr(dk),
+        bwd = _lib.load().mmae_attn_bwd if q.t.dtype == torch.bfloat16 else _lib.load().mmae_attn_bwd_f32x3
+        check(bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(d_out), state[1].data_ptr(), _ptr(dq), _ptr(dk),
                                         _ptr(dv), B, H, Nq, Nk, hd, Nq * q.ld, q.ld, Nk * k.ld, k.ld, Nk * v.ld, v.ld, Nq * out.ld,
                                         out.ld, Nq * dq.ld, dq.ld, Nk * dk.ld, dk.ld, Nk * dv.ld, dv.ld, scale, _stream()), 'attn_bwd')
         return

@@ -136,7 +136,8 @@ class SpatialOutputAdapter(nn.Module):
         return ps
 
     def forward(self, encoder_tokens: torch.Tensor, input_info: Dict, ids_keep: torch.Tensor, ids_restore: torch.Tensor,
-                act_dtype: Optional[torch.dtype] = None, on_done=None, f32_gemm: str = 'exact'):
+                act_dtype: Optional[torch.dtype] = None, on_done=None, f32_gemm: str = 'exact',
+                encoder_tokens_act: Optional[torch.Tensor] = None):
         """(B, n_keep+G, D_enc) encoder tokens -> (B, C, H_t, W_t) prediction (output_adapters.py:236-282)."""
         assert self.dim_tokens_enc is not None, 'Need to call init(dim_tokens_enc) function first'
         if self.task_embeddings is None:
@@ -157,5 +158,6 @@ class SpatialOutputAdapter(nn.Module):
         G = input_info.get('num_global_tokens', 0)
         cfg = _cfg(self, act=act_dtype, heads=self.num_heads, eps=self.query_norm.eps, task_offsets=offs,
                    q_task=in_tasks.index(self.task), G=G, D=self.dim_tokens, pos=self._pos_tokens(nh, nw), depth=self.depth,
-                   C=self.num_channels, nh=nh, nw=nw, ph=self.P_H, pw=self.P_W, on_done=on_done, f32_gemm=f32_gemm)
+                   C=self.num_channels, nh=nh, nw=nw, ph=self.P_H, pw=self.P_W, on_done=on_done, f32_gemm=f32_gemm,
+                   enc_act=encoder_tokens_act)
         return SpatialAdapterFn.apply(cfg, encoder_tokens, ids_keep.contiguous(), ids_restore.contiguous(), *self._params(in_tasks))

@@ -302,13 +302,14 @@ def _train_steps(n_steps, use_graph, fixed_masks):
 
 def test_step_graph_replay_matches_eager_steps():
     """The whole step captured as ONE hipGraph (all adapter / weight-gradient streams as graph branches, AdamW scalars
-    through HBM) and replayed 4x == 5 eager steps on the same masks: same loss curve and same final parameters (up to
-    the float-atomic class-embedding gradient)."""
+    through HBM) and replayed 4x == 5 eager steps on the same masks: same loss curve and same final parameters."""
     le, pe, _ = _train_steps(5, False, True)
     lg, pg, _ = _train_steps(5, True, True)
-    assert max(abs(a - b) for a, b in zip(le, lg)) < 2e-4, (le, lg)
+    # bf16 speed mode: the float-atomic class-embedding gradient differs in the last bits from run to run, which bf16 roundings
+    # amplify over the steps -- same loss curve to ~1e-3, not bit-identical
+    assert max(abs(a - b) / abs(a) for a, b in zip(le, lg)) < 2e-3, (le, lg)
     assert le[-1] < le[0]
-    assert rel_err(pg, pe) < 1e-5
+    assert rel_err(pg, pe) < 2e-3
 
 
 def test_step_graph_resamples_masks_every_replay():
