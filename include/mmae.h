@@ -181,6 +181,43 @@ int mmae_attn_bwd_f32x3(const void* q, const void* k, const void* v, const void*
 
 
 /* ------------------------------------------------------------------------- *
+ * One pre-LN transformer block (multimae_utils.py:217-232: x + attn(norm1(x)), then x + mlp(norm2(x))) as ONE call per
+ * direction: the library enqueues the block's whole kernel sequence (forward 7 launches; backward ~20, with the
+ * weight-gradient GEMMs and the parameter-gradient reductions on `side_stream`, ordered against `stream` with events).
+ * Same kernels, same order and same results as issuing the individual entry points; what it removes is ~25 host
+ * round trips per block (the host, not the GPU, paced the adapters' backward passes).
+ * Every buffer is the caller's: activations (forward writes, backward reads), backward temporaries, gradient
+ * destinations, and two f32 workspaces (split-K slabs / reduction scratch) private to the two streams.
+ * act_dtype MMAE_BF16, or MMAE_F32 with f32_gemm = MMAE_F32X3 (fp32 adapters in speed mode).  Needs the fused attention
+ * kernel's geometry (head_dim 32 / 64, N <= 256); otherwise MMAE_ESUPPORT and the caller issues the steps itself.
+ * ------------------------------------------------------------------------- */
+typedef struct mmae_block_desc {
+    int32_t B, N, D, heads, Hd;                  /* R = B*N rows of width D; Hd = MLP hidden width */
+    int32_t act_dtype, f32_gemm;
+    float eps;
+    const void *qkv_w, *proj_w, *fc1_w, *fc2_w;  /* act dtype: [3D][D], [D][D], [Hd][D], [D][Hd] */
+    const float *n1_w, *n1_b, *qkv_b, *proj_b, *n2_w, *n2_b, *fc1_b, *fc2_b;
+    const float* x0;                             /* block input, f32 [R][D] */
+    void* ln1; float* mean1; float* rstd1; void* qkv; float* lse; void* ao; float* x1;
+    void* ln2; float* mean2; float* rstd2; void* hpre; void* hact;
+    float* x2;                                   /* block output, f32 [R][D] */
+    const float* dx; const void* dx_act;         /* backward in: d(x2) f32 and its act-dtype copy (== dx when act is f32) */
+    float* dx0; void* dx0_act;                   /* backward out: d(x0) (dx0_act NULL when act is f32) */
+    void *d_hpre, *d_ln2, *d_ao, *d_qkv, *d_ln1; float* dx1; void* dx1_act;     /* backward temporaries */
+    float *part_h, *part1, *part2;               /* [ceil(R/64)][Hd], [nblk][3D], [nblk][3D]; nblk = mmae_layernorm_bwd_nblk(R) */
+    float *g_n1_w, *g_n1_b, *g_qkv_w, *g_qkv_b, *g_proj_w, *g_proj_b, *g_n2_w, *g_n2_b, *g_fc1_w, *g_fc1_b, *g_fc2_w, *g_fc2_b;
+    float* g_cs;                                 /* NULL or f32 [D]: receives colsum(dx0), the bias gradient of the Linear that produced x0 */
+    int32_t grad_acc;                            /* gradients are added to (1) or stored into (0) their destinations */
+    int32_t fc2_b_done;                          /* the producer of dx already delivered fc2's bias gradient: skip it */
+    float* ws_main; int64_t ws_main_elems;       /* f32 scratch used by launches on `stream` */
+    float* ws_side; int64_t ws_side_elems;       /* f32 scratch used by launches on `side_stream` */
+} mmae_block_desc;
+
+int mmae_block_fwd(const mmae_block_desc* d, void* stream);
+/* side_stream may equal stream (or be NULL): everything then runs in order on `stream`. */
+int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream);
+
+/* ------------------------------------------------------------------------- *
  * Casts.  f32 master weights -> act-dtype shadows (optionally transposed so that
  * dX = dY.W is again an "NT" product).
  * ------------------------------------------------------------------------- */

@@ -44,6 +44,23 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+
+
+class BlockDesc(ctypes.Structure):
+    """mirror of mmae_block_desc"""
+    _fields_ = ([(n, _I) for n in ('B', 'N', 'D', 'heads', 'Hd', 'act_dtype', 'f32_gemm')] + [('eps', _F)]
+                + [(n, _P) for n in ('qkv_w', 'proj_w', 'fc1_w', 'fc2_w',
+                                     'n1_w', 'n1_b', 'qkv_b', 'proj_b', 'n2_w', 'n2_b', 'fc1_b', 'fc2_b',
+                                     'x0', 'ln1', 'mean1', 'rstd1', 'qkv', 'lse', 'ao', 'x1', 'ln2', 'mean2', 'rstd2', 'hpre', 'hact', 'x2',
+                                     'dx', 'dx_act', 'dx0', 'dx0_act',
+                                     'd_hpre', 'd_ln2', 'd_ao', 'd_qkv', 'd_ln1', 'dx1', 'dx1_act',
+                                     'part_h', 'part1', 'part2',
+                                     'g_n1_w', 'g_n1_b', 'g_qkv_w', 'g_qkv_b', 'g_proj_w', 'g_proj_b', 'g_n2_w', 'g_n2_b',
+                                     'g_fc1_w', 'g_fc1_b', 'g_fc2_w', 'g_fc2_b', 'g_cs')]
+                + [('grad_acc', _I), ('fc2_b_done', _I), ('ws_main', _P), ('ws_main_elems', _L), ('ws_side', _P), ('ws_side_elems', _L)])
+
+
 class PatchSrc(ctypes.Structure):
     """mirror of mmae_patch_src"""
     _fields_ = [

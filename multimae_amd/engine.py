@@ -90,15 +90,26 @@ def mark_side_dirty(side: 'torch.cuda.Stream') -> None:
     _dirty_sides.add(side)
 
 
+_side_keepalive = []
+
+
+def keep_until_join(obj) -> None:
+    """Hold tensors a side stream may still be reading until the compute stream has joined it (then the caching allocator
+    may hand their memory out again: anything enqueued afterwards is ordered behind the side stream's work)."""
+    _side_keepalive.append(obj)
+
+
 def join_wgrad_streams() -> None:
     """Make the current stream wait for every weight-gradient side stream that was handed work since the last join.
     (Only those: inside a hipGraph capture a wait on a stream that is not part of the capture is an error.)"""
     if not _dirty_sides:
+        _side_keepalive.clear()
         return
     cur = torch.cuda.current_stream()
     for s in list(_dirty_sides):
         cur.wait_stream(s)
     _dirty_sides.clear()
+    _side_keepalive.clear()
 
 
 # ---------------------------------------------------------------------------------------------

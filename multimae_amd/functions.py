@@ -163,6 +163,8 @@ def block_fwd(x: Tensor, P: Sequence[Tensor], wc, heads: int, eps: float, act, B
     n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b = P
     R, D = x.shape
     hd = D // heads
+    if ops.block_composite_ok(x, act, heads, N):          # the whole block as one library call (same kernels)
+        return ops.block_fwd_composite(x, P, (wc(qkvw), wc(projw), wc(fc1w), wc(fc2w)), heads, eps, act, B, N)
     ln1, mean1, rstd1 = ops.layernorm_fwd(x, n1w, n1b, eps, act)
     qkv = ops.linear_fwd(ln1, wc(qkvw), qkvb, _new((R, 3 * D), x, act))
     ao = _new((R, D), x, act)
@@ -190,6 +192,10 @@ def block_bwd(dx: Tensor, dx_act: Tensor, fc2b_done: bool, saved, P: Sequence[Te
     hd = D // heads
     Hd = fc1w.shape[0]
     lnact = None if act == torch.float32 else act
+    if Pm[0] == 'fused' and ops.block_composite_ok(x0, act, heads, N):
+        out = _block_bwd_composite(dx, dx_act, fc2b_done, saved, P, wc, sink, heads, act, B, N, cs_param)
+        if out is not None:
+            return out
     # MLP
     part_h = _new(ops.dx_colsum_part_shape(R, Hd), dx, torch.float32) if fc1b.requires_grad else None
     d_hpre = ops.linear_dx(dx_act, wc(fc2w), _new(hpre.shape, dx, act), aux=hpre, epi=EPI_DGELU, colsum_part=part_h)
@@ -219,6 +225,35 @@ def block_bwd(dx: Tensor, dx_act: Tensor, fc2b_done: bool, saved, P: Sequence[Te
     g_n1w, g_n1b, g_cs = sink.colsums(part1, D, [n1w, n1b, cs_param])
     grads = (g_n1w, g_n1b, g_qkvw, g_qkvb, g_projw, g_projb, g_n2w, g_n2b, g_fc1w, g_fc1b, g_fc2w, g_fc2b)
     return dx0, dx0_act, g_cs, grads
+
+
+def _block_bwd_composite(dx, dx_act, fc2b_done, saved, P, wc, sink: GradSink, heads, act, B, N, cs_param):
+    """block_bwd through ONE mmae_block_bwd call; None if the gradient destinations do not allow it (mixed bound / unbound
+    .grad views)."""
+    n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b = P
+    dsts: List[Optional[Tensor]] = []
+    accs = set()
+    for p in list(P) + [cs_param]:
+        if p is None or not p.requires_grad:
+            dsts.append(None)
+            continue
+        t, a = sink._target(p)
+        dsts.append(t)
+        accs.add(a)
+    if len(accs) > 1:
+        return None
+    acc = accs.pop() if accs else False
+    use_side = sink.side is not None and acc
+    dx0, dx0_act, keep = ops.block_bwd_composite(dx, dx_act, fc2b_done, saved, P, (wc(qkvw), wc(projw), wc(fc1w), wc(fc2w)), dsts[:12],
+                                                 dsts[12], acc, heads, act, B, N, sink.side.cuda_stream if use_side else None)
+    if use_side:
+        engine.mark_side_dirty(sink.side)
+        engine.keep_until_join(keep)
+    if acc:
+        return dx0, dx0_act, None, (None,) * 12
+    if fc2b_done:
+        dsts[11] = None
+    return dx0, dx0_act, dsts[12], tuple(dsts[:12])
 
 
 class _Cfg:

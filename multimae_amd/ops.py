@@ -14,7 +14,7 @@ import torch
 from . import _lib
 import contextlib
 
-from ._lib import BF16, F32, F32X3, EPI_NONE, EPI_GELU, EPI_DGELU, GemmDesc, PatchSrc, check
+from ._lib import BF16, F32, F32X3, EPI_NONE, EPI_GELU, EPI_DGELU, BlockDesc, GemmDesc, PatchSrc, check
 
 Tensor = torch.Tensor
 
@@ -168,6 +168,121 @@ def linear_dw(dy: Tensor, x: Tensor, dw: Tensor, accumulate: bool, *, db: Option
     if db is not None and not fused:
         colsum(dy, db, db_accumulate)
     return dw
+
+
+# ------------------------------------------------------ composite transformer block --
+_COMPOSITE = [_os.environ.get('MMAE_COMPOSITE', '1') != '0']
+_WS = {}
+_WS_ELEMS = [40 << 20]          # f32 elements per stream workspace (160 MB: the largest split-K slab set of ViT-B / ViT-L is 17 M)
+
+
+def _device_ok(t: Tensor) -> bool:
+    return t.is_cuda
+
+
+def set_composite_blocks(flag: bool) -> None:
+    """Transformer blocks as one library call per direction (mmae_block_fwd / mmae_block_bwd) instead of one host launch
+    per kernel.  Same kernels and results; default on."""
+    _COMPOSITE[0] = bool(flag)
+
+
+def stream_workspace(stream_handle: int, device, elems: Optional[int] = None) -> Tensor:
+    """Persistent f32 scratch private to one HIP stream (split-K slabs, reduction partials of the composite calls).
+    Launches on a stream execute in order, so consecutive calls on that stream can share it."""
+    elems = elems or _WS_ELEMS[0]
+    key = (str(device), stream_handle)
+    w = _WS.get(key)
+    if w is None or w.numel() < elems:
+        w = torch.empty((elems,), device=device, dtype=torch.float32)
+        _WS[key] = w
+    return w
+
+
+def block_composite_ok(x: Tensor, act: torch.dtype, heads: int, N: int) -> bool:
+    D = x.shape[1]
+    hd = D // heads
+    if not (_COMPOSITE[0] and _FUSED_ATTN[0] and _device_ok(x) and hd in (32, 64) and N <= 256 and D % 8 == 0):
+        return False
+    if act == torch.bfloat16:
+        return True
+    lds_bwd = 4 * 2 * round_up(N, 32) * hd * 2 + 8 * round_up(N, 32)
+    return act == torch.float32 and _F32_GEMM[0] == 'x3' and lds_bwd <= 160 * 1024
+
+
+def _block_desc(P: Sequence[Tensor], wts: Sequence[Tensor], heads: int, eps: float, act: torch.dtype, B: int, N: int, D: int) -> 'BlockDesc':
+    n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b = P
+    d = BlockDesc()
+    d.B, d.N, d.D, d.heads, d.Hd = B, N, D, heads, fc1w.shape[0]
+    d.act_dtype, d.f32_gemm, d.eps = dcode(act), (F32X3 if _F32_GEMM[0] == 'x3' else F32), eps
+    d.qkv_w, d.proj_w, d.fc1_w, d.fc2_w = (w.data_ptr() for w in wts)
+    d.n1_w, d.n1_b, d.qkv_b, d.proj_b = n1w.data_ptr(), n1b.data_ptr(), qkvb.data_ptr(), projb.data_ptr()
+    d.n2_w, d.n2_b, d.fc1_b, d.fc2_b = n2w.data_ptr(), n2b.data_ptr(), fc1b.data_ptr(), fc2b.data_ptr()
+    return d
+
+
+def block_fwd_composite(x: Tensor, P: Sequence[Tensor], wts: Sequence[Tensor], heads: int, eps: float, act: torch.dtype, B: int, N: int):
+    """x f32 [B*N, D] -> (x2, saved) with the layout functions.block_fwd produces."""
+    R, D = x.shape
+    Hd = P[8].shape[0]
+    dev, f = x.device, torch.float32
+    e = lambda shape, dt: torch.empty(shape, device=dev, dtype=dt)
+    ln1, qkv, ao, ln2, hpre, hact = e((R, D), act), e((R, 3 * D), act), e((R, D), act), e((R, D), act), e((R, Hd), act), e((R, Hd), act)
+    stats = e((4, R), f)
+    lse = e((B, heads, N), f)
+    x1, x2 = e((R, D), f), e((R, D), f)
+    d = _block_desc(P, wts, heads, eps, act, B, N, D)
+    d.x0, d.ln1, d.mean1, d.rstd1, d.qkv, d.lse, d.ao, d.x1 = (x.data_ptr(), ln1.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+                                                               qkv.data_ptr(), lse.data_ptr(), ao.data_ptr(), x1.data_ptr())
+    d.ln2, d.mean2, d.rstd2, d.hpre, d.hact, d.x2 = ln2.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), hpre.data_ptr(), hact.data_ptr(), x2.data_ptr()
+    st = _stream()
+    ws = stream_workspace(st, dev)
+    d.ws_main, d.ws_main_elems = ws.data_ptr(), ws.numel()
+    check(_lib.load().mmae_block_fwd(ctypes.byref(d), st), 'block_fwd')
+    saved = (x, ln1, stats[0], stats[1], qkv, ('fused', lse), ao, x1, ln2, stats[2], stats[3], hpre, hact)
+    return x2, saved
+
+
+def block_bwd_composite(dx: Tensor, dx_act: Tensor, fc2b_done: bool, saved, P: Sequence[Tensor], wts: Sequence[Tensor], grads: Sequence[Optional[Tensor]],
+                        g_cs: Optional[Tensor], grad_acc: bool, heads: int, act: torch.dtype, B: int, N: int, side_handle: Optional[int]):
+    """One mmae_block_bwd call.  grads: 12 f32 destinations (None = not wanted) in BLOCK_PARAMS order; g_cs: destination of
+    colsum(dx0) or None.  Returns (dx0, dx0_act, temporaries to keep alive while the side stream may still read them)."""
+    x0, ln1, mean1, rstd1, qkv, Pm, ao, x1, ln2, mean2, rstd2, hpre, hact = saved
+    R, D = x0.shape
+    Hd = P[8].shape[0]
+    dev, f = dx.device, torch.float32
+    lib = _lib.load()
+    e = lambda shape, dt: torch.empty(shape, device=dev, dtype=dt)
+    bf = act != f
+    d_hpre, d_ln2, d_ao, d_qkv, d_ln1 = e((R, Hd), act), e((R, D), act), e((R, D), act), e((R, 3 * D), act), e((R, D), act)
+    dx1, dx0 = e((R, D), f), e((R, D), f)
+    dx1_act = e((R, D), act) if bf else None
+    dx0_act = e((R, D), act) if bf else None
+    nblk = lib.mmae_layernorm_bwd_nblk(R)
+    part = e((2 * nblk * 3 * D + ((R + 63) // 64) * Hd,), f)
+    d = _block_desc(P, wts, heads, 0.0, act, B, N, D)
+    d.x0, d.ln1, d.mean1, d.rstd1, d.qkv, d.lse, d.ao, d.x1 = (x0.data_ptr(), ln1.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(),
+                                                               qkv.data_ptr(), Pm[1].data_ptr(), ao.data_ptr(), x1.data_ptr())
+    d.ln2, d.mean2, d.rstd2, d.hpre, d.hact = ln2.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), hpre.data_ptr(), hact.data_ptr()
+    d.dx, d.dx_act, d.dx0, d.dx0_act = dx.data_ptr(), dx_act.data_ptr(), dx0.data_ptr(), _p(dx0_act)
+    d.d_hpre, d.d_ln2, d.d_ao, d.d_qkv, d.d_ln1, d.dx1, d.dx1_act = (d_hpre.data_ptr(), d_ln2.data_ptr(), d_ao.data_ptr(), d_qkv.data_ptr(),
+                                                                      d_ln1.data_ptr(), dx1.data_ptr(), _p(dx1_act))
+    es = 4
+    d.part1 = part.data_ptr()
+    d.part2 = part.data_ptr() + nblk * 3 * D * es
+    d.part_h = part.data_ptr() + 2 * nblk * 3 * D * es
+    (d.g_n1_w, d.g_n1_b, d.g_qkv_w, d.g_qkv_b, d.g_proj_w, d.g_proj_b, d.g_n2_w, d.g_n2_b, d.g_fc1_w, d.g_fc1_b, d.g_fc2_w,
+     d.g_fc2_b) = (_p(g) for g in grads)
+    d.g_cs = _p(g_cs)
+    d.grad_acc, d.fc2_b_done = int(grad_acc), int(fc2b_done)
+    st = _stream()
+    wm = stream_workspace(st, dev)
+    d.ws_main, d.ws_main_elems = wm.data_ptr(), wm.numel()
+    sd = side_handle if side_handle is not None else st
+    wsd = stream_workspace(sd, dev) if sd != st else wm
+    d.ws_side, d.ws_side_elems = wsd.data_ptr(), wsd.numel()
+    check(lib.mmae_block_bwd(ctypes.byref(d), st, sd), 'block_bwd')
+    keep = (d_hpre, d_ln2, d_ao, d_qkv, d_ln1, dx1, dx1_act, part, dx, dx_act, saved)
+    return dx0, (dx0_act if bf else dx0), keep
 
 
 # ------------------------------------------------------------------- row kernels --

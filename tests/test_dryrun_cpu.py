@@ -10,10 +10,12 @@ from helpers import MINI, build_mini_engine, load_mini
 def stubbed(monkeypatch):
     from multimae_amd import _lib, ops
     import dryrun_harness
-    old = (_lib._lib, ops._require_gpu, ops._stream)
+    old = (_lib._lib, ops._require_gpu, ops._stream, ops._device_ok, ops._WS_ELEMS[0])
     dryrun_harness.install()
     yield
-    _lib._lib, ops._require_gpu, ops._stream = old
+    _lib._lib, ops._require_gpu, ops._stream, ops._device_ok, ops._WS_ELEMS[0] = old
+    ops._WS.clear()
+    ops.set_composite_blocks(True)
 
 
 def _step(model, mode, direct, x, fp32_adapters=()):
@@ -36,8 +38,11 @@ def _step(model, mode, direct, x, fp32_adapters=()):
 
 @pytest.mark.parametrize('mode', ['fp32', 'bf16'])
 @pytest.mark.parametrize('direct', [False, True])
-def test_full_step_control_flow(stubbed, mode, direct):
+@pytest.mark.parametrize('composite', [True, False])
+def test_full_step_control_flow(stubbed, mode, direct, composite):
     import multimae_amd as M
+    from multimae_amd import ops
+    ops.set_composite_blocks(composite)
     g = load_mini()
     model = build_mini_engine()
     model.load_state_dict(g['sd'])
