@@ -118,10 +118,20 @@ __global__ void __launch_bounds__(256) ce_fwd_kernel(const float* __restrict__ l
         const int y = px / W, x = px % W;
         if (mask[(long long)b * np + (y / P) * nw + x / P] == 0) continue;
         const float* l = logits + (long long)b * C * HW + px;
-        float mx = -INFINITY;
-        for (int c = 0; c < C; ++c) mx = fmaxf(mx, l[(long long)c * HW]);
-        float s = 0.f;
-        for (int c = 0; c < C; ++c) s += expf(l[(long long)c * HW] - mx);
+        // one pass over the C channel planes: running max + rescaled sum (the two-pass form read the logits twice)
+        float mx = l[0], s = 1.f;
+        int c = 1;
+        for (; c + 4 <= C; c += 4) {
+            const float v0 = l[(long long)c * HW], v1 = l[(long long)(c + 1) * HW], v2 = l[(long long)(c + 2) * HW], v3 = l[(long long)(c + 3) * HW];
+            const float m4 = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+            if (m4 > mx) { s *= expf(mx - m4); mx = m4; }
+            s += (expf(v0 - mx) + expf(v1 - mx)) + (expf(v2 - mx) + expf(v3 - mx));
+        }
+        for (; c < C; ++c) {
+            const float v = l[(long long)c * HW];
+            if (v > mx) { s *= expf(mx - v); mx = v; }
+            s += expf(v - mx);
+        }
         const float ls = mx + logf(s);
         lse[(long long)b * HW + px] = ls;
         acc += ls - l[target[(long long)b * HW + px] * HW];
@@ -148,6 +158,57 @@ __global__ void ce_bwd_kernel(const float* __restrict__ logits, const long long*
         g = wgt * (sm - (target[b * HW + px] == c ? 1.f : 0.f));
     }
     d_logits[i] = g;
+}
+
+// float4 flavours of the two backward kernels (W % 4 == 0 and P % 4 == 0: four consecutive pixels share a row and a patch,
+// hence one mask / stats / weight lookup): the scalar ones spend their time in per-element div/mod chains (1.7 TB/s).
+__global__ void __launch_bounds__(256) pixel_loss_bwd4_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                              const long long* __restrict__ mask, int kind, int norm_pix, int C, int H, int W, int P,
+                                                              const float* __restrict__ stats, const float* __restrict__ per_sample,
+                                                              const float* __restrict__ loss, const float* __restrict__ upstream,
+                                                              float* __restrict__ d_pred, long long total4) {
+    const long long i4 = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i4 >= total4) return;
+    const long long i = i4 * 4;
+    const int x = (int)(i % W); long long r = i / W;
+    const int y = (int)(r % H); r /= H;
+    const long long b = r / C;
+    const int nw = W / P, np = (H / P) * nw, p = (y / P) * nw + x / P;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    if (mask[b * np + p] != 0) {
+        float mu = 0.f, rs = 1.f;
+        if (norm_pix) { mu = stats[(b * np + p) * 2]; rs = stats[(b * np + p) * 2 + 1]; }
+        const f32x4 pr = ld4(pred + i), tg = ld4(target + i);
+        const float wgt = upstream[0] / (loss[1] * per_sample[b * 2 + 1] * (float)C);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = pr[j] - (tg[j] - mu) * rs;
+            g[j] = wgt * (kind == 0 ? 2.f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)));
+        }
+    }
+    st4(d_pred + i, g);
+}
+
+__global__ void __launch_bounds__(256) ce_bwd4_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
+                                                      const long long* __restrict__ mask, int C, int H, int W, int P, const float* __restrict__ lse,
+                                                      const float* __restrict__ per_sample, const float* __restrict__ loss,
+                                                      const float* __restrict__ upstream, float* __restrict__ d_logits, long long total4) {
+    const long long i4 = (long long)blockIdx.x * 256 + threadIdx.x;          // over B*C*H*W / 4
+    if (i4 >= total4) return;
+    const long long i = i4 * 4;
+    const int HW = H * W;
+    const int px = (int)(i % HW); long long r = i / HW;
+    const int c = (int)(r % C); const long long b = r / C;
+    const int y = px / W, x = px % W, nw = W / P, np = (H / P) * nw;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    if (mask[b * np + (y / P) * nw + x / P] != 0) {
+        const float wgt = upstream[0] / (loss[1] * per_sample[b * 2 + 1]);
+        const f32x4 lg = ld4(logits + i), ls = ld4(lse + b * HW + px);
+        const long long* t = target + b * HW + px;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = wgt * (expf(lg[j] - ls[j]) - (t[j] == c ? 1.f : 0.f));
+    }
+    st4(d_logits + i, g);
 }
 
 // ---- optimiser ----------------------------------------------------------------------------
@@ -228,6 +289,10 @@ int mmae_masked_pixel_loss_bwd(const float* pred, const float* target, const int
                                const float* upstream, float* d_pred, void* stream) {
     MMAE_REQUIRE(pred && target && mask && per_sample && loss && upstream && d_pred, "pixel_loss_bwd: null pointer");
     const long long total = (long long)B * C * H * W;
+    if (W % 4 == 0 && patch % 4 == 0 && ((uintptr_t)pred % 16 == 0) && ((uintptr_t)target % 16 == 0) && ((uintptr_t)d_pred % 16 == 0))
+        hipLaunchKernelGGL(pixel_loss_bwd4_kernel, dim3((unsigned)cdiv64(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, pred, target,
+                           (const long long*)mask, kind, norm_pix, C, H, W, patch, stats, per_sample, loss, upstream, d_pred, total / 4);
+    else
     hipLaunchKernelGGL(pixel_loss_bwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, pred, target,
                        (const long long*)mask, kind, norm_pix, C, H, W, patch, stats, per_sample, loss, upstream, d_pred, total);
     return mmae_check_launch("pixel_loss_bwd");
@@ -252,6 +317,10 @@ int mmae_masked_ce_bwd(const float* logits, const int64_t* target, const int64_t
                        void* stream) {
     MMAE_REQUIRE(logits && target && mask && lse && per_sample && loss && upstream && d_logits, "ce_bwd: null pointer");
     const long long total = (long long)B * C * H * W;
+    if (W % 4 == 0 && patch % 4 == 0 && ((uintptr_t)logits % 16 == 0) && ((uintptr_t)lse % 16 == 0) && ((uintptr_t)d_logits % 16 == 0))
+        hipLaunchKernelGGL(ce_bwd4_kernel, dim3((unsigned)cdiv64(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, logits,
+                           (const long long*)target, (const long long*)mask, C, H, W, patch, lse, per_sample, loss, upstream, d_logits, total / 4);
+    else
     hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, logits, (const long long*)target,
                        (const long long*)mask, C, H, W, patch, lse, per_sample, loss, upstream, d_logits, total);
     return mmae_check_launch("ce_bwd");

@@ -159,10 +159,10 @@ __global__ void __launch_bounds__(256) tokens_assemble_bwd_kernel(const float* _
 #pragma unroll
     for (int i = 0; i < MAX_TASKS; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const long long n_rows = (long long)B * (n_sel + G);
-    for (long long rowg = blockIdx.x; rowg < n_rows; rowg += gridDim.x) {
+    // two rows per iteration (two independent 16-byte loads in flight per lane) over up to 1 024 workgroups: with one
+    // dependent load per iteration and 99 rows per workgroup this pass ran at 0.4 TB/s
+    auto one = [&](long long rowg, const f32x4& v) {
         const int b = (int)(rowg / (n_sel + G)), r = (int)(rowg % (n_sel + G));
-        if (c >= D) continue;
-        const f32x4 v = ld4(d_tok + rowg * D + c);
         int slot;
         if (r < n_sel) {
             st4(d_proj + ((long long)b * n_sel + r) * D + c, v);
@@ -173,6 +173,15 @@ __global__ void __launch_bounds__(256) tokens_assemble_bwd_kernel(const float* _
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] += v[j];
         }
+    };
+    if (c < D) {
+        long long rowg = blockIdx.x;
+        for (; rowg + gridDim.x < n_rows; rowg += 2LL * gridDim.x) {
+            const f32x4 v0 = ld4(d_tok + rowg * D + c), v1 = ld4(d_tok + (rowg + gridDim.x) * D + c);
+            one(rowg, v0);
+            one(rowg + gridDim.x, v1);
+        }
+        if (rowg < n_rows) one(rowg, ld4(d_tok + rowg * D + c));
     }
     if (c < D) {
         const int ns = tt.T + G;
@@ -231,51 +240,85 @@ __global__ void __launch_bounds__(256) decoder_build_bwd_kernel(const float* __r
                                                                 const long long* __restrict__ ids_keep, const long long* __restrict__ ids_restore,
                                                                 const TaskTable tt, int q_task, int B, int n_keep, int G, int D, int n_q,
                                                                 int Ntot, float* __restrict__ d_ctx, float* __restrict__ part) {
-    const int c = threadIdx.x * 4;
+    // D / 4 lanes cover a row; the workgroup's 256 / (D / 4) lane groups ("phases") and the SPLIT workgroups of a sample take
+    // the sample's NC + n_q rows round-robin (one 64-lane group walking all 295 rows of a sample was pure latency: 154 us
+    // for 100 MB); phases are combined through LDS, workgroups through the caller's column-sum pass over part.
+    __shared__ f32x4 red[4][MAX_TASKS + 1][64];
+    const int cg = D >> 2;                                // lanes per row
+    const int phases = (cg <= 64) ? 4 : 1;
+    const int ph = threadIdx.x / cg, lane = threadIdx.x % cg;
+    const int c = lane * 4;
     const int NC = n_keep + G;
+    const int split = gridDim.y;
     f32x4 acc[MAX_TASKS + 1];
 #pragma unroll
     for (int i = 0; i <= MAX_TASKS; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (c < D) {
+    if (ph < phases) {
+        const int stride = phases * split, first = blockIdx.y * phases + ph;
         for (int b = blockIdx.x; b < B; b += gridDim.x) {
-            // context rows
-            for (int r = 0; r < NC; ++r) {
-                f32x4 v = ld4(d_context + ((long long)b * NC + r) * D + c);
-                if (r < n_keep) {
-                    const int idx = (int)ids_keep[(long long)b * n_keep + r];
-                    const int t = task_of(tt, idx);
+            for (int rr = first; rr < NC + n_q; rr += stride) {
+                if (rr < NC) {                            // context row
+                    const int r = rr;
+                    f32x4 v = ld4(d_context + ((long long)b * NC + r) * D + c);
+                    if (r < n_keep) {
+                        const int idx = (int)ids_keep[(long long)b * n_keep + r];
+                        const int t = task_of(tt, idx);
 #pragma unroll
-                    for (int i = 0; i < MAX_TASKS; ++i) if (i == t) {
+                        for (int i = 0; i < MAX_TASKS; ++i) if (i == t) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) acc[i][k] += v[k];
+                            for (int k = 0; k < 4; ++k) acc[i][k] += v[k];
+                        }
+                        if (t == q_task) {
+                            const f32x4 q = ld4(d_queries + ((long long)b * n_q + (idx - tt.off[t])) * D + c);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] += q[k];
+                        }
                     }
-                    if (t == q_task) {
-                        const f32x4 q = ld4(d_queries + ((long long)b * n_q + (idx - tt.off[t])) * D + c);
+                    st4(d_ctx + ((long long)b * NC + r) * D + c, v);
+                } else {                                  // query row: task embedding of the query task + mask token of the masked ones
+                    const int j = rr - NC;
+                    const f32x4 q = ld4(d_queries + ((long long)b * n_q + j) * D + c);
+                    const bool vis = ids_restore[(long long)b * Ntot + tt.off[q_task] + j] < n_keep;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] += q[k];
+                    for (int i = 0; i < MAX_TASKS; ++i) if (i == q_task) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[i][k] += q[k];
                     }
-                }
-                st4(d_ctx + ((long long)b * NC + r) * D + c, v);
-            }
-            // query rows: task embedding of the query task + mask token of the masked ones
-            for (int j = 0; j < n_q; ++j) {
-                const f32x4 q = ld4(d_queries + ((long long)b * n_q + j) * D + c);
-                const bool vis = ids_restore[(long long)b * Ntot + tt.off[q_task] + j] < n_keep;
+                    if (!vis) {
 #pragma unroll
-                for (int i = 0; i < MAX_TASKS; ++i) if (i == q_task) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) acc[i][k] += q[k];
-                }
-                if (!vis) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) acc[MAX_TASKS][k] += q[k];
+                        for (int k = 0; k < 4; ++k) acc[MAX_TASKS][k] += q[k];
+                    }
                 }
             }
         }
-        const int ns = tt.T + 1;
+    }
+    const int ns = tt.T + 1;
+    const long long prow = (long long)blockIdx.y * gridDim.x + blockIdx.x;          // this workgroup's row of part
+    if (phases == 1) {
+        if (ph == 0) {
 #pragma unroll
-        for (int i = 0; i < MAX_TASKS; ++i) if (i < tt.T) st4(part + ((long long)blockIdx.x * ns + i) * D + c, acc[i]);
-        st4(part + ((long long)blockIdx.x * ns + tt.T) * D + c, acc[MAX_TASKS]);
+            for (int i = 0; i < MAX_TASKS; ++i) if (i < tt.T) st4(part + (prow * ns + i) * D + c, acc[i]);
+            st4(part + (prow * ns + tt.T) * D + c, acc[MAX_TASKS]);
+        }
+        return;
+    }
+    if (ph < phases) {
+#pragma unroll
+        for (int i = 0; i <= MAX_TASKS; ++i) red[ph][i][lane] = acc[i];
+    }
+    __syncthreads();
+    if (ph == 0) {
+#pragma unroll
+        for (int i = 0; i <= MAX_TASKS; ++i) {
+            if (i < tt.T || i == MAX_TASKS) {
+                f32x4 t = red[0][i][lane];
+                for (int p = 1; p < phases; ++p) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[k] += red[p][i][lane][k];
+                }
+                st4(part + (prow * ns + (i == MAX_TASKS ? tt.T : i)) * D + c, t);
+            }
+        }
     }
 }
 
@@ -428,7 +471,7 @@ int mmae_tokens_assemble(float* tok, const float* proj, const float* const* bias
     return mmae_check_launch("tokens_assemble");
 }
 
-int mmae_tokens_assemble_bwd_nblk(int B) { return B < 256 ? B : 256; }
+int mmae_tokens_assemble_bwd_nblk(int B) { const long long n = 4LL * B; return (int)(n < 1024 ? n : 1024); }
 
 int mmae_tokens_assemble_bwd(const float* d_tok, void* d_proj, int proj_dtype, const int32_t* task_offsets_host, int T,
                              const int64_t* sel, float* part, int B, int n_sel, int G, int D, void* stream) {
@@ -457,7 +500,8 @@ int mmae_decoder_build(const float* ctx, const int64_t* ids_keep, const int64_t*
     return mmae_check_launch("decoder_build");
 }
 
-int mmae_decoder_build_bwd_nblk(int B) { return B < 256 ? B : 256; }
+static int dbb_split(int B) { return B <= 512 ? 4 : 1; }
+int mmae_decoder_build_bwd_nblk(int B) { return (B < 1024 ? B : 1024) * dbb_split(B); }
 
 int mmae_decoder_build_bwd(const float* d_queries, const float* d_context, const int64_t* ids_keep, const int64_t* ids_restore,
                            const int32_t* task_offsets_host, int T, int q_task, int B, int n_keep, int G, int D, int n_q,
@@ -466,7 +510,7 @@ int mmae_decoder_build_bwd(const float* d_queries, const float* d_context, const
     MMAE_REQUIRE(D % 4 == 0 && D <= 1024 && B > 0, "decoder_build_bwd: bad sizes");
     TaskTable tt;
     MMAE_REQUIRE(fill_tt(tt, task_offsets_host, T) == 0 && q_task >= 0 && q_task < T, "decoder_build_bwd: bad task table");
-    hipLaunchKernelGGL(decoder_build_bwd_kernel, dim3(mmae_decoder_build_bwd_nblk(B)), dim3(256), 0, (hipStream_t)stream, d_queries,
+    hipLaunchKernelGGL(decoder_build_bwd_kernel, dim3(B < 1024 ? B : 1024, dbb_split(B)), dim3(256), 0, (hipStream_t)stream, d_queries,
                        d_context, (const long long*)ids_keep, (const long long*)ids_restore, tt, q_task, B, n_keep, G, D, n_q,
                        tt.off[T], d_ctx, part);
     return mmae_check_launch("decoder_build_bwd");

@@ -388,11 +388,13 @@ def test_patchify_roundtrip_and_layout(geom):
     assert back16.shape == pat.shape and torch.equal(back16.float().cpu(), bf(pat))
 
 
+@pytest.mark.parametrize('S,P', [(32, 8), (24, 6)])
 @pytest.mark.parametrize('kind,norm_pix', [(0, False), (0, True), (1, False)])
-def test_masked_pixel_losses(kind, norm_pix):
+def test_masked_pixel_losses(kind, norm_pix, S, P):
+    """patch 8 takes the float4 backward kernel, patch 6 the scalar one; 16 patches either way."""
     import multimae_amd as M
     torch.manual_seed(7)
-    B, C, S, P = 5, 3, 32, 8
+    B, C = 5, 3
     pred, tgt = torch.randn(B, C, S, S), torch.randn(B, C, S, S)
     mask = (torch.rand(B, 16) < 0.7).long()
     mask[1] = 0                                           # a sample with no masked token drops out (nanmean)
@@ -415,18 +417,20 @@ def test_masked_pixel_losses(kind, norm_pix):
     assert float(z) == 0.0
 
 
-def test_masked_cross_entropy():
+@pytest.mark.parametrize('S,patch', [(8, 8), (16, 16)])
+def test_masked_cross_entropy(S, patch):
+    """semseg map S x S at stride 4: effective patch 2 (scalar backward kernel) and 4 (the float4 one, as at 224^2 / 16)."""
     import multimae_amd as M
     torch.manual_seed(8)
-    B, C, S, P = 4, 133, 8, 2            # semseg map 8x8, patch 2 (stride 4 of an 8-px patch)
+    B, C = 4, 133
     logits, tgt = torch.randn(B, C, S, S) * 2, torch.randint(0, C, (B, S, S))
     mask = (torch.rand(B, 16) < 0.6).long()
     mask[2] = 0
     lr = logits.clone().requires_grad_(True)
-    ref = orc.masked_ce(lr, tgt, mask, 8, 4)
+    ref = orc.masked_ce(lr, tgt, mask, patch, 4)
     ref.backward()
     ld = logits.to(DEV).requires_grad_(True)
-    out = M.MaskedCrossEntropyLoss(8, 4)(ld, tgt.to(DEV), mask=mask.to(DEV))
+    out = M.MaskedCrossEntropyLoss(patch, 4)(ld, tgt.to(DEV), mask=mask.to(DEV))
     out.backward()
     assert abs(float(out) - float(ref)) < 5e-6
     keep = [0, 1, 3]                                    # sample 2: no masked token (reference grad is NaN, engine 0)
