@@ -364,6 +364,15 @@ int mmae_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, cons
                    float beta2, float eps, const float* grad_scale_dev, const int32_t* skip_flag, void* shadow,
                    int shadow_dtype, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Truncated depth standardisation, the step right before the model in the training loop
+ * (run_pretraining_multimae.py:487-492): per sample, mean / unbiased variance of the values of rank [lo, hi) among
+ * the n = c*h*w values (the reference: torch.sort, slice [int(0.1 n), int(0.9 n)), mean, var), then
+ * y = (x - mean) / sqrt(var + eps) over the whole map.  x, y f32 [B][n] (y may alias x).  Rank selection by radix
+ * select, no sort; ties at the cuts are counted by rank like the sorted slice.
+ * ------------------------------------------------------------------------- */
+int mmae_depth_standardize(const float* x, float* y, int B, int n, int lo, int hi, float eps, void* stream);
+
 /* hardware probes used by tests/ to pin instruction semantics the kernels rely on */
 int mmae_probe_tr16(const uint16_t* lds_image_1024, const uint32_t* lane_byte_addr_64, uint16_t* out_64x4,
                     void* stream);

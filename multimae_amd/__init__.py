@@ -6,6 +6,7 @@ SpatialOutputAdapter; plus the engine controls (precision, parameter arena, fuse
 data-parallel gradient reducer).
 """
 from . import engine  # noqa: F401
+from .data_ops import truncated_depth_standardize  # noqa: F401
 from .criterion import MaskedCrossEntropyLoss, MaskedL1Loss, MaskedMSELoss  # noqa: F401
 from .input_adapters import PatchedInputAdapter, SemSegInputAdapter  # noqa: F401
 from .multimae import (MultiMAE, MultiViT, multivit_base, multivit_large,  # noqa: F401

@@ -242,6 +242,9 @@ class ParamArena:
                 self._params[n] = p
                 self._views[id(p)] = view
         module._mmae_arena = self
+        # load_state_dict() copies new values into the arena views: the bf16 shadow the optimiser vouched for is stale then
+        if hasattr(module, 'register_load_state_dict_post_hook'):
+            module.register_load_state_dict_post_hook(lambda m, incompatible: setattr(self, '_shadow_token', False))
 
     # -- integrity -----------------------------------------------------------------
     def intact(self) -> bool:

@@ -445,6 +445,19 @@ def pretrain_losses(preds: Dict[str, Tensor], targets: Dict[str, Tensor], mask_a
     return out
 
 
+def truncated_depth_standardize(depth: Tensor, lo: float = 0.1, hi: float = 0.9, eps: float = 1e-6) -> Tensor:
+    """Truncated depth standardisation of the training loop (run_pretraining_multimae.py:487-492): per sample, sort all
+    c*h*w values, drop the bottom and top 10 % (slice [int(lo*n), int(hi*n)) of the sorted row), and standardise the whole map
+    with that slice's mean and UNBIASED variance:  (x - mean) / sqrt(var + 1e-6)."""
+    B = depth.shape[0]
+    flat = torch.sort(depth.reshape(B, -1), dim=1)[0]
+    n = flat.shape[1]
+    trunc = flat[:, int(lo * n):int(hi * n)]
+    mean = trunc.mean(dim=1)[:, None, None, None]
+    var = trunc.var(dim=1)[:, None, None, None]
+    return (depth - mean) / torch.sqrt(var + eps)
+
+
 def adamw_step(params: Dict[str, Tensor], grads: Dict[str, Tensor], m: Dict[str, Tensor], v: Dict[str, Tensor],
                step: int, lr: float, wd: float, beta1: float = 0.9, beta2: float = 0.95, eps: float = 1e-8):
     """torch.optim.AdamW semantics as the reference uses it (optim_factory.py:138-174:

@@ -1,0 +1,93 @@
+"""CPU: checkpoint compatibility -- key maps against outputs of the reference's own converter functions
+(tests/golden/ckpt_maps.npz, generator committed), optimiser-state interchange with torch.optim.AdamW, save / auto-resume."""
+import os
+import types
+
+import numpy as np
+import torch
+
+from multimae_amd import checkpoint as ck
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ckpt_maps.npz')
+
+
+def _group(z, pre):
+    return {k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)}
+
+
+def test_key_maps_match_reference_converters():
+    z = np.load(GOLD)
+    sd = _group(z, 'in/')
+    for fn, pre in ((ck.multimae_to_vit, 'vit/'), (ck.multimae_to_vitmultimae, 'vitmm/')):
+        got, exp = fn({k: v.clone() for k, v in sd.items()}), _group(z, pre)
+        assert set(got) == set(exp)
+        for k in exp:
+            assert got[k].shape == exp[k].shape and torch.equal(got[k], exp[k]), (pre, k)
+    got, exp = ck.vit_to_multimae({k: v.clone() for k, v in _group(z, 'vit_in/').items()}), _group(z, 'back/')
+    assert set(got) == set(exp)
+    for k in exp:
+        assert torch.equal(got[k].contiguous(), exp[k]), k
+    # round trip: MultiMAE -> ViT -> MultiMAE restores the encoder / patch-embed / pos-emb tensors
+    rt = ck.vit_to_multimae(ck.multimae_to_vit({k: v.clone() for k, v in sd.items()}))
+    for k in ('input_adapters.rgb.pos_emb', 'input_adapters.rgb.proj.weight', 'encoder.0.attn.qkv.weight', 'global_tokens'):
+        assert torch.equal(rt[k].contiguous(), sd[k]), k
+
+
+def test_pos_emb_resize_matches_reference():
+    z = np.load(GOLD)
+    sd = _group(z, 'in/')
+    D = sd['input_adapters.rgb.pos_emb'].shape[1]
+    model = types.SimpleNamespace(input_adapters=types.SimpleNamespace(rgb=types.SimpleNamespace(pos_emb=torch.zeros(1, D, 5, 4))))
+    ck.interpolate_pos_embed_multimae(model, sd)
+    exp = torch.from_numpy(z['resized/input_adapters.rgb.pos_emb'])
+    assert sd['input_adapters.rgb.pos_emb'].shape == (1, D, 5, 4)
+    assert torch.allclose(sd['input_adapters.rgb.pos_emb'], exp, rtol=0, atol=1e-6)
+
+
+def _same_moments(a, b):
+    """equal on every parameter's slice (the 64-element alignment padding between tensors carries no state)"""
+    return all(torch.equal(a.m[o:o + n], b.m[o:o + n]) and torch.equal(a.v[o:o + n], b.v[o:o + n]) for _, o, n, _ in ck._trainable(a))
+
+
+def _fake_fused(model, step=3):
+    """FusedAdamW-shaped object on CPU tensors (the real one needs the GPU only for its step kernel)."""
+    from multimae_amd import engine
+    arena = engine.ParamArena(model)
+    opt = types.SimpleNamespace(arena=arena, m=torch.randn(arena.n_trainable), v=torch.rand(arena.n_trainable), step_count=step,
+                                param_groups=[dict(lr=1e-3, weight_decay=0.05, lr_scale=1.0, betas=(0.9, 0.95), eps=1e-8)])
+    return opt
+
+
+def test_optimizer_state_interchanges_with_torch_adamw(tmp_path):
+    """The exported state loads into a real torch.optim.AdamW over the same parameters (the reference's optimiser,
+    utils/optim_factory.py:166) and comes back bit-identical; a checkpoint written here resumes with model + moments + epoch."""
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.LayerNorm(5), torch.nn.Linear(5, 3))
+    model[1].bias.requires_grad_(False)                 # a frozen tensor: not part of the optimiser (pos-emb case)
+    opt = _fake_fused(model)
+    sd = ck.optimizer_state_to_torch(opt)
+    ref = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
+    ref.load_state_dict(sd)                              # torch validates group sizes / shapes here
+    for i, p in enumerate(p for p in model.parameters() if p.requires_grad):
+        assert torch.equal(ref.state[p]['exp_avg'], sd['state'][i]['exp_avg']) and ref.state[p]['exp_avg'].shape == p.shape
+    back = _fake_fused(model, step=0)
+    back.m.zero_(); back.v.zero_()
+    ck.optimizer_state_from_torch(back, ref.state_dict())
+    assert back.step_count == 3 and _same_moments(back, opt)
+    # files: save twice, auto-resume picks the latest, state comes back
+    d = str(tmp_path)
+    ck.save_checkpoint(d, 4, model, opt)
+    with torch.no_grad():
+        model[0].weight.add_(1.0)
+    p9 = ck.save_checkpoint(d, 9, model, opt, args={'epochs': 10})
+    assert ck.latest_checkpoint(d) == p9 and sorted(os.listdir(d)) == ['checkpoint-4.pth', 'checkpoint-9.pth']
+    saved = torch.load(p9, weights_only=False)
+    assert set(saved) == {'model', 'optimizer', 'epoch', 'scaler', 'args'} and saved['epoch'] == 9
+    w9 = model[0].weight.detach().clone()
+    with torch.no_grad():
+        model[0].weight.zero_()
+    fresh = _fake_fused(model, step=0)
+    fresh.m.zero_()
+    assert ck.load_checkpoint(p9, model, fresh) == 10
+    assert torch.equal(model[0].weight, w9) and _same_moments(fresh, opt) and fresh.step_count == 3
+    assert ck.latest_checkpoint(str(tmp_path / 'nothing_here')) is None

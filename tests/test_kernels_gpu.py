@@ -438,6 +438,26 @@ def test_masked_cross_entropy(S, patch):
     assert rel_err(ld.grad[keep], lr.grad[keep]) < 1e-5
 
 
+def test_truncated_depth_standardize_vs_reference_golden():
+    """run_pretraining_multimae.py:487-492 (fixture produced by executing those reference lines, tests/golden/make_golden_depth.py):
+    continuous maps, 8-bit quantised maps whose 10 % / 90 % cuts fall inside runs of equal values, a constant map (var = 0),
+    and the real 224 x 224 geometry.  fp tolerance 2e-6 relative to the output range (the reference sums in fp32)."""
+    import numpy as np, os
+    import multimae_amd as M
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'depth_std.npz'))
+    for k in [f[2:] for f in z.files if f.startswith('x/')]:
+        x, y = torch.from_numpy(z['x/' + k]), torch.from_numpy(z['y/' + k])
+        out = M.truncated_depth_standardize(x.to(DEV)).cpu()
+        scale = float(y.abs().max())
+        assert float((out - y).abs().max()) <= 2e-6 * scale + 1e-6, (k, float((out - y).abs().max()), scale)
+        assert torch.equal(orc.truncated_depth_standardize(x), y) or float((orc.truncated_depth_standardize(x) - y).abs().max()) < 1e-6 * scale
+    # size-independent property at the full batch geometry: an affine map of the depth leaves the result unchanged
+    torch.manual_seed(12)
+    d = (torch.rand(16, 1, 224, 224, device=DEV) ** 2) * 50
+    a, b = M.truncated_depth_standardize(d), M.truncated_depth_standardize(d * 3.0 + 7.0)
+    assert float((a - b).abs().max()) < 2e-3
+
+
 def test_adamw_and_sumsq():
     from multimae_amd import ops
     torch.manual_seed(9)

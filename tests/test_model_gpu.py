@@ -319,6 +319,60 @@ def test_step_graph_resamples_masks_every_replay():
     assert not torch.equal(masks[1], masks[2]) and not torch.equal(masks[2], masks[3])
 
 
+def test_checkpoint_resume_and_shadow_invalidation(tmp_path):
+    """save_checkpoint / load_checkpoint (reference file format, utils/checkpoint.py:75-131) around the fused optimiser:
+    training 2 steps, saving, and continuing == loading the file into a fresh model + optimiser and continuing.
+    Also: load_state_dict() after an optimiser step must drop the bf16 weight shadow the optimiser vouched for."""
+    import multimae_amd as M
+    from multimae_amd import checkpoint as ck
+    from multimae_amd.optim import FusedAdamW
+    g = load_mini()
+    fns = _loss_fns(MINI['P'])
+    tm = {d: g['mask'][d].to(DEV) for d in MINI['doms']}
+    ids = (g['ids_keep'].to(DEV), g['ids_restore'].to(DEV))
+    xd = {k: v.to(DEV) for k, v in g['x'].items()}
+    tgt = dict(xd, norm_rgb=xd['rgb'])
+
+    def make():
+        model = build_mini_engine()
+        model.load_state_dict(g['sd'])
+        model.to(DEV)
+        model.build_arena()
+        model.generate_random_masks = lambda *a, **k: (tm, ids[0], ids[1])
+        return model, FusedAdamW(model, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
+
+    def step(model, opt, update=True):
+        opt.zero_grad()
+        preds, masks = model(xd, num_encoded_tokens=MINI['nvis'])
+        mk = dict(masks, norm_rgb=masks['rgb'])
+        loss = sum(fns[k](preds[k].float(), tgt[k], mask=mk[k]) for k in preds)
+        if update:
+            loss.backward()
+            opt.step()
+        return float(loss.detach())
+
+    M.engine.set_direct_grads(True)
+    try:
+        model, opt = make()
+        l0 = step(model, opt, update=False)
+        sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        step(model, opt); step(model, opt)
+        path = ck.save_checkpoint(str(tmp_path), 1, model, opt)
+        l_cont = step(model, opt)                       # loss after 2 steps, then a third update
+        p_cont = model._mmae_arena.param.clone()
+        model2, opt2 = make()
+        assert ck.load_checkpoint(path, model2, opt2) == 2 and opt2.step_count == 2
+        l_res = step(model2, opt2)
+        assert abs(l_res - l_cont) < 2e-3 * abs(l_cont)
+        assert rel_err(model2._mmae_arena.param, p_cont) < 1e-4
+        # stale-shadow guard: the optimiser has just written the bf16 shadow of the step-3 weights; loading the initial weights
+        # must invalidate it, so the next forward sees the loaded values
+        model.load_state_dict(sd0)
+        assert abs(step(model, opt, update=False) - l0) < 1e-6 * abs(l0)
+    finally:
+        M.engine.set_direct_grads(False)
+
+
 def _known_answer_case(name, doms, P, S, nvis, enc, posemb, mode, fp32_adapters=()):
     """Reproduce the reference's recorded step (tests/golden/scalars.json, SURVEY Appendix B recipe): same seeded init
     (bit-identical weights), same inputs (seed stream), same masks (the reference drew them on the CPU generator after

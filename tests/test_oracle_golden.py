@@ -75,3 +75,14 @@ def test_oracle_adamw_matches_torch():
         orc.adamw_step(p, gr, m, v_, step, 1e-3, 0.05)
     for k in p:
         assert torch.allclose(p[k], ref[k].detach(), atol=1e-6)
+
+
+def test_oracle_truncated_depth_standardize_matches_reference_fixture():
+    """oracle.truncated_depth_standardize vs the outputs of the reference's own lines (run_pretraining_multimae.py:487-492)."""
+    import numpy as np, os
+    import multimae_oracle as orc
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'depth_std.npz'))
+    for k in [f[2:] for f in z.files if f.startswith('x/')]:
+        x, y = torch.from_numpy(z['x/' + k]), torch.from_numpy(z['y/' + k])
+        out = orc.truncated_depth_standardize(x)
+        assert float((out - y).abs().max()) <= 1e-6 * float(y.abs().max()), k
