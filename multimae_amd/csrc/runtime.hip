@@ -47,7 +47,8 @@ void gemm_plan(const mmae_gemm_desc* d, int* tile_out, int* split_out) {
         tile = 3;
         if (d->ab_dtype == MMAE_BF16 && d->batch == 1) {
             const long long t4 = ((d->M + 255) / 256) * nt256, t5 = ((d->M + 319) / 320) * nt256;
-            if (d->M >= 2048 && d->N >= 192 && d->K >= 128) {
+            static const int env_min_k = getenv("MMAE_PP_MIN_K") ? atoi(getenv("MMAE_PP_MIN_K")) : 128;
+            if (d->M >= 2048 && d->N >= 192 && d->K >= env_min_k) {
                 // whole rounds of 256 workgroups x rows per tile: 320-row tiles when they waste less of the last round
                 const long long c4 = ((t4 + 255) / 256) * 256, c5 = ((t5 + 255) / 256) * 320;
                 tile = (c5 <= c4 && !d->a_trans && !d->colsum_part) ? 10 : 9;

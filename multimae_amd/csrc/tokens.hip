@@ -382,6 +382,51 @@ __global__ void __launch_bounds__(256) patchify4_kernel(const float* __restrict_
     st4(pat + tok * ld + ((long long)c * ph + iy) * pw + q * 4, ld4(img + ((b * C + c) * H + py * ph + iy) * W + px * pw + q * 4));
 }
 
+// Narrow patches (pw = 4 or 8: the stride-4 semseg maps): a 16-byte patch-row chunk is a quarter / half of a 64-byte
+// sector, and the walk of the kernels above touches the other chunks of that sector from workgroups far apart -- PMC: 2.4 GB
+// fetched for a 427 MB logits gradient.  Here a workgroup moves one (sample, patch row, channel block) tile through LDS:
+// whole image rows on one side, whole per-token channel blocks on the other; every global access is a full contiguous run.
+template <typename PT, bool TO_PATCH>
+__global__ void __launch_bounds__(256) patch_tile_kernel(const float* __restrict__ src, PT* __restrict__ dst, long long ld, int C, int nh,
+                                                         int nw, int ph, int pw, int CB) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];              // [CB][ph][W]
+    const int W = nw * pw, H = nh * ph, ncb = (C + CB - 1) / CB;
+    const int cb = blockIdx.x % ncb; long long r = blockIdx.x / ncb;
+    const int py = (int)(r % nh); const long long b = r / nh;
+    const int c0 = cb * CB, cn = (C - c0 < CB) ? C - c0 : CB;
+    const int rowW4 = W >> 2, pw4 = pw >> 2;
+    const int n_img4 = cn * ph * rowW4;                                       // float4 chunks on the image side (= patch side)
+    if (TO_PATCH) {
+        for (int e = threadIdx.x; e < n_img4; e += 256) {                     // image rows -> LDS (contiguous W-float runs)
+            const int x4 = e % rowW4, rr = e / rowW4, iy = rr % ph, cl = rr / ph;
+            *reinterpret_cast<f32x4*>(tile + (cl * ph + iy) * W + x4 * 4) = ld4(src + ((b * C + c0 + cl) * H + py * ph + iy) * W + x4 * 4);
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < n_img4; e += 256) {                     // LDS -> per-token channel blocks (contiguous cn*ph*pw floats)
+            const int q = e % pw4; int rr = e / pw4;
+            const int iy = rr % ph; rr /= ph;
+            const int cl = rr % cn, px = rr / cn;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tile + (cl * ph + iy) * W + px * pw + q * 4);
+            st4(dst + ((b * nh + py) * nw + px) * ld + ((long long)(c0 + cl) * ph + iy) * pw + q * 4, v);
+        }
+    } else {
+        for (int e = threadIdx.x; e < n_img4; e += 256) {                     // patch rows -> LDS
+            const int q = e % pw4; int rr = e / pw4;
+            const int iy = rr % ph; rr /= ph;
+            const int cl = rr % cn, px = rr / cn;
+            *reinterpret_cast<f32x4*>(tile + (cl * ph + iy) * W + px * pw + q * 4) =
+                ld4(src + ((b * nh + py) * nw + px) * ld + ((long long)(c0 + cl) * ph + iy) * pw + q * 4);
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < n_img4; e += 256) {                     // LDS -> image rows
+            const int x4 = e % rowW4, rr = e / rowW4, iy = rr % ph, cl = rr / ph;
+            st4(dst + ((b * C + c0 + cl) * H + py * ph + iy) * W + x4 * 4, *reinterpret_cast<const f32x4*>(tile + (cl * ph + iy) * W + x4 * 4));
+        }
+    }
+}
+// channels per tile: <= 16, LDS tile <= 32 KB
+inline int patch_tile_cb(int ph, int W) { int cb = 8192 / (ph * W); return cb < 1 ? 0 : (cb > 16 ? 16 : cb); }
+
 // hardware probe: what does ds_read_b64_tr_b16 return for a given LDS image / lane addresses
 __global__ void probe_tr16_kernel(const uint16_t* __restrict__ image, const uint32_t* __restrict__ addr, uint16_t* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint16_t lds[1024];
@@ -519,6 +564,13 @@ int mmae_decoder_build_bwd(const float* d_queries, const float* d_context, const
 int mmae_unpatchify(const float* patches, float* img, int B, int C, int nh, int nw, int ph, int pw, void* stream) {
     MMAE_REQUIRE(patches && img && B > 0 && C > 0, "unpatchify: bad argument");
     const long long total = (long long)B * C * nh * ph * nw * pw;
+    const int cbu = (pw % 4 == 0 && pw < 16) ? patch_tile_cb(ph, nw * pw) : 0;
+    if (cbu > 0 && ((uintptr_t)patches % 16 == 0) && ((uintptr_t)img % 16 == 0)) {
+        const long long nblk = (long long)B * nh * ((C + cbu - 1) / cbu);
+        hipLaunchKernelGGL((patch_tile_kernel<float, false>), dim3((unsigned)nblk), dim3(256), (size_t)cbu * ph * nw * pw * 4, (hipStream_t)stream,
+                           patches, img, (long long)C * ph * pw, C, nh, nw, ph, pw, cbu);
+        return mmae_check_launch("unpatchify");
+    }
     if (pw % 4 == 0 && ((uintptr_t)patches % 16 == 0) && ((uintptr_t)img % 16 == 0))
         hipLaunchKernelGGL(unpatchify4_kernel, dim3((unsigned)cdiv64(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, patches, img, C,
                            nh, nw, ph, pw, total / 4);
@@ -532,6 +584,14 @@ int mmae_patchify(const float* img, void* patches, int patches_dtype, int64_t ld
     MMAE_REQUIRE(patches && img && B > 0 && C > 0 && ld >= (int64_t)C * ph * pw, "patchify: bad argument");
     const long long total = (long long)B * C * nh * ph * nw * pw;
     hipStream_t st = (hipStream_t)stream;
+    const int cbp = (pw % 4 == 0 && pw < 16 && ld % 4 == 0) ? patch_tile_cb(ph, nw * pw) : 0;
+    if (cbp > 0 && ((uintptr_t)patches % 16 == 0) && ((uintptr_t)img % 16 == 0)) {
+        const dim3 grid((unsigned)((long long)B * nh * ((C + cbp - 1) / cbp)));
+        const size_t lds = (size_t)cbp * ph * nw * pw * 4;
+        if (patches_dtype == MMAE_BF16) hipLaunchKernelGGL((patch_tile_kernel<uint16_t, true>), grid, dim3(256), lds, st, img, (uint16_t*)patches, (long long)ld, C, nh, nw, ph, pw, cbp);
+        else hipLaunchKernelGGL((patch_tile_kernel<float, true>), grid, dim3(256), lds, st, img, (float*)patches, (long long)ld, C, nh, nw, ph, pw, cbp);
+        return mmae_check_launch("patchify");
+    }
     if (pw % 4 == 0 && ld % 4 == 0 && ((uintptr_t)patches % 16 == 0) && ((uintptr_t)img % 16 == 0)) {
         const dim3 grid((unsigned)cdiv64(total / 4, 256));
         if (patches_dtype == MMAE_BF16) hipLaunchKernelGGL((patchify4_kernel<uint16_t>), grid, dim3(256), 0, st, img, (uint16_t*)patches, (long long)ld, C, nh, nw, ph, pw, total / 4);
