@@ -225,6 +225,10 @@ int mmae_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int mmae_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 /* dst[c][r] = src[r][c], src f32 [rows][cols]; dst act dtype [cols][rows] */
 int mmae_transpose_cast(const float* src, void* dst, int dst_dtype, int rows, int cols, void* stream);
+/* mean pooling over tokens, LinearOutputAdapter.forward (output_adapters.py:346-347):  y[b][:] = mean_n x[b][n][:]
+ * (x f32 [B][N][D], y f32 [B][D]) and its backward dx[b][n][:] = dy[b][:] / N. */
+int mmae_token_mean_fwd(const float* x, float* y, int B, int N, int D, void* stream);
+int mmae_token_mean_bwd(const float* dy, float* dx, int B, int N, int D, void* stream);
 /* y (+)= a*x elementwise, f32 */
 int mmae_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream);
 

@@ -11,7 +11,7 @@ from .criterion import MaskedCrossEntropyLoss, MaskedL1Loss, MaskedMSELoss  # no
 from .input_adapters import PatchedInputAdapter, SemSegInputAdapter  # noqa: F401
 from .multimae import (MultiMAE, MultiViT, multivit_base, multivit_large,  # noqa: F401
                        pretrain_multimae_base, pretrain_multimae_large)
-from .output_adapters import SpatialOutputAdapter  # noqa: F401
+from .output_adapters import LinearOutputAdapter, SpatialOutputAdapter  # noqa: F401
 from .registry import create_model, register_model  # noqa: F401
 
 __version__ = '0.1.0'

@@ -244,6 +244,20 @@ __global__ void __launch_bounds__(256) colsum_kernel(const DT* __restrict__ dy, 
     }
 }
 
+// any N / ld (class counts that are not multiples of 4): one column per lane
+template <typename DT>
+__global__ void __launch_bounds__(256) colsum_scalar_kernel(const DT* __restrict__ dy, long long M, int N, long long ld,
+                                                            float* __restrict__ ws) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < N) for (long long r = (long long)blockIdx.y * 4 + w; r < M; r += (long long)gridDim.y * 4) s += ActT<DT>::ld(dy + r * ld + c);
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && c < N) ws[(long long)blockIdx.y * N + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
 // ------------------------------------------------------------------------------------------
 // Row softmax over materialised scores, n <= 256.  One wave per row; lane l owns l, l+64, ...
 // ------------------------------------------------------------------------------------------
@@ -349,6 +363,39 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
     }
 }
 
+// y[b][:] = mean_n x[b][n][:]   and its backward  dx[b][n][:] = dy[b][:] / N   (LinearOutputAdapter's mean pooling)
+__global__ void __launch_bounds__(256) token_mean_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int D) {
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= D) return;
+    const float* xb = x + (long long)blockIdx.y * N * D + c;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    int n = 0;
+    for (; n + 1 < N; n += 2) {
+        const f32x4 a = ld4(xb + (long long)n * D), b = ld4(xb + (long long)(n + 1) * D);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s0[j] += a[j]; s1[j] += b[j]; }
+    }
+    if (n < N) { const f32x4 a = ld4(xb + (long long)n * D);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s0[j] += a[j];
+    }
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (s0[j] + s1[j]) / (float)N;
+    st4(y + (long long)blockIdx.y * D + c, o);
+}
+__global__ void __launch_bounds__(256) token_mean_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int D, long long total4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // float4 index over [B][N][D]
+    if (i >= total4) return;
+    const int d4 = D >> 2;
+    const long long b = i / ((long long)N * d4);
+    const int c = (int)(i % d4) * 4;
+    f32x4 g = ld4(dy + b * D + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] /= (float)N;
+    st4(dx + i * 4, g);
+}
+
 inline int stream_grid(long long n_vec4) { long long b = (n_vec4 + 255) / 256; return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); }
 
 // out[m] (+)= sum_s part[s][m]   (fixed order)
@@ -443,8 +490,16 @@ static int colsum_impl(const void* dy, int dtype, int64_t M, int N, int64_t ld, 
                        void* stream) {
     const int ns = colsum_nsplit(M);
     if (ns == 1 && dtype == MMAE_F32 && ld == N) return launch_partials((const float*)dy, d, (int)M, N, accumulate, stream);
-    dim3 grid((N + 255) / 256, ns), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (N % 4 != 0 || ld % 4 != 0) {
+        dim3 g1((N + 63) / 64, ns);
+        if (dtype == MMAE_BF16) hipLaunchKernelGGL((colsum_scalar_kernel<uint16_t>), g1, dim3(256), 0, st, (const uint16_t*)dy, (long long)M, N, (long long)ld, ws);
+        else hipLaunchKernelGGL((colsum_scalar_kernel<float>), g1, dim3(256), 0, st, (const float*)dy, (long long)M, N, (long long)ld, ws);
+        int rc1 = mmae_check_launch("colsum");
+        if (rc1) return rc1;
+        return launch_partials(ws, d, ns, N, accumulate, stream);
+    }
+    dim3 grid((N + 255) / 256, ns), block(256);
     if (dtype == MMAE_BF16) hipLaunchKernelGGL((colsum_kernel<uint16_t>), grid, block, 0, st, (const uint16_t*)dy, (long long)M, N, (long long)ld, ws);
     else hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, st, (const float*)dy, (long long)M, N, (long long)ld, ws);
     int rc = mmae_check_launch("colsum");
@@ -455,7 +510,6 @@ static int colsum_impl(const void* dy, int dtype, int64_t M, int N, int64_t ld, 
 int mmae_colsum(const void* dy, int dtype, int64_t M, int N, int64_t ld, float* out, int accumulate, float* ws,
                 void* stream) {
     MMAE_REQUIRE(dy && out && ws && M > 0 && N > 0, "colsum: bad argument");
-    MMAE_REQUIRE(N % 4 == 0 && ld % 4 == 0, "colsum: N and ld must be multiples of 4");
     ColDst d = {};
     d.dst[0] = out; d.seg_w = N;
     return colsum_impl(dy, dtype, M, N, ld, d, accumulate, ws, stream);
@@ -464,7 +518,6 @@ int mmae_colsum(const void* dy, int dtype, int64_t M, int N, int64_t ld, float* 
 int mmae_colsum_scatter(const void* dy, int dtype, int64_t M, int N, int64_t ld, int seg_w, const void* dsts, int nseg,
                         int accumulate, float* ws, void* stream) {
     MMAE_REQUIRE(dy && dsts && ws && M > 0 && N > 0, "colsum_scatter: bad argument");
-    MMAE_REQUIRE(N % 4 == 0 && ld % 4 == 0, "colsum_scatter: N and ld must be multiples of 4");
     MMAE_REQUIRE(seg_w > 0 && nseg >= 1 && nseg <= 8 && (int64_t)seg_w * nseg >= N, "colsum_scatter: need 1..8 segments covering N columns");
     ColDst d = {};
     for (int i = 0; i < nseg; ++i) d.dst[i] = ((float* const*)dsts)[i];
@@ -514,6 +567,19 @@ int mmae_transpose_cast(const float* src, void* dst, int dst_dtype, int rows, in
     if (dst_dtype == MMAE_BF16) hipLaunchKernelGGL((transpose_cast_kernel<uint16_t>), grid, block, 0, (hipStream_t)stream, src, (uint16_t*)dst, rows, cols);
     else hipLaunchKernelGGL((transpose_cast_kernel<float>), grid, block, 0, (hipStream_t)stream, src, (float*)dst, rows, cols);
     return mmae_check_launch("transpose_cast");
+}
+int mmae_token_mean_fwd(const float* x, float* y, int B, int N, int D, void* stream) {
+    MMAE_REQUIRE(x && y && B > 0 && N > 0 && D > 0 && D % 4 == 0, "token_mean_fwd: bad argument");
+    MMAE_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0), "token_mean_fwd: unaligned");
+    hipLaunchKernelGGL(token_mean_fwd_kernel, dim3((D / 4 + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, y, N, D);
+    return mmae_check_launch("token_mean_fwd");
+}
+int mmae_token_mean_bwd(const float* dy, float* dx, int B, int N, int D, void* stream) {
+    MMAE_REQUIRE(dy && dx && B > 0 && N > 0 && D > 0 && D % 4 == 0, "token_mean_bwd: bad argument");
+    MMAE_REQUIRE(((uintptr_t)dy % 16 == 0) && ((uintptr_t)dx % 16 == 0), "token_mean_bwd: unaligned");
+    const long long total4 = (long long)B * N * (D / 4);
+    hipLaunchKernelGGL(token_mean_bwd_kernel, dim3((unsigned)cdiv64(total4, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, D, total4);
+    return mmae_check_launch("token_mean_bwd");
 }
 int mmae_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream) {
     MMAE_REQUIRE(y && x && n >= 0, "axpy: bad argument");

@@ -591,6 +591,30 @@ class LayerNormFn(torch.autograd.Function):
         return dx.view(ctx.shp), sink.vec(ctx.wb[0], dg), sink.vec(ctx.wb[1], db), None
 
 
+class TokenMeanFn(torch.autograd.Function):
+    """(B, N, D) -> (B, D) mean over tokens (LinearOutputAdapter's pooling, output_adapters.py:346-347)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        from . import _lib
+        ops._require_gpu(x, 'token mean input')
+        B, N, D = x.shape
+        x = x.contiguous().float()
+        y = torch.empty((B, D), device=x.device, dtype=torch.float32)
+        ops.check(_lib.load().mmae_token_mean_fwd(x.data_ptr(), y.data_ptr(), B, N, D, ops._stream()), 'token_mean_fwd')
+        ctx.dims = (B, N, D)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        from . import _lib
+        B, N, D = ctx.dims
+        dy = dy.contiguous().float()
+        dx = torch.empty((B, N, D), device=dy.device, dtype=torch.float32)
+        ops.check(_lib.load().mmae_token_mean_bwd(dy.data_ptr(), dx.data_ptr(), B, N, D, ops._stream()), 'token_mean_bwd')
+        return dx
+
+
 class AttentionCoreFn(torch.autograd.Function):
     """softmax(q k^T scale) v on packed activations; used by the stand-alone Attention / CrossAttention modules."""
 

@@ -8,8 +8,9 @@ in init()).  forward() is ONE autograd node (functions.SpatialAdapterFn) whose f
 backward are fixed HIP kernel sequences; the (B, N_total, D) mask-token tensor of the
 reference is never materialised.
 
-The fine-tuning heads of the reference (Linear / Segmenter / ConvNeXt / DPT adapters) are out
-of scope for the pre-training hot path.
+LinearOutputAdapter (output_adapters.py:285-356, the classification head of the MultiViT fine-tuning forward,
+SURVEY.md section 8f row 4) is built on the same kernels.  The dense-prediction fine-tuning heads (Segmenter / ConvNeXt /
+DPT adapters) are out of scope for the pre-training hot path.
 """
 from __future__ import annotations
 
@@ -21,7 +22,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import engine
-from .functions import SpatialAdapterFn
+from .functions import SpatialAdapterFn, TokenMeanFn
 from .multimae_utils import (Block, CrossAttention, LayerNorm, Linear, Mlp, _as_hip_norm, _cfg, block_params,
                              build_2d_sincos_posemb, pair, trunc_normal_)
 
@@ -161,3 +162,51 @@ class SpatialOutputAdapter(nn.Module):
                    C=self.num_channels, nh=nh, nw=nw, ph=self.P_H, pw=self.P_W, on_done=on_done, f32_gemm=f32_gemm,
                    enc_act=encoder_tokens_act)
         return SpatialAdapterFn.apply(cfg, encoder_tokens, ids_keep.contiguous(), ids_restore.contiguous(), *self._params(in_tasks))
+
+
+class LinearOutputAdapter(nn.Module):
+    """Linear classification head (output_adapters.py:285-356): mean over the encoder tokens (or the last = global token),
+    LayerNorm, Linear.  Same constructor, parameter names (norm.*, head.*) and seeded initialisation as the reference."""
+
+    def __init__(self, num_classes: int, dim_tokens_enc: Optional[int] = None, use_mean_pooling: bool = True,
+                 norm_layer: nn.Module = partial(nn.LayerNorm, eps=1e-6), init_scale: float = 1.0):
+        super().__init__()
+        self.num_classes = num_classes
+        self.dim_tokens_enc = dim_tokens_enc
+        self.use_mean_pooling = use_mean_pooling
+        self.norm_layer = norm_layer
+        self.init_scale = init_scale
+        if self.dim_tokens_enc is not None:
+            self.init(dim_tokens_enc=dim_tokens_enc)
+
+    def init(self, dim_tokens_enc: int = 768):
+        self.dim_tokens_enc = dim_tokens_enc
+        self.norm = _as_hip_norm(self.norm_layer, self.dim_tokens_enc)
+        self.head = Linear(dim_tokens_enc, self.num_classes) if self.num_classes > 0 else nn.Identity()
+        self.apply(self._init_weights)
+        if self.num_classes > 0:
+            self.head.weight.data.mul_(self.init_scale)
+            self.head.bias.data.mul_(self.init_scale)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def get_classifier(self):
+        return self.head
+
+    def reset_classifier(self, num_classes, global_pool=''):
+        self.num_classes = num_classes
+        self.init(dim_tokens_enc=self.dim_tokens_enc)
+
+    def forward(self, encoder_tokens: torch.Tensor, **kwargs):
+        if self.use_mean_pooling:
+            x = TokenMeanFn.apply(encoder_tokens)
+        else:
+            x = encoder_tokens[:, -1]                       # the global token is appended last (multimae.py:344-347)
+        return self.head(self.norm(x))

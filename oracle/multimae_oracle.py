@@ -445,6 +445,14 @@ def pretrain_losses(preds: Dict[str, Tensor], targets: Dict[str, Tensor], mask_a
     return out
 
 
+def linear_output_adapter(encoder_tokens: Tensor, sd: Dict[str, Tensor], prefix: str = '', use_mean_pooling: bool = True,
+                          eps: float = 1e-6) -> Tensor:
+    """LinearOutputAdapter.forward (output_adapters.py:341-352): mean over tokens (or the last token), LayerNorm, Linear."""
+    x = encoder_tokens.mean(1) if use_mean_pooling else encoder_tokens[:, -1]
+    x = F.layer_norm(x, (x.shape[-1],), sd[prefix + 'norm.weight'], sd[prefix + 'norm.bias'], eps)
+    return F.linear(x, sd[prefix + 'head.weight'], sd[prefix + 'head.bias'])
+
+
 def truncated_depth_standardize(depth: Tensor, lo: float = 0.1, hi: float = 0.9, eps: float = 1e-6) -> Tensor:
     """Truncated depth standardisation of the training loop (run_pretraining_multimae.py:487-492): per sample, sort all
     c*h*w values, drop the bottom and top 10 % (slice [int(lo*n), int(hi*n)) of the sorted row), and standardise the whole map

@@ -164,3 +164,21 @@ def test_host_inputs_refresh_protocol():
     # eager mode: host_input just evaluates the thunk
     assert engine.capturing() is None
     assert float(engine.host_input(make('c'), 'cpu')) == 5.0
+
+
+def test_linear_output_adapter_seeded_init_and_oracle():
+    """Same RNG consumption as the reference's LinearOutputAdapter.init (trunc-normal head, output_adapters.py:313-336): a
+    seeded construction reproduces its weights bit for bit; the oracle restatement reproduces the reference outputs."""
+    import os
+    import numpy as np
+    import multimae_amd as M
+    import multimae_oracle as orc
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'linear_head.npz'))
+    torch.manual_seed(32)
+    h = M.LinearOutputAdapter(num_classes=10, dim_tokens_enc=32)
+    assert list(h.state_dict()) == ['norm.weight', 'norm.bias', 'head.weight', 'head.bias']
+    assert torch.equal(h.head.weight.detach(), torch.from_numpy(z['init/head.weight']))
+    for pool in ('mean', 'last'):
+        sd = {k[len(pool) + 4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pool + '/sd/')}
+        y = orc.linear_output_adapter(torch.from_numpy(z[pool + '/x']), sd, use_mean_pooling=(pool == 'mean'))
+        assert torch.allclose(y, torch.from_numpy(z[pool + '/y']), atol=1e-6)

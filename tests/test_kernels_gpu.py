@@ -288,6 +288,11 @@ def test_softmax_colsum_cast_transpose():
         out = torch.ones(264, device=DEV)
         ops.colsum(dyd, out, True)
         assert rel_err(out, 1.0 + dyd.float().cpu().sum(0)) < 1e-5
+    # ragged widths (a 7-class head): the one-column-per-lane kernel
+    dy = torch.randn(1003, 7).to(DEV)
+    out = torch.zeros(7, device=DEV)
+    ops.colsum(dy, out, False)
+    assert rel_err(out, dy.double().sum(0).cpu()) < 1e-5
     # scattered column sums: short/wide partial blocks (the LayerNorm / dGELU reductions), segments to separate
     # destinations, a dropped segment, accumulate on and off
     for M_, seg, nseg in ((512, 768, 3), (396, 3072, 1), (7, 64, 5), (25344, 256, 2)):

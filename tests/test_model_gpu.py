@@ -373,6 +373,29 @@ def test_checkpoint_resume_and_shadow_invalidation(tmp_path):
         M.engine.set_direct_grads(False)
 
 
+@pytest.mark.parametrize('pool', ['mean', 'last'])
+def test_linear_output_adapter_vs_reference_golden(pool):
+    """LinearOutputAdapter (output_adapters.py:285-356; fixture from the reference class, tests/golden/make_golden_linear.py):
+    forward and all gradients in the fp32 parity mode, forward within bf16 tolerance in speed mode."""
+    import numpy as np, os
+    import multimae_amd as M
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'linear_head.npz'))
+    g = lambda k: torch.from_numpy(z[f'{pool}/{k}'])
+    head = M.LinearOutputAdapter(num_classes=7, dim_tokens_enc=16, use_mean_pooling=(pool == 'mean'))
+    head.load_state_dict({k[len(pool) + 4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pool + '/sd/')})
+    head.to(DEV)
+    with M.engine.precision('fp32'):
+        x = g('x').to(DEV).requires_grad_(True)
+        y = head(x)
+        (y * g('w').to(DEV)).sum().backward()
+    assert rel_err(y, g('y')) < 2e-5
+    assert rel_err(x.grad, g('dx')) < 2e-4
+    for n, p in head.named_parameters():
+        assert rel_err(p.grad, g('grad/' + n)) < 2e-4, n
+    with M.engine.precision('bf16'):
+        assert rel_err(head(g('x').to(DEV)), g('y')) < 1.5e-2
+
+
 def _known_answer_case(name, doms, P, S, nvis, enc, posemb, mode, fp32_adapters=()):
     """Reproduce the reference's recorded step (tests/golden/scalars.json, SURVEY Appendix B recipe): same seeded init
     (bit-identical weights), same inputs (seed stream), same masks (the reference drew them on the CPU generator after
