@@ -396,6 +396,64 @@ def test_linear_output_adapter_vs_reference_golden(pool):
         assert rel_err(head(g('x').to(DEV)), g('y')) < 1.5e-2
 
 
+def test_forward_api_edge_paths_vs_reference_golden():
+    """The rarely used branches of MultiMAE.forward / generate_random_masks against outputs of the reference model on the same
+    weights (tests/golden/make_golden_api.py): uniform task sampling with per-task alphas (multimae.py:148-162,182-186; same CPU
+    RNG stream, the reference's four noise draws injected), task_masks= for B = 1 (the notebook path, :335-338 -- the visible
+    token ORDER is implementation-defined there, the predictions are not), mask_inputs=False (:324-326), and the two
+    AttributeErrors the reference raises."""
+    import numpy as np, os
+    import multimae_amd as M
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'api_paths.npz'))
+    g = load_mini()
+    model = build_mini_engine()
+    model.load_state_dict(g['sd'])
+    model.to(DEV).eval()
+    doms = MINI['doms']
+    # ---- uniform task sampling: masks / ids bit-exact
+    noise = [torch.from_numpy(z[f'uniform/noise{i}']).to(DEV) for i in range(4)]
+    it = iter(noise)
+    real_rand = torch.rand
+
+    def fake_rand(*size, **kw):
+        if kw.get('device') is not None and torch.device(kw['device']).type == 'cuda':
+            return next(it)
+        return real_rand(*size, **kw)
+    torch.manual_seed(5)
+    torch.rand = fake_rand
+    try:
+        tm, k, r = model.generate_random_masks({d: 16 for d in doms}, MINI['nvis'], alphas=[1.0, 0.5, 2.0], sample_tasks_uniformly=True,
+                                               batch_size=3, device=DEV)
+    finally:
+        torch.rand = real_rand
+    assert torch.equal(k.cpu(), torch.from_numpy(z['uniform/ids_keep'])) and torch.equal(r.cpu(), torch.from_numpy(z['uniform/ids_restore']))
+    for d in doms:
+        assert torch.equal(tm[d].cpu(), torch.from_numpy(z['uniform/mask/' + d]))
+    x = {kk: v.to(DEV) for kk, v in g['x'].items()}
+    with M.engine.precision('fp32'), torch.no_grad():
+        # ---- given masks, B = 1
+        x1 = {kk: v[:1] for kk, v in x.items()}
+        given = {d: torch.from_numpy(z['given/in/' + d]).to(DEV) for d in doms}
+        preds, masks = model(x1, task_masks=given)
+        for d in doms:
+            assert torch.equal(masks[d].cpu(), torch.from_numpy(z['given/mask/' + d]))
+        for kk in preds:
+            assert rel_err(preds[kk], torch.from_numpy(z['given/pred/' + kk])) < 5e-5, kk
+        # ---- every token encoded
+        x2 = {kk: v[:2] for kk, v in x.items()}
+        preds, masks = model(x2, mask_inputs=False)
+        assert all(int(m.sum()) == 0 for m in masks.values())
+        for kk in preds:
+            assert rel_err(preds[kk], torch.from_numpy(z['nomask/pred/' + kk])) < 5e-5, kk
+    with pytest.raises(AttributeError):
+        model(x, num_encoded_tokens=None)
+    with pytest.raises(AttributeError):
+        M.SpatialOutputAdapter(num_channels=3, stride_level=1, patch_size_full=8, dim_tokens_enc=128, dim_tokens=64, task='rgb',
+                               context_tasks=None, image_size=32).to(DEV)(torch.zeros(1, 13, 128, device=DEV), {'image_size': (32, 32), 'tasks': {}},
+                                                                          torch.zeros(1, 12, dtype=torch.long, device=DEV),
+                                                                          torch.zeros(1, 48, dtype=torch.long, device=DEV))
+
+
 def _known_answer_case(name, doms, P, S, nvis, enc, posemb, mode, fp32_adapters=()):
     """Reproduce the reference's recorded step (tests/golden/scalars.json, SURVEY Appendix B recipe): same seeded init
     (bit-identical weights), same inputs (seed stream), same masks (the reference drew them on the CPU generator after
