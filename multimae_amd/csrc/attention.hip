@@ -281,10 +281,15 @@ __global__ void __launch_bounds__(256, (NT == 4 && !X3) ? 3 : (NT <= 7 ? 2 : 1))
 }
 
 // -------------------------------------------------------------------------------------------------
-// 512 threads: after the shared prologue (tiles -> LDS, delta), waves 0-3 run pass 1 and waves 4-7 run
-// pass 2 concurrently (the passes only read LDS and write disjoint outputs).
-template <int HD, bool X3>
-__global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs a) {
+// NW = 8 (512 threads): after the shared prologue (tiles -> LDS, delta), waves 0-3 run pass 1 and waves 4-7 run pass 2
+// concurrently (the passes only read LDS and write disjoint outputs).  NW = 4 (256 threads): the same four waves run pass 1,
+// then pass 2.  At head_dim 64 the passes need ~209 VGPRs, so a CU holds 8 waves either way -- as ONE 8-wave workgroup whose
+// prologue (tile loads, LDS commit, delta, barrier) nothing overlaps, or as TWO 4-wave workgroups that overlap each other's
+// prologue and compute: 111 vs 132 us on the encoder geometry.  At head_dim 32 (123 VGPRs, two 8-wave workgroups per CU
+// already) the 8-wave form is the faster one (107 vs 120 us).
+template <int HD, bool X3, int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(const AttnArgs a) {
+    constexpr int NTH = NW * 64;
     typedef typename ActOf<X3>::T AT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
@@ -304,27 +309,27 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs a) {
     const AT* vg = (const AT*)a.v + b * a.v_sb + h * HD;
     if constexpr (X3) {
         {
-            TileLoaderF32<HD, 512> lq, ld;
+            TileLoaderF32<HD, NTH> lq, ld;
             lq.issue(qg, a.q_sr, a.Nq, a.nqp, tid);
             ld.issue(dog, a.o_sr, a.Nq, a.nqp, tid);
-            for (int q = tid; q < a.nqp; q += 512) lse_s[q] = q < a.Nq ? a.lse[((long long)b * a.H + h) * a.Nq + q] : 0.f;
+            for (int q = tid; q < a.nqp; q += NTH) lse_s[q] = q < a.Nq ? a.lse[((long long)b * a.H + h) * a.Nq + q] : 0.f;
             lq.commit(Qs, lo, a.nqp, tid);
             ld.commit(dOs, lo, a.nqp, tid);
         }
         {
-            TileLoaderF32<HD, 512> lk, lv;
+            TileLoaderF32<HD, NTH> lk, lv;
             lk.issue(kg, a.k_sr, a.Nk, a.nkp, tid);
             lv.issue(vg, a.v_sr, a.Nk, a.nkp, tid);
             lk.commit(Ks, lo, a.nkp, tid);
             lv.commit(Vs, lo, a.nkp, tid);
         }
     } else {
-        TileLoader<HD, 512> lq, ld, lk, lv;
+        TileLoader<HD, NTH> lq, ld, lk, lv;
         lq.issue(qg, a.q_sr, a.Nq, a.nqp, tid);
         ld.issue(dog, a.o_sr, a.Nq, a.nqp, tid);
         lk.issue(kg, a.k_sr, a.Nk, a.nkp, tid);
         lv.issue(vg, a.v_sr, a.Nk, a.nkp, tid);
-        for (int q = tid; q < a.nqp; q += 512) lse_s[q] = q < a.Nq ? a.lse[((long long)b * a.H + h) * a.Nq + q] : 0.f;
+        for (int q = tid; q < a.nqp; q += NTH) lse_s[q] = q < a.Nq ? a.lse[((long long)b * a.H + h) * a.Nq + q] : 0.f;
         lq.commit(Qs, a.nqp, tid);
         ld.commit(dOs, a.nqp, tid);
         lk.commit(Ks, a.nkp, tid);
@@ -334,7 +339,7 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs a) {
     const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void*)og, 0, 0x80000000, 0x00020000);
     const auto rsdO = __builtin_amdgcn_make_buffer_rsrc((void*)dog, 0, 0x80000000, 0x00020000);
     // delta[q] = sum_d dO[q][d] * O[q][d]
-    for (int qblk = wave; qblk < nqb; qblk += 8) {
+    for (int qblk = wave; qblk < nqb; qblk += NW) {
         const int q = qblk * 32 + (lane & 31);
         const bool qok = q < a.Nq;
         float d = 0.f;
@@ -361,7 +366,7 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs a) {
     __syncthreads();
 
     // ---- pass 1 (waves 0-3): lane = query row -> dQ
-    for (int qblk = wave; wave < 4 && qblk < nqb; qblk += 4) {
+    for (int qblk = wave; (NW == 4 || wave < 4) && qblk < nqb; qblk += 4) {
         const int q = qblk * 32 + (lane & 31);
         const bool qok = q < a.Nq;
         bf16x8 qf[HD / 16], dof[HD / 16], ql[HD / 16], dol[HD / 16];
@@ -415,8 +420,8 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs a) {
         }
     }
 
-    // ---- pass 2 (waves 4-7): lane = key row -> dK, dV
-    for (int kblk = wave - 4; wave >= 4 && kblk < nt; kblk += 4) {
+    // ---- pass 2 (NW = 8: waves 4-7; NW = 4: the same waves again): lane = key row -> dK, dV
+    for (int kblk = (NW == 8 ? wave - 4 : wave); (NW == 4 || wave >= 4) && kblk < nt; kblk += 4) {
         const int key = kblk * 32 + (lane & 31);
         bf16x8 kf[HD / 16], vf[HD / 16], kl[HD / 16], vl[HD / 16];
 #pragma unroll
@@ -540,14 +545,15 @@ static int attn_bwd_impl(bool x3, const void* q, const void* k, const void* v, c
     const size_t lds = (size_t)2 * (a.nqp + a.nkp) * hd * 2 * (x3 ? 2 : 1) + (size_t)2 * a.nqp * 4;
     if (lds > 160 * 1024) { mmae_set_error("attn_bwd: tiles exceed the 160 KB LDS (f32 split path: (Nq + Nk) * head_dim too large)"); return MMAE_ESUPPORT; }
     hipStream_t st_ = (hipStream_t)stream;
-    dim3 grid(B * H), block(512);
-#define LAUNCH_BWD(HD, X3)                                                                                                   \
+    dim3 grid(B * H);
+#define LAUNCH_BWD(HD, X3, NW)                                                                                               \
     do {                                                                                                                     \
-        hipFuncSetAttribute((const void*)attn_bwd_kernel<HD, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
-        hipLaunchKernelGGL((attn_bwd_kernel<HD, X3>), grid, block, lds, st_, a);                                             \
+        hipFuncSetAttribute((const void*)attn_bwd_kernel<HD, X3, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((attn_bwd_kernel<HD, X3, NW>), grid, dim3(NW * 64), lds, st_, a);                                 \
     } while (0)
-    if (x3) { if (hd == 64) LAUNCH_BWD(64, true); else LAUNCH_BWD(32, true); }
-    else { if (hd == 64) LAUNCH_BWD(64, false); else LAUNCH_BWD(32, false); }
+    if (x3) { if (hd == 64) LAUNCH_BWD(64, true, 8); else LAUNCH_BWD(32, true, 8); }
+    else if (hd == 64) { if (lds <= 80 * 1024) LAUNCH_BWD(64, false, 4); else LAUNCH_BWD(64, false, 8); }
+    else LAUNCH_BWD(32, false, 8);
 #undef LAUNCH_BWD
     return mmae_check_launch("attn_bwd");
 }
