@@ -453,7 +453,9 @@ int mmae_layernorm_fwd(const float* x, const float* gamma, const float* beta, vo
     return mmae_check_launch("layernorm_fwd");
 }
 
-int mmae_layernorm_bwd_nblk(int64_t R) { const int64_t b = cdiv64(R, 4); return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }
+// workgroups (= rows of the partial block): 4 rows per workgroup pass, capped at 1 024 -- 2 048 for the long, narrow decoder
+// activations (50 176 x 256), whose one-float4-per-lane rows need more waves in flight to cover the HBM latency
+int mmae_layernorm_bwd_nblk(int64_t R) { const int64_t b = cdiv64(R, 4), cap = R >= 32768 ? 2048 : 1024; return (int)(b < 1 ? 1 : (b > cap ? cap : b)); }
 
 int mmae_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
                        const float* rstd, const float* dx_in, float* dx_out, void* dx_act, int dx_act_dtype, float* part,
