@@ -68,3 +68,69 @@ def test_grad_allreduce_world2_gloo():
     for rank, ok, launched_mid in res:
         assert ok, f'rank {rank}: {launched_mid}'
         assert any(launched_mid) and not all(launched_mid), 'buckets must launch incrementally as layers finish'
+
+
+def _model_worker(rank, world, port, q):
+    try:
+        import sys
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path[:0] = [here, os.path.join(os.path.dirname(here), 'oracle')]
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        import dryrun_harness
+        dryrun_harness.install()                      # C ABI stubbed: the host-side control flow runs, kernels do not
+        import multimae_amd as M
+        from multimae_amd.dist import attach, broadcast_parameters
+        from helpers import MINI, build_mini_engine, load_mini
+        torch.manual_seed(100 + rank)                 # ranks build different initial weights (run_pretraining_multimae.py:300)
+        model = build_mini_engine()
+        arena = model.build_arena()
+        before = arena.param.clone()
+        broadcast_parameters(arena)                   # DDP-constructor semantics: rank 0's values everywhere
+        gathered = [torch.empty_like(arena.param) for _ in range(world)]
+        dist.all_gather(gathered, arena.param)
+        same_params = all(torch.equal(g, gathered[0]) for g in gathered)
+        red = GradAllReducer.for_arena(arena, bucket_mb=0.25)
+        attach(model, red)
+        order = []
+        launch = red._launch
+        red._launch = lambda i: (order.append(i) if not red._launched[i] else None, launch(i))[1]
+        g = load_mini()
+        P = MINI['P']
+        fns = {'rgb': M.MaskedMSELoss(P, 1), 'depth': M.MaskedL1Loss(P, 1), 'semseg': M.MaskedCrossEntropyLoss(P, 4),
+               'norm_rgb': M.MaskedMSELoss(P, 1, norm_pix=True)}
+        M.engine.set_direct_grads(True)
+        arena.grad.fill_(float(rank + 1))             # stand-in gradients (the stubbed kernels write nothing)
+        with M.engine.precision('bf16'):
+            preds, masks = model(g['x'], num_encoded_tokens=MINI['nvis'], alphas=1.0, fp32_output_adapters=['semseg'])
+            mk = dict(masks, norm_rgb=masks['rgb'])
+            tgt = dict(g['x'], norm_rgb=g['x']['rgb'])
+            sum(fns[k](preds[k].float(), tgt[k], mask=mk[k]) for k in preds).backward()
+        mid = sum(red._launched)
+        red.finish()
+        ok = bool(torch.allclose(arena.grad, torch.full_like(arena.grad, (1 + world) / 2)))
+        q.put((rank, ok and same_params and (rank == 0 or not torch.equal(before, arena.param)), order, mid, len(red.buckets)))
+        dist.destroy_process_group()
+    except Exception as e:          # noqa: BLE001
+        import traceback
+        q.put((rank, False, traceback.format_exc(), 0, 0))
+
+
+def test_model_backward_drives_reducer_world2_gloo():
+    """The real model's backward (host control flow on the stubbed C ABI) drives the bucketed all-reduce on two gloo ranks: the
+    adapters' and encoder layers' completion callbacks launch buckets in the SAME order on both ranks while backward is still
+    running, finish() reduces the rest, every gradient element ends up averaged, and broadcast_parameters leaves both ranks
+    with rank 0's weights."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_model_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    for rank, ok, order, mid, nb in res:
+        assert ok, f'rank {rank}: {order}'
+        assert nb >= 4 and 0 < mid < nb, (mid, nb)            # some buckets launched from inside backward, not all
+    assert res[0][2] == res[1][2], 'ranks must issue their collectives in the same order'
