@@ -152,6 +152,8 @@ def main():
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--adapter-streams', type=int, default=1, help='1: output adapters on separate HIP streams')
     ap.add_argument('--wgrad-stream', type=int, default=1, help='1: weight-gradient GEMMs on a side stream')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend for --gpus > 1 ('nccl' = RCCL; 'gloo' for functional tests)")
+    ap.add_argument('--share-device', type=int, default=0, help='1: every rank uses cuda:0 (functional test of the multi-process path on one GPU; use with --backend gloo)')
     ap.add_argument('--graph', type=int, default=-1, help='1: capture the step once as a hipGraph and replay it (multimae_amd.graph.StepGraph; 1 GPU only). Default 0: on ROCm 7.2 the replay of this ~1 100-node, 10-stream graph measured 46.2 ms/step against 44.1 ms eager')
     args = ap.parse_args()
 
@@ -164,10 +166,15 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.share_device:
+        local = 0
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, f'launch with torch.distributed.run --nproc-per-node {args.gpus}'
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(args.backend)
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
 
