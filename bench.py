@@ -24,13 +24,13 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-ALG_GFLOP_PER_IMG = {'cfg3': 65.4, 'cfg2': 57.4}   # GEMM flops fwd+bwd, visible-patch embedding (SURVEY 8d / BASELINE.md 2)
+ALG_GFLOP_PER_IMG = {'cfg3': 65.4, 'cfg2': 57.4, 'cfg5': 382.0}   # GEMM flops fwd+bwd, visible-patch embedding (SURVEY 8d / BASELINE.md 2; cfg5: 385.39 with all patches embedded)
 PEAK_BF16_TFLOPS = 2500.0                            # dense MFMA bf16, MI355X_MICROARCH.md
 
 
 def build_model(cfg: str):
     import multimae_amd as M
-    doms = ['rgb', 'depth', 'semseg'] if cfg == 'cfg3' else ['rgb']
+    doms = ['rgb'] if cfg == 'cfg2' else ['rgb', 'depth', 'semseg']
     ins = {}
     for d in doms:
         if d == 'semseg':
@@ -44,7 +44,7 @@ def build_model(cfg: str):
         outs[key] = M.SpatialOutputAdapter(num_channels=ch, stride_level=4 if task == 'semseg' else 1, patch_size_full=16,
                                            dim_tokens=256, depth=2, num_heads=8, use_task_queries=True, task=task,
                                            context_tasks=list(doms), use_xattn=True)
-    model = M.create_model('pretrain_multimae_base', input_adapters=ins, output_adapters=outs, num_global_tokens=1,
+    model = M.create_model('pretrain_multimae_large' if cfg == 'cfg5' else 'pretrain_multimae_base', input_adapters=ins, output_adapters=outs, num_global_tokens=1,
                            drop_path_rate=0.0)
     return model.train(), doms
 
@@ -142,8 +142,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=256, help='per-GPU batch')
-    ap.add_argument('--config', default='cfg3', choices=['cfg3', 'cfg2'])
+    ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default 256; 128 for cfg5)')
+    ap.add_argument('--config', default='cfg3', choices=['cfg3', 'cfg2', 'cfg5'],
+                    help='cfg3 = BASELINE.json configs[2] (the metric), cfg2 = configs[1] (RGB-only), cfg5 = configs[4] geometry (ViT-L, 196 visible tokens; bf16 -- the MX-fp8 path is not built)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-batch', type=int, default=8)
@@ -191,7 +192,8 @@ def main():
     M.engine.set_direct_grads(True)
     M.engine.set_adapter_streams(bool(args.adapter_streams))
     M.engine.set_wgrad_stream(bool(args.wgrad_stream))
-    B = args.batch
+    B = args.batch or (128 if args.config == 'cfg5' else 256)
+    n_vis = 196 if args.config == 'cfg5' else 98
     lr = 1e-4 * B * world / 256                                   # blr * global_bs / 256 (:372-373)
     opt = FusedAdamW(model, lr=lr, betas=(0.9, 0.95), weight_decay=0.05)
     x = synthetic_batch(doms, B, device, seed=rank)
@@ -202,7 +204,7 @@ def main():
 
     def step():
         opt.zero_grad()
-        preds, masks = model(x, num_encoded_tokens=98, alphas=1.0, sample_tasks_uniformly=False, fp32_output_adapters=fp32_adapters)
+        preds, masks = model(x, num_encoded_tokens=n_vis, alphas=1.0, sample_tasks_uniformly=False, fp32_output_adapters=fp32_adapters)
         mk = dict(masks, norm_rgb=masks['rgb'])
         losses = {k: fns[k](preds[k].float(), tgt[k], mask=mk[k]) for k in preds}
         loss = sum(losses.values())
@@ -305,21 +307,23 @@ def main():
                 'whole_step_frac_of_peak': round(ALG_GFLOP_PER_IMG[args.config] * 1e9 * B / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config != 'cfg5':      # the CPU leg is sized for the ViT-B configs
         M.engine.set_direct_grads(False)
         cpu = cpu_baseline(args.config, args.cpu_sample_batch, args.cpu_steps, args.cpu_threads)
 
     if rank == 0:
         out = {
-            'metric': 'pre-train images/sec (whole node), ViT-B RGB+D+S 224^2 98-vis-tok' if args.config == 'cfg3'
-                      else 'pre-train images/sec (whole node), ViT-B RGB-only 224^2 98-vis-tok',
+            'metric': {'cfg3': 'pre-train images/sec (whole node), ViT-B RGB+D+S 224^2 98-vis-tok',
+                       'cfg2': 'pre-train images/sec (whole node), ViT-B RGB-only 224^2 98-vis-tok',
+                       'cfg5': 'pre-train images/sec (whole node), ViT-L RGB+D+S 224^2 196-vis-tok'}[args.config],
             'value': round(img_s, 1), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.precision if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
-            'config': {'workload': f'BASELINE.json configs[{2 if args.config == "cfg3" else 1}]: ViT-B, '
-                                   + ('RGB+depth+semseg' if args.config == 'cfg3' else 'RGB-only')
-                                   + ', 224^2, Dirichlet alpha=1.0, 98 visible tokens, 4 cross-attention decoders (dim 256, depth 2), '
-                                     'fp32 semseg adapter, AdamW; fwd+losses+bwd+optimizer',
+            'config': {'workload': f'BASELINE.json configs[{ {"cfg3": 2, "cfg2": 1, "cfg5": 4}[args.config] }]: '
+                                   + ('ViT-L (bf16; the MX-fp8 path is not built), ' if args.config == 'cfg5' else 'ViT-B, ')
+                                   + ('RGB-only' if args.config == 'cfg2' else 'RGB+depth+semseg')
+                                   + f', 224^2, Dirichlet alpha=1.0, {n_vis} visible tokens, {len(doms) + 1} cross-attention decoders (dim 256, depth 2), '
+                                   + ('fp32 semseg adapter, ' if 'semseg' in doms else '') + 'AdamW; fwd+losses+bwd+optimizer',
                        'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}'},
             'final_loss': round(final_loss, 5), 'launch': 'hipGraph replay of the captured step' if use_graph else 'eager (one host launch per kernel)',
             'host_enqueue_ms_per_step': round(host_ms, 3),
