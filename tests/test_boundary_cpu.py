@@ -182,3 +182,25 @@ def test_linear_output_adapter_seeded_init_and_oracle():
         sd = {k[len(pool) + 4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pool + '/sd/')}
         y = orc.linear_output_adapter(torch.from_numpy(z[pool + '/x']), sd, use_mean_pooling=(pool == 'mean'))
         assert torch.allclose(y, torch.from_numpy(z[pool + '/y']), atol=1e-6)
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """The newest committed bench line (profiles/r01_bench_cfg3_v*.json, written by bench.py on an MI355X) carries every field of
+    the measurement contract: the driver's keys, the roofline object of the dominant kernel and the CPU baseline."""
+    import glob
+    import json
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, 'profiles', 'r01_bench_cfg3_v*.json')), key=lambda f: int(re.search(r'_v(\d+)', f).group(1)))
+    d = json.load(open(files[-1]))
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
+              'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['unit'] == 'images/s' and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert d['dtype'] == 'bf16' and d['data'] == 'synthetic' and 'workload' in d['config'] and 'model' not in d['config']
+    assert abs(d['value'] - d['config']['global_batch'] / d['ms_per_step'] * 1e3) < 0.01 * d['value']
+    r = d['roofline']
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    assert r['traffic'] is None or r['traffic'] > 0
+    c = d['cpu_baseline']
+    assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['sample']
