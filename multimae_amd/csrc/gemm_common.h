@@ -19,6 +19,7 @@ struct GemmArgs {
     int xcd_swizzle;
     float* acs;                   // optional [splitk][M] partial column sums of the k-strided A operand (ping-pong kernel)
     float* colpart;               // optional [ceil(M/64)][N] column sums of the epilogue output (dGELU flavour)
+    int wide_st;                  // bf16 epilogues with 8-column (16-byte) lanes (store_tile64_bf16x8); env MMAE_EPI_WIDE=0 turns it off
 };
 
 // XCD-aware tile order (MI355X: workgroup b runs on XCD b % 8, each XCD has its own 4 MiB L2): hand every XCD a
@@ -247,6 +248,88 @@ __device__ __forceinline__ void store_tile64_fast(const GemmArgs& g, char* Cbase
     }
 }
 
+// bf16 C (and bf16 aux) with 16-byte global accesses: a lane owns EIGHT consecutive columns of a row (8 lanes x 8 columns
+// per 64-column row, 8 rows per step, 4 steps per 32-row MFMA tile), so every store / aux access is a dwordx4 instead of the
+// dwordx2 of the 4-column layout above -- half the vector-memory instructions.  The epilogue's tail is store-ISSUE-bound
+// (MI355X_MICROARCH.md: 16 x dwordx2 per lane ~ 2x the cycles of 8 x dwordx4), and the GELU / dGELU products issue two bf16
+// streams per element.  Needs N, ldc (and ldaux) multiples of 8 and 16-byte aligned bases; flavours: bf16 C, no residual,
+// no accumulate, bf16 aux.
+__device__ __forceinline__ i32x4 pack8_bf16(const f32x4 a, const f32x4 b) {
+    const i32x2 lo = pack4_bf16(a), hi = pack4_bf16(b);
+    i32x4 r; r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
+    return r;
+}
+template <bool BIAS, int EPI, bool COLSUM>
+__device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cbase, char* wave_lds, int lane, const f32x16 (&acc)[2][2],
+                                                    int m_base, int n_base, int ntm) {
+    constexpr unsigned OOB_OFF = 0x80000000u;
+    const int c8 = lane & 7, r8 = lane >> 3;
+    const int n = n_base + c8 * 8;
+    const bool n_ok = n < g.N;
+    const int rows_left = g.M - m_base;
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (BIAS && n_ok) { b0 = ld4(g.bias + n); b1 = ld4(g.bias + n + 4); }
+    f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = cs0;
+    const auto rsC = row_rsrc((uint16_t*)Cbase, m_base, g.ldc);
+    const auto rsAux = (EPI != MMAE_EPI_NONE) ? row_rsrc((uint16_t*)g.aux, m_base, g.ldaux) : rsC;
+    auto voff = [&](int gi, long long ld) -> int {       // gi = global 8-row step: tm * 4 + it
+        const int r = gi * 8 + r8;
+        return (n_ok && r < rows_left) ? (int)((r * ld + n) * 2) : (int)OOB_OFF;
+    };
+    const int nsteps = ntm * 4;
+    constexpr int PD = 4;                                // dGELU: pre-activation rows prefetched 4 steps (32 rows) ahead
+    i32x4 pre_aux[PD];
+    if (EPI == MMAE_EPI_DGELU) {
+#pragma unroll
+        for (int gi = 0; gi < PD; ++gi) if (gi < nsteps) pre_aux[gi] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, voff(gi, g.ldaux), 0, 0);
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+        if (tm < ntm) {
+            stage_acc_tile(wave_lds, lane, acc, tm);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int gi = tm * 4 + it, r = it * 8 + r8;
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(wave_lds + r * 256 + (((2 * c8) ^ (r & 15)) << 4));
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(wave_lds + r * 256 + (((2 * c8 + 1) ^ (r & 15)) << 4));
+                const bool ok = n_ok && (tm * 32 + r) < rows_left;
+                if (BIAS) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v0[j] += b0[j]; v1[j] += b1[j]; }
+                }
+                if (EPI == MMAE_EPI_GELU) {
+                    __builtin_amdgcn_raw_buffer_store_b128(pack8_bf16(v0, v1), rsAux, voff(gi, g.ldaux), 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v0[j] = gelu_erf(v0[j]); v1[j] = gelu_erf(v1[j]); }
+                } else if (EPI == MMAE_EPI_DGELU) {
+                    const i32x4 pa = pre_aux[gi % PD];
+                    i32x2 lo2, hi2; lo2[0] = pa[0]; lo2[1] = pa[1]; hi2[0] = pa[2]; hi2[1] = pa[3];
+                    const f32x4 p0 = unpack4_bf16(lo2), p1 = unpack4_bf16(hi2);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v0[j] *= gelu_erf_grad(p0[j]); v1[j] *= gelu_erf_grad(p1[j]); }
+                    if (gi + PD < nsteps) pre_aux[gi % PD] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, voff(gi + PD, g.ldaux), 0, 0);
+                }
+                if (COLSUM) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { cs0[j] += ok ? v0[j] : 0.f; cs1[j] += ok ? v1[j] : 0.f; }
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(pack8_bf16(v0, v1), rsC, voff(gi, g.ldc), 0, 0);
+            }
+        }
+    }
+    if (COLSUM) {       // the 8 lanes that share a column group (r8 = 0..7) -> one 64-row partial per column
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cs0[j] += __shfl_xor(cs0[j], 8, 64); cs0[j] += __shfl_xor(cs0[j], 16, 64); cs0[j] += __shfl_xor(cs0[j], 32, 64);
+            cs1[j] += __shfl_xor(cs1[j], 8, 64); cs1[j] += __shfl_xor(cs1[j], 16, 64); cs1[j] += __shfl_xor(cs1[j], 32, 64);
+        }
+        if (r8 == 0 && n_ok && m_base < g.M) {
+            float* cp = g.colpart + (long long)(m_base >> 6) * g.N + n;
+            st4(cp, cs0); st4(cp + 4, cs1);
+        }
+    }
+}
+
 __device__ __forceinline__ void gemm_store_tile64(const GemmArgs& g, char* Cz, char* wave_lds, int lane, f32x16 (&acc)[2][2],
                                                   int m_base, int n_base, int ntm = 2) {
     const bool aligned = g.vec && ((g.N & 3) == 0) && g.alpha == 1.0f;
@@ -267,6 +350,20 @@ __device__ __forceinline__ void gemm_store_tile64(const GemmArgs& g, char* Cz, c
             }
         }
         if (aux_ok) {
+            if (!g.c_f32 && !resid && !g.accumulate && g.wide_st && (g.N & 7) == 0 && (g.ldc & 7) == 0 && (((uintptr_t)Cz) & 15) == 0 &&
+                (g.epi == MMAE_EPI_NONE || ((g.ldaux & 7) == 0 && (((uintptr_t)g.aux) & 15) == 0)) && (!bias || (((uintptr_t)g.bias) & 15) == 0)) {
+                if (g.epi == MMAE_EPI_NONE) {
+                    if (bias) store_tile64_bf16x8<true, MMAE_EPI_NONE, false>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
+                    else store_tile64_bf16x8<false, MMAE_EPI_NONE, false>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
+                    return;
+                }
+                if (g.epi == MMAE_EPI_GELU && bias) { store_tile64_bf16x8<true, MMAE_EPI_GELU, false>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm); return; }
+                if (g.epi == MMAE_EPI_DGELU && !bias) {
+                    if (g.colpart) store_tile64_bf16x8<false, MMAE_EPI_DGELU, true>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
+                    else store_tile64_bf16x8<false, MMAE_EPI_DGELU, false>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
+                    return;
+                }
+            }
             if (!g.c_f32 && !resid && !g.accumulate) {
                 if (g.epi == MMAE_EPI_NONE) {
                     if (bias) { store_tile64_fast<true, 0, false, false, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm); return; }

@@ -109,6 +109,8 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     g.colpart = d->colsum_part;
     static const int env_swz = getenv("MMAE_GEMM_XCD") ? atoi(getenv("MMAE_GEMM_XCD")) : 1;
     g.xcd_swizzle = env_swz;
+    static const int env_wide = getenv("MMAE_EPI_WIDE") ? atoi(getenv("MMAE_EPI_WIDE")) : 1;
+    g.wide_st = env_wide;
     MMAE_REQUIRE(!d->colsum_part || (d->epi == MMAE_EPI_DGELU && !d->bias && !d->resid && !d->accumulate && d->batch == 1 && d->split_k <= 1 &&
                                      d->alpha == 1.0f && d->N % 4 == 0) ,
                  "gemm: colsum_part is only supported with the plain dGELU epilogue");
