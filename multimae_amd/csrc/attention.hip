@@ -171,6 +171,32 @@ __device__ __forceinline__ void store4(float* p, float a, float b, float c, floa
     f32x4 t = {a, b, c, d};
     st4(p, t);
 }
+// One row's 16 values of a 32-column MFMA tile (a lane holds columns 8g + 4*hi .. +3 for g = 0..3; lanes l and l + 32 hold the
+// two halves of the same row) -> TWO 16-byte stores per lane instead of four 8-byte ones: v_permlane32_swap exchanges the
+// half-waves' column groups pairwise so that a lane ends up with 8 contiguous columns (the store tail of a row-per-lane
+// epilogue is issue-bound: half the store instructions, same bytes -- MI355X guide, technique T21).  Every lane must execute
+// the swaps; `ok` only gates the stores.
+__device__ __forceinline__ i32x2 pack4_bf16_rne(float a, float b, float c, float d) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+    bf16x4_t v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+    return __builtin_bit_cast(i32x2, v);
+}
+__device__ __forceinline__ void store_row32(uint16_t* p, const f32x16& v, float s, int hi, bool ok) {    // p: column 0 of this tile's row
+#pragma unroll
+    for (int g = 0; g < 4; g += 2) {
+        const i32x2 a = pack4_bf16_rne(v[g * 4] * s, v[g * 4 + 1] * s, v[g * 4 + 2] * s, v[g * 4 + 3] * s);
+        const i32x2 b = pack4_bf16_rne(v[g * 4 + 4] * s, v[g * 4 + 5] * s, v[g * 4 + 6] * s, v[g * 4 + 7] * s);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+        i32x4 o; o[0] = r0[0]; o[1] = r1[0]; o[2] = r0[1]; o[3] = r1[1];
+        if (ok) *reinterpret_cast<i32x4*>(p + (g + hi) * 8) = o;
+    }
+}
+__device__ __forceinline__ void store_row32(float* p, const f32x16& v, float s, int hi, bool ok) {       // f32 rows: already 16-byte stores
+    if (!ok) return;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) store4(p + rg * 8 + 4 * hi, v[rg * 4] * s, v[rg * 4 + 1] * s, v[rg * 4 + 2] * s, v[rg * 4 + 3] * s);
+}
 template <bool X3> struct ActOf { typedef uint16_t T; };
 template <> struct ActOf<true> { typedef float T; };
 
@@ -267,15 +293,11 @@ __global__ void __launch_bounds__(256, (NT == 4 && !X3) ? 3 : (NT <= 7 ? 2 : 1))
                 }
             }
         }
-        if (qok) {
+        {
             const float inv = 1.0f / l;
 #pragma unroll
-            for (int dt = 0; dt < HD / 32; ++dt)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg)
-                    store4(ob + q * a.o_sr + dt * 32 + rg * 8 + 4 * hi, o[dt][rg * 4] * inv, o[dt][rg * 4 + 1] * inv,
-                           o[dt][rg * 4 + 2] * inv, o[dt][rg * 4 + 3] * inv);
-            if (hi == 0) a.lse[((long long)b * a.H + h) * a.Nq + q] = m + __logf(l);
+            for (int dt = 0; dt < HD / 32; ++dt) store_row32(ob + q * a.o_sr + dt * 32, o[dt], inv, hi, qok);
+            if (qok && hi == 0) a.lse[((long long)b * a.H + h) * a.Nq + q] = m + __logf(l);
         }
     }
 }
@@ -410,13 +432,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
                 }
             }
         }
-        if (qok) {
+        {
             AT* dst = (AT*)a.dq + b * a.dq_sb + h * HD + q * a.dq_sr;
 #pragma unroll
-            for (int dt = 0; dt < HD / 32; ++dt)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg)
-                    store4(dst + dt * 32 + rg * 8 + 4 * hi, dq[dt][rg * 4], dq[dt][rg * 4 + 1], dq[dt][rg * 4 + 2], dq[dt][rg * 4 + 3]);
+            for (int dt = 0; dt < HD / 32; ++dt) store_row32(dst + dt * 32, dq[dt], 1.0f, hi, qok);
         }
     }
 
@@ -467,16 +486,15 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
                 }
             }
         }
-        if (key < a.Nk) {
+        {
+            const bool kok = key < a.Nk;
             AT* dkd = (AT*)a.dk + b * a.dk_sb + h * HD + key * a.dk_sr;
             AT* dvd = (AT*)a.dv + b * a.dv_sb + h * HD + key * a.dv_sr;
 #pragma unroll
-            for (int dt = 0; dt < HD / 32; ++dt)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    store4(dkd + dt * 32 + rg * 8 + 4 * hi, dk[dt][rg * 4], dk[dt][rg * 4 + 1], dk[dt][rg * 4 + 2], dk[dt][rg * 4 + 3]);
-                    store4(dvd + dt * 32 + rg * 8 + 4 * hi, dv[dt][rg * 4], dv[dt][rg * 4 + 1], dv[dt][rg * 4 + 2], dv[dt][rg * 4 + 3]);
-                }
+            for (int dt = 0; dt < HD / 32; ++dt) {
+                store_row32(dkd + dt * 32, dk[dt], 1.0f, hi, kok);
+                store_row32(dvd + dt * 32, dv[dt], 1.0f, hi, kok);
+            }
         }
     }
 }
@@ -499,7 +517,7 @@ static int attn_fwd_impl(bool x3, const void* q, const void* k, const void* v, v
     const long long st[] = {q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr};
     const int rc = check_common(B, H, Nq, Nk, hd, st, 8);
     MMAE_REQUIRE(rc == 0, rc == -2 ? "attn: head_dim must be 32 or 64" : (rc == -3 ? "attn: strides must be multiples of 8" : "attn: need 1 <= Nq, Nk <= 256"));
-    MMAE_REQUIRE(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)o % (x3 ? 16 : 8) == 0), "attn_fwd: unaligned pointer");
+    MMAE_REQUIRE(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)o % 16 == 0), "attn_fwd: unaligned pointer");
     AttnArgs a = {};
     a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.nqp = (Nq + 31) / 32 * 32; a.nkp = (Nk + 31) / 32 * 32;
@@ -532,6 +550,7 @@ static int attn_bwd_impl(bool x3, const void* q, const void* k, const void* v, c
                          int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr, int64_t dq_sb, int64_t dq_sr, int64_t dk_sb, int64_t dk_sr,
                          int64_t dv_sb, int64_t dv_sr, float scale, void* stream) {
     MMAE_REQUIRE(q && k && v && o && d_o && lse && dq && dk && dv, "attn_bwd: null pointer");
+    MMAE_REQUIRE(((uintptr_t)dq % 16 == 0) && ((uintptr_t)dk % 16 == 0) && ((uintptr_t)dv % 16 == 0), "attn_bwd: unaligned output pointer");
     const long long st[] = {q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, dq_sb, dq_sr, dk_sb, dk_sr, dv_sb, dv_sr};
     const int rc = check_common(B, H, Nq, Nk, hd, st, 14);
     MMAE_REQUIRE(rc == 0, rc == -2 ? "attn: head_dim must be 32 or 64" : (rc == -3 ? "attn: strides must be multiples of 8" : "attn: need 1 <= Nq, Nk <= 256"));
