@@ -329,6 +329,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
     const AT* dog = (const AT*)a.d_o + b * a.o_sb + h * HD;
     const AT* kg = (const AT*)a.k + b * a.k_sb + h * HD;
     const AT* vg = (const AT*)a.v + b * a.v_sb + h * HD;
+    bf16x8 of0[HD / 16];                                 // bf16 path: O fragments of query block `wave`, fetched with the tiles
     if constexpr (X3) {
         {
             TileLoaderF32<HD, NTH> lq, ld;
@@ -351,6 +352,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
         ld.issue(dog, a.o_sr, a.Nq, a.nqp, tid);
         lk.issue(kg, a.k_sr, a.Nk, a.nkp, tid);
         lv.issue(vg, a.v_sr, a.Nk, a.nkp, tid);
+        // the O rows of this wave's first query block (for delta) ride in the same burst: loaded after the LDS commit they
+        // were a second, serial HBM round trip in front of the first MFMA
+        {
+            const auto rsO0 = __builtin_amdgcn_make_buffer_rsrc((void*)og, 0, 0x80000000, 0x00020000);
+            const int q0 = wave * 32 + (lane & 31);
+#pragma unroll
+            for (int ks = 0; ks < HD / 16; ++ks) of0[ks] = load_frag_global(rsO0, q0 < a.Nq, q0, a.o_sr, ks, hi);
+        }
         for (int q = tid; q < a.nqp; q += NTH) lse_s[q] = q < a.Nq ? a.lse[((long long)b * a.H + h) * a.Nq + q] : 0.f;
         lq.commit(Qs, a.nqp, tid);
         ld.commit(dOs, a.nqp, tid);
@@ -361,6 +370,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
     const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void*)og, 0, 0x80000000, 0x00020000);
     const auto rsdO = __builtin_amdgcn_make_buffer_rsrc((void*)dog, 0, 0x80000000, 0x00020000);
     // delta[q] = sum_d dO[q][d] * O[q][d]
+    if constexpr (!X3) __syncthreads();                  // bf16 path reads dO from its LDS tile
     for (int qblk = wave; qblk < nqb; qblk += NW) {
         const int q = qblk * 32 + (lane & 31);
         const bool qok = q < a.Nq;
@@ -377,7 +387,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
                     for (int j = 0; j < 4; ++j) d += of[j] * df[j];
                 }
             } else {
-                const bf16x8 of = load_frag_global(rsO, qok, q, a.o_sr, ks, hi), df = load_frag_global(rsdO, qok, q, a.o_sr, ks, hi);
+                const bf16x8 of = (qblk == wave) ? of0[ks] : load_frag_global(rsO, qok, q, a.o_sr, ks, hi);
+                const bf16x8 df = frag_rows<HD>(dOs, qblk * 32, ks, lane);      // rows >= Nq are zero-padded
 #pragma unroll
                 for (int j = 0; j < 8; ++j) d += (float)of[j] * (float)df[j];
             }
