@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMAE_ABI_VERSION 1
+#define MMAE_ABI_VERSION 2
 
 #define MMAE_F32  0
 #define MMAE_BF16 1
@@ -211,11 +211,111 @@ typedef struct mmae_block_desc {
     int32_t fc2_b_done;                          /* the producer of dx already delivered fc2's bias gradient: skip it */
     float* ws_main; int64_t ws_main_elems;       /* f32 scratch used by launches on `stream` */
     float* ws_side; int64_t ws_side_elems;       /* f32 scratch used by launches on `side_stream` */
+    /* stochastic depth (DropPath, multimae_utils.py:105-135,229-232): per-sample scales f32 [B] = mask_b / keep_prob of the
+     * attention branch (dp1) and the MLP branch (dp2); NULL = branch kept for every sample.  x1 = x0 + dp1[b] * attn(..),
+     * x2 = x1 + dp2[b] * mlp(..).  With a scale set, `branch` (f32 [R][D], forward) and `dxs_act` (act [R][D], backward)
+     * are scratch the caller provides. */
+    const float* dp1; const float* dp2;
+    float* branch; void* dxs_act;
 } mmae_block_desc;
 
 int mmae_block_fwd(const mmae_block_desc* d, void* stream);
 /* side_stream may equal stream (or be NULL): everything then runs in order on `stream`. */
 int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream);
+
+/* ------------------------------------------------------------------------- *
+ * A stack of L pre-LN transformer blocks (the ViT encoder, multimae.py:94-98,350, or an adapter's decoder_transformer,
+ * output_adapters.py:127-133,271) as ONE call per direction: the library lays the saved activations of all blocks out in
+ * one caller-provided slab and enqueues every block's kernel sequence (mmae_block_fwd / mmae_block_bwd).  A ViT-B encoder
+ * step is then 2 host round trips instead of 24 (or ~600 single launches).
+ *   w   host array [L][4]  act-dtype weights  qkv_w, proj_w, fc1_w, fc2_w
+ *   p   host array [L][8]  f32                n1_w, n1_b, qkv_b, proj_b, n2_w, n2_b, fc1_b, fc2_b
+ *   g   host array [L][12] gradient destinations in the order n1_w n1_b qkv_w qkv_b proj_w proj_b n2_w n2_b fc1_w fc1_b
+ *       fc2_w fc2_b (NULL entries = not wanted); grad_acc: add to (1) / store into (0) them
+ *   dp  NULL or host array [L][2] of device f32 [B] stochastic-depth scales (see mmae_block_desc.dp1 / dp2)
+ *   act slab of mmae_stack_act_bytes() bytes: forward writes, backward reads; block l's output (f32 [R][D]) lives at byte
+ *       offset mmae_stack_out_offset(d, l) -- the stack's result is the last one.
+ * Backward handles blocks l_end-1 ... l_begin (a data-parallel caller splits the stack at its gradient-bucket borders
+ * and launches a bucket's all-reduce between two calls; otherwise l_begin = 0, l_end = L).  d_out[l] (host array [L], f32
+ * [R][D] or NULL) is the gradient arriving at block l's output from outside the stack; d_out[L-1] is required.  The
+ * gradient of the stack input is written to dx when l_begin == 0.  tmp: slab of mmae_stack_tmp_bytes() bytes that must
+ * stay untouched between the calls of one backward pass and alive until side_stream has drained.
+ * Geometry / dtype limits are those of mmae_block_fwd (MMAE_ESUPPORT otherwise).
+ * ------------------------------------------------------------------------- */
+typedef struct mmae_stack_desc {
+    int32_t L, B, N, D, heads, Hd;
+    int32_t act_dtype, f32_gemm;
+    float eps;
+    int32_t grad_acc;
+    const void* const* w;
+    const float* const* p;
+    const float* const* dp;
+    const float* x;                              /* stack input, f32 [R][D] */
+    void* act; int64_t act_bytes;
+    float* const* g;
+    const float* const* d_out;
+    float* dx;
+    void* tmp; int64_t tmp_bytes;
+    int32_t l_begin, l_end;
+    float* ws_main; int64_t ws_main_elems;
+    float* ws_side; int64_t ws_side_elems;
+} mmae_stack_desc;
+
+int64_t mmae_stack_act_bytes(const mmae_stack_desc* d);
+int64_t mmae_stack_tmp_bytes(const mmae_stack_desc* d);
+int64_t mmae_stack_out_offset(const mmae_stack_desc* d, int l);
+int mmae_stack_fwd(const mmae_stack_desc* d, void* stream);
+int mmae_stack_bwd(const mmae_stack_desc* d, void* stream, void* side_stream);
+
+/* ------------------------------------------------------------------------- *
+ * SpatialOutputAdapter.forward (output_adapters.py:236-282) and its autograd as ONE call per direction: proj_context,
+ * query / context build (:183-234), the cross-attention layer with its MLP (:262-266), the decoder_transformer blocks
+ * (:271), out_proj (:274) and the patch -> image rearrangement (:277-280).  Same kernels and order as the individual
+ * entry points; ~45 host round trips forward and ~125 backward become one each.
+ *   enc      f32 [B][NC][Denc] encoder tokens (NC = n_keep + G); enc_act: their act-dtype copy (== enc when act is f32)
+ *   w        host array [6 + 4*depth] act-dtype weights: q, kv, proj, fc1, fc2, then per block qkv, proj, fc1, fc2,
+ *            then out_proj; proj_context LAST
+ *   p        host array [12 + 8*depth + 2] f32: q_b kv_b proj_b ctxn_w ctxn_b qn_w qn_b outn_w outn_b fc1_b fc2_b
+ *            (11 entries), then per block the 8 of mmae_stack_desc.p, then out_proj_b, proj_context_b
+ *   mask_token f32 [D]; task_emb host array [T] of f32 [D] (NULL = task without embedding -> zeros)
+ *   pos      f32 [n_q][D] decoder position table (all tasks share the grid)
+ *   act / tmp slabs as in mmae_stack_desc; pat (f32 [B*n_q][C*ph*pw]) is kept in act for a patch-domain loss
+ *   (mmae_adapter_pat_offset); img f32 [B][C][nh*ph][nw*pw] is the API result.
+ * Backward: d_img (image-domain gradient) or d_pat (act dtype [B*n_q][ld_pat], already in patch layout) -- exactly one;
+ *   g host array in the parameter order  mask_token, task_emb[0..T-1], q_w q_b kv_w kv_b proj_w proj_b ctxn_w ctxn_b qn_w
+ *   qn_b outn_w outn_b fc1_w fc1_b fc2_w fc2_b, 12 per block, out_proj_w out_proj_b, proj_context_w proj_context_b;
+ *   d_enc f32 [B][NC][Denc] receives the gradient of the encoder tokens.
+ * ------------------------------------------------------------------------- */
+typedef struct mmae_adapter_desc {
+    int32_t B, NC, Denc, D, heads, Hd, depth, T, q_task, G, n_q;
+    int32_t C, nh, nw, ph, pw;
+    int32_t act_dtype, f32_gemm;
+    float eps;
+    int32_t grad_acc;
+    const int32_t* task_offsets_host;            /* [T+1] */
+    const void* const* w;
+    const float* const* p;
+    const float* mask_token;
+    const float* const* task_emb;
+    const float* pos;
+    const float* enc; const void* enc_act;
+    const int64_t* ids_keep; const int64_t* ids_restore;
+    void* act; int64_t act_bytes;
+    float* img;                                  /* forward result; NULL = do not materialise the image */
+    /* backward */
+    const float* d_img; const void* d_pat; int64_t ld_pat;
+    float* const* g;
+    float* d_enc;
+    void* tmp; int64_t tmp_bytes;
+    float* ws_main; int64_t ws_main_elems;
+    float* ws_side; int64_t ws_side_elems;
+} mmae_adapter_desc;
+
+int64_t mmae_adapter_act_bytes(const mmae_adapter_desc* d);
+int64_t mmae_adapter_tmp_bytes(const mmae_adapter_desc* d);
+int64_t mmae_adapter_pat_offset(const mmae_adapter_desc* d);
+int mmae_adapter_fwd(const mmae_adapter_desc* d, void* stream);
+int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream);
 
 /* ------------------------------------------------------------------------- *
  * Casts.  f32 master weights -> act-dtype shadows (optionally transposed so that
@@ -231,6 +331,11 @@ int mmae_token_mean_fwd(const float* x, float* y, int B, int N, int D, void* str
 int mmae_token_mean_bwd(const float* dy, float* dx, int B, int N, int D, void* stream);
 /* y (+)= a*x elementwise, f32 */
 int mmae_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream);
+/* stochastic depth (multimae_utils.py:105-122) on 2-D activations, rows grouped N per sample, s f32 [R/N]:
+ *   rowscale_add:  out[r][:] = resid[r][:] + s[r / N] * y[r][:]                 (f32, out may alias resid)
+ *   rowscale_cast: out[r][:] = cast(s[r / N] * x[r][:])   (x f32; out act dtype) */
+int mmae_rowscale_add(const float* resid, const float* y, const float* s, float* out, int64_t R, int N, int D, void* stream);
+int mmae_rowscale_cast(const float* x, const float* s, void* out, int out_dtype, int64_t R, int N, int D, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Mask sampler: deterministic core of MultiMAE.generate_random_masks
@@ -367,6 +472,32 @@ int mmae_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr
 int mmae_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev, float beta1,
                    float beta2, float eps, const float* grad_scale_dev, const int32_t* skip_flag, void* shadow,
                    int shadow_dtype, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * The whole optimiser step of the training loop as one call: gradient 2-norm (get_grad_norm_,
+ * utils/native_scaler.py:49-62), clip / skip decision (:22-35), the non-finite guards (GradScaler.step skipping an
+ * update with inf / NaN gradients; the loop's isfinite(loss) check, run_pretraining_multimae.py:529-531) and AdamW --
+ * with every decision taken ON THE DEVICE (no host synchronisation):
+ *   norm   = grad_prescale * |g|_2                       (grad_prescale = 1 / world_size for SUMMED data-parallel gradients)
+ *   skip   = !finite(norm) || (skip_grad > 0 && norm >= skip_grad) || (loss_dev && !finite(*loss_dev))
+ *   scale  = grad_prescale * (clip_grad > 0 ? min(1, clip_grad / (norm + 1e-6)) : 1)
+ *   !skip: step += 1;  AdamW with lr, weight_decay (host values, or lrwd_dev[0..1] when given -- the per-iteration cosine
+ *          tables of run_pretraining_multimae.py:474-480) and the bias corrections of the DEVICE step counter, so a skipped
+ *          iteration does not advance Adam's step (the reference never calls optimizer.step() for it).
+ * state  f32 [8]:  [0] sum of squares  [1] norm  [2] scale  [3..6] lr, weight_decay, 1 - beta1^t, sqrt(1 - beta2^t)
+ * istate i32 [4]:  [0] skip flag of this step  [1] t = updates applied so far  [2] steps whose loss was not finite
+ *                  [3] steps skipped for any reason.     ws: f32 scratch >= 1024.
+ * ------------------------------------------------------------------------- */
+typedef struct mmae_opt_desc {
+    float* p; const float* g; float* m; float* v; int64_t n;
+    void* shadow; int32_t shadow_dtype;          /* optional act-dtype copy of the updated parameters */
+    float lr, weight_decay, beta1, beta2, eps;
+    const float* lrwd_dev;
+    float clip_grad, skip_grad, grad_prescale;
+    const float* loss_dev;
+    float* state; int32_t* istate; float* ws;
+} mmae_opt_desc;
+int mmae_opt_step(const mmae_opt_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Truncated depth standardisation, the step right before the model in the training loop

@@ -1,78 +1,90 @@
-// Composite entry points: a whole transformer block per call (see mmae.h, mmae_block_desc).
+// Composite entry points: a transformer block, a stack of blocks, a whole SpatialOutputAdapter, the optimiser step -- one
+// library call per direction each (see mmae.h: mmae_block_desc, mmae_stack_desc, mmae_adapter_desc, mmae_opt_desc).
 //
-// Nothing here is a new kernel: the functions below enqueue the same launches, through the same public C entry points, that
-// the Python side (multimae_amd/functions.py::block_fwd / block_bwd) issues one by one.  The point is the host: at B = 256 a
-// ViT-B step is ~1 000 launches and Python spends 20-25 us on each; the four output adapters' backward passes (short
-// kernels, ~125 launches each) were paced by the host, not by the GPU.  One call per block per direction brings a cfg3
-// step from ~1 040 host round trips to ~500.
+// No GEMM / attention / LayerNorm kernel is new here: the functions below enqueue the same launches, through the same public C
+// entry points, that the Python side (multimae_amd/functions.py) can issue one by one.  The point is the host: at B = 256 a
+// cfg3 step is ~1 000 launches; issued from Python (20-60 us each, ~520 ctypes calls with the per-block composites of round 1)
+// the host needed 20-33 ms per step and paced the four output adapters' backward passes.  With one call per stack / adapter a
+// step is ~40 library calls.
+#include <math.h>
 #include <mutex>
 #include "gemm_common.h"
 
 namespace {
 
-struct Lin {
-    const mmae_block_desc* d;
-    int ab() const { return d->act_dtype == MMAE_BF16 ? MMAE_BF16 : d->f32_gemm; }
+// what the linear helpers need to know about the call they serve
+struct Ctx {
+    int act_dtype, f32_gemm, grad_acc;
+    float* ws_main; int64_t ws_main_elems;
+    float* ws_side; int64_t ws_side_elems;
+    int ab() const { return act_dtype == MMAE_BF16 ? MMAE_BF16 : f32_gemm; }
+    size_t es() const { return act_dtype == MMAE_BF16 ? 2 : 4; }
 };
 
-// events that order the side stream behind the main stream.  A wait captures the event's state when it is enqueued, so
-// the ring only has to outlive the hipStreamWaitEvent call that follows each record.
-hipEvent_t next_event() {
-    static std::mutex mu;
-    static hipEvent_t ring[64];
-    static int made = 0, pos = 0;
-    std::lock_guard<std::mutex> lk(mu);
-    if (made < 64) { if (hipEventCreateWithFlags(&ring[made], hipEventDisableTiming) != hipSuccess) return nullptr; ++made; pos = made - 1; return ring[pos]; }
-    pos = (pos + 1) & 63;
-    return ring[pos];
-}
+Ctx ctx_of(const mmae_block_desc* d) { return {d->act_dtype, d->f32_gemm, d->grad_acc, d->ws_main, d->ws_main_elems, d->ws_side, d->ws_side_elems}; }
+
+// events that order one stream behind another.  A wait captures the event's state when it is enqueued, so a ring entry only
+// has to outlive the hipStreamWaitEvent call that consumes it.  Two rings: `fork` entries are consumed immediately; `held`
+// entries are kept across a few more launches (side-stream progress marks of mmae_stack_bwd) and get a longer ring.
+struct EventRing {
+    std::mutex mu;
+    hipEvent_t ring[256];
+    int made = 0, pos = 0;
+    hipEvent_t next() {
+        std::lock_guard<std::mutex> lk(mu);
+        if (made < 256) { if (hipEventCreateWithFlags(&ring[made], hipEventDisableTiming) != hipSuccess) return nullptr; ++made; pos = made - 1; return ring[pos]; }
+        pos = (pos + 1) & 255;
+        return ring[pos];
+    }
+};
+EventRing g_fork_ring, g_held_ring;
 
 int fork_to(hipStream_t from, hipStream_t to) {      // `to` continues after everything enqueued so far on `from`
     if (from == to) return 0;
-    hipEvent_t e = next_event();
+    hipEvent_t e = g_fork_ring.next();
     if (!e || hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess) {
-        mmae_set_error("block: could not order the side stream behind the compute stream");
+        mmae_set_error("composite: could not order one stream behind the other");
         return MMAE_ELAUNCH;
     }
     return 0;
 }
 
 // out[M,N] = x[M,K] w[N,K]^T (+ bias, epilogue, residual) -- ops.linear_fwd
-int lin_fwd(const mmae_block_desc* b, const void* x, const void* w, const float* bias, void* out, int out_dtype, int M, int N, int K,
+int lin_fwd(const Ctx& c, const void* x, const void* w, const float* bias, void* out, int out_dtype, int M, int N, int K,
             const float* resid, void* aux, int epi, hipStream_t st) {
     mmae_gemm_desc g = {};
     g.A = x; g.B = w; g.C = out;
-    g.ab_dtype = b->act_dtype == MMAE_BF16 ? MMAE_BF16 : b->f32_gemm;
+    g.ab_dtype = c.ab();
     g.c_dtype = out_dtype;
     g.M = M; g.N = N; g.K = K;
     g.lda = K; g.ldb = K; g.ldc = N;
     g.batch = g.batch_inner = 1;
     g.bias = bias; g.resid = resid; g.ldr = N;
-    g.aux = aux; g.ldaux = N; g.aux_dtype = b->act_dtype;
+    g.aux = aux; g.ldaux = N; g.aux_dtype = c.act_dtype;
     g.epi = epi; g.alpha = 1.0f;
     int tile = 0, split = 1;
     int rc = mmae_gemm_plan(&g, &tile, &split);
     if (rc) return rc;
     g.tile = tile; g.split_k = split;
     if (split > 1) {
-        if ((int64_t)split * M * N > b->ws_main_elems) { mmae_set_error("block: ws_main too small"); return MMAE_EINVAL; }
-        g.ws = b->ws_main; g.ws_elems = b->ws_main_elems;
+        if ((int64_t)split * M * N > c.ws_main_elems) { mmae_set_error("composite: ws_main too small"); return MMAE_EINVAL; }
+        g.ws = c.ws_main; g.ws_elems = c.ws_main_elems;
     }
     return mmae_gemm(&g, st);
 }
 
-// out[M,K] = dy[M,N] w[N,K] (+ dGELU epilogue with column-sum partials) -- ops.linear_dx
-int lin_dx(const mmae_block_desc* b, const void* dy, const void* w, void* out, int out_dtype, int M, int N, int K, void* aux, int epi,
+// out[M,K] = dy[M,N] w[N,K] (+ dGELU epilogue with column-sum partials) -- ops.linear_dx.  ldy: row stride of dy.
+int lin_dx(const Ctx& c, const void* dy, int64_t ldy, const void* w, void* out, int out_dtype, int M, int N, int K, void* aux, int epi,
            float* colsum_part, hipStream_t st) {
     mmae_gemm_desc g = {};
     g.A = dy; g.B = w; g.C = out;
-    g.ab_dtype = b->act_dtype == MMAE_BF16 ? MMAE_BF16 : b->f32_gemm;
+    g.ab_dtype = c.ab();
     g.c_dtype = out_dtype;
     g.M = M; g.N = K; g.K = N;
-    g.lda = N; g.ldb = K; g.ldc = K;
+    g.lda = ldy; g.ldb = K; g.ldc = K;
     g.b_trans = 1;
     g.batch = g.batch_inner = 1;
-    g.aux = aux; g.ldaux = K; g.aux_dtype = b->act_dtype;
+    g.aux = aux; g.ldaux = K; g.aux_dtype = c.act_dtype;
     g.epi = epi; g.alpha = 1.0f;
     g.colsum_part = colsum_part;
     int tile = 0, split = 1;
@@ -80,24 +92,23 @@ int lin_dx(const mmae_block_desc* b, const void* dy, const void* w, void* out, i
     if (rc) return rc;
     g.tile = tile; g.split_k = split;
     if (split > 1) {
-        if ((int64_t)split * M * K > b->ws_main_elems) { mmae_set_error("block: ws_main too small"); return MMAE_EINVAL; }
-        g.ws = b->ws_main; g.ws_elems = b->ws_main_elems;
+        if ((int64_t)split * M * K > c.ws_main_elems) { mmae_set_error("composite: ws_main too small"); return MMAE_EINVAL; }
+        g.ws = c.ws_main; g.ws_elems = c.ws_main_elems;
     }
     return mmae_gemm(&g, st);
 }
 
 // dw[N,K] (+)= dy[M,N]^T x[M,K]; db[N] (+)= column sums of dy (inside the GEMM where the kernel can) -- ops.linear_dw
-int lin_dw(const mmae_block_desc* b, const void* dy, const void* x, float* dw, float* db, int M, int N, int K, hipStream_t st) {
+int lin_dw(const Ctx& c, const void* dy, int64_t ldy, const void* x, float* dw, float* db, int M, int N, int K, hipStream_t st) {
     if (!dw && !db) return 0;
-    const int acc = b->grad_acc;
-    int64_t ws_used = 0;
+    const int acc = c.grad_acc;
     if (dw) {
         mmae_gemm_desc g = {};
         g.A = dy; g.B = x; g.C = dw;
-        g.ab_dtype = b->act_dtype == MMAE_BF16 ? MMAE_BF16 : b->f32_gemm;
+        g.ab_dtype = c.ab();
         g.c_dtype = MMAE_F32;
         g.M = N; g.N = K; g.K = M;
-        g.lda = N; g.ldb = K; g.ldc = K;
+        g.lda = ldy; g.ldb = K; g.ldc = K;
         g.a_trans = g.b_trans = 1;
         g.batch = g.batch_inner = 1;
         g.accumulate = acc; g.alpha = 1.0f;
@@ -106,25 +117,35 @@ int lin_dw(const mmae_block_desc* b, const void* dy, const void* x, float* dw, f
         if (rc) return rc;
         g.tile = tile; g.split_k = split;
         const bool fused_db = db && tile == 9 && g.ab_dtype == MMAE_BF16;
-        ws_used = (split > 1 ? (int64_t)split * N * K : 0) + (fused_db ? (int64_t)(split > 1 ? split : 1) * N : 0);
-        if (ws_used > b->ws_side_elems) { mmae_set_error("block: ws_side too small"); return MMAE_EINVAL; }
-        if (ws_used) { g.ws = b->ws_side; g.ws_elems = b->ws_side_elems; }
+        const int64_t ws_used = (split > 1 ? (int64_t)split * N * K : 0) + (fused_db ? (int64_t)(split > 1 ? split : 1) * N : 0);
+        if (ws_used > c.ws_side_elems) { mmae_set_error("composite: ws_side too small"); return MMAE_EINVAL; }
+        if (ws_used) { g.ws = c.ws_side; g.ws_elems = c.ws_side_elems; }
         if (fused_db) { g.a_colsum = db; g.a_colsum_acc = acc; db = nullptr; }
         rc = mmae_gemm(&g, st);
         if (rc) return rc;
     }
     if (db) {
-        if (mmae_colsum_ws_elems(M, N) > b->ws_side_elems) { mmae_set_error("block: ws_side too small"); return MMAE_EINVAL; }
-        return mmae_colsum(dy, b->act_dtype, M, N, N, db, acc, b->ws_side, st);
+        if (mmae_colsum_ws_elems(M, N) > c.ws_side_elems) { mmae_set_error("composite: ws_side too small"); return MMAE_EINVAL; }
+        return mmae_colsum(dy, c.act_dtype, M, N, ldy, db, acc, c.ws_side, st);
     }
     return 0;
 }
 
-int scatter3(const mmae_block_desc* b, const float* part, int rows, int seg_w, float* d0, float* d1, float* d2, hipStream_t st) {
-    if (!d0 && !d1 && !d2) return 0;
+// column sums of part [rows][nseg * seg_w] scattered into up to 8 gradient destinations (NULL = dropped)
+int scatter(const Ctx& c, const float* part, int rows, int seg_w, float* const* dsts, int nseg, hipStream_t st) {
+    bool any = false;
+    for (int i = 0; i < nseg; ++i) any = any || dsts[i];
+    if (!any) return 0;
+    if (mmae_colsum_ws_elems(rows, nseg * seg_w) > c.ws_side_elems) { mmae_set_error("composite: ws_side too small"); return MMAE_EINVAL; }
+    return mmae_colsum_scatter(part, MMAE_F32, rows, nseg * seg_w, nseg * seg_w, seg_w, dsts, nseg, c.grad_acc, c.ws_side, st);
+}
+int scatter3(const Ctx& c, const float* part, int rows, int seg_w, float* d0, float* d1, float* d2, hipStream_t st) {
     float* dsts[3] = {d0, d1, d2};
-    if (mmae_colsum_ws_elems(rows, 3 * seg_w) > b->ws_side_elems) { mmae_set_error("block: ws_side too small"); return MMAE_EINVAL; }
-    return mmae_colsum_scatter(part, MMAE_F32, rows, 3 * seg_w, 3 * seg_w, seg_w, dsts, 3, b->grad_acc, b->ws_side, st);
+    return scatter(c, part, rows, seg_w, dsts, 3, st);
+}
+
+int cast_to_act(int act, const float* src, void* dst, int64_t n, hipStream_t st) {       // f32 -> act dtype (bf16 only: f32 callers alias)
+    return act == MMAE_BF16 ? mmae_cast_f32_to_bf16(src, dst, n, st) : 0;
 }
 
 int check_desc(const mmae_block_desc* d) {
@@ -151,6 +172,155 @@ int attn_strides_fwd(const mmae_block_desc* d, hipStream_t st) {
               (int64_t)N * 3 * D, 3 * D, (int64_t)N * 3 * D, 3 * D, (int64_t)N * D, D, scale, st);
 }
 
+// byte-slab carving, 256-byte aligned
+struct Carver {             // base 0: the returned "pointers" are plain byte offsets (layout queries)
+    uintptr_t base; int64_t off;
+    explicit Carver(const void* b) : base((uintptr_t)b), off(0) {}
+    void* take(int64_t bytes) { void* p = (void*)(base + (uintptr_t)off); off += (bytes + 255) / 256 * 256; return p; }
+    template <typename T> T* takeT(int64_t n) { return (T*)take(n * (int64_t)sizeof(T)); }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// stack layouts
+// ------------------------------------------------------------------------------------------------------------------
+struct BlockAct {       // saved activations of one block (inside the act slab)
+    void *ln1, *qkv, *ao, *ln2, *hpre, *hact;
+    float *mean1, *rstd1, *mean2, *rstd2, *lse, *x1, *x2;
+};
+BlockAct carve_block_act(Carver& cv, int B, int N, int D, int heads, int Hd, size_t es) {
+    const int64_t R = (int64_t)B * N;
+    BlockAct a;
+    a.ln1 = cv.take(R * D * es); a.qkv = cv.take(R * 3 * D * es); a.ao = cv.take(R * D * es); a.ln2 = cv.take(R * D * es);
+    a.hpre = cv.take(R * Hd * es); a.hact = cv.take(R * Hd * es);
+    a.mean1 = cv.takeT<float>(R); a.rstd1 = cv.takeT<float>(R); a.mean2 = cv.takeT<float>(R); a.rstd2 = cv.takeT<float>(R);
+    a.lse = cv.takeT<float>((int64_t)B * heads * N);
+    a.x1 = cv.takeT<float>(R * D); a.x2 = cv.takeT<float>(R * D);
+    return a;
+}
+
+struct BlockTmp {       // backward temporaries of one block
+    void *d_hpre, *d_ln2, *d_ao, *d_qkv, *d_ln1, *dx1_act, *dx0_act, *dxs_act;
+    float *dx1, *dx0, *part_h, *part1, *part2;
+};
+BlockTmp carve_block_tmp(Carver& cv, int B, int N, int D, int Hd, size_t es, bool bf, bool dp) {
+    const int64_t R = (int64_t)B * N;
+    const int nblk = mmae_layernorm_bwd_nblk(R);
+    BlockTmp t;
+    t.d_hpre = cv.take(R * Hd * es); t.d_ln2 = cv.take(R * D * es); t.d_ao = cv.take(R * D * es); t.d_qkv = cv.take(R * 3 * D * es);
+    t.d_ln1 = cv.take(R * D * es);
+    t.dx1 = cv.takeT<float>(R * D); t.dx0 = cv.takeT<float>(R * D);
+    t.dx1_act = bf ? cv.take(R * D * es) : nullptr;
+    t.dx0_act = bf ? cv.take(R * D * es) : nullptr;
+    t.dxs_act = dp ? cv.take(R * D * es) : nullptr;
+    t.part_h = cv.takeT<float>((R + 63) / 64 * Hd);
+    t.part1 = cv.takeT<float>((int64_t)nblk * 3 * D); t.part2 = cv.takeT<float>((int64_t)nblk * 3 * D);
+    return t;
+}
+
+constexpr int NSET = 3;      // backward temporary sets of a stack (block l uses set l % NSET)
+
+bool stack_has_dp(const mmae_stack_desc* d) {
+    if (!d->dp) return false;
+    for (int i = 0; i < 2 * d->L; ++i) if (d->dp[i]) return true;
+    return false;
+}
+
+int check_stack(const mmae_stack_desc* d) {
+    MMAE_REQUIRE(d, "stack: null descriptor");
+    MMAE_REQUIRE(d->L > 0 && d->B > 0 && d->N > 0 && d->D > 0 && d->heads > 0 && d->Hd > 0 && d->D % d->heads == 0, "stack: bad geometry");
+    MMAE_REQUIRE(d->act_dtype == MMAE_BF16 || (d->act_dtype == MMAE_F32 && d->f32_gemm == MMAE_F32X3),
+                 "stack: activations must be bf16, or f32 with split-bf16 (MMAE_F32X3) products");
+    const int hd = d->D / d->heads;
+    if ((hd != 32 && hd != 64) || d->N > 256) { mmae_set_error("stack: geometry outside the fused attention kernel (head_dim 32/64, N <= 256)"); return MMAE_ESUPPORT; }
+    MMAE_REQUIRE(d->w && d->p && d->x && d->act, "stack: null pointer");
+    return 0;
+}
+
+void fill_block_params(mmae_block_desc& b, int B, int N, int D, int heads, int Hd, int act, int f32g, float eps, const void* const* w,
+                       const float* const* p) {
+    b.B = B; b.N = N; b.D = D; b.heads = heads; b.Hd = Hd;
+    b.act_dtype = act; b.f32_gemm = f32g; b.eps = eps;
+    b.qkv_w = w[0]; b.proj_w = w[1]; b.fc1_w = w[2]; b.fc2_w = w[3];
+    b.n1_w = p[0]; b.n1_b = p[1]; b.qkv_b = p[2]; b.proj_b = p[3]; b.n2_w = p[4]; b.n2_b = p[5]; b.fc1_b = p[6]; b.fc2_b = p[7];
+}
+void fill_block_act(mmae_block_desc& b, const float* x0, const BlockAct& a) {
+    b.x0 = x0; b.ln1 = a.ln1; b.mean1 = a.mean1; b.rstd1 = a.rstd1; b.qkv = a.qkv; b.lse = a.lse; b.ao = a.ao; b.x1 = a.x1;
+    b.ln2 = a.ln2; b.mean2 = a.mean2; b.rstd2 = a.rstd2; b.hpre = a.hpre; b.hact = a.hact; b.x2 = a.x2;
+}
+void fill_block_tmp(mmae_block_desc& b, const BlockTmp& t) {
+    b.d_hpre = t.d_hpre; b.d_ln2 = t.d_ln2; b.d_ao = t.d_ao; b.d_qkv = t.d_qkv; b.d_ln1 = t.d_ln1; b.dx1 = t.dx1; b.dx1_act = t.dx1_act;
+    b.dx0 = t.dx0; b.dx0_act = t.dx0_act; b.part_h = t.part_h; b.part1 = t.part1; b.part2 = t.part2; b.dxs_act = t.dxs_act;
+}
+void fill_block_grads(mmae_block_desc& b, float* const* g) {
+    b.g_n1_w = g[0]; b.g_n1_b = g[1]; b.g_qkv_w = g[2]; b.g_qkv_b = g[3]; b.g_proj_w = g[4]; b.g_proj_b = g[5];
+    b.g_n2_w = g[6]; b.g_n2_b = g[7]; b.g_fc1_w = g[8]; b.g_fc1_b = g[9]; b.g_fc2_w = g[10]; b.g_fc2_b = g[11];
+}
+
+// backward of blocks hi-1 ... lo of a stack whose saved activations are acts[], with temporaries tmps[l % nset].
+//   dx_top / dx_top_act: gradient of block hi-1's output.
+//   extra[l] (or NULL): gradient arriving at block l's output from outside (added before block l runs), l < hi-1.
+//   cs_first: destination of colsum(d(stack input)) -- the bias gradient of the Linear that produced the stack input -- or NULL.
+//   first_fc2_b_done: the producer of dx_top already delivered the last block's fc2 bias gradient.
+// Returns through *dx_out / *dx_out_act the gradient of block lo's input (buffers of tmps[lo % nset], or dx_final when given).
+struct StackRun {
+    int B, N, D, heads, Hd, act, f32g, grad_acc;
+    const void* const* w; const float* const* p; const float* const* dp; float* const* g;
+    const float* x_in; const BlockAct* acts; BlockTmp* tmps; int nset;
+    float* ws_main; int64_t ws_main_elems; float* ws_side; int64_t ws_side_elems;
+};
+
+int run_blocks_bwd(const StackRun& s, int lo, int hi, const float* dx_top, const void* dx_top_act, bool top_in_sets, bool first_fc2_b_done,
+                   const float* const* extra, float* cs_first, float* dx_final, hipStream_t st, hipStream_t sd,
+                   const float** dx_out, const void** dx_out_act) {
+    const int64_t R = (int64_t)s.B * s.N;
+    const float* dx = dx_top;
+    const void* dx_act = dx_top_act;
+    bool fc2_done = first_fc2_b_done;
+    hipEvent_t side_done[4] = {nullptr, nullptr, nullptr, nullptr};       // side_done[l % nset]: side work of block l enqueued
+    int rc;
+    for (int l = hi - 1; l >= lo; --l) {
+        BlockTmp t = s.tmps[l % s.nset];
+        // Block l overwrites set l % nset.  The SIDE stream reads, for block k: its own set k % nset and its input gradient,
+        // which block k + 1 left in set (k + 1) % nset.  So the side work of block l + nset (own set) and of block l + nset - 1
+        // (input gradient; only if that gradient lives in the sets: block l + nset exists, or the top gradient was carried
+        // over from the previous call, top_in_sets) must have drained.  Both sit on one in-order stream: wait for the later.
+        if (sd != st && l + s.nset < hi + (top_in_sets ? 1 : 0) && side_done[(l + s.nset - 1) % s.nset]) {
+            if (hipStreamWaitEvent(st, side_done[(l + s.nset - 1) % s.nset], 0) != hipSuccess) { mmae_set_error("stack_bwd: stream wait failed"); return MMAE_ELAUNCH; }
+        }
+        if (extra && l < hi - 1 && extra[l]) {                 // more gradient for this block's output: dx += extra (in place: dx is ours)
+            if ((rc = mmae_axpy_f32((float*)dx, extra[l], 1.0f, R * s.D, st))) return rc;
+            if (s.act == MMAE_BF16) { if ((rc = mmae_cast_f32_to_bf16(dx, (void*)dx_act, R * s.D, st))) return rc; }
+            fc2_done = false;
+        }
+        mmae_block_desc b = {};
+        fill_block_params(b, s.B, s.N, s.D, s.heads, s.Hd, s.act, s.f32g, 0.f, s.w + 4 * l, s.p + 8 * l);
+        fill_block_act(b, l == 0 ? s.x_in : s.acts[l - 1].x2, s.acts[l]);
+        if (l == lo && dx_final) { t.dx0 = dx_final; }
+        fill_block_tmp(b, t);
+        b.dx = dx; b.dx_act = dx_act;
+        float* none[12] = {};
+        fill_block_grads(b, s.g ? s.g + 12 * l : none);
+        b.dp1 = s.dp ? s.dp[2 * l] : nullptr; b.dp2 = s.dp ? s.dp[2 * l + 1] : nullptr;
+        // the bias gradient of the Linear that produced this block's input = colsum(dx0): rides along with the LayerNorm-1
+        // reduction -- unless more gradient joins dx0 before the producer sees it, or the producer's output was rescaled
+        const bool below_clean = l > 0 && !(extra && extra[l - 1]) && !(s.dp && s.dp[2 * (l - 1) + 1]);
+        b.g_cs = l > 0 ? ((below_clean && s.g) ? s.g[12 * (l - 1) + 11] : nullptr) : cs_first;
+        b.grad_acc = s.grad_acc; b.fc2_b_done = fc2_done ? 1 : 0;
+        b.ws_main = s.ws_main; b.ws_main_elems = s.ws_main_elems; b.ws_side = s.ws_side; b.ws_side_elems = s.ws_side_elems;
+        if ((rc = mmae_block_bwd(&b, st, sd))) return rc;
+        if (sd != st) {
+            hipEvent_t e = g_held_ring.next();
+            if (!e || hipEventRecord(e, sd) != hipSuccess) { mmae_set_error("stack_bwd: event record failed"); return MMAE_ELAUNCH; }
+            side_done[l % s.nset] = e;
+        }
+        fc2_done = b.g_cs != nullptr;
+        dx = t.dx0;
+        dx_act = s.act == MMAE_BF16 ? (const void*)t.dx0_act : (const void*)t.dx0;
+    }
+    *dx_out = dx; *dx_out_act = dx_act;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -159,15 +329,26 @@ int mmae_block_fwd(const mmae_block_desc* d, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     MMAE_REQUIRE(d->x2, "block_fwd: null output");
+    MMAE_REQUIRE(!(d->dp1 || d->dp2) || d->branch, "block_fwd: stochastic depth needs the branch scratch buffer");
     hipStream_t st = (hipStream_t)stream;
+    const Ctx c = ctx_of(d);
     const int R = d->B * d->N, D = d->D, Hd = d->Hd, act = d->act_dtype;
     if ((rc = mmae_layernorm_fwd(d->x0, d->n1_w, d->n1_b, d->ln1, act, d->mean1, d->rstd1, R, D, d->eps, st))) return rc;
-    if ((rc = lin_fwd(d, d->ln1, d->qkv_w, d->qkv_b, d->qkv, act, R, 3 * D, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;
+    if ((rc = lin_fwd(c, d->ln1, d->qkv_w, d->qkv_b, d->qkv, act, R, 3 * D, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;
     if ((rc = attn_strides_fwd(d, st))) return rc;
-    if ((rc = lin_fwd(d, d->ao, d->proj_w, d->proj_b, d->x1, MMAE_F32, R, D, D, d->x0, nullptr, MMAE_EPI_NONE, st))) return rc;
+    if (d->dp1) {
+        if ((rc = lin_fwd(c, d->ao, d->proj_w, d->proj_b, d->branch, MMAE_F32, R, D, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;
+        if ((rc = mmae_rowscale_add(d->x0, d->branch, d->dp1, d->x1, R, d->N, D, st))) return rc;
+    } else {
+        if ((rc = lin_fwd(c, d->ao, d->proj_w, d->proj_b, d->x1, MMAE_F32, R, D, D, d->x0, nullptr, MMAE_EPI_NONE, st))) return rc;
+    }
     if ((rc = mmae_layernorm_fwd(d->x1, d->n2_w, d->n2_b, d->ln2, act, d->mean2, d->rstd2, R, D, d->eps, st))) return rc;
-    if ((rc = lin_fwd(d, d->ln2, d->fc1_w, d->fc1_b, d->hact, act, R, Hd, D, nullptr, d->hpre, MMAE_EPI_GELU, st))) return rc;
-    return lin_fwd(d, d->hact, d->fc2_w, d->fc2_b, d->x2, MMAE_F32, R, D, Hd, d->x1, nullptr, MMAE_EPI_NONE, st);
+    if ((rc = lin_fwd(c, d->ln2, d->fc1_w, d->fc1_b, d->hact, act, R, Hd, D, nullptr, d->hpre, MMAE_EPI_GELU, st))) return rc;
+    if (d->dp2) {
+        if ((rc = lin_fwd(c, d->hact, d->fc2_w, d->fc2_b, d->branch, MMAE_F32, R, D, Hd, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;
+        return mmae_rowscale_add(d->x1, d->branch, d->dp2, d->x2, R, d->N, D, st);
+    }
+    return lin_fwd(c, d->hact, d->fc2_w, d->fc2_b, d->x2, MMAE_F32, R, D, Hd, d->x1, nullptr, MMAE_EPI_NONE, st);
 }
 
 int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
@@ -178,31 +359,44 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
     const int act = d->act_dtype;
     MMAE_REQUIRE(act == MMAE_F32 || (d->dx1_act && d->dx0_act), "block_bwd: bf16 activations need dx1_act / dx0_act");
     MMAE_REQUIRE(!d->g_fc1_b || d->part_h, "block_bwd: part_h needed for the fc1 bias gradient");
+    MMAE_REQUIRE(!(d->dp1 || d->dp2) || d->dxs_act, "block_bwd: stochastic depth needs the dxs_act scratch buffer");
+    MMAE_REQUIRE(!(d->dp2 && d->fc2_b_done), "block_bwd: with a scaled MLP branch the fc2 bias gradient cannot come from the producer of dx");
     hipStream_t st = (hipStream_t)stream;
     hipStream_t sd = side_stream ? (hipStream_t)side_stream : st;
+    const Ctx c = ctx_of(d);
     const int R = d->B * d->N, D = d->D, Hd = d->Hd, N = d->N, hd = D / d->heads;
     const int nblk = mmae_layernorm_bwd_nblk(R);
     const int hrows = (R + 63) / 64;
-    // ---- MLP
+    // ---- MLP: x2 = x1 + dp2 * mlp(norm2(x1))
+    const void* dm_act = d->dx_act;                                  // gradient of the MLP branch output, act dtype
+    if (d->dp2) {
+        if ((rc = mmae_rowscale_cast(d->dx, d->dp2, d->dxs_act, act, R, N, D, st))) return rc;
+        dm_act = d->dxs_act;
+    }
     float* part_h = d->g_fc1_b ? d->part_h : nullptr;
-    if ((rc = lin_dx(d, d->dx_act, d->fc2_w, d->d_hpre, act, R, D, Hd, d->hpre, MMAE_EPI_DGELU, part_h, st))) return rc;
+    if ((rc = lin_dx(c, dm_act, D, d->fc2_w, d->d_hpre, act, R, D, Hd, d->hpre, MMAE_EPI_DGELU, part_h, st))) return rc;
     if ((rc = fork_to(st, sd))) return rc;                          // dx_act, d_hpre ready for the weight-gradient stream
-    if ((rc = lin_dw(d, d->dx_act, d->hact, d->g_fc2_w, d->fc2_b_done ? nullptr : d->g_fc2_b, R, D, Hd, sd))) return rc;
-    if ((rc = lin_dx(d, d->d_hpre, d->fc1_w, d->d_ln2, act, R, Hd, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
-    if ((rc = lin_dw(d, d->d_hpre, d->ln2, d->g_fc1_w, nullptr, R, Hd, D, sd))) return rc;
+    if ((rc = lin_dw(c, dm_act, D, d->hact, d->g_fc2_w, d->fc2_b_done ? nullptr : d->g_fc2_b, R, D, Hd, sd))) return rc;
+    if ((rc = lin_dx(c, d->d_hpre, Hd, d->fc1_w, d->d_ln2, act, R, Hd, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
+    if ((rc = lin_dw(c, d->d_hpre, Hd, d->ln2, d->g_fc1_w, nullptr, R, Hd, D, sd))) return rc;
     if (part_h) {
         float* dst[1] = {d->g_fc1_b};
-        if (mmae_colsum_ws_elems(hrows, Hd) > d->ws_side_elems) { mmae_set_error("block: ws_side too small"); return MMAE_EINVAL; }
-        if ((rc = mmae_colsum_scatter(part_h, MMAE_F32, hrows, Hd, Hd, Hd, dst, 1, d->grad_acc, d->ws_side, sd))) return rc;
+        if ((rc = scatter(c, part_h, hrows, Hd, dst, 1, sd))) return rc;
     }
     void* dx1_act = act == MMAE_F32 ? nullptr : d->dx1_act;
     if ((rc = mmae_layernorm_bwd(d->d_ln2, act, d->x1, d->n2_w, d->mean2, d->rstd2, d->dx, d->dx1, dx1_act, act, d->part2, R, D, st))) return rc;
-    const void* dx1a = act == MMAE_F32 ? (const void*)d->dx1 : (const void*)d->dx1_act;
-    // ---- attention
-    if ((rc = lin_dx(d, dx1a, d->proj_w, d->d_ao, act, R, D, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
+    // ---- attention: x1 = x0 + dp1 * attn(norm1(x0))
+    const void* da_act = act == MMAE_F32 ? (const void*)d->dx1 : (const void*)d->dx1_act;
+    if (d->dp1) {
+        if (d->dp2 && (rc = fork_to(sd, st))) return rc;           // dxs_act is still being read by the fc2 weight gradient
+        if ((rc = mmae_rowscale_cast(d->dx1, d->dp1, d->dxs_act, act, R, N, D, st))) return rc;
+        da_act = d->dxs_act;
+    }
+    if ((rc = lin_dx(c, da_act, D, d->proj_w, d->d_ao, act, R, D, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
     if ((rc = fork_to(st, sd))) return rc;                          // part2, dx1_act
-    if ((rc = scatter3(d, d->part2, nblk, D, d->g_n2_w, d->g_n2_b, d->g_proj_b, sd))) return rc;
-    if ((rc = lin_dw(d, dx1a, d->ao, d->g_proj_w, nullptr, R, D, D, sd))) return rc;
+    // proj's bias gradient: colsum(dx1) from the LayerNorm partials, or colsum of the rescaled copy under stochastic depth
+    if ((rc = scatter3(c, d->part2, nblk, D, d->g_n2_w, d->g_n2_b, d->dp1 ? nullptr : d->g_proj_b, sd))) return rc;
+    if ((rc = lin_dw(c, da_act, D, d->ao, d->g_proj_w, d->dp1 ? d->g_proj_b : nullptr, R, D, D, sd))) return rc;
     {
         const size_t es = act == MMAE_BF16 ? 2 : 4;
         const char* qkv = (const char*)d->qkv;
@@ -213,13 +407,379 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
                      d->B, d->heads, N, N, hd, sb3, 3 * D, sb3, 3 * D, sb3, 3 * D, sb1, D, sb3, 3 * D, sb3, 3 * D, sb3, 3 * D,
                      1.0f / sqrtf((float)hd), st))) return rc;
     }
-    if ((rc = lin_dx(d, d->d_qkv, d->qkv_w, d->d_ln1, act, R, 3 * D, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
+    if ((rc = lin_dx(c, d->d_qkv, 3 * D, d->qkv_w, d->d_ln1, act, R, 3 * D, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
     if ((rc = fork_to(st, sd))) return rc;                          // d_qkv
-    if ((rc = lin_dw(d, d->d_qkv, d->ln1, d->g_qkv_w, d->g_qkv_b, R, 3 * D, D, sd))) return rc;
+    if ((rc = lin_dw(c, d->d_qkv, 3 * D, d->ln1, d->g_qkv_w, d->g_qkv_b, R, 3 * D, D, sd))) return rc;
     void* dx0_act = act == MMAE_F32 ? nullptr : d->dx0_act;
     if ((rc = mmae_layernorm_bwd(d->d_ln1, act, d->x0, d->n1_w, d->mean1, d->rstd1, d->dx1, d->dx0, dx0_act, act, d->part1, R, D, st))) return rc;
     if ((rc = fork_to(st, sd))) return rc;                          // part1
-    return scatter3(d, d->part1, nblk, D, d->g_n1_w, d->g_n1_b, d->g_cs, sd);
+    return scatter3(c, d->part1, nblk, D, d->g_n1_w, d->g_n1_b, d->g_cs, sd);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// stack of blocks
+// ------------------------------------------------------------------------------------------------------------------
+int64_t mmae_stack_act_bytes(const mmae_stack_desc* d) {
+    if (!d || d->L <= 0) return 0;
+    Carver cv(nullptr);
+    const size_t es = d->act_dtype == MMAE_BF16 ? 2 : 4;
+    for (int l = 0; l < d->L; ++l) (void)carve_block_act(cv, d->B, d->N, d->D, d->heads, d->Hd, es);
+    if (stack_has_dp(d)) (void)cv.takeT<float>((int64_t)d->B * d->N * d->D);
+    return cv.off;
+}
+
+int64_t mmae_stack_out_offset(const mmae_stack_desc* d, int l) {
+    if (!d || l < 0 || l >= d->L) return -1;
+    Carver cv(nullptr);
+    const size_t es = d->act_dtype == MMAE_BF16 ? 2 : 4;
+    BlockAct a = {};
+    for (int i = 0; i <= l; ++i) a = carve_block_act(cv, d->B, d->N, d->D, d->heads, d->Hd, es);
+    return (int64_t)(uintptr_t)a.x2;
+}
+
+int64_t mmae_stack_tmp_bytes(const mmae_stack_desc* d) {
+    if (!d || d->L <= 0) return 0;
+    Carver cv(nullptr);
+    const size_t es = d->act_dtype == MMAE_BF16 ? 2 : 4;
+    const bool bf = d->act_dtype == MMAE_BF16;
+    const int nset = d->L < NSET ? d->L : NSET;
+    for (int s = 0; s < nset; ++s) (void)carve_block_tmp(cv, d->B, d->N, d->D, d->Hd, es, bf, stack_has_dp(d));
+    if (bf) (void)cv.take((int64_t)d->B * d->N * d->D * es);       // act-dtype copy of the incoming gradient
+    return cv.off;
+}
+
+int mmae_stack_fwd(const mmae_stack_desc* d, void* stream) {
+    int rc = check_stack(d);
+    if (rc) return rc;
+    MMAE_REQUIRE(d->act_bytes >= mmae_stack_act_bytes(d), "stack_fwd: activation slab too small");
+    hipStream_t st = (hipStream_t)stream;
+    Carver cv(d->act);
+    const size_t es = d->act_dtype == MMAE_BF16 ? 2 : 4;
+    const float* x = d->x;
+    BlockAct acts[64];
+    MMAE_REQUIRE(d->L <= 64, "stack: at most 64 blocks");
+    for (int l = 0; l < d->L; ++l) acts[l] = carve_block_act(cv, d->B, d->N, d->D, d->heads, d->Hd, es);
+    float* branch = stack_has_dp(d) ? cv.takeT<float>((int64_t)d->B * d->N * d->D) : nullptr;
+    for (int l = 0; l < d->L; ++l) {
+        mmae_block_desc b = {};
+        fill_block_params(b, d->B, d->N, d->D, d->heads, d->Hd, d->act_dtype, d->f32_gemm, d->eps, d->w + 4 * l, d->p + 8 * l);
+        fill_block_act(b, x, acts[l]);
+        b.dp1 = d->dp ? d->dp[2 * l] : nullptr; b.dp2 = d->dp ? d->dp[2 * l + 1] : nullptr; b.branch = branch;
+        b.ws_main = d->ws_main; b.ws_main_elems = d->ws_main_elems;
+        if ((rc = mmae_block_fwd(&b, st))) return rc;
+        x = acts[l].x2;
+    }
+    return 0;
+}
+
+int mmae_stack_bwd(const mmae_stack_desc* d, void* stream, void* side_stream) {
+    int rc = check_stack(d);
+    if (rc) return rc;
+    MMAE_REQUIRE(d->L <= 64, "stack: at most 64 blocks");
+    MMAE_REQUIRE(d->tmp && d->tmp_bytes >= mmae_stack_tmp_bytes(d) && d->act_bytes >= mmae_stack_act_bytes(d), "stack_bwd: slab too small");
+    MMAE_REQUIRE(0 <= d->l_begin && d->l_begin < d->l_end && d->l_end <= d->L, "stack_bwd: bad block range");
+    MMAE_REQUIRE(d->d_out && d->d_out[d->L - 1], "stack_bwd: the gradient of the last block's output is required");
+    MMAE_REQUIRE(d->l_begin > 0 || d->dx, "stack_bwd: null dx");
+    hipStream_t st = (hipStream_t)stream;
+    hipStream_t sd = side_stream ? (hipStream_t)side_stream : st;
+    const size_t es = d->act_dtype == MMAE_BF16 ? 2 : 4;
+    const bool bf = d->act_dtype == MMAE_BF16;
+    const int64_t RD = (int64_t)d->B * d->N * d->D;
+    Carver ca(d->act);
+    BlockAct acts[64];
+    for (int l = 0; l < d->L; ++l) acts[l] = carve_block_act(ca, d->B, d->N, d->D, d->heads, d->Hd, es);
+    Carver ct(d->tmp);
+    const int nset = d->L < NSET ? d->L : NSET;
+    BlockTmp tmps[NSET];
+    for (int s = 0; s < nset; ++s) tmps[s] = carve_block_tmp(ct, d->B, d->N, d->D, d->Hd, es, bf, stack_has_dp(d));
+    void* top_act = bf ? ct.take(RD * es) : nullptr;
+    // a continuation call (l_end < L) may overwrite temporaries that the previous call's side-stream work still reads
+    if (d->l_end < d->L && (rc = fork_to(sd, st))) return rc;
+    const float* dx; const void* dx_act;
+    bool fc2_done = false;
+    if (d->l_end == d->L) {
+        dx = d->d_out[d->L - 1];
+        if (bf) { if ((rc = mmae_cast_f32_to_bf16(dx, top_act, RD, st))) return rc; dx_act = top_act; } else dx_act = dx;
+    } else {
+        // input gradient of block l_end, left in its temporary set by the previous call
+        const BlockTmp& t = tmps[d->l_end % nset];
+        dx = t.dx0; dx_act = bf ? (const void*)t.dx0_act : (const void*)t.dx0;
+        const int le = d->l_end;
+        const bool clean = !(d->d_out[le - 1]) && !(d->dp && d->dp[2 * (le - 1) + 1]);
+        fc2_done = clean && d->g && d->g[12 * (le - 1) + 11];
+        if (d->d_out[le - 1]) {
+            if ((rc = mmae_axpy_f32((float*)dx, d->d_out[le - 1], 1.0f, RD, st))) return rc;
+            if (bf && (rc = mmae_cast_f32_to_bf16(dx, (void*)dx_act, RD, st))) return rc;
+        }
+    }
+    StackRun s = {d->B, d->N, d->D, d->heads, d->Hd, d->act_dtype, d->f32_gemm, d->grad_acc, d->w, d->p, d->dp, d->g, d->x, acts, tmps, nset,
+                  d->ws_main, d->ws_main_elems, d->ws_side, d->ws_side_elems};
+    const float* o; const void* oa;
+    return run_blocks_bwd(s, d->l_begin, d->l_end, dx, dx_act, d->l_end < d->L, fc2_done, d->d_out, nullptr, d->l_begin == 0 ? d->dx : nullptr, st, sd, &o, &oa);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// SpatialOutputAdapter
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct AdapterAct {
+    float *ctx_tok, *te, *queries, *context, *qmean, *qrstd, *cmean, *crstd, *lse, *x, *omean, *orstd, *x1, *pat;
+    void *enc_act, *qn, *cn, *q, *kv, *xo, *on, *hpre, *hact, *h_act;
+    BlockAct blocks[8];
+};
+int kp_of(const mmae_adapter_desc* d) { return d->C * d->ph * d->pw; }
+
+AdapterAct carve_adapter_act(Carver& cv, const mmae_adapter_desc* d) {
+    const size_t es = d->act_dtype == MMAE_BF16 ? 2 : 4;
+    const int64_t Rq = (int64_t)d->B * d->n_q, Rc = (int64_t)d->B * d->NC;
+    const int D = d->D;
+    AdapterAct a;
+    a.enc_act = (d->act_dtype == MMAE_BF16 && !d->enc_act) ? cv.take(Rc * d->Denc * es) : nullptr;
+    a.ctx_tok = cv.takeT<float>(Rc * D); a.te = cv.takeT<float>((int64_t)d->T * D);
+    a.queries = cv.takeT<float>(Rq * D); a.context = cv.takeT<float>(Rc * D);
+    a.qn = cv.take(Rq * D * es); a.cn = cv.take(Rc * D * es);
+    a.qmean = cv.takeT<float>(Rq); a.qrstd = cv.takeT<float>(Rq); a.cmean = cv.takeT<float>(Rc); a.crstd = cv.takeT<float>(Rc);
+    a.q = cv.take(Rq * D * es); a.kv = cv.take(Rc * 2 * D * es); a.xo = cv.take(Rq * D * es);
+    a.lse = cv.takeT<float>((int64_t)d->B * d->heads * d->n_q);
+    a.x = cv.takeT<float>(Rq * D); a.on = cv.take(Rq * D * es); a.omean = cv.takeT<float>(Rq); a.orstd = cv.takeT<float>(Rq);
+    a.hpre = cv.take(Rq * d->Hd * es); a.hact = cv.take(Rq * d->Hd * es); a.x1 = cv.takeT<float>(Rq * D);
+    for (int l = 0; l < d->depth; ++l) a.blocks[l] = carve_block_act(cv, d->B, d->n_q, D, d->heads, d->Hd, es);
+    a.h_act = d->act_dtype == MMAE_BF16 ? cv.take(Rq * D * es) : nullptr;
+    a.pat = cv.takeT<float>(Rq * kp_of(d));
+    return a;
+}
+
+struct AdapterTmp {
+    void *d_pat, *dh_act, *d_hpre, *d_on, *dx_act, *d_xo, *d_q, *d_kv, *d_qn, *d_cn, *d_ctx_act;
+    float *dh, *part_h, *dx, *part_o, *d_queries, *part_q, *d_context, *part_c, *d_ctx, *part_b;
+    BlockTmp blocks[8];
+};
+int64_t ldpat_of(const mmae_adapter_desc* d) { return (kp_of(d) + 7) / 8 * 8; }
+
+AdapterTmp carve_adapter_tmp(Carver& cv, const mmae_adapter_desc* d) {
+    const size_t es = d->act_dtype == MMAE_BF16 ? 2 : 4;
+    const bool bf = d->act_dtype == MMAE_BF16;
+    const int64_t Rq = (int64_t)d->B * d->n_q, Rc = (int64_t)d->B * d->NC;
+    const int D = d->D;
+    AdapterTmp t;
+    t.d_pat = cv.take(Rq * ldpat_of(d) * es);
+    t.dh_act = cv.take(Rq * D * es);
+    t.dh = bf ? cv.takeT<float>(Rq * D) : nullptr;
+    for (int l = 0; l < d->depth; ++l) t.blocks[l] = carve_block_tmp(cv, d->B, d->n_q, D, d->Hd, es, bf, false);
+    t.part_h = cv.takeT<float>((Rq + 63) / 64 * d->Hd);
+    t.d_hpre = cv.take(Rq * d->Hd * es); t.d_on = cv.take(Rq * D * es);
+    t.dx = cv.takeT<float>(Rq * D); t.dx_act = bf ? cv.take(Rq * D * es) : nullptr;
+    t.part_o = cv.takeT<float>((int64_t)mmae_layernorm_bwd_nblk(Rq) * 3 * D);
+    t.d_xo = cv.take(Rq * D * es); t.d_q = cv.take(Rq * D * es); t.d_kv = cv.take(Rc * 2 * D * es);
+    t.d_qn = cv.take(Rq * D * es); t.d_cn = cv.take(Rc * D * es);
+    t.d_queries = cv.takeT<float>(Rq * D); t.part_q = cv.takeT<float>((int64_t)mmae_layernorm_bwd_nblk(Rq) * 3 * D);
+    t.d_context = cv.takeT<float>(Rc * D); t.part_c = cv.takeT<float>((int64_t)mmae_layernorm_bwd_nblk(Rc) * 3 * D);
+    t.d_ctx = cv.takeT<float>(Rc * D); t.part_b = cv.takeT<float>((int64_t)mmae_decoder_build_bwd_nblk(d->B) * (d->T + 1) * D);
+    t.d_ctx_act = bf ? cv.take(Rc * D * es) : nullptr;
+    return t;
+}
+
+int check_adapter(const mmae_adapter_desc* d) {
+    MMAE_REQUIRE(d, "adapter: null descriptor");
+    MMAE_REQUIRE(d->B > 0 && d->NC > 0 && d->Denc > 0 && d->D > 0 && d->heads > 0 && d->Hd > 0 && d->D % d->heads == 0 && d->depth >= 0 &&
+                 d->depth <= 8 && d->T >= 1 && d->T <= 7 && d->q_task >= 0 && d->q_task < d->T && d->G >= 0 && d->n_q > 0 && d->NC > d->G,
+                 "adapter: bad geometry");
+    MMAE_REQUIRE(d->C > 0 && d->nh > 0 && d->nw > 0 && d->ph > 0 && d->pw > 0 && d->nh * d->nw == d->n_q, "adapter: bad patch geometry");
+    MMAE_REQUIRE(d->act_dtype == MMAE_BF16 || (d->act_dtype == MMAE_F32 && d->f32_gemm == MMAE_F32X3),
+                 "adapter: activations must be bf16, or f32 with split-bf16 (MMAE_F32X3) products");
+    const int hd = d->D / d->heads;
+    if ((hd != 32 && hd != 64) || d->n_q > 256 || d->NC > 256) { mmae_set_error("adapter: geometry outside the fused attention kernel"); return MMAE_ESUPPORT; }
+    if (d->act_dtype == MMAE_F32) {
+        const int64_t qp = (d->n_q + 31) / 32 * 32, kp = (d->NC + 31) / 32 * 32;
+        if (4 * (qp + kp) * hd * 2 + 8 * qp > 160 * 1024) { mmae_set_error("adapter: f32 attention tiles exceed the LDS"); return MMAE_ESUPPORT; }
+    }
+    if ((d->D % 8) || (d->Denc % 8) || (d->Hd % 8) || (kp_of(d) % 4)) { mmae_set_error("adapter: widths must be multiples of 8 (patch row of 4)"); return MMAE_ESUPPORT; }
+    MMAE_REQUIRE(d->task_offsets_host && d->w && d->p && d->mask_token && d->task_emb && d->pos && d->enc && d->ids_keep && d->ids_restore && d->act,
+                 "adapter: null pointer");
+    MMAE_REQUIRE(d->act_dtype == MMAE_BF16 || d->enc_act == nullptr || d->enc_act == (const void*)d->enc, "adapter: enc_act must alias enc for f32 activations");
+    return 0;
+}
+
+Ctx ctx_of(const mmae_adapter_desc* d) { return {d->act_dtype, d->f32_gemm, d->grad_acc, d->ws_main, d->ws_main_elems, d->ws_side, d->ws_side_elems}; }
+
+}  // namespace
+
+int64_t mmae_adapter_act_bytes(const mmae_adapter_desc* d) {
+    if (!d || d->depth < 0 || d->depth > 8) return 0;
+    Carver cv(nullptr);
+    (void)carve_adapter_act(cv, d);
+    return cv.off;
+}
+int64_t mmae_adapter_tmp_bytes(const mmae_adapter_desc* d) {
+    if (!d || d->depth < 0 || d->depth > 8) return 0;
+    Carver cv(nullptr);
+    (void)carve_adapter_tmp(cv, d);
+    return cv.off;
+}
+int64_t mmae_adapter_pat_offset(const mmae_adapter_desc* d) {
+    if (!d || d->depth < 0 || d->depth > 8) return -1;
+    Carver cv(nullptr);
+    AdapterAct a = carve_adapter_act(cv, d);
+    return (int64_t)(uintptr_t)a.pat;
+}
+
+int mmae_adapter_fwd(const mmae_adapter_desc* d, void* stream) {
+    int rc = check_adapter(d);
+    if (rc) return rc;
+    MMAE_REQUIRE(d->act_bytes >= mmae_adapter_act_bytes(d), "adapter_fwd: activation slab too small");
+    hipStream_t st = (hipStream_t)stream;
+    const Ctx c = ctx_of(d);
+    const int act = d->act_dtype, D = d->D, Hd = d->Hd, B = d->B, NC = d->NC, n_q = d->n_q, T = d->T, depth = d->depth;
+    const int Rq = B * n_q, Rc = B * NC, hd = D / d->heads, KP = kp_of(d);
+    const size_t es = c.es();
+    Carver cv(d->act);
+    AdapterAct a = carve_adapter_act(cv, d);
+    const void* const* w = d->w; const float* const* p = d->p;
+    const void *qw = w[0], *kvw = w[1], *pw = w[2], *f1w = w[3], *f2w = w[4], *ow = w[5 + 4 * depth], *pcw = w[6 + 4 * depth];
+    const float *qb = p[0], *kvb = p[1], *pb = p[2], *cnw = p[3], *cnb = p[4], *qnw = p[5], *qnb = p[6], *onw = p[7], *onb = p[8], *f1b = p[9],
+                *f2b = p[10], *ob = p[11 + 8 * depth], *pcb = p[12 + 8 * depth];
+    const void* enc_act = act == MMAE_F32 ? (const void*)d->enc : d->enc_act;
+    if (!enc_act) {
+        if ((rc = mmae_cast_f32_to_bf16(d->enc, a.enc_act, (int64_t)Rc * d->Denc, st))) return rc;
+        enc_act = a.enc_act;
+    }
+    if ((rc = lin_fwd(c, enc_act, pcw, pcb, a.ctx_tok, MMAE_F32, Rc, D, d->Denc, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;      // :258
+    for (int t = 0; t < T; ++t) {
+        hipError_t e = d->task_emb[t] ? hipMemcpyAsync(a.te + (size_t)t * D, d->task_emb[t], (size_t)D * 4, hipMemcpyDeviceToDevice, st)
+                                      : hipMemsetAsync(a.te + (size_t)t * D, 0, (size_t)D * 4, st);
+        if (e != hipSuccess) { mmae_set_error("adapter_fwd: task embedding copy failed"); return MMAE_ELAUNCH; }
+    }
+    if ((rc = mmae_decoder_build(a.ctx_tok, d->ids_keep, d->ids_restore, d->mask_token, a.te, d->pos, d->task_offsets_host, T, d->q_task, B,
+                                 NC - d->G, d->G, D, n_q, a.queries, a.context, st))) return rc;                                       // :183-234
+    if ((rc = mmae_layernorm_fwd(a.queries, qnw, qnb, a.qn, act, a.qmean, a.qrstd, Rq, D, d->eps, st))) return rc;
+    if ((rc = mmae_layernorm_fwd(a.context, cnw, cnb, a.cn, act, a.cmean, a.crstd, Rc, D, d->eps, st))) return rc;
+    if ((rc = lin_fwd(c, a.qn, qw, qb, a.q, act, Rq, D, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;
+    if ((rc = lin_fwd(c, a.cn, kvw, kvb, a.kv, act, Rc, 2 * D, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;
+    {
+        auto fn = act == MMAE_BF16 ? mmae_attn_fwd : mmae_attn_fwd_f32x3;
+        const char* kv = (const char*)a.kv;
+        if ((rc = fn(a.q, kv, kv + (size_t)D * es, a.xo, a.lse, B, d->heads, n_q, NC, hd, (int64_t)n_q * D, D, (int64_t)NC * 2 * D, 2 * D,
+                     (int64_t)NC * 2 * D, 2 * D, (int64_t)n_q * D, D, 1.0f / sqrtf((float)hd), st))) return rc;
+    }
+    if ((rc = lin_fwd(c, a.xo, pw, pb, a.x, MMAE_F32, Rq, D, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;                      // :265
+    if ((rc = mmae_layernorm_fwd(a.x, onw, onb, a.on, act, a.omean, a.orstd, Rq, D, d->eps, st))) return rc;
+    if ((rc = lin_fwd(c, a.on, f1w, f1b, a.hact, act, Rq, Hd, D, nullptr, a.hpre, MMAE_EPI_GELU, st))) return rc;
+    if ((rc = lin_fwd(c, a.hact, f2w, f2b, a.x1, MMAE_F32, Rq, D, Hd, a.x, nullptr, MMAE_EPI_NONE, st))) return rc;                    // :266
+    const float* h = a.x1;
+    for (int l = 0; l < depth; ++l) {                                                                                                // :271
+        mmae_block_desc b = {};
+        fill_block_params(b, B, n_q, D, d->heads, Hd, act, d->f32_gemm, d->eps, w + 5 + 4 * l, p + 11 + 8 * l);
+        fill_block_act(b, h, a.blocks[l]);
+        b.ws_main = d->ws_main; b.ws_main_elems = d->ws_main_elems;
+        if ((rc = mmae_block_fwd(&b, st))) return rc;
+        h = a.blocks[l].x2;
+    }
+    const void* h_act = h;
+    if (act == MMAE_BF16) { if ((rc = mmae_cast_f32_to_bf16(h, a.h_act, (int64_t)Rq * D, st))) return rc; h_act = a.h_act; }
+    if ((rc = lin_fwd(c, h_act, ow, ob, a.pat, MMAE_F32, Rq, KP, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;                  // :274
+    if (d->img) return mmae_unpatchify(a.pat, d->img, B, d->C, d->nh, d->nw, d->ph, d->pw, st);                                       // :277-280
+    return 0;
+}
+
+int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream) {
+    int rc = check_adapter(d);
+    if (rc) return rc;
+    MMAE_REQUIRE(d->tmp && d->tmp_bytes >= mmae_adapter_tmp_bytes(d) && d->act_bytes >= mmae_adapter_act_bytes(d), "adapter_bwd: slab too small");
+    MMAE_REQUIRE((d->d_img != nullptr) != (d->d_pat != nullptr), "adapter_bwd: exactly one of d_img / d_pat");
+    MMAE_REQUIRE(d->g && d->d_enc, "adapter_bwd: null gradient destination table / d_enc");
+    hipStream_t st = (hipStream_t)stream;
+    hipStream_t sd = side_stream ? (hipStream_t)side_stream : st;
+    const Ctx c = ctx_of(d);
+    const int act = d->act_dtype, D = d->D, Hd = d->Hd, B = d->B, NC = d->NC, n_q = d->n_q, T = d->T, depth = d->depth;
+    const int Rq = B * n_q, Rc = B * NC, hd = D / d->heads, KP = kp_of(d);
+    const size_t es = c.es();
+    const bool bf = act == MMAE_BF16;
+    Carver ca(d->act);
+    AdapterAct a = carve_adapter_act(ca, d);
+    Carver ct(d->tmp);
+    AdapterTmp t = carve_adapter_tmp(ct, d);
+    const void* const* w = d->w; const float* const* p = d->p;
+    const void *qw = w[0], *kvw = w[1], *pw = w[2], *f1w = w[3], *f2w = w[4], *ow = w[5 + 4 * depth], *pcw = w[6 + 4 * depth];
+    const float *cnw = p[3], *qnw = p[5], *onw = p[7];
+    float* const* g = d->g;
+    float* g_mask = g[0];
+    float* const* g_temb = g + 1;
+    float* const* gb = g + 1 + T;          // q_w q_b kv_w kv_b proj_w proj_b ctxn_w ctxn_b qn_w qn_b outn_w outn_b fc1_w fc1_b fc2_w fc2_b
+    float* const* gblk = gb + 16;
+    float* const* gtail = gblk + 12 * depth;   // out_proj_w out_proj_b pc_w pc_b
+    const void* enc_act = act == MMAE_F32 ? (const void*)d->enc : (d->enc_act ? d->enc_act : a.enc_act);
+    const void* h_act = depth > 0 ? (bf ? a.h_act : (void*)a.blocks[depth - 1].x2) : (bf ? a.h_act : (void*)a.x1);
+
+    // ---- out_proj
+    const void* d_pat = d->d_pat; int64_t ldp = d->ld_pat;
+    if (!d_pat) {
+        ldp = ldpat_of(d);
+        if (ldp != KP && hipMemsetAsync(t.d_pat, 0, (size_t)Rq * ldp * es, st) != hipSuccess) { mmae_set_error("adapter_bwd: memset failed"); return MMAE_ELAUNCH; }
+        if ((rc = mmae_patchify(d->d_img, t.d_pat, act, ldp, B, d->C, d->nh, d->nw, d->ph, d->pw, st))) return rc;
+        d_pat = t.d_pat;
+    }
+    MMAE_REQUIRE(ldp >= KP && ldp % 4 == 0, "adapter_bwd: bad ld_pat");
+    if ((rc = fork_to(st, sd))) return rc;
+    if ((rc = lin_dw(c, d_pat, ldp, h_act, gtail[0], gtail[1], Rq, KP, D, sd))) return rc;
+    if ((rc = lin_dx(c, d_pat, ldp, ow, t.dh_act, act, Rq, KP, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
+    const float* dh = (const float*)t.dh_act;
+    if (bf) { if ((rc = mmae_cast_bf16_to_f32(t.dh_act, t.dh, (int64_t)Rq * D, st))) return rc; dh = t.dh; }
+    const void* dh_act = t.dh_act;
+    // ---- decoder_transformer blocks
+    bool fc2_done = false;
+    if (depth > 0) {
+        // parameter / gradient tables of the blocks in stack order
+        StackRun s = {B, n_q, D, d->heads, Hd, act, d->f32_gemm, d->grad_acc, w + 5, p + 11, nullptr, gblk, a.x1, a.blocks, t.blocks, depth,
+                      d->ws_main, d->ws_main_elems, d->ws_side, d->ws_side_elems};
+        const float* o; const void* oa;
+        if ((rc = run_blocks_bwd(s, 0, depth, dh, dh_act, false, false, nullptr, gb[15], nullptr, st, sd, &o, &oa))) return rc;
+        dh = o; dh_act = oa;
+        fc2_done = gb[15] != nullptr;
+    }
+    // ---- x1 = x + mlp(out_norm(x))
+    if ((rc = lin_dx(c, dh_act, D, f2w, t.d_hpre, act, Rq, D, Hd, a.hpre, MMAE_EPI_DGELU, gb[13] ? t.part_h : nullptr, st))) return rc;
+    if ((rc = fork_to(st, sd))) return rc;
+    if ((rc = lin_dw(c, dh_act, D, a.hact, gb[14], fc2_done ? nullptr : gb[15], Rq, D, Hd, sd))) return rc;
+    if ((rc = lin_dx(c, t.d_hpre, Hd, f1w, t.d_on, act, Rq, Hd, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
+    if ((rc = lin_dw(c, t.d_hpre, Hd, a.on, gb[12], nullptr, Rq, Hd, D, sd))) return rc;
+    if (gb[13]) { float* dst[1] = {gb[13]}; if ((rc = scatter(c, t.part_h, (Rq + 63) / 64, Hd, dst, 1, sd))) return rc; }
+    if ((rc = mmae_layernorm_bwd(t.d_on, act, a.x, onw, a.omean, a.orstd, dh, t.dx, bf ? t.dx_act : nullptr, act, t.part_o, Rq, D, st))) return rc;
+    const void* dx_act = bf ? (const void*)t.dx_act : (const void*)t.dx;
+    // ---- x = proj(attn(q, k, v))
+    if ((rc = lin_dx(c, dx_act, D, pw, t.d_xo, act, Rq, D, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
+    if ((rc = fork_to(st, sd))) return rc;
+    if ((rc = scatter3(c, t.part_o, mmae_layernorm_bwd_nblk(Rq), D, gb[10], gb[11], gb[5], sd))) return rc;      // outn_w, outn_b, proj_b
+    if ((rc = lin_dw(c, dx_act, D, a.xo, gb[4], nullptr, Rq, D, D, sd))) return rc;
+    {
+        auto fn = bf ? mmae_attn_bwd : mmae_attn_bwd_f32x3;
+        const char* kv = (const char*)a.kv; char* dkv = (char*)t.d_kv;
+        if ((rc = fn(a.q, kv, kv + (size_t)D * es, a.xo, t.d_xo, a.lse, t.d_q, dkv, dkv + (size_t)D * es, B, d->heads, n_q, NC, hd,
+                     (int64_t)n_q * D, D, (int64_t)NC * 2 * D, 2 * D, (int64_t)NC * 2 * D, 2 * D, (int64_t)n_q * D, D, (int64_t)n_q * D, D,
+                     (int64_t)NC * 2 * D, 2 * D, (int64_t)NC * 2 * D, 2 * D, 1.0f / sqrtf((float)hd), st))) return rc;
+    }
+    if ((rc = lin_dx(c, t.d_q, D, qw, t.d_qn, act, Rq, D, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
+    if ((rc = lin_dx(c, t.d_kv, 2 * D, kvw, t.d_cn, act, Rc, 2 * D, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
+    if ((rc = fork_to(st, sd))) return rc;
+    if ((rc = lin_dw(c, t.d_q, D, a.qn, gb[0], gb[1], Rq, D, D, sd))) return rc;
+    if ((rc = lin_dw(c, t.d_kv, 2 * D, a.cn, gb[2], gb[3], Rc, 2 * D, D, sd))) return rc;
+    if ((rc = mmae_layernorm_bwd(t.d_qn, act, a.queries, qnw, a.qmean, a.qrstd, nullptr, t.d_queries, nullptr, MMAE_F32, t.part_q, Rq, D, st))) return rc;
+    if ((rc = mmae_layernorm_bwd(t.d_cn, act, a.context, cnw, a.cmean, a.crstd, nullptr, t.d_context, nullptr, MMAE_F32, t.part_c, Rc, D, st))) return rc;
+    if ((rc = mmae_decoder_build_bwd(t.d_queries, t.d_context, d->ids_keep, d->ids_restore, d->task_offsets_host, T, d->q_task, B, NC - d->G, d->G, D,
+                                     n_q, t.d_ctx, t.part_b, st))) return rc;
+    const void* d_ctx_act = t.d_ctx;
+    if (bf) { if ((rc = mmae_cast_f32_to_bf16(t.d_ctx, t.d_ctx_act, (int64_t)Rc * D, st))) return rc; d_ctx_act = t.d_ctx_act; }
+    if ((rc = fork_to(st, sd))) return rc;
+    if ((rc = scatter3(c, t.part_q, mmae_layernorm_bwd_nblk(Rq), D, gb[8], gb[9], nullptr, sd))) return rc;      // qn_w, qn_b
+    if ((rc = scatter3(c, t.part_c, mmae_layernorm_bwd_nblk(Rc), D, gb[6], gb[7], nullptr, sd))) return rc;      // ctxn_w, ctxn_b
+    {
+        float* dst[8];
+        for (int i = 0; i < T; ++i) dst[i] = g_temb[i];
+        dst[T] = g_mask;
+        if ((rc = scatter(c, t.part_b, mmae_decoder_build_bwd_nblk(B), D, dst, T + 1, sd))) return rc;
+    }
+    if ((rc = lin_dw(c, d_ctx_act, D, enc_act, gtail[2], gtail[3], Rc, D, d->Denc, sd))) return rc;
+    return lin_dx(c, d_ctx_act, D, pcw, d->d_enc, MMAE_F32, Rc, D, d->Denc, nullptr, MMAE_EPI_NONE, nullptr, st);
 }
 
 }  // extern "C"

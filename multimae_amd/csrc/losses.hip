@@ -228,6 +228,29 @@ __global__ void __launch_bounds__(256) sumsq_stage2(const float* __restrict__ ws
     if (threadIdx.x == 0) out[0] = s;
 }
 
+// Every decision of the optimiser step on the device (mmae_opt_step): norm, clip / skip, non-finite guards, Adam's step
+// counter and bias corrections.  One thread.
+__global__ void opt_finalize_kernel(float* __restrict__ state, int* __restrict__ istate, float lr, float wd, const float* __restrict__ lrwd,
+                                    float b1, float b2, float clip, float skip_at, float prescale, const float* __restrict__ loss) {
+    const float norm = sqrtf(state[0]) * prescale;
+    const bool loss_bad = loss && !isfinite(loss[0]);
+    const bool skip = !isfinite(norm) || (skip_at > 0.f && norm >= skip_at) || loss_bad;
+    float scale = prescale;
+    if (clip > 0.f) { const float cc = clip / (norm + 1e-6f); scale *= cc < 1.f ? cc : 1.f; }
+    int t = istate[1];
+    if (!skip) t += 1;
+    istate[0] = skip ? 1 : 0;
+    istate[1] = t;
+    if (loss_bad) istate[2] += 1;
+    if (skip) istate[3] += 1;
+    state[1] = norm; state[2] = scale;
+    state[3] = lrwd ? lrwd[0] : lr;
+    state[4] = lrwd ? lrwd[1] : wd;
+    const int te = t > 0 ? t : 1;
+    state[5] = (float)(1.0 - pow((double)b1, (double)te));
+    state[6] = (float)sqrt(1.0 - pow((double)b2, (double)te));
+}
+
 template <typename ST>
 __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
@@ -370,6 +393,19 @@ int mmae_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, cons
     else
         hipLaunchKernelGGL((adamw_kernel<float>), dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, (long long)n, 0.f, beta1, beta2, eps, 0.f, 1.f, 1.f, grad_scale_dev, (const int*)skip_flag, (float*)shadow, hyper_dev);
     return mmae_check_launch("adamw_dev");
+}
+
+int mmae_opt_step(const mmae_opt_desc* d, void* stream) {
+    MMAE_REQUIRE(d && d->p && d->g && d->m && d->v && d->n > 0 && d->state && d->istate && d->ws, "opt_step: bad argument");
+    MMAE_REQUIRE(d->grad_prescale > 0.f, "opt_step: grad_prescale must be positive (1 for a single process)");
+    int rc = mmae_sumsq(d->g, d->n, d->state, d->ws, stream);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(opt_finalize_kernel, dim3(1), dim3(1), 0, st, d->state, d->istate, d->lr, d->weight_decay, d->lrwd_dev, d->beta1, d->beta2,
+                       d->clip_grad, d->skip_grad, d->grad_prescale, d->loss_dev);
+    if ((rc = mmae_check_launch("opt_finalize"))) return rc;
+    return mmae_adamw_dev(d->p, d->g, d->m, d->v, d->n, d->state + 3, d->beta1, d->beta2, d->eps, d->state + 2, d->istate, d->shadow,
+                          d->shadow_dtype, stream);
 }
 
 }  // extern "C"

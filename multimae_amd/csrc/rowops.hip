@@ -372,6 +372,30 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
     }
 }
 
+// stochastic depth on [R][D] activations, N rows per sample: out = resid + s[r / N] * y  /  out = cast(s[r / N] * x)
+__global__ void __launch_bounds__(256) rowscale_add_kernel(const float* __restrict__ resid, const float* __restrict__ y, const float* __restrict__ s,
+                                                           float* __restrict__ out, long long total4, int d4, int N) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const float sc = s[(i / d4) / N];
+        const f32x4 r = ld4(resid + i * 4), v = ld4(y + i * 4);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = r[j] + sc * v[j];
+        st4(out + i * 4, o);
+    }
+}
+template <typename DT>
+__global__ void __launch_bounds__(256) rowscale_cast_kernel(const float* __restrict__ x, const float* __restrict__ s, DT* __restrict__ out,
+                                                            long long total4, int d4, int N) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const float sc = s[(i / d4) / N];
+        f32x4 v = ld4(x + i * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= sc;
+        st4(out + i * 4, v);
+    }
+}
+
 // y[b][:] = mean_n x[b][n][:]   and its backward  dx[b][n][:] = dy[b][:] / N   (LinearOutputAdapter's mean pooling)
 __global__ void __launch_bounds__(256) token_mean_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int D) {
     const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -591,6 +615,21 @@ int mmae_token_mean_bwd(const float* dy, float* dx, int B, int N, int D, void* s
     const long long total4 = (long long)B * N * (D / 4);
     hipLaunchKernelGGL(token_mean_bwd_kernel, dim3((unsigned)cdiv64(total4, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, D, total4);
     return mmae_check_launch("token_mean_bwd");
+}
+int mmae_rowscale_add(const float* resid, const float* y, const float* s, float* out, int64_t R, int N, int D, void* stream) {
+    MMAE_REQUIRE(resid && y && s && out && R > 0 && N > 0 && D > 0 && D % 4 == 0 && R % N == 0, "rowscale_add: bad argument");
+    MMAE_REQUIRE(((uintptr_t)resid % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)out % 16 == 0), "rowscale_add: unaligned");
+    const long long total4 = (long long)R * (D / 4);
+    hipLaunchKernelGGL(rowscale_add_kernel, dim3(stream_grid(total4)), dim3(256), 0, (hipStream_t)stream, resid, y, s, out, total4, D / 4, N);
+    return mmae_check_launch("rowscale_add");
+}
+int mmae_rowscale_cast(const float* x, const float* s, void* out, int out_dtype, int64_t R, int N, int D, void* stream) {
+    MMAE_REQUIRE(x && s && out && R > 0 && N > 0 && D > 0 && D % 4 == 0 && R % N == 0, "rowscale_cast: bad argument");
+    MMAE_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0), "rowscale_cast: unaligned");
+    const long long total4 = (long long)R * (D / 4);
+    if (out_dtype == MMAE_BF16) hipLaunchKernelGGL((rowscale_cast_kernel<uint16_t>), dim3(stream_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, s, (uint16_t*)out, total4, D / 4, N);
+    else hipLaunchKernelGGL((rowscale_cast_kernel<float>), dim3(stream_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, s, (float*)out, total4, D / 4, N);
+    return mmae_check_launch("rowscale_cast");
 }
 int mmae_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream) {
     MMAE_REQUIRE(y && x && n >= 0, "axpy: bad argument");
