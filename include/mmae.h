@@ -39,6 +39,9 @@ extern "C" {
 #define MMAE_ESUPPORT (-3)   /* combination not implemented by this build       */
 
 int mmae_abi_version(void);
+/* sizeof the descriptor structs as this build of the library sees them (0 gemm, 1 block, 2 stack, 3 adapter, 4 opt,
+ * 5 patch_src; -1 for an unknown index): a binding checks its own struct mirrors against these at load time. */
+int mmae_struct_size(int which);
 /* last HIP error string seen by this thread's launches (static storage). */
 const char* mmae_last_error(void);
 

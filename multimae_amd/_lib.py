@@ -58,7 +58,34 @@ class BlockDesc(ctypes.Structure):
                                      'part_h', 'part1', 'part2',
                                      'g_n1_w', 'g_n1_b', 'g_qkv_w', 'g_qkv_b', 'g_proj_w', 'g_proj_b', 'g_n2_w', 'g_n2_b',
                                      'g_fc1_w', 'g_fc1_b', 'g_fc2_w', 'g_fc2_b', 'g_cs')]
-                + [('grad_acc', _I), ('fc2_b_done', _I), ('ws_main', _P), ('ws_main_elems', _L), ('ws_side', _P), ('ws_side_elems', _L)])
+                + [('grad_acc', _I), ('fc2_b_done', _I), ('ws_main', _P), ('ws_main_elems', _L), ('ws_side', _P), ('ws_side_elems', _L)]
+                + [(n, _P) for n in ('dp1', 'dp2', 'branch', 'dxs_act')])
+
+
+class StackDesc(ctypes.Structure):
+    """mirror of mmae_stack_desc"""
+    _fields_ = ([(n, _I) for n in ('L', 'B', 'N', 'D', 'heads', 'Hd', 'act_dtype', 'f32_gemm')] + [('eps', _F), ('grad_acc', _I)]
+                + [(n, _P) for n in ('w', 'p', 'dp', 'x', 'act')] + [('act_bytes', _L)]
+                + [(n, _P) for n in ('g', 'd_out', 'dx', 'tmp')] + [('tmp_bytes', _L), ('l_begin', _I), ('l_end', _I)]
+                + [('ws_main', _P), ('ws_main_elems', _L), ('ws_side', _P), ('ws_side_elems', _L)])
+
+
+class AdapterDesc(ctypes.Structure):
+    """mirror of mmae_adapter_desc"""
+    _fields_ = ([(n, _I) for n in ('B', 'NC', 'Denc', 'D', 'heads', 'Hd', 'depth', 'T', 'q_task', 'G', 'n_q', 'C', 'nh', 'nw', 'ph', 'pw',
+                                   'act_dtype', 'f32_gemm')] + [('eps', _F), ('grad_acc', _I)]
+                + [(n, _P) for n in ('task_offsets_host', 'w', 'p', 'mask_token', 'task_emb', 'pos', 'enc', 'enc_act', 'ids_keep',
+                                     'ids_restore', 'act')] + [('act_bytes', _L), ('img', _P)]
+                + [('d_img', _P), ('d_pat', _P), ('ld_pat', _L), ('g', _P), ('d_enc', _P), ('tmp', _P), ('tmp_bytes', _L)]
+                + [('ws_main', _P), ('ws_main_elems', _L), ('ws_side', _P), ('ws_side_elems', _L)])
+
+
+class OptDesc(ctypes.Structure):
+    """mirror of mmae_opt_desc"""
+    _fields_ = [('p', _P), ('g', _P), ('m', _P), ('v', _P), ('n', _L), ('shadow', _P), ('shadow_dtype', _I),
+                ('lr', _F), ('weight_decay', _F), ('beta1', _F), ('beta2', _F), ('eps', _F), ('lrwd_dev', _P),
+                ('clip_grad', _F), ('skip_grad', _F), ('grad_prescale', _F), ('loss_dev', _P),
+                ('state', _P), ('istate', _P), ('ws', _P)]
 
 
 class PatchSrc(ctypes.Structure):
@@ -122,8 +149,11 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = ret
         fn.argtypes = argtypes
-    if lib.mmae_abi_version() != 1:
+    if lib.mmae_abi_version() != 2:
         raise RuntimeError('libmmae_hip.so ABI version mismatch')
+    for which, cls in enumerate((GemmDesc, BlockDesc, StackDesc, AdapterDesc, OptDesc, PatchSrc)):
+        if lib.mmae_struct_size(which) != ctypes.sizeof(cls):
+            raise RuntimeError(f'{cls.__name__}: ctypes mirror ({ctypes.sizeof(cls)} B) != library struct ({lib.mmae_struct_size(which)} B)')
     _lib = lib
     return lib
 

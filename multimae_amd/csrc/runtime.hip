@@ -83,6 +83,17 @@ void gemm_plan(const mmae_gemm_desc* d, int* tile_out, int* split_out) {
 extern "C" {
 
 int mmae_abi_version(void) { return MMAE_ABI_VERSION; }
+int mmae_struct_size(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(mmae_gemm_desc);
+        case 1: return (int)sizeof(mmae_block_desc);
+        case 2: return (int)sizeof(mmae_stack_desc);
+        case 3: return (int)sizeof(mmae_adapter_desc);
+        case 4: return (int)sizeof(mmae_opt_desc);
+        case 5: return (int)sizeof(mmae_patch_src);
+        default: return -1;
+    }
+}
 const char* mmae_last_error(void) { return g_err; }
 
 int mmae_gemm(const mmae_gemm_desc* d, void* stream) {

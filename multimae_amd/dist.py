@@ -3,29 +3,42 @@
 Replaces torch DDP's reducer for this engine (reference: run_pretraining_multimae.py:380-387 wraps
 the model in DistributedDataParallel; collective inventory SURVEY.md section 2.4 C1-C4).
 
-Design for xGMI (8 GPUs fully connected, 7 links x ~153 GB/s each): few LARGE buckets (default 64 MiB
-instead of DDP's 25 MB) over contiguous slices of the gradient arena, launched as soon as the
-backward pass has finished the parameters they cover (the encoder stack and each output adapter
-report completion), on RCCL's own stream so they overlap the remaining backward kernels.  The
-arena is laid out in module registration order, so "encoder layer l done" == "a contiguous range is
-final".  Averaging (1/world) is folded into the all-reduce via a pre-scale of the bucket.
+Design for xGMI (8 GPUs fully connected, 7 links x ~153 GB/s each):
 
-Backend-agnostic (torch.distributed): "nccl" == RCCL on ROCm; the world_size-2 gloo CPU test runs the
-same bucket logic on CPU tensors.
+* The arena is laid out in the order the backward pass FINISHES gradients (engine.ParamArena readiness order: output
+  adapters, encoder.L-1 ... encoder.0, then the input adapters and the global token), so "the next unit is done" always
+  means "the next contiguous range is final" and the buckets -- few and LARGE, default 64 MiB instead of DDP's 25 MB -- are
+  contiguous slices that complete one after another while backward is still running.  The last bucket (input adapters +
+  global token, ~8 MB for ViT-B) is cut off on its own: it is the only all-reduce that cannot overlap backward.
+* A bucket is SUMMED (no pre-scale pass over the arena); the 1/world_size average is folded into the fused optimiser's
+  gradient scale (FusedAdamW.grad_prescale, mmae_opt_step) -- 392 MB less read-modify-write per step than a mul_.
+* Stream ordering: every readiness report records an event on the stream that ran that unit's backward (the main stream or
+  an output adapter's stream) and on its weight-gradient side stream; a bucket's all-reduce is issued from a dedicated launch
+  stream that first waits for the events of EVERY unit inside the bucket, so it cannot start before any contributing
+  gradient kernel has finished, whichever stream wrote it.  The compute streams are never blocked by the exchange;
+  finish() makes the calling stream wait for all collectives.
+* Readiness callbacks only make sense when backward writes straight into the arena (engine.set_direct_grads(True)); with
+  autograd-delivered gradients (AccumulateGrad runs after the node returns) they are ignored and finish() reduces everything.
+
+Backend-agnostic (torch.distributed): "nccl" == RCCL on ROCm; the gloo CPU tests run the same bucket logic on CPU tensors.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
 
-def plan_buckets(sizes: List[Tuple[str, int, int]], bucket_elems: int) -> List[Tuple[int, int, List[str]]]:
-    """sizes: [(name, offset, padded_numel)] in arena order.  Returns contiguous buckets
-    (start, end, names) of about bucket_elems elements, never splitting a tensor."""
+def plan_buckets(sizes: List[Tuple[str, int, int]], bucket_elems: int, cut_before: Iterable[str] = ()) -> List[Tuple[int, int, List[str]]]:
+    """sizes: [(name, offset, padded_numel)] in arena order.  Returns contiguous buckets (start, end, names) of about
+    bucket_elems elements, never splitting a tensor; a bucket also ends right before every name in cut_before."""
+    cut = set(cut_before)
     buckets, cur, start, end = [], [], None, None
     for name, off, n in sizes:
+        if cur and name in cut:
+            buckets.append((start, end, cur))
+            cur, start = [], None
         if start is None:
             start = off
         cur.append(name)
@@ -39,76 +52,140 @@ def plan_buckets(sizes: List[Tuple[str, int, int]], bucket_elems: int) -> List[T
 
 
 class GradAllReducer:
-    """Bucketed, overlap-capable all-reduce(mean) of a flat gradient buffer."""
+    """Bucketed, overlap-capable all-reduce(sum) of a flat gradient buffer; average = sum * grad_prescale in the optimiser."""
 
     def __init__(self, grad: torch.Tensor, sizes: List[Tuple[str, int, int]], bucket_mb: float = 64.0,
-                 group: Optional[dist.ProcessGroup] = None):
+                 group: Optional[dist.ProcessGroup] = None, cut_before: Iterable[str] = (), average_in_place: bool = False):
         self.grad = grad
         self.group = group
-        self.join = None
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.buckets = plan_buckets(sizes, int(bucket_mb * 1024 * 1024 / 4))
+        self.buckets = plan_buckets(sizes, int(bucket_mb * 1024 * 1024 / 4), cut_before)
+        self.average_in_place = average_in_place        # tests / callers without the fused optimiser: scale the bucket after the sum
+        self.direct_grads = lambda: True                # for_arena() binds engine.direct_grads
         self._bucket_of: Dict[str, int] = {}
         for i, (_, _, names) in enumerate(self.buckets):
             for n in names:
                 self._bucket_of[n] = i
-        self._pending: List[int] = []
         self._remaining: List[int] = []
         self._handles = []
         self._launched: List[bool] = []
+        self._events: List[list] = []
+        self._launch_stream = None
+        self._side_of = None
         self.reset()
 
     @classmethod
     def for_arena(cls, arena, **kw) -> 'GradAllReducer':
+        from . import engine
         from .engine import ALIGN
         sizes = [(n, arena.offsets[n], (arena.sizes[n] + ALIGN - 1) // ALIGN * ALIGN) for n in arena.names if arena.trainable[n]]
+        kw.setdefault('cut_before', arena.tail_names()[:1])      # the tail starts its own bucket(s)
         r = cls(arena.grad, sizes, **kw)
-        from . import engine
-        r.join = engine.join_wgrad_streams
+        r.direct_grads = engine.direct_grads
+        r._side_of = engine.existing_side_stream_of
         return r
+
+    @property
+    def grad_prescale(self) -> float:
+        """What the optimiser must multiply the (summed) gradients by: FusedAdamW.grad_prescale = reducer.grad_prescale."""
+        return 1.0 if self.average_in_place else 1.0 / self.world
 
     def reset(self) -> None:
         self._remaining = [len(names) for _, _, names in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._events = [[] for _ in self.buckets]
         self._handles = []
 
+    # -- stream bookkeeping -------------------------------------------------------------------------------------------
+    def _record(self, buckets: Sequence[int]) -> None:
+        """Remember "everything enqueued so far on the current stream and its weight-gradient side stream" for these buckets."""
+        if not self.grad.is_cuda:
+            return
+        cur = torch.cuda.current_stream(self.grad.device)
+        evs = [cur.record_event()]
+        side = self._side_of(cur) if self._side_of is not None else None
+        if side is not None:
+            evs.append(side.record_event())
+        for i in buckets:
+            self._events[i].extend(evs)
+
     def _launch(self, i: int) -> None:
-        if self._launched[i] or self.world == 1:
-            self._launched[i] = True
+        if self._launched[i]:
+            return
+        self._launched[i] = True
+        if self.world == 1:
             return
         s, e, _ = self.buckets[i]
         view = self.grad[s:e]
-        if self.join is not None:
-            self.join()                      # weight-gradient side streams -> current stream
-        view.mul_(1.0 / self.world)
-        self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        self._launched[i] = True
+        if self.grad.is_cuda:
+            if self._launch_stream is None:
+                self._launch_stream = torch.cuda.Stream(device=self.grad.device)
+            self._record([i])                            # whatever the launching stream itself has written
+            ls = self._launch_stream
+            for ev in self._events[i]:
+                ls.wait_event(ev)
+            with torch.cuda.stream(ls):
+                h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._handles.append((h, i))
 
+    # -- readiness ----------------------------------------------------------------------------------------------------
     def mark_ready(self, names: List[str]) -> None:
-        """The gradients of these parameters are final: launch every bucket that became complete."""
+        """The gradients of these parameters are final (written by kernels already enqueued on the current stream or its
+        side stream): launch every bucket that became complete."""
+        if not self.direct_grads():
+            return                                       # autograd still has to deliver them: finish() reduces everything
+        touched, done = set(), []
         for n in names:
             i = self._bucket_of.get(n)
             if i is None:
                 continue
+            touched.add(i)
             self._remaining[i] -= 1
             if self._remaining[i] == 0:
-                self._launch(i)
+                done.append(i)
+        if touched:
+            self._record(sorted(touched))
+        for i in done:
+            self._launch(i)
 
     def mark_prefix_ready(self, prefix: str) -> None:
         self.mark_ready([n for n in self._bucket_of if n.startswith(prefix + '.') or n == prefix])
 
     def finish(self) -> None:
-        """Launch whatever is left (parameters that never reported) and wait for all buckets."""
-        for i in range(len(self.buckets)):
+        """Launch whatever is left (parameters that never reported) and make the current stream wait for all buckets."""
+        pending = [i for i in range(len(self.buckets)) if not self._launched[i]]
+        if pending and self.grad.is_cuda and self.world > 1:
+            # gradients that were not reported may have been written on any stream: order behind all of them (autograd has
+            # joined the streams it ran backward nodes on with the caller's stream; the side streams are joined here)
+            self._join_all(pending)
+        for i in pending:
             self._launch(i)
-        for h in self._handles:
+        for h, i in self._handles:
             h.wait()
+            if self.average_in_place and self.world > 1:
+                s, e, _ = self.buckets[i]
+                self.grad[s:e].mul_(1.0 / self.world)
         self.reset()
 
+    def _join_all(self, buckets: Sequence[int]) -> None:
+        from . import engine
+        evs = engine.all_stream_events(self.grad.device)
+        for i in buckets:
+            self._events[i].extend(evs)
 
-def attach(model, reducer: GradAllReducer) -> None:
-    """Wire a MultiMAE model's backward-progress callbacks to the reducer (overlap with backward)."""
+
+def attach(model, reducer: GradAllReducer, optimizer=None) -> None:
+    """Wire a MultiMAE model's backward-progress callbacks to the reducer (overlap with backward) and, when given, fold the
+    1 / world_size average into the optimiser's gradient scale."""
     model._grad_ready_cb = reducer.mark_prefix_ready
+    # encoder backward as several library calls, one per gradient bucket's worth of layers, so buckets launch in between
+    per_layer = sum(p.numel() for n, p in model.named_parameters() if n.startswith('encoder.0.') and p.requires_grad)
+    bucket = max((e - s for s, e, _ in reducer.buckets), default=0)
+    model._bwd_chunk_layers = max(1, int(round(bucket / per_layer))) if per_layer else 1
+    if optimizer is not None:
+        optimizer.grad_prescale = reducer.grad_prescale
 
 
 def broadcast_parameters(arena, src: int = 0, group=None) -> None:

@@ -86,6 +86,21 @@ def side_stream_of(stream: 'torch.cuda.Stream') -> 'torch.cuda.Stream':
     return s
 
 
+def existing_side_stream_of(stream: 'torch.cuda.Stream') -> Optional['torch.cuda.Stream']:
+    """The weight-gradient side stream of `stream` if one was ever created (else None; never creates one)."""
+    return _side_streams.get((stream.device, stream.cuda_stream))
+
+
+def all_stream_events(device=None) -> list:
+    """Events marking "everything enqueued so far" on the current stream and on every weight-gradient side stream: a
+    consumer that waits for all of them is ordered behind every gradient kernel of a finished backward pass (autograd itself
+    joins the streams it ran nodes on with the stream that called backward(); the side streams are ours to join)."""
+    evs = [torch.cuda.current_stream(device).record_event()]
+    for s in _side_streams.values():
+        evs.append(s.record_event())
+    return evs
+
+
 def mark_side_dirty(side: 'torch.cuda.Stream') -> None:
     _dirty_sides.add(side)
 
@@ -199,12 +214,28 @@ def set_direct_grads(flag: bool) -> None:
 
 
 class ParamArena:
-    """Flat fp32 parameter / gradient arenas (+ optional bf16 shadow) for one module tree."""
+    """Flat fp32 parameter / gradient arenas (+ optional bf16 shadow) for one module tree.
 
-    def __init__(self, module: nn.Module, device: Optional[torch.device] = None):
+    ``groups``: name prefixes in the order the backward pass finishes their gradients (for MultiMAE: output adapters,
+    encoder.L-1 ... encoder.0); parameters are laid out group by group, everything not named by a prefix last (the
+    ``tail``: input adapters + global token, whose gradients are final only when backward ends).  A data-parallel reducer then
+    sees contiguous ranges complete one after another (dist.GradAllReducer).  state_dict() order is unaffected."""
+
+    def __init__(self, module: nn.Module, device: Optional[torch.device] = None, groups: Optional[List[str]] = None):
         params = [(n, p) for n, p in module.named_parameters()]
         if not params:
             raise ValueError('module has no parameters')
+        self._tail: List[str] = []
+        if groups:
+            taken, ordered_all = set(), []
+            for pre in groups:
+                for n, p in params:
+                    if n not in taken and (n == pre or n.startswith(pre)):
+                        taken.add(n)
+                        ordered_all.append((n, p))
+            tail = [(n, p) for n, p in params if n not in taken]
+            self._tail = [n for n, p in tail if p.requires_grad]
+            params = ordered_all + tail
         device = device or params[0][1].device
         self.device = device
         self.names: List[str] = []
@@ -245,6 +276,10 @@ class ParamArena:
         # load_state_dict() copies new values into the arena views: the bf16 shadow the optimiser vouched for is stale then
         if hasattr(module, 'register_load_state_dict_post_hook'):
             module.register_load_state_dict_post_hook(lambda m, incompatible: setattr(self, '_shadow_token', False))
+
+    def tail_names(self) -> List[str]:
+        """Trainable parameters laid out after every readiness group (their bucket is cut off on its own, dist.plan_buckets)."""
+        return list(self._tail)
 
     # -- integrity -----------------------------------------------------------------
     def intact(self) -> bool:

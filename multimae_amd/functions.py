@@ -159,29 +159,37 @@ BLOCK_PARAMS = ('norm1.weight', 'norm1.bias', 'attn.qkv.weight', 'attn.qkv.bias'
                 'norm2.weight', 'norm2.bias', 'mlp.fc1.weight', 'mlp.fc1.bias', 'mlp.fc2.weight', 'mlp.fc2.bias')
 
 
-def block_fwd(x: Tensor, P: Sequence[Tensor], wc, heads: int, eps: float, act, B: int, N: int, save: bool):
+def block_fwd(x: Tensor, P: Sequence[Tensor], wc, heads: int, eps: float, act, B: int, N: int, save: bool, dp=(None, None)):
+    """dp = (s1, s2): per-sample stochastic-depth scales f32 [B] of the attention / MLP branch (None = branch kept)."""
     n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b = P
     R, D = x.shape
     hd = D // heads
-    if ops.block_composite_ok(x, act, heads, N):          # the whole block as one library call (same kernels)
+    s1, s2 = dp
+    if s1 is None and s2 is None and ops.block_composite_ok(x, act, heads, N):   # the whole block as one library call (same kernels)
         return ops.block_fwd_composite(x, P, (wc(qkvw), wc(projw), wc(fc1w), wc(fc2w)), heads, eps, act, B, N)
     ln1, mean1, rstd1 = ops.layernorm_fwd(x, n1w, n1b, eps, act)
     qkv = ops.linear_fwd(ln1, wc(qkvw), qkvb, _new((R, 3 * D), x, act))
     ao = _new((R, D), x, act)
     Pm = ops.attention_fwd(AttnView(qkv, 0, 3 * D, N), AttnView(qkv, D, 3 * D, N), AttnView(qkv, 2 * D, 3 * D, N),
                            AttnView(ao, 0, D, N), B, heads, hd, hd ** -0.5)
-    x1 = ops.linear_fwd(ao, wc(projw), projb, _new((R, D), x, torch.float32), resid=x)
+    if s1 is None:
+        x1 = ops.linear_fwd(ao, wc(projw), projb, _new((R, D), x, torch.float32), resid=x)
+    else:                                                   # x1 = x + s1[b] * attn(..)   (multimae_utils.py:229 with DropPath)
+        x1 = ops.rowscale_add(x, ops.linear_fwd(ao, wc(projw), projb, _new((R, D), x, torch.float32)), s1, N)
     ln2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w, n2b, eps, act)
     Hd = fc1w.shape[0]
     hpre = _new((R, Hd), x, act)
     hact = ops.linear_fwd(ln2, wc(fc1w), fc1b, _new((R, Hd), x, act), aux=hpre, epi=EPI_GELU)
-    x2 = ops.linear_fwd(hact, wc(fc2w), fc2b, _new((R, D), x, torch.float32), resid=x1)
+    if s2 is None:
+        x2 = ops.linear_fwd(hact, wc(fc2w), fc2b, _new((R, D), x, torch.float32), resid=x1)
+    else:
+        x2 = ops.rowscale_add(x1, ops.linear_fwd(hact, wc(fc2w), fc2b, _new((R, D), x, torch.float32)), s2, N)
     saved = (x, ln1, mean1, rstd1, qkv, Pm, ao, x1, ln2, mean2, rstd2, hpre, hact) if save else None
     return x2, saved
 
 
 def block_bwd(dx: Tensor, dx_act: Tensor, fc2b_done: bool, saved, P: Sequence[Tensor], wc, sink: GradSink, heads: int, act,
-              B: int, N: int, cs_param: Optional[Tensor] = None):
+              B: int, N: int, cs_param: Optional[Tensor] = None, dp=(None, None)):
     """dx f32 [R,D] (+ its act-dtype copy) -> (dx0, dx0_act, g_cs, 12 parameter grads).
     fc2b_done: the bias gradient of fc2 (column sums of dx) was already delivered by the producer of dx.
     cs_param: the parameter whose gradient is colsum(dx0) -- the bias of the Linear that produced this block's input
@@ -192,27 +200,39 @@ def block_bwd(dx: Tensor, dx_act: Tensor, fc2b_done: bool, saved, P: Sequence[Te
     hd = D // heads
     Hd = fc1w.shape[0]
     lnact = None if act == torch.float32 else act
-    if Pm[0] == 'fused' and ops.block_composite_ok(x0, act, heads, N):
+    s1, s2 = dp
+    if s1 is None and s2 is None and Pm[0] == 'fused' and ops.block_composite_ok(x0, act, heads, N):
         out = _block_bwd_composite(dx, dx_act, fc2b_done, saved, P, wc, sink, heads, act, B, N, cs_param)
         if out is not None:
             return out
-    # MLP
+    # MLP: x2 = x1 + s2[b] * mlp(norm2(x1)); the branch sees the per-sample rescaled gradient
+    dm_act = dx_act if s2 is None else ops.rowscale_cast(dx, s2, N, act)
+    assert not (s2 is not None and fc2b_done)
     part_h = _new(ops.dx_colsum_part_shape(R, Hd), dx, torch.float32) if fc1b.requires_grad else None
-    d_hpre = ops.linear_dx(dx_act, wc(fc2w), _new(hpre.shape, dx, act), aux=hpre, epi=EPI_DGELU, colsum_part=part_h)
+    d_hpre = ops.linear_dx(dm_act, wc(fc2w), _new(hpre.shape, dx, act), aux=hpre, epi=EPI_DGELU, colsum_part=part_h)
     if fc2b_done:
-        g_fc2w, g_fc2b = sink.weight(fc2w, dx_act, hact), None
+        g_fc2w, g_fc2b = sink.weight(fc2w, dm_act, hact), None
     else:
-        g_fc2w, g_fc2b = sink.linear(fc2w, fc2b, dx_act, hact)
+        g_fc2w, g_fc2b = sink.linear(fc2w, fc2b, dm_act, hact)
     d_ln2 = ops.linear_dx(d_hpre, wc(fc1w), _new((R, D), dx, act))
     g_fc1w = sink.weight(fc1w, d_hpre, ln2)
     g_fc1b = sink.colsums(part_h, Hd, [fc1b])[0] if part_h is not None else None
     dx1, dx1_act, part2 = ops.layernorm_bwd_part(d_ln2, x1, n2w, mean2, rstd2, dx, lnact)
     if dx1_act is None:
         dx1_act = dx1
-    g_n2w, g_n2b, g_projb = sink.colsums(part2, D, [n2w, n2b, projb])
-    # attention
-    d_ao = ops.linear_dx(dx1_act, wc(projw), _new((R, D), dx, act))
-    g_projw = sink.weight(projw, dx1_act, ao)
+    # attention: x1 = x0 + s1[b] * attn(norm1(x0))
+    if s1 is None:
+        g_n2w, g_n2b, g_projb = sink.colsums(part2, D, [n2w, n2b, projb])
+        da_act = dx1_act
+        g_projw = None
+    else:
+        g_n2w, g_n2b, _ = sink.colsums(part2, D, [n2w, n2b, None])
+        da_act = ops.rowscale_cast(dx1, s1, N, act)
+    d_ao = ops.linear_dx(da_act, wc(projw), _new((R, D), dx, act))
+    if s1 is None:
+        g_projw = sink.weight(projw, da_act, ao)
+    else:
+        g_projw, g_projb = sink.linear(projw, projb, da_act, ao)
     d_qkv = _new((R, 3 * D), dx, act)
     ops.attention_bwd(AttnView(qkv, 0, 3 * D, N), AttnView(qkv, D, 3 * D, N), AttnView(qkv, 2 * D, 3 * D, N), Pm,
                       AttnView(ao, 0, D, N), AttnView(d_ao, 0, D, N), AttnView(d_qkv, 0, 3 * D, N), AttnView(d_qkv, D, 3 * D, N),
@@ -263,8 +283,28 @@ class _Cfg:
         self.__dict__.update(kw)
 
 
+def _grad_targets(sink: GradSink, params: Sequence[Optional[Tensor]]):
+    """Gradient destinations for a composite backward call: every wanted gradient goes either into the arena-backed .grad
+    (accumulate) or into a fresh tensor handed to autograd.  A mix of bound and unbound parameters falls back to fresh tensors
+    for all of them (autograd then accumulates), so one flag describes the whole call."""
+    live = [p for p in params if p is not None and p.requires_grad]
+    direct = sink.direct and all(p.grad is not None for p in live)
+    dsts: List[Optional[Tensor]] = []
+    for p in params:
+        if p is None or not p.requires_grad:
+            dsts.append(None)
+        elif direct:
+            dsts.append(p.grad)
+        else:
+            dsts.append(torch.empty(p.shape, device=p.device, dtype=torch.float32))
+    return dsts, direct
+
+
 class EncoderStackFn(torch.autograd.Function):
-    """L transformer blocks in one autograd node.  forward(cfg, x[B,N,D] f32, *params(12 per layer))"""
+    """L transformer blocks in one autograd node.  forward(cfg, x[B,N,D] f32, *params(12 per layer))
+
+    cfg: act, wc, heads, eps, all_layers, on_layer_done; optional dp (2 L per-sample stochastic-depth scale tensors or None
+    entries), bwd_chunk (layers per backward library call when a gradient reducer wants per-layer progress)."""
 
     @staticmethod
     def forward(ctx, cfg: _Cfg, x: Tensor, *params: Tensor):
@@ -273,13 +313,23 @@ class EncoderStackFn(torch.autograd.Function):
         L = len(params) // 12
         save = any(ctx.needs_input_grad)
         h = x.contiguous().view(B * N, D)
+        dp = getattr(cfg, 'dp', None)
+        ctx.cfg, ctx.params, ctx.shape = cfg, params, (B, N, D)
+        ctx.stack, ctx.saved = None, None
+        if ops.stack_composites() and L <= 64 and ops.block_composite_ok(h, cfg.act, cfg.heads, N):
+            outs, state = ops.stack_fwd(h, params, cfg.wc, cfg.heads, cfg.eps, cfg.act, B, N, dp)
+            ctx.stack = state if save else None
+            if cfg.all_layers:
+                return tuple(o.view(B, N, D) for o in outs)
+            return outs[-1].view(B, N, D)
         saved, outs = [], []
         for l in range(L):
-            h, s = block_fwd(h, params[12 * l:12 * l + 12], cfg.wc, cfg.heads, cfg.eps, cfg.act, B, N, save)
+            dpl = (None, None) if dp is None else (dp[2 * l], dp[2 * l + 1])
+            h, s = block_fwd(h, params[12 * l:12 * l + 12], cfg.wc, cfg.heads, cfg.eps, cfg.act, B, N, save, dpl)
             saved.append(s)
             if cfg.all_layers:
                 outs.append(h.view(B, N, D))
-        ctx.cfg, ctx.saved, ctx.params, ctx.shape = cfg, saved, params, (B, N, D)
+        ctx.saved = saved
         if cfg.all_layers:
             return tuple(outs)
         return h.view(B, N, D)
@@ -290,6 +340,32 @@ class EncoderStackFn(torch.autograd.Function):
         B, N, D = ctx.shape
         L = len(params) // 12
         sink = GradSink(engine.direct_grads())
+        dp = getattr(cfg, 'dp', None)
+        if ctx.stack is not None:
+            d_outs: List[Optional[Tensor]] = [None] * L
+            for l in range(L):
+                dl = douts[l] if cfg.all_layers else (douts[0] if l == L - 1 else None)
+                if dl is not None:
+                    d_outs[l] = dl.contiguous().view(B * N, D)
+            if d_outs[L - 1] is None:                       # nothing reached the last block: zero gradient there
+                d_outs[L - 1] = torch.zeros((B * N, D), device=params[0].device, dtype=torch.float32)
+            dsts, acc = _grad_targets(sink, params)
+            use_side = sink.side is not None and acc
+            chunks, on_chunk = None, None
+            if cfg.on_layer_done is not None:
+                c = max(1, int(getattr(cfg, 'bwd_chunk', 1) or 1))
+                chunks = [(max(0, hi - c), hi) for hi in range(L, 0, -c)]
+
+                def on_chunk(lo, hi):
+                    for l in reversed(range(lo, hi)):
+                        cfg.on_layer_done(l)
+            dx, keep = ops.stack_bwd(ctx.stack, d_outs, dsts, acc, sink.side.cuda_stream if use_side else None, chunks, on_chunk)
+            ctx.stack = None
+            if use_side:
+                engine.mark_side_dirty(sink.side)
+                engine.keep_until_join(keep)
+            grads = [None] * (12 * L) if acc else dsts
+            return (None, dx.view(B, N, D), *grads)
         grads: List[Optional[Tensor]] = [None] * (12 * L)
         dx, dx_act = None, None
         fc2b_done, g_cs = False, None
@@ -304,10 +380,13 @@ class EncoderStackFn(torch.autograd.Function):
             if dx_act is None:
                 dx_act = ops.cast(dx, cfg.act)
             # the bias gradient of block l-1's fc2 (column sums of this block's input gradient) rides along with this
-            # block's LayerNorm-1 reduction -- unless more gradient is added to dx before block l-1 sees it (all_layers)
-            cs_param = params[12 * (l - 1) + 11] if (l > 0 and not cfg.all_layers) else None
+            # block's LayerNorm-1 reduction -- unless more gradient is added to dx before block l-1 sees it (all_layers) or
+            # block l-1's MLP branch was rescaled per sample (stochastic depth)
+            below_scaled = dp is not None and l > 0 and dp[2 * (l - 1) + 1] is not None
+            cs_param = params[12 * (l - 1) + 11] if (l > 0 and not cfg.all_layers and not below_scaled) else None
+            dpl = (None, None) if dp is None else (dp[2 * l], dp[2 * l + 1])
             dx, dx_act, g_cs_next, g = block_bwd(dx, dx_act, fc2b_done, ctx.saved[l], params[12 * l:12 * l + 12], cfg.wc, sink,
-                                                 cfg.heads, cfg.act, B, N, cs_param)
+                                                 cfg.heads, cfg.act, B, N, cs_param, dpl)
             grads[12 * l:12 * l + 12] = g
             if fc2b_done:
                 grads[12 * l + 11] = g_cs
@@ -385,6 +464,8 @@ class EmbedFn(torch.autograd.Function):
                 ge = sink.vec(emb, ge_buf)
             out += [None, gw, gb, ge]
         g_glob = g_small[T] if G > 0 else None
+        if getattr(cfg, 'on_done', None) is not None:
+            cfg.on_done()
         return (None, None, g_glob, *out)
 
 
@@ -434,6 +515,22 @@ class SpatialAdapterFn(torch.autograd.Function):
         enc2 = enc.contiguous().view(B * NC, Denc)
         enc_act = getattr(cfg, 'enc_act', None)      # act-dtype copy shared by all adapters of one forward (MultiMAE.forward)
         if enc_act is None or enc_act.dtype != act or enc_act.shape != enc2.shape:
+            enc_act = None
+        ctx.comp = None
+        KP = cfg.C * cfg.ph * cfg.pw
+        if ops.adapter_composite_ok(enc2, act, heads, D, n_q, NC, cfg.depth, T, KP):
+            # the whole adapter as ONE library call (same kernels, same order)
+            w_list = [wc(qw), wc(kvw), wc(pw_), wc(f1w), wc(f2w)] + [wc(blocks[12 * l + i]) for l in range(cfg.depth) for i in (2, 4, 8, 10)] \
+                + [wc(ow), wc(pcw)]
+            p_list = [qb, kvb, pb, cnw, cnb, qnw, qnb, onw, onb, f1b, f2b] \
+                + [blocks[12 * l + i] for l in range(cfg.depth) for i in (0, 1, 3, 5, 6, 7, 9, 11)] + [ob, pcb]
+            img, state = ops.adapter_fwd(enc.contiguous(), enc_act, ids_keep, ids_restore, cfg, w_list, p_list, mask_token.detach().reshape(D),
+                                         [None if t is None else t.detach().reshape(D) for t in temb])
+            ctx.comp = state if save else None
+            ctx.cfg, ctx.params, ctx.ids = cfg, params, (ids_keep, ids_restore)
+            ctx.dims = (B, NC, Denc, n_keep, n_q, T)
+            return img
+        if enc_act is None:
             enc_act = ops.cast(enc2, act)
         ctx_tok = _lin_fwd(enc_act, pcw, pcb, wc, torch.float32)                        # :258
         te = torch.zeros((T, D), device=dev, dtype=torch.float32)
@@ -476,6 +573,19 @@ class SpatialAdapterFn(torch.autograd.Function):
         B, NC, Denc, n_keep, n_q, T = ctx.dims
         act, wc, D, G, heads = cfg.act, cfg.wc, cfg.D, cfg.G, cfg.heads
         lnact = None if act == torch.float32 else act
+        if getattr(ctx, 'comp', None) is not None:
+            sink = GradSink(engine.direct_grads())
+            dsts, acc = _grad_targets(sink, params)
+            use_side = sink.side is not None and acc
+            d_enc, keep = ops.adapter_bwd(ctx.comp, d_img, None, [None if t is None else t.view(-1) for t in dsts], acc,
+                                          sink.side.cuda_stream if use_side else None)
+            ctx.comp = None
+            if use_side:
+                engine.mark_side_dirty(sink.side)
+                engine.keep_until_join(keep)
+            if cfg.on_done is not None:
+                cfg.on_done()
+            return (None, d_enc, None, None, *([None] * len(params) if acc else dsts))
         (enc_act, queries, context, qn, qmean, qrstd, cn, cmean, crstd, q, kv, Pm, xo, x, on, omean, orstd, hpre, hact, h_act,
          bsaved) = ctx.saved
         mask_token = params[0]

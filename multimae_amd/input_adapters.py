@@ -182,7 +182,7 @@ class SemSegInputAdapter(nn.Module, _PosEmbMixin):
 
 
 def embed_tokens(owner: nn.Module, adapters: Dict[str, nn.Module], x: Dict[str, torch.Tensor], sel: torch.Tensor,
-                 global_tokens: Optional[torch.Tensor]) -> torch.Tensor:
+                 global_tokens: Optional[torch.Tensor], on_done=None) -> torch.Tensor:
     """Gather-first embedding of the selected tokens of several modalities (+ global tokens last).
     sel: (B, n_sel) int64 indices into the concatenated token axis (= ids_keep)."""
     tasks, tens, offs, k_off = [], [], [0], 0
@@ -196,7 +196,7 @@ def embed_tokens(owner: nn.Module, adapters: Dict[str, nn.Module], x: Dict[str, 
         tens += list(t)
         D = ad.dim_tokens
     G = 0 if global_tokens is None else global_tokens.shape[1]
-    cfg = _cfg(owner, tasks=tasks, task_offsets=offs, D=D, G=G)
+    cfg = _cfg(owner, tasks=tasks, task_offsets=offs, D=D, G=G, on_done=on_done)
     return EmbedFn.apply(cfg, sel, global_tokens, *tens)
 
 

@@ -106,7 +106,13 @@ class MultiMAE(nn.Module):
         """Move every parameter into one flat HBM arena (idempotent; call after .to(device))."""
         a = engine.arena_of(self)
         if a is None:
-            a = engine.ParamArena(self)
+            # gradient-readiness order (see engine.ParamArena): autograd runs the output adapters' backward in reverse
+            # forward order, then the encoder from its last block down; the embedding gradients come last
+            groups = []
+            if self.output_adapters is not None:
+                groups += [f'output_adapters.{d}.' for d in reversed(list(self.output_adapters))]
+            groups += [f'encoder.{l}.' for l in reversed(range(len(self.encoder)))]
+            a = engine.ParamArena(self, groups=groups)
         return a
 
     # -- mask sampling ----------------------------------------------------------------------
@@ -238,9 +244,11 @@ class MultiMAE(nn.Module):
             _, ids_keep, ids_restore = ops.mask_sample(torch.zeros((B, 1), dtype=torch.int64), zeros, mask_all.float(), offs, n_keep)
 
         adapters = OrderedDict((d, self.input_adapters[d]) for d in counts)
-        tokens = embed_tokens(self, adapters, x, ids_keep, self.global_tokens if self.num_global_tokens > 0 else None)
+        tokens = embed_tokens(self, adapters, x, ids_keep, self.global_tokens if self.num_global_tokens > 0 else None,
+                              on_done=self._embed_done_cb())
 
-        encoder_tokens = run_blocks(self.encoder, tokens, root=self, on_layer_done=self._layer_done_cb())
+        encoder_tokens = run_blocks(self.encoder, tokens, root=self, on_layer_done=self._layer_done_cb(),
+                                    bwd_chunk=getattr(self, '_bwd_chunk_layers', 1))
 
         if self.output_adapters is None:
             return encoder_tokens, task_masks
@@ -298,6 +306,16 @@ class MultiMAE(nn.Module):
     def _adapter_done_cb(self, domain):
         cb = self._grad_ready_cb
         return None if cb is None else (lambda: cb(f'output_adapters.{domain}'))
+
+    def _embed_done_cb(self):
+        cb = self._grad_ready_cb
+        if cb is None:
+            return None
+
+        def done():                     # arena order of the tail: registration order (global_tokens, then the input adapters)
+            cb('global_tokens')
+            cb('input_adapters')
+        return done
 
 
 @register_model

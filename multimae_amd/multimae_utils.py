@@ -90,15 +90,46 @@ class LayerNorm(nn.LayerNorm):
         return LayerNormFn.apply(x, self.weight, self.bias, self.eps)
 
 
+def _drop_path_rand(shape, device) -> torch.Tensor:
+    """The uniform draw behind a stochastic-depth mask (multimae_utils.py:117: torch.rand(shape, device=x.device)).  Tests
+    replace this hook to inject a fixed draw on both sides of a comparison."""
+    return torch.rand(shape, dtype=torch.float32, device=device)
+
+
+def drop_path_scale(batch: int, drop_prob: float, device) -> torch.Tensor:
+    """Per-sample scale of a residual branch under stochastic depth: floor(keep + u) / keep, u ~ U[0,1), f32 [B]
+    (multimae_utils.py:115-120: ``x.div(keep_prob) * floor(keep_prob + rand)``)."""
+    keep = 1.0 - drop_prob
+    u = _drop_path_rand((batch,), device)
+    return ((keep + u).floor_() / keep).contiguous()
+
+
 def drop_path(x, drop_prob: float = 0., training: bool = False):
-    """Stochastic depth per sample (multimae_utils.py:105-122).  Identity at the pre-training
-    default (rate 0); the Bernoulli mask is a (B,1,..) broadcast multiply."""
+    """Stochastic depth per sample (multimae_utils.py:105-122).  Identity at the pre-training default (rate 0); otherwise
+    one row-scale kernel (and the same kernel on the gradient)."""
     if drop_prob == 0. or not training:
         return x
-    keep = 1 - drop_prob
-    shape = (x.shape[0],) + (1,) * (x.ndim - 1)
-    mask = (keep + torch.rand(shape, dtype=x.dtype, device=x.device)).floor_()
-    return x.div(keep) * mask
+    return DropPathFn.apply(x, drop_path_scale(x.shape[0], drop_prob, x.device))
+
+
+class DropPathFn(torch.autograd.Function):
+    """y[b] = s[b] * x[b] on the HIP row-scale kernel (stand-alone DropPath modules; inside Blocks the scale is folded into the
+    residual add, functions.block_fwd)."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        from . import ops
+        ops._require_gpu(x, 'drop_path input')
+        shp = x.shape
+        x2 = x.contiguous().float().view(shp[0], -1)
+        ctx.s, ctx.shp = s, shp
+        return ops.rowscale_cast(x2, s, 1, torch.float32).view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        d2 = dy.contiguous().float().view(ctx.shp[0], -1)
+        return ops.rowscale_cast(d2, ctx.s, 1, torch.float32).view(ctx.shp), None
 
 
 class DropPath(nn.Module):
@@ -193,13 +224,7 @@ class Block(nn.Module):
             raise NotImplementedError('qkv_bias=False is not built (every reference factory uses True)')
 
     def forward(self, x):
-        if isinstance(self.drop_path, nn.Identity) or not self.training:
-            cfg = _cfg(self, heads=self.attn.num_heads, eps=self.norm1.eps, all_layers=False, on_layer_done=None)
-            return EncoderStackFn.apply(cfg, x, *block_params(self))
-        # stochastic depth: per-sample residual scaling needs the two branches separately
-        x = x + self.drop_path(self.attn(self.norm1(x)))
-        x = x + self.drop_path(self.mlp(self.norm2(x)))
-        return x
+        return run_blocks([self], x)
 
 
 def _as_hip_norm(norm_layer, dim):
@@ -213,20 +238,27 @@ def _as_hip_norm(norm_layer, dim):
     raise NotImplementedError(f'norm layer {type(m)} is not built in the HIP engine')
 
 
-def run_blocks(blocks, x, root=None, all_layers=False, on_layer_done=None):
-    """Run a sequence of Blocks as ONE autograd node (the encoder / decoder_transformer fast path)."""
+def _stack_drop_path(blocks, batch: int, device):
+    """Per-block stochastic-depth scales [(attention branch, MLP branch)] * L, drawn in the reference's order (two draws per
+    block as the blocks execute, multimae_utils.py:229-232); None when no block drops paths (eval mode, rate 0)."""
+    if not any((not isinstance(b.drop_path, nn.Identity)) and b.training and (b.drop_path.drop_prob or 0.) > 0. for b in blocks):
+        return None
+    dp = []
+    for b in blocks:
+        rate = 0. if isinstance(b.drop_path, nn.Identity) or not b.training else float(b.drop_path.drop_prob or 0.)
+        dp += [drop_path_scale(batch, rate, device), drop_path_scale(batch, rate, device)] if rate > 0. else [None, None]
+    return dp
+
+
+def run_blocks(blocks, x, root=None, all_layers=False, on_layer_done=None, bwd_chunk: int = 1):
+    """Run a sequence of Blocks as ONE autograd node (the encoder / decoder_transformer fast path), stochastic depth
+    included: the per-sample scales are drawn here and folded into the blocks' residual adds."""
     blocks = list(blocks)
     if not blocks:
         return [] if all_layers else x
-    if any((not isinstance(b.drop_path, nn.Identity)) and b.training for b in blocks):
-        outs = []
-        for b in blocks:
-            x = b(x)
-            outs.append(x)
-        return outs if all_layers else x
     b0 = blocks[0]
     cfg = _cfg(b0 if root is None else root, heads=b0.attn.num_heads, eps=b0.norm1.eps, all_layers=all_layers,
-               on_layer_done=on_layer_done)
+               on_layer_done=on_layer_done, dp=_stack_drop_path(blocks, x.shape[0], x.device), bwd_chunk=bwd_chunk)
     params = [p for b in blocks for p in block_params(b)]
     out = EncoderStackFn.apply(cfg, x, *params)
     return list(out) if all_layers else out

@@ -14,7 +14,7 @@ import torch
 from . import _lib
 import contextlib
 
-from ._lib import BF16, F32, F32X3, EPI_NONE, EPI_GELU, EPI_DGELU, BlockDesc, GemmDesc, PatchSrc, check
+from ._lib import BF16, F32, F32X3, EPI_NONE, EPI_GELU, EPI_DGELU, AdapterDesc, BlockDesc, GemmDesc, OptDesc, PatchSrc, StackDesc, check
 
 Tensor = torch.Tensor
 
@@ -285,6 +285,208 @@ def block_bwd_composite(dx: Tensor, dx_act: Tensor, fc2b_done: bool, saved, P: S
     return dx0, (dx0_act if bf else dx0), keep
 
 
+# ------------------------------------------------ per-stack / per-adapter composites --
+_STACK = [_os.environ.get('MMAE_STACK_COMPOSITE', '1') != '0']
+
+
+def set_stack_composites(flag: bool) -> None:
+    """Encoder stack / output adapters as ONE library call per direction (mmae_stack_fwd/bwd, mmae_adapter_fwd/bwd): same
+    kernels and results as the per-block / per-kernel launch sequences, ~40 instead of ~520 host round trips per step."""
+    _STACK[0] = bool(flag)
+
+
+def stack_composites() -> bool:
+    return _STACK[0]
+
+
+def _ptr_arr(ptrs: Sequence[Optional[int]]):
+    return (ctypes.c_void_p * len(ptrs))(*ptrs)
+
+
+class _PtrCache:
+    """ctypes pointer tables of a parameter list, rebuilt only when a watched address changes (the arena views and their
+    bf16 shadows never move; stand-alone modules re-cast their weights every forward and simply miss)."""
+
+    def __init__(self):
+        self.tabs = {}
+
+    def get(self, key, probe, build):
+        e = self.tabs.get(key)
+        if e is not None and e[0] == probe:
+            return e[1]
+        val = build()
+        if len(self.tabs) > 64:
+            self.tabs.clear()
+        self.tabs[key] = (probe, val)
+        return val
+
+
+_PTRS = _PtrCache()
+
+
+def _slab(nbytes: int, device) -> Tensor:
+    return torch.empty((max(int(nbytes), 256),), device=device, dtype=torch.uint8)
+
+
+class StackState:
+    """What mmae_stack_bwd needs from the forward: the descriptor (geometry + pointer tables) and the activation slab."""
+    __slots__ = ('desc', 'act', 'keep', 'x', 'L', 'shape', 'act_dtype', 'dp')
+
+
+def stack_fwd(x: Tensor, params: Sequence[Tensor], wc, heads: int, eps: float, act: torch.dtype, B: int, N: int,
+              dp: Optional[Sequence[Optional[Tensor]]] = None):
+    """L = len(params) // 12 pre-LN blocks on x f32 [B*N, D] in one library call.
+    Returns ([output of every block as f32 [B*N, D] views of the slab], StackState)."""
+    lib = _lib.load()
+    R, D = x.shape
+    L = len(params) // 12
+    Hd = params[8].shape[0]
+    d = StackDesc()
+    d.L, d.B, d.N, d.D, d.heads, d.Hd = L, B, N, D, heads, Hd
+    d.act_dtype, d.f32_gemm, d.eps = dcode(act), (F32X3 if _F32_GEMM[0] == 'x3' else F32), eps
+    wts = [wc(params[12 * l + i]) for l in range(L) for i in (2, 4, 8, 10)]
+    probe = (wts[0].data_ptr(), wts[-1].data_ptr(), params[0].data_ptr(), params[-1].data_ptr())
+    w_arr, p_arr = _PTRS.get(('stack', id(params[0]), L, act), probe, lambda: (
+        _ptr_arr([w.data_ptr() for w in wts]),
+        _ptr_arr([params[12 * l + i].data_ptr() for l in range(L) for i in (0, 1, 3, 5, 6, 7, 9, 11)])))
+    d.w, d.p = ctypes.cast(w_arr, ctypes.c_void_p), ctypes.cast(p_arr, ctypes.c_void_p)
+    dp_arr = None
+    if dp is not None and any(t is not None for t in dp):
+        dp_arr = _ptr_arr([_p(t) for t in dp])
+        d.dp = ctypes.cast(dp_arr, ctypes.c_void_p)
+    d.x = x.data_ptr()
+    nbytes = lib.mmae_stack_act_bytes(ctypes.byref(d))
+    slab = _slab(nbytes, x.device)
+    d.act, d.act_bytes = slab.data_ptr(), slab.numel()
+    st = _stream()
+    ws = stream_workspace(st, x.device)
+    d.ws_main, d.ws_main_elems = ws.data_ptr(), ws.numel()
+    check(lib.mmae_stack_fwd(ctypes.byref(d), st), 'stack_fwd')
+    outs = []
+    for l in range(L):
+        off = lib.mmae_stack_out_offset(ctypes.byref(d), l)
+        outs.append(slab[off:off + R * D * 4].view(torch.float32).view(R, D))
+    s = StackState()
+    s.desc, s.act, s.keep, s.x, s.L, s.shape, s.act_dtype, s.dp = d, slab, (w_arr, p_arr, dp_arr, wts, dp), x, L, (B, N, D, Hd), act, dp
+    return outs, s
+
+
+def stack_bwd(s: StackState, d_outs: Sequence[Optional[Tensor]], grads: Sequence[Optional[Tensor]], grad_acc: bool,
+              side_handle: Optional[int], chunks: Optional[Sequence] = None, on_chunk=None):
+    """Backward of stack_fwd.  d_outs[l]: f32 [R, D] gradient of block l's output or None (the last one is required);
+    grads: 12 L destinations (None = not wanted).  chunks: [(lo, hi), ...] from the top down (default one call);
+    on_chunk(lo, hi) runs after each chunk is enqueued.  Returns (dx f32 [R, D], tensors to keep alive until the side
+    stream has drained)."""
+    lib = _lib.load()
+    B, N, D, Hd = s.shape
+    R = B * N
+    d = s.desc
+    dev = s.x.device
+    d_outs = [None if t is None else t.contiguous() for t in d_outs]
+    do_arr = _ptr_arr([_p(t) for t in d_outs])
+    g_arr = _ptr_arr([_p(g) for g in grads])
+    d.d_out, d.g = ctypes.cast(do_arr, ctypes.c_void_p), ctypes.cast(g_arr, ctypes.c_void_p)
+    d.grad_acc = int(grad_acc)
+    dx = torch.empty((R, D), device=dev, dtype=torch.float32)
+    d.dx = dx.data_ptr()
+    tmp = _slab(lib.mmae_stack_tmp_bytes(ctypes.byref(d)), dev)
+    d.tmp, d.tmp_bytes = tmp.data_ptr(), tmp.numel()
+    st = _stream()
+    wm = stream_workspace(st, dev)
+    d.ws_main, d.ws_main_elems = wm.data_ptr(), wm.numel()
+    sd = side_handle if side_handle is not None else st
+    wsd = stream_workspace(sd, dev) if sd != st else wm
+    d.ws_side, d.ws_side_elems = wsd.data_ptr(), wsd.numel()
+    for lo, hi in (chunks or [(0, s.L)]):
+        d.l_begin, d.l_end = lo, hi
+        check(lib.mmae_stack_bwd(ctypes.byref(d), st, sd), 'stack_bwd')
+        if on_chunk is not None:
+            on_chunk(lo, hi)
+    return dx, (tmp, s.act, s.keep, d_outs, do_arr, g_arr, grads)
+
+
+class AdapterState:
+    __slots__ = ('desc', 'act', 'keep', 'pat', 'ld_pat')
+
+
+def adapter_composite_ok(enc: Tensor, act: torch.dtype, heads: int, D: int, n_q: int, NC: int, depth: int, T: int, KP: int) -> bool:
+    hd = D // heads
+    if not (_STACK[0] and _COMPOSITE[0] and _FUSED_ATTN[0] and enc.is_cuda and hd in (32, 64) and n_q <= 256 and NC <= 256 and depth <= 8
+            and T <= 7 and D % 8 == 0 and enc.shape[-1] % 8 == 0 and KP % 4 == 0):
+        return False
+    if act == torch.bfloat16:
+        return True
+    lds_bwd = 4 * (round_up(n_q, 32) + round_up(NC, 32)) * hd * 2 + 8 * round_up(n_q, 32)
+    return act == torch.float32 and _F32_GEMM[0] == 'x3' and lds_bwd <= 160 * 1024
+
+
+def adapter_fwd(enc: Tensor, enc_act: Optional[Tensor], ids_keep: Tensor, ids_restore: Tensor, cfg, w_list: Sequence[Tensor],
+                p_list: Sequence[Tensor], mask_token: Tensor, temb: Sequence[Optional[Tensor]], want_img: bool = True):
+    """SpatialOutputAdapter.forward in one library call.  enc f32 [B, NC, Denc]; w_list / p_list in mmae_adapter_desc order.
+    Returns (img or None, AdapterState)."""
+    lib = _lib.load()
+    B, NC, Denc = enc.shape
+    T = len(cfg.task_offsets) - 1
+    n_q = cfg.task_offsets[cfg.q_task + 1] - cfg.task_offsets[cfg.q_task]
+    d = AdapterDesc()
+    d.B, d.NC, d.Denc, d.D, d.heads, d.Hd, d.depth, d.T, d.q_task, d.G, d.n_q = (B, NC, Denc, cfg.D, cfg.heads, w_list[3].shape[0], cfg.depth, T,
+                                                                                  cfg.q_task, cfg.G, n_q)
+    d.C, d.nh, d.nw, d.ph, d.pw = cfg.C, cfg.nh, cfg.nw, cfg.ph, cfg.pw
+    d.act_dtype, d.f32_gemm, d.eps = dcode(cfg.act), (F32X3 if _F32_GEMM[0] == 'x3' else F32), cfg.eps
+    offs = _i32_array(cfg.task_offsets)
+    d.task_offsets_host = ctypes.cast(offs, ctypes.c_void_p)
+    probe = (w_list[0].data_ptr(), w_list[-1].data_ptr(), p_list[0].data_ptr(), p_list[-1].data_ptr(), mask_token.data_ptr())
+    w_arr, p_arr, te_arr = _PTRS.get(('adapter', id(p_list[0]), len(w_list), cfg.act), probe, lambda: (
+        _ptr_arr([w.data_ptr() for w in w_list]), _ptr_arr([t.data_ptr() for t in p_list]), _ptr_arr([_p(t) for t in temb])))
+    d.w, d.p, d.task_emb = ctypes.cast(w_arr, ctypes.c_void_p), ctypes.cast(p_arr, ctypes.c_void_p), ctypes.cast(te_arr, ctypes.c_void_p)
+    d.mask_token, d.pos = mask_token.data_ptr(), cfg.pos.data_ptr()
+    d.enc = enc.data_ptr()
+    d.enc_act = enc.data_ptr() if cfg.act == torch.float32 else _p(enc_act)
+    d.ids_keep, d.ids_restore = ids_keep.data_ptr(), ids_restore.data_ptr()
+    slab = _slab(lib.mmae_adapter_act_bytes(ctypes.byref(d)), enc.device)
+    d.act, d.act_bytes = slab.data_ptr(), slab.numel()
+    img = torch.empty((B, cfg.C, cfg.nh * cfg.ph, cfg.nw * cfg.pw), device=enc.device, dtype=torch.float32) if want_img else None
+    d.img = _p(img)
+    st = _stream()
+    ws = stream_workspace(st, enc.device)
+    d.ws_main, d.ws_main_elems = ws.data_ptr(), ws.numel()
+    check(lib.mmae_adapter_fwd(ctypes.byref(d), st), 'adapter_fwd')
+    s = AdapterState()
+    KP = cfg.C * cfg.ph * cfg.pw
+    off = lib.mmae_adapter_pat_offset(ctypes.byref(d))
+    s.pat = slab[off:off + B * n_q * KP * 4].view(torch.float32).view(B * n_q, KP)
+    s.desc, s.act, s.ld_pat = d, slab, KP
+    s.keep = (offs, w_arr, p_arr, te_arr, w_list, p_list, temb, mask_token, enc, enc_act, ids_keep, ids_restore, cfg.pos)
+    return img, s
+
+
+def adapter_bwd(s: AdapterState, d_img: Optional[Tensor], d_pat: Optional[Tensor], grads: Sequence[Optional[Tensor]], grad_acc: bool,
+                side_handle: Optional[int]):
+    """Backward of adapter_fwd from the image-domain gradient d_img (f32 [B,C,H,W]) or the patch-domain gradient d_pat (act
+    dtype [B*n_q, ld]).  grads: destinations in mmae_adapter_desc.g order.  Returns (d_enc f32 [B, NC, Denc], keep-alives)."""
+    lib = _lib.load()
+    d = s.desc
+    dev = s.act.device
+    if d_img is not None:
+        d_img = d_img.contiguous()
+    d.d_img, d.d_pat = _p(d_img), _p(d_pat)
+    d.ld_pat = d_pat.stride(0) if d_pat is not None else 0
+    g_arr = _ptr_arr([_p(g) for g in grads])
+    d.g, d.grad_acc = ctypes.cast(g_arr, ctypes.c_void_p), int(grad_acc)
+    d_enc = torch.empty((d.B, d.NC, d.Denc), device=dev, dtype=torch.float32)
+    d.d_enc = d_enc.data_ptr()
+    tmp = _slab(lib.mmae_adapter_tmp_bytes(ctypes.byref(d)), dev)
+    d.tmp, d.tmp_bytes = tmp.data_ptr(), tmp.numel()
+    st = _stream()
+    wm = stream_workspace(st, dev)
+    d.ws_main, d.ws_main_elems = wm.data_ptr(), wm.numel()
+    sd = side_handle if side_handle is not None else st
+    wsd = stream_workspace(sd, dev) if sd != st else wm
+    d.ws_side, d.ws_side_elems = wsd.data_ptr(), wsd.numel()
+    check(lib.mmae_adapter_bwd(ctypes.byref(d), st, sd), 'adapter_bwd')
+    return d_enc, (tmp, s.act, s.keep, d_img, d_pat, g_arr, grads)
+
+
 # ------------------------------------------------------------------- row kernels --
 def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out_dtype: torch.dtype):
     _require_gpu(x, 'layernorm input')
@@ -386,6 +588,22 @@ def cast_into(src: Tensor, dst: Tensor) -> None:
     lib = _lib.load()
     assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
     check(lib.mmae_cast_f32_to_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), 'cast_f32_to_bf16')
+
+
+def rowscale_add(resid: Tensor, y: Tensor, s: Tensor, N: int) -> Tensor:
+    """resid + s[row // N] * y on f32 [R, D] activations (stochastic depth: per-sample scale of a residual branch)."""
+    R, D = y.shape
+    out = torch.empty((R, D), device=y.device, dtype=torch.float32)
+    check(_lib.load().mmae_rowscale_add(resid.data_ptr(), y.data_ptr(), s.data_ptr(), out.data_ptr(), R, N, D, _stream()), 'rowscale_add')
+    return out
+
+
+def rowscale_cast(x: Tensor, s: Tensor, N: int, dtype: torch.dtype) -> Tensor:
+    """cast(s[row // N] * x) for f32 x [R, D]."""
+    R, D = x.shape
+    out = torch.empty((R, D), device=x.device, dtype=dtype)
+    check(_lib.load().mmae_rowscale_cast(x.data_ptr(), s.data_ptr(), out.data_ptr(), dcode(dtype), R, N, D, _stream()), 'rowscale_cast')
+    return out
 
 
 def axpy_(y: Tensor, x: Tensor, a: float = 1.0) -> Tensor:
@@ -634,3 +852,18 @@ def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, *, lr: float, beta1: float
     check(_lib.load().mmae_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
                                  weight_decay, step, _p(grad_scale), _p(skip_flag), _p(shadow),
                                  dcode(shadow.dtype) if shadow is not None else F32, _stream()), 'adamw')
+
+
+def opt_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, state: Tensor, istate: Tensor, ws: Tensor, *, lr: float, weight_decay: float,
+             beta1: float, beta2: float, eps: float, clip_grad: Optional[float], skip_grad: Optional[float], grad_prescale: float = 1.0,
+             lrwd_dev: Optional[Tensor] = None, loss_dev: Optional[Tensor] = None, shadow: Optional[Tensor] = None) -> None:
+    """mmae_opt_step: grad-norm, clip / skip / non-finite decisions, step counter and AdamW -- all on the device."""
+    d = OptDesc()
+    d.p, d.g, d.m, d.v, d.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+    d.shadow, d.shadow_dtype = _p(shadow), (dcode(shadow.dtype) if shadow is not None else F32)
+    d.lr, d.weight_decay, d.beta1, d.beta2, d.eps = lr, weight_decay, beta1, beta2, eps
+    d.lrwd_dev, d.loss_dev = _p(lrwd_dev), _p(loss_dev)
+    d.clip_grad, d.skip_grad, d.grad_prescale = (clip_grad or 0.0), (skip_grad or 0.0), grad_prescale
+    assert state.dtype == torch.float32 and state.numel() >= 8 and istate.dtype == torch.int32 and istate.numel() >= 4
+    d.state, d.istate, d.ws = state.data_ptr(), istate.data_ptr(), ws.data_ptr()
+    check(_lib.load().mmae_opt_step(ctypes.byref(d), _stream()), 'opt_step')

@@ -5,8 +5,8 @@ torch.optim.AdamW as configured by utils/optim_factory.py:138-174: ONE param gro
 weight decay on EVERY trainable tensor (biases, LayerNorm, tokens included -- the reference's
 dict branch never consults no_weight_decay()), betas (0.9, 0.95).
 
-bf16 needs no loss scaling, so there is no GradScaler; a non-finite gradient norm skips the update
-on the device (no host sync).  lr / weight_decay are read from ``param_groups[0]`` each step so the
+bf16 needs no loss scaling, so there is no GradScaler; a non-finite gradient norm (or loss) skips the update
+on the device (no host sync) and does not advance Adam's step counter, which lives on the device too.  lr / weight_decay are read from ``param_groups[0]`` each step so the
 reference's per-iteration cosine tables (run_pretraining_multimae.py:474-480) plug in unchanged.
 """
 from __future__ import annotations
@@ -21,6 +21,12 @@ from . import engine, ops
 
 
 class FusedAdamW:
+    """state (device, mmae_opt_desc): ``_state`` f32[8] = [sum of squares, gradient norm, applied gradient scale, lr, weight
+    decay, 1 - beta1^t, sqrt(1 - beta2^t), -]; ``_istate`` i32[4] = [skip flag of the last step, t = updates applied, steps
+    with a non-finite loss, skipped steps].  The step counter lives on the device: a skipped iteration (non-finite gradient
+    norm or loss, skip_grad) does not advance Adam's t -- the reference never calls optimizer.step() for it
+    (utils/native_scaler.py:27-31, GradScaler.step)."""
+
     def __init__(self, model: nn.Module, lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.95), eps: float = 1e-8,
                  weight_decay: float = 0.05, clip_grad: Optional[float] = None, skip_grad: Optional[float] = None):
         self.arena = engine.arena_of(model) or engine.ParamArena(model)
@@ -30,12 +36,26 @@ class FusedAdamW:
         self.v = torch.zeros(n, device=a.device, dtype=torch.float32)
         self.param_groups = [dict(lr=lr, weight_decay=weight_decay, lr_scale=1.0, betas=betas, eps=eps)]
         self.clip_grad, self.skip_grad = clip_grad, skip_grad
-        self.step_count = 0
-        self._sumsq = torch.zeros(1, device=a.device, dtype=torch.float32)
+        self.grad_prescale = 1.0          # 1 / world_size when the gradient arena holds rank SUMS (dist.GradAllReducer sets it)
+        self._state = torch.zeros(8, device=a.device, dtype=torch.float32)
+        self._istate = torch.zeros(4, device=a.device, dtype=torch.int32)
         self._ws = torch.empty(1024, device=a.device, dtype=torch.float32)
-        self._scale = torch.ones(1, device=a.device, dtype=torch.float32)
-        self._skip = torch.zeros(1, device=a.device, dtype=torch.int32)
-        self.grad_norm = torch.zeros(1, device=a.device, dtype=torch.float32)
+        self.grad_norm = self._state[1:2]
+
+    # Adam's t.  Reading it synchronises with the device: checkpoints and tests only, never inside the step.
+    @property
+    def step_count(self) -> int:
+        return int(self._istate[1])
+
+    @step_count.setter
+    def step_count(self, t: int) -> None:
+        self._istate[1] = int(t)
+
+    def counters(self) -> dict:
+        """{'steps', 'nonfinite_loss', 'skipped'} (one host read; poll at logging time to mirror the reference's
+        isfinite(loss) exit, run_pretraining_multimae.py:529-531, without a per-step synchronisation)."""
+        c = self._istate.tolist()
+        return dict(steps=c[1], nonfinite_loss=c[2], skipped=c[3])
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         engine.join_wgrad_streams()
@@ -43,37 +63,29 @@ class FusedAdamW:
         self.arena.rebind_grads()
 
     @torch.no_grad()
-    def step(self) -> torch.Tensor:
-        """One AdamW update; returns the (device) gradient 2-norm, as the reference's loss_scaler does."""
+    def step(self, loss: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One AdamW update in ONE library call (mmae_opt_step); returns the (device) gradient 2-norm, as the reference's
+        loss_scaler does.  lr / weight_decay are read from ``param_groups[0]`` (the reference's per-iteration cosine tables,
+        run_pretraining_multimae.py:474-480, plug in unchanged).  ``loss``: optional device scalar; a non-finite value skips
+        the update and is counted (``counters()``)."""
         a, g = self.arena, self.param_groups[0]
         n = a.n_trainable
         engine.join_wgrad_streams()
-        ops.sumsq(a.grad, self._sumsq, self._ws)
-        # scalar bookkeeping on 1-element device tensors (no host sync)
-        torch.sqrt(self._sumsq, out=self.grad_norm)
-        finite = torch.isfinite(self.grad_norm)
-        self._skip.copy_((~finite).to(torch.int32))
-        if self.skip_grad is not None:
-            self._skip.add_((self.grad_norm >= self.skip_grad).to(torch.int32))
-        if self.clip_grad is not None:
-            torch.clamp(self.clip_grad / (self.grad_norm + 1e-6), max=1.0, out=self._scale)
         b1, b2 = g['betas']
         shadow = a.shadow[:n] if a.shadow is not None else None
         cap = engine.capturing()
+        lrwd = None
         if cap is not None:
-            # hipGraph capture: the step-dependent scalars come from HBM, refreshed by the host before every replay
+            # hipGraph capture: the schedule values come from HBM, refreshed by the host before every replay
             def hyper():
-                self.step_count += 1
                 gg = self.param_groups[0]
-                return torch.tensor([gg['lr'] * gg.get('lr_scale', 1.0), gg['weight_decay'], 1.0 - b1 ** self.step_count,
-                                     math.sqrt(1.0 - b2 ** self.step_count)], dtype=torch.float32)
-            ops.adamw_dev(a.param[:n], a.grad, self.m, self.v, cap.add(hyper, a.device), beta1=b1, beta2=b2, eps=g['eps'],
-                          grad_scale=self._scale if self.clip_grad is not None else None, skip_flag=self._skip, shadow=shadow)
-        else:
-            self.step_count += 1
-            ops.adamw(a.param[:n], a.grad, self.m, self.v, lr=g['lr'] * g.get('lr_scale', 1.0), beta1=b1, beta2=b2, eps=g['eps'],
-                      weight_decay=g['weight_decay'], step=self.step_count,
-                      grad_scale=self._scale if self.clip_grad is not None else None, skip_flag=self._skip, shadow=shadow)
+                return torch.tensor([gg['lr'] * gg.get('lr_scale', 1.0), gg['weight_decay']], dtype=torch.float32)
+            lrwd = cap.add(hyper, a.device)
+        if loss is not None:
+            loss = loss.detach().float().reshape(1)
+        ops.opt_step(a.param[:n], a.grad, self.m, self.v, self._state, self._istate, self._ws, lr=g['lr'] * g.get('lr_scale', 1.0),
+                     weight_decay=g['weight_decay'], beta1=b1, beta2=b2, eps=g['eps'], clip_grad=self.clip_grad, skip_grad=self.skip_grad,
+                     grad_prescale=self.grad_prescale, lrwd_dev=lrwd, loss_dev=loss, shadow=shadow)
         if shadow is not None:
             a.mark_shadow_fresh()
         return self.grad_norm

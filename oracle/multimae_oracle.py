@@ -236,18 +236,37 @@ def mlp(x: Tensor, sd, prefix: str) -> Tensor:
     return h @ sd[prefix + 'fc2.weight'].t() + sd[prefix + 'fc2.bias']
 
 
-def block(x: Tensor, sd, prefix: str, heads: int, eps: float) -> Tensor:
-    """Block.forward, multimae_utils.py:229-232 (drop_path = identity)."""
-    x = x + self_attention(layer_norm(x, sd[prefix + 'norm1.weight'], sd[prefix + 'norm1.bias'], eps),
-                           sd, prefix + 'attn.', heads)
-    x = x + mlp(layer_norm(x, sd[prefix + 'norm2.weight'], sd[prefix + 'norm2.bias'], eps), sd, prefix + 'mlp.')
+def drop_path(x: Tensor, u: Optional[Tensor], drop_prob: float) -> Tensor:
+    """drop_path, multimae_utils.py:105-120, with the uniform draw u (B,) supplied by the caller:
+    x.div(keep_prob) * floor(keep_prob + u).  u None or drop_prob 0 = identity."""
+    if u is None or drop_prob == 0.0:
+        return x
+    keep = 1.0 - drop_prob
+    mask = (keep + u.to(x.dtype)).floor().view(-1, *([1] * (x.ndim - 1)))
+    return x.div(keep) * mask
+
+
+def block(x: Tensor, sd, prefix: str, heads: int, eps: float, drop_prob: float = 0.0, u=(None, None)) -> Tensor:
+    """Block.forward, multimae_utils.py:229-232; u = the two uniform draws (attention branch, MLP branch) of this
+    block's DropPath when drop_prob > 0."""
+    x = x + drop_path(self_attention(layer_norm(x, sd[prefix + 'norm1.weight'], sd[prefix + 'norm1.bias'], eps),
+                                     sd, prefix + 'attn.', heads), u[0], drop_prob)
+    x = x + drop_path(mlp(layer_norm(x, sd[prefix + 'norm2.weight'], sd[prefix + 'norm2.bias'], eps), sd, prefix + 'mlp.'), u[1], drop_prob)
     return x
 
 
-def encoder(x: Tensor, sd, cfg: OracleConfig, return_all_layers: bool = False):
+def drop_path_rates(drop_path_rate: float, depth: int):
+    """Per-block rates, multimae.py:93: torch.linspace(0, drop_path_rate, depth)."""
+    return [float(v) for v in torch.linspace(0, drop_path_rate, depth)]
+
+
+def encoder(x: Tensor, sd, cfg: OracleConfig, return_all_layers: bool = False, drop_path_rate: float = 0.0, drop_path_u=None):
+    """drop_path_u: per block a pair of (B,) uniform draws (or None); rates follow drop_path_rates()."""
     outs = []
+    rates = drop_path_rates(drop_path_rate, cfg.depth)
     for i in range(cfg.depth):
-        x = block(x, sd, f'encoder.{i}.', cfg.num_heads, cfg.ln_eps)
+        u = (None, None) if drop_path_u is None or drop_path_u[i] is None else drop_path_u[i]
+        x = block(x, sd, f'encoder.{i}.', cfg.num_heads, cfg.ln_eps, rates[i], u)
         outs.append(x)
     return outs if return_all_layers else x
 
@@ -395,7 +414,7 @@ def image_hw_of(x: Dict[str, Tensor], cfg: OracleConfig) -> Tuple[int, int]:
 
 
 def multimae_forward(x: Dict[str, Tensor], sd, cfg: OracleConfig, ids_keep: Tensor, ids_restore: Tensor,
-                     return_intermediates: bool = False):
+                     return_intermediates: bool = False, drop_path_rate: float = 0.0, drop_path_u=None):
     """MultiMAE.forward (multimae.py:271-379) with the (ids_keep, ids_restore) pair
     supplied by the caller (see masks_from_noise).  Returns preds keyed like
     cfg.out_tasks; with return_intermediates also the selected input tokens and the
@@ -407,7 +426,7 @@ def multimae_forward(x: Dict[str, Tensor], sd, cfg: OracleConfig, ids_keep: Tens
     sel = torch.gather(cat, 1, ids_keep[:, :, None].expand(-1, -1, cat.shape[2]))          # :343
     g = sd['global_tokens'].expand(B, -1, -1)
     enc_in = torch.cat([sel, g], dim=1)                                                     # :346-347 (global LAST)
-    enc = encoder(enc_in, sd, cfg)
+    enc = encoder(enc_in, sd, cfg, drop_path_rate=drop_path_rate, drop_path_u=drop_path_u)
     hw = image_hw_of(x, cfg)
     preds = {key: spatial_adapter(enc, sd, cfg, key, task, tokens_per_task, ids_keep, ids_restore, hw)
              for key, task in cfg.out_tasks}

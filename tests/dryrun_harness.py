@@ -23,7 +23,21 @@ class FakeLib:
                     ok = isinstance(a, int)
                 assert ok, (name, i, type(a), t)
             if name == 'mmae_abi_version':
-                return 1
+                return 2
+            if name == 'mmae_struct_size':
+                return ctypes.sizeof((_lib.GemmDesc, _lib.BlockDesc, _lib.StackDesc, _lib.AdapterDesc, _lib.OptDesc, _lib.PatchSrc)[args[0]])
+            # slab layouts of the composite entry points: enough room for the views the host code cuts out of them
+            if name in ('mmae_stack_act_bytes', 'mmae_stack_out_offset'):
+                d = args[0]._obj
+                per = d.B * d.N * d.D * 4
+                return d.L * per + 256 if name == 'mmae_stack_act_bytes' else args[1] * per
+            if name == 'mmae_adapter_act_bytes':
+                d = args[0]._obj
+                return d.B * d.n_q * d.C * d.ph * d.pw * 4 + 256
+            if name in ('mmae_stack_tmp_bytes', 'mmae_adapter_tmp_bytes'):
+                return 256
+            if name == 'mmae_adapter_pat_offset':
+                return 0
             if name == 'mmae_loss_split':
                 return 8
             if name == 'mmae_layernorm_bwd_nblk':

@@ -12,8 +12,8 @@ re-creates the identical weights / inputs / masks from the seeds and only the re
 
   * every gradient tensor with <= 4096 elements whole (all biases, LayerNorm affines, task_embeddings, mask_token,
     global_tokens, ...),
-  * every larger gradient (and every prediction) as a sketch: its 2-norm, 8 dot products with fixed +-1 vectors
-    (sketch_signs below: an integer hash of the element index, no RNG) and a strided sample of 2048 elements.
+  * every larger gradient (and every prediction) as a sketch (tests/golden/sketch.py): its 2-norm, 8 dot products with fixed
+    +-1 vectors (an integer hash of the element index, no RNG) and a strided sample of 2048 elements.
     For a difference d = g_test - g_ref the 8 projections estimate |d|_2 (E[(r.d)^2] = |d|^2), so a test gets the
     relative L2 error of the whole 2-million-element tensor from 8 numbers.
 
@@ -30,30 +30,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import make_golden as mg  # noqa: E402
 
-WHOLE_MAX = 4096
-N_PROJ = 8
-N_SAMPLE = 2048
-
-
-def sketch_signs(n: int, k: int) -> np.ndarray:
-    """+-1 vector number k of length n: bit 16 of a 32-bit multiplicative hash of (index, k).  Pure integer arithmetic
-    (no RNG), so the test side rebuilds exactly the same vectors."""
-    i = np.arange(n, dtype=np.uint64)
-    h = (i * np.uint64(2654435761) + np.uint64(k) * np.uint64(0x9E3779B1) + np.uint64(12345)) & np.uint64(0xFFFFFFFF)
-    h = (h ^ (h >> np.uint64(15))) * np.uint64(2246822519) & np.uint64(0xFFFFFFFF)
-    h = h ^ (h >> np.uint64(13))
-    return (((h >> np.uint64(16)) & np.uint64(1)).astype(np.float64) * 2.0 - 1.0)
-
-
-def sample_index(n: int) -> np.ndarray:
-    return np.linspace(0, n - 1, N_SAMPLE).astype(np.int64)
-
-
-def sketch(t: torch.Tensor):
-    v = t.detach().double().reshape(-1).numpy()
-    n = v.size
-    proj = np.array([float(np.dot(sketch_signs(n, k), v)) for k in range(N_PROJ)])
-    return dict(norm=np.float64(np.linalg.norm(v)), proj=proj, sample=v[sample_index(n)].astype(np.float32))
+from sketch import store  # noqa: E402
 
 
 def run_case(rm, ria, roa, rc, orc, name, doms, out):
@@ -89,18 +66,10 @@ def run_case(rm, ria, roa, rc, orc, name, doms, out):
     out[pre + 'grad_norm'] = np.float64(mg.grad_norm(model))
     out[pre + 'ids_keep_checksum'] = np.int64(int(ids_keep.sum()))
     for k, v in preds.items():
-        s = sketch(v)
-        for kk, vv in s.items():
-            out[pre + 'pred/' + k + '/' + kk] = vv
-    n_whole = 0
+        store(out, pre + 'pred/' + k, v)
     for n, g in grads.items():
-        if g.numel() <= WHOLE_MAX:
-            out[pre + 'grad/' + n + '/whole'] = g.numpy().astype(np.float32)
-            n_whole += 1
-        else:
-            s = sketch(g)
-            for kk, vv in s.items():
-                out[pre + 'grad/' + n + '/' + kk] = vv
+        store(out, pre + 'grad/' + n, g)
+    n_whole = sum(1 for g in grads.values() if g.numel() <= 4096)
     print(f'{name}: {n_whole} gradients stored whole, {len(grads) - n_whole} as sketches', flush=True)
 
 

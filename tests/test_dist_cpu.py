@@ -19,6 +19,10 @@ def test_plan_buckets_contiguous_cover():
     for (s0, e0, _), (s1, e1, _) in zip(b, b[1:]):
         assert e0 == s1
     assert sum(len(n) for _, _, n in b) == len(sizes)
+    # a forced cut: the bucket in progress ends right before the named tensor (the small, exposed tail bucket)
+    c = plan_buckets(sizes, 1000, cut_before=['p5'])
+    assert any(names[0] == 'p5' for _, _, names in c) and c[-1][1] == off
+    assert sum(len(n) for _, _, n in c) == len(sizes)
 
 
 def _free_port():
@@ -42,7 +46,7 @@ def _worker_body(rank, world, port, q):
     grad = torch.randn(off)
     mine = grad.clone()
     red = GradAllReducer(grad, sizes, bucket_mb=700 * 4 / (1024 * 1024))
-    assert len(red.buckets) >= 3
+    assert len(red.buckets) >= 3 and red.grad_prescale == 0.5          # buckets are SUMMED; the optimiser applies 1 / world
     # backward order: last layers first; a bucket only launches when ALL its tensors reported
     for i in reversed(range(3, 7)):
         red.mark_prefix_ready(f'encoder.{i}')
@@ -51,7 +55,7 @@ def _worker_body(rank, world, port, q):
     other = torch.empty_like(mine)
     torch.manual_seed(1 - rank)
     other = torch.randn(off)
-    q.put((rank, torch.allclose(grad, (mine + other) / 2, atol=1e-6), launched_mid))
+    q.put((rank, torch.allclose(grad, mine + other, atol=1e-6), launched_mid))
     dist.destroy_process_group()
 
 
@@ -70,7 +74,7 @@ def test_grad_allreduce_world2_gloo():
         assert any(launched_mid) and not all(launched_mid), 'buckets must launch incrementally as layers finish'
 
 
-def _model_worker(rank, world, port, q):
+def _model_worker(rank, world, port, q, direct=True, average=False):
     try:
         import sys
         here = os.path.dirname(os.path.abspath(__file__))
@@ -90,8 +94,17 @@ def _model_worker(rank, world, port, q):
         gathered = [torch.empty_like(arena.param) for _ in range(world)]
         dist.all_gather(gathered, arena.param)
         same_params = all(torch.equal(g, gathered[0]) for g in gathered)
-        red = GradAllReducer.for_arena(arena, bucket_mb=0.25)
+        red = GradAllReducer.for_arena(arena, bucket_mb=0.25, average_in_place=average)
         attach(model, red)
+        # arena = gradient-readiness order: last output adapter first, encoder from the top down, embedding parameters last
+        names = [n for n in arena.names if arena.trainable[n]]
+        assert names[0].startswith('output_adapters.norm_rgb.') and names[-1] in arena.tail_names(), (names[0], names[-1])
+        enc_first = [i for i, n in enumerate(names) if n.startswith('encoder.')][0]
+        assert names[enc_first].startswith(f'encoder.{len(model.encoder) - 1}.')
+        tail = set(arena.tail_names())
+        for _, _, bn in red.buckets:                  # the embedding parameters never share a bucket with anything else
+            assert set(bn) <= tail or not (set(bn) & tail), bn
+        assert set(red.buckets[-1][2]) <= tail
         order = []
         launch = red._launch
         red._launch = lambda i: (order.append(i) if not red._launched[i] else None, launch(i))[1]
@@ -99,7 +112,7 @@ def _model_worker(rank, world, port, q):
         P = MINI['P']
         fns = {'rgb': M.MaskedMSELoss(P, 1), 'depth': M.MaskedL1Loss(P, 1), 'semseg': M.MaskedCrossEntropyLoss(P, 4),
                'norm_rgb': M.MaskedMSELoss(P, 1, norm_pix=True)}
-        M.engine.set_direct_grads(True)
+        M.engine.set_direct_grads(direct)
         arena.grad.fill_(float(rank + 1))             # stand-in gradients (the stubbed kernels write nothing)
         with M.engine.precision('bf16'):
             preds, masks = model(g['x'], num_encoded_tokens=MINI['nvis'], alphas=1.0, fp32_output_adapters=['semseg'])
@@ -107,8 +120,14 @@ def _model_worker(rank, world, port, q):
             tgt = dict(g['x'], norm_rgb=g['x']['rgb'])
             sum(fns[k](preds[k].float(), tgt[k], mask=mk[k]) for k in preds).backward()
         mid = sum(red._launched)
+        if not direct:
+            # autograd delivered the (stub) gradients with AccumulateGrad AFTER the nodes returned: the callbacks must have been
+            # ignored, or the buckets would have been reduced before the gradients existed (dist.py:111)
+            assert mid == 0, mid
+            arena.grad.fill_(float(rank + 1))
         red.finish()
-        ok = bool(torch.allclose(arena.grad, torch.full_like(arena.grad, (1 + world) / 2)))
+        total = sum(range(1, world + 1))
+        ok = bool(torch.allclose(arena.grad, torch.full_like(arena.grad, total / world if average else float(total))))
         q.put((rank, ok and same_params and (rank == 0 or not torch.equal(before, arena.param)), order, mid, len(red.buckets)))
         dist.destroy_process_group()
     except Exception as e:          # noqa: BLE001
@@ -132,5 +151,40 @@ def test_model_backward_drives_reducer_world2_gloo():
         p.join(timeout=60)
     for rank, ok, order, mid, nb in res:
         assert ok, f'rank {rank}: {order}'
-        assert nb >= 4 and 0 < mid < nb, (mid, nb)            # some buckets launched from inside backward, not all
+        assert nb >= 4 and 0 < mid <= nb, (mid, nb)           # buckets launched from inside backward
+        assert order == sorted(order), f'buckets complete in arena order (= readiness order): {order}'
     assert res[0][2] == res[1][2], 'ranks must issue their collectives in the same order'
+
+
+def _run_model_workers(world, **kw):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_model_worker, args=(r, world, port, q), kwargs=kw) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    return res
+
+
+def test_reducer_ignores_callbacks_without_direct_grads_world2_gloo():
+    """engine.set_direct_grads(False): the hand-written backward hands its gradients to autograd, which adds them into .grad only
+    after the node returned -- a bucket launched from the node's completion callback would be reduced before its gradients
+    exist.  The reducer must ignore the callbacks then and reduce everything in finish() (here with in-place averaging)."""
+    res = _run_model_workers(2, direct=False, average=True)
+    for rank, ok, order, mid, nb in res:
+        assert ok, f'rank {rank}: {order}'
+        assert mid == 0
+    assert res[0][2] == res[1][2]
+
+
+def test_model_backward_drives_reducer_world4_gloo():
+    """Four ranks, 0.25 MB buckets: several buckets close inside each output adapter's backward (on the GPU: on that adapter's
+    stream -- the events recorded per readiness report order the all-reduce behind every contributing stream)."""
+    res = _run_model_workers(4)
+    for rank, ok, order, mid, nb in res:
+        assert ok, f'rank {rank}: {order}'
+        assert order == sorted(order) and mid >= nb - 1, (order, mid, nb)      # everything but the tail launched inside backward
+    assert all(r[2] == res[0][2] for r in res)
