@@ -69,33 +69,100 @@ def loss_fns():
 
 def pmc_traffic(dom):
     """HBM bytes per bf16-GEMM launch (average over the launches of one step) from the committed rocprofv3 PMC passes of this
-    same command (tools/pmc_traffic.py -> profiles/r01_pmc_traffic.json; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).
-    Counters cannot be read from inside the process, so this is the recorded figure, or None if no PMC pass is committed."""
+    same command (tools/pmc_traffic.py -> profiles/*_pmc_traffic.json; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).
+    Counters cannot be read from inside the process, so this is a RECORDED figure (the JSON line says which file it came from:
+    roofline.traffic_source), or None if no PMC pass is committed."""
     if dom != torch.bfloat16:
-        return None
-    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
-    try:
-        return json.load(open(f)).get('gemm_bf16_traffic_per_launch')
-    except (OSError, ValueError):
-        return None
+        return None, None
+    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+        f = os.path.join(ROOT, 'profiles', name)
+        try:
+            return json.load(open(f)).get('gemm_bf16_traffic_per_launch'), f'recorded: profiles/{name} (rocprofv3 --pmc passes of this command; not measured in this run)'
+        except (OSError, ValueError):
+            continue
+    return None, None
 
 
 def log(msg):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
 
-def cpu_baseline(cfg: str, sample_B: int, steps: int, threads: int = 0):
-    """The oracle (CPU restatement pinned to the reference, oracle/multimae_oracle.py) timed on the host
-    cores: the same step (fwd -> 4 losses -> backward -> AdamW) in fp32."""
+def cpu_model_name():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown CPU'
+
+
+REF = '/root/reference'
+
+
+def _reference_step_fn(cfg: str, B: int):
+    """The reference's own classes (SURVEY.md Appendix B import recipe) when its checkout is present (the build container;
+    never on the GPU box): returns a callable running one fwd -> 4 losses -> backward -> AdamW step, or None."""
+    if not os.path.isdir(os.path.join(REF, 'multimae')):
+        return None
+    import types
+    saved_mods = {k: sys.modules.get(k) for k in ('utils', 'multimae')}
+    try:
+        pkg = types.ModuleType('utils')
+        pkg.__path__ = [os.path.join(REF, 'utils')]
+        sys.modules['utils'] = pkg
+        for k in [k for k in sys.modules if k == 'multimae' or k.startswith('multimae.')]:
+            del sys.modules[k]
+        sys.path.insert(0, REF)
+        sys.dont_write_bytecode = True
+        import multimae.multimae as rm
+        import multimae.input_adapters as ria
+        import multimae.output_adapters as roa
+        import multimae.criterion as rc
+        sys.path.remove(REF)
+    except Exception as e:                                  # noqa: BLE001 -- any import trouble: fall back to the oracle
+        log(f'cpu_baseline: reference import failed ({e!r}); using the oracle port')
+        return None
+    doms = ['rgb'] if cfg == 'cfg2' else ['rgb', 'depth', 'semseg']
+    ins = {}
+    for d in doms:
+        if d == 'semseg':
+            ins[d] = ria.SemSegInputAdapter(num_classes=133, dim_class_emb=64, interpolate_class_emb=False, stride_level=4, patch_size_full=16)
+        else:
+            ins[d] = ria.PatchedInputAdapter(num_channels=3 if d == 'rgb' else 1, stride_level=1, patch_size_full=16)
+    outs = {}
+    for key, task in [(d, d) for d in doms] + [('norm_rgb', 'rgb')]:
+        ch = {'rgb': 3, 'depth': 1, 'semseg': 133}[task]
+        outs[key] = roa.SpatialOutputAdapter(num_channels=ch, stride_level=4 if task == 'semseg' else 1, patch_size_full=16, dim_tokens=256,
+                                             depth=2, num_heads=8, use_task_queries=True, task=task, context_tasks=list(doms), use_xattn=True)
+    torch.manual_seed(0)
+    model = rm.pretrain_multimae_base(ins, outs, num_global_tokens=1, drop_path_rate=0.0).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+    fns = {'rgb': rc.MaskedMSELoss(16, 1), 'depth': rc.MaskedL1Loss(16, 1), 'semseg': rc.MaskedCrossEntropyLoss(16, 4),
+           'norm_rgb': rc.MaskedMSELoss(16, 1, norm_pix=True)}
+    x = {}
+    if 'rgb' in doms:
+        x['rgb'] = torch.randn(B, 3, 224, 224)
+    if 'depth' in doms:
+        x['depth'] = torch.randn(B, 1, 224, 224)
+    if 'semseg' in doms:
+        x['semseg'] = torch.randint(0, 133, (B, 56, 56))
+    tgt = dict(x, norm_rgb=x['rgb'])
+
+    def step():
+        preds, masks = model(x, num_encoded_tokens=98, alphas=1.0, fp32_output_adapters=['semseg'] if 'semseg' in doms else [])
+        masks = dict(masks, norm_rgb=masks['rgb'])
+        loss = sum(fns[k](preds[k].float(), tgt[k], mask=masks[k]) for k in preds)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    return step
+
+
+def _oracle_step_fn(cfg: str, B: int):
+    """The oracle (CPU restatement pinned to the reference, oracle/multimae_oracle.py): the same step in fp32."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import multimae_oracle as orc
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = threads or min(avail, 64)
-    torch.set_num_threads(cores)
-    log(f'cpu_baseline: {avail} cores available, using {cores} threads, B={sample_B}, {steps}+1 steps')
     model, doms = build_model(cfg)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     train = {n for n, p in model.named_parameters() if p.requires_grad}
@@ -104,17 +171,18 @@ def cpu_baseline(cfg: str, sample_B: int, steps: int, threads: int = 0):
     torch.manual_seed(0)
     x = {}
     if 'rgb' in doms:
-        x['rgb'] = torch.randn(sample_B, 3, 224, 224)
+        x['rgb'] = torch.randn(B, 3, 224, 224)
     if 'depth' in doms:
-        x['depth'] = torch.randn(sample_B, 1, 224, 224)
+        x['depth'] = torch.randn(B, 1, 224, 224)
     if 'semseg' in doms:
-        x['semseg'] = torch.randint(0, 133, (sample_B, 56, 56))
+        x['semseg'] = torch.randint(0, 133, (B, 56, 56))
     m = {n: torch.zeros_like(sd[n]) for n in train}
     v = {n: torch.zeros_like(sd[n]) for n in train}
-    times = []
-    for step in range(1, steps + 2):
-        t0 = time.perf_counter()
-        dist, tn, an = orc.draw_mask_randoms(sample_B, [196] * len(doms), 1.0)
+    count = [0]
+
+    def step():
+        count[0] += 1
+        dist, tn, an = orc.draw_mask_randoms(B, [196] * len(doms), 1.0)
         spt = orc.samples_per_task_from_dirichlet(dist, 98)
         mask_all, ik, ir = orc.masks_from_noise(spt, tn, an, 98)
         sdo = {k: (t.requires_grad_(True) if k in train else t) for k, t in sd.items()}
@@ -125,16 +193,52 @@ def cpu_baseline(cfg: str, sample_B: int, steps: int, threads: int = 0):
             grads = {n: sdo[n].grad for n in train}
             for n in train:
                 sdo[n].requires_grad_(False)
-            orc.adamw_step({n: sd[n] for n in train}, grads, m, v, step, 1e-4, 0.05)
+            orc.adamw_step({n: sd[n] for n in train}, grads, m, v, count[0], 1e-4, 0.05)
             for n in train:
                 sd[n].grad = None
-        times.append(time.perf_counter() - t0)
-        log(f'cpu_baseline step {step}: {times[-1]:.2f} s')
-    times = sorted(times[1:])
-    med = times[len(times) // 2]
-    return {'value': round(sample_B / med, 3), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{steps} timed steps (median) of the same {cfg} step at B={sample_B}, fp32, oracle/multimae_oracle.py + torch autograd, '
-                      f'{cores} threads'}
+    return step
+
+
+def cpu_baseline(cfg: str, sample_B: int, steps: int, threads: int = 0):
+    """BASELINE.md section 3 protocol: the same step (fwd -> 4 losses -> backward -> AdamW) in fp32 on the host cores, B = 16,
+    1 warm-up + `steps` timed steps, median; the thread count is the best of a quick 8/16/32/64 sweep (1 + 1 steps each).
+    Runs the reference's own classes where /root/reference exists (kind "reference"); on the GPU box, where it does not, the
+    oracle port of the same arithmetic (kind "port")."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    step = _reference_step_fn(cfg, sample_B)
+    kind = 'reference' if step is not None else 'port'
+    if step is None:
+        step = _oracle_step_fn(cfg, sample_B)
+
+    def timed(n_threads, n_steps):
+        torch.set_num_threads(n_threads)
+        ts = []
+        for i in range(n_steps + 1):
+            t0 = time.perf_counter()
+            step()
+            ts.append(time.perf_counter() - t0)
+        ts = sorted(ts[1:])
+        return ts[(len(ts) - 1) // 2]
+    sweep = {}
+    if threads:
+        cores = threads
+    else:
+        for c in sorted({min(c, avail) for c in (8, 16, 32, 64)}):
+            sweep[c] = timed(c, 2)
+            log(f'cpu_baseline sweep: {c} threads -> {sweep[c]:.2f} s/step ({sample_B / sweep[c]:.2f} img/s)')
+        cores = min(sweep, key=sweep.get)
+    med = timed(cores, steps)
+    log(f'cpu_baseline: {kind}, {cores} of {avail} cores, B={sample_B}: median {med:.2f} s/step = {sample_B / med:.2f} img/s')
+    return {'value': round(sample_B / med, 3), 'unit': 'images/s', 'cores': cores, 'kind': kind, 'cpu': cpu_model_name(),
+            'cores_available': avail, 'thread_sweep_img_s': {str(c): round(sample_B / t, 2) for c, t in sweep.items()},
+            'sample': f'BASELINE.md section 3 protocol: median of {steps} timed steps after 1 warm-up of the same {cfg} step (fwd, 4 losses, '
+                      f'backward, AdamW) at B={sample_B}, fp32, '
+                      + ('the reference classes (/root/reference, Appendix B import)' if kind == 'reference'
+                         else 'oracle/multimae_oracle.py + torch autograd (the reference checkout does not exist on this box)')
+                      + f', {cores} threads (best of the 8/16/32/64 sweep)'}
 
 
 def main():
@@ -147,9 +251,10 @@ def main():
                     help='cfg3 = BASELINE.json configs[2] (the metric), cfg2 = configs[1] (RGB-only), cfg5 = configs[4] geometry (ViT-L, 196 visible tokens; bf16 -- the MX-fp8 path is not built)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-batch', type=int, default=8)
-    ap.add_argument('--cpu-threads', type=int, default=0)
-    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--cpu-sample-batch', type=int, default=16)
+    ap.add_argument('--cpu-threads', type=int, default=0, help='0: best of an 8/16/32/64 sweep')
+    ap.add_argument('--cpu-steps', type=int, default=5)
+    ap.add_argument('--total-steps', type=int, default=1000, help='length of the cosine lr / wd tables the loop walks (run_pretraining_multimae.py:474-480)')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--adapter-streams', type=int, default=1, help='1: output adapters on separate HIP streams')
     ap.add_argument('--wgrad-stream', type=int, default=1, help='1: weight-gradient GEMMs on a side stream')
@@ -187,7 +292,6 @@ def main():
     if world > 1:
         broadcast_parameters(arena)
         reducer = GradAllReducer.for_arena(arena)
-        attach(model, reducer)
     M.engine.set_precision(args.precision)
     M.engine.set_direct_grads(True)
     M.engine.set_adapter_streams(bool(args.adapter_streams))
@@ -196,6 +300,16 @@ def main():
     n_vis = 196 if args.config == 'cfg5' else 98
     lr = 1e-4 * B * world / 256                                   # blr * global_bs / 256 (:372-373)
     opt = FusedAdamW(model, lr=lr, betas=(0.9, 0.95), weight_decay=0.05)
+    if reducer is not None:
+        attach(model, reducer, opt)                               # buckets are summed; 1 / world is folded into the optimiser's scale
+    # per-iteration cosine tables, assigned to the param group before every step as the reference loop does (:474-480)
+    import math
+    n_tab = max(args.total_steps, args.steps + args.warmup + 8)
+    warm = max(1, n_tab // 20)
+    lr_tab = [lr * (i + 1) / warm if i < warm else 1e-6 + 0.5 * (lr - 1e-6) * (1 + math.cos(math.pi * (i - warm) / max(1, n_tab - warm)))
+              for i in range(n_tab)]
+    wd_tab = [0.05] * n_tab
+    it = [0]
     x = synthetic_batch(doms, B, device, seed=rank)
     tgt = dict(x, norm_rgb=x['rgb'])
     fns = loss_fns()
@@ -203,6 +317,9 @@ def main():
     last = {}
 
     def step():
+        g = opt.param_groups[0]
+        g['lr'], g['weight_decay'] = lr_tab[min(it[0], n_tab - 1)] * g['lr_scale'], wd_tab[min(it[0], n_tab - 1)]
+        it[0] += 1
         opt.zero_grad()
         preds, masks = model(x, num_encoded_tokens=n_vis, alphas=1.0, sample_tasks_uniformly=False, fp32_output_adapters=fp32_adapters)
         mk = dict(masks, norm_rgb=masks['rgb'])
@@ -211,7 +328,7 @@ def main():
         loss.backward()
         if reducer is not None:
             reducer.finish()
-        opt.step()
+        opt.step(loss)                          # isfinite(loss) guard + grad-norm + AdamW: one call, every decision on the device
         last['loss'] = loss
 
     def sync():
@@ -249,6 +366,7 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     img_s = B * world * args.steps / dt
     final_loss = float(last['loss'].detach())
+    counters = opt.counters()
     log(f'timed region done: {ms_per_step:.2f} ms/step, {img_s:.1f} img/s, loss {final_loss:.4f} (host enqueue {host_ms:.2f} ms/step)')
 
     # per-kernel timing pass (outside the timed region): HIP events around every MFMA GEMM launch.  The pass runs with the
@@ -261,6 +379,7 @@ def main():
         M.engine.set_adapter_streams(False)
         M.engine.set_wgrad_stream(False)
         ops.set_composite_blocks(False)            # every GEMM through ops.gemm, where the events are
+        ops.set_stack_composites(False)
         step()
         torch.cuda.synchronize()
         rec = []
@@ -285,6 +404,7 @@ def main():
         torch.cuda.synchronize()
         ops.gemm = orig
         ops.set_composite_blocks(True)
+        ops.set_stack_composites(True)
         M.engine.set_adapter_streams(bool(args.adapter_streams))
         M.engine.set_wgrad_stream(bool(args.wgrad_stream))
         log('kernel timing pass done')
@@ -298,8 +418,9 @@ def main():
         dom = torch.bfloat16 if args.precision == 'bf16' else torch.float32
         peak = PEAK_BF16_TFLOPS if dom == torch.bfloat16 else 157.3
         ach = tot_fl[dom] / (tot_ms[dom] * 1e-3) / 1e12 if tot_ms[dom] > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(dom)
         roof = {'bound': 'mfma', 'kernel': 'gemm_bf16_pp_kernel / gemm_bf16_kernel (all bf16 MFMA GEMM launches of one step, each timed alone on its stream)' if dom == torch.bfloat16 else 'gemm_f32_kernel',
-                'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': pmc_traffic(dom),
+                'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_source': traffic_src,
                 'launches_per_step': cnt[dom], 'gemm_ms_per_step': round(tot_ms[dom], 3),
                 'gemm_gflop_per_step': round(tot_fl[dom] / 1e9, 1),
                 'f32_adapter_gemm_ms_per_step': round(tot_ms[torch.float32], 3) if dom == torch.bfloat16 else None,
@@ -325,8 +446,8 @@ def main():
                                    + f', 224^2, Dirichlet alpha=1.0, {n_vis} visible tokens, {len(doms) + 1} cross-attention decoders (dim 256, depth 2), '
                                    + ('fp32 semseg adapter, ' if 'semseg' in doms else '') + 'AdamW; fwd+losses+bwd+optimizer',
                        'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}'},
-            'final_loss': round(final_loss, 5), 'launch': 'hipGraph replay of the captured step' if use_graph else 'eager (one host launch per kernel)',
-            'host_enqueue_ms_per_step': round(host_ms, 3),
+            'final_loss': round(final_loss, 5), 'launch': 'hipGraph replay of the captured step' if use_graph else 'eager, one library call per encoder stack / output adapter / loss / optimiser step',
+            'host_enqueue_ms_per_step': round(host_ms, 3), 'optimizer_counters': counters,
             'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(out))
