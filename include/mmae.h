@@ -40,7 +40,7 @@ extern "C" {
 
 int mmae_abi_version(void);
 /* sizeof the descriptor structs as this build of the library sees them (0 gemm, 1 block, 2 stack, 3 adapter, 4 opt,
- * 5 patch_src; -1 for an unknown index): a binding checks its own struct mirrors against these at load time. */
+ * 5 patch_src, 6 dw_group; -1 for an unknown index): a binding checks its own struct mirrors against these at load time. */
 int mmae_struct_size(int which);
 /* last HIP error string seen by this thread's launches (static storage). */
 const char* mmae_last_error(void);
@@ -110,6 +110,30 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream);
 int mmae_gemm_plan(const mmae_gemm_desc* d, int* tile, int* split_k);
 /* suggested number of K slices for a dW-shaped (both operands k-strided) [M,N,K] product (1 = do not split) */
 int mmae_gemm_auto_splitk(int M, int N, int K, int ab_dtype);
+
+/* ------------------------------------------------------------------------- *
+ * Grouped weight gradients: up to 8 products dw_i[n_out_i][k_in_i] (+)= dy_i[rows][n_out_i]^T . x_i[rows][k_in_i] (the dW of
+ * nn.Linear layers that saw the same rows, e.g. the four of a transformer block, multimae_utils.py:143-153,165-180) in ONE
+ * MFMA launch + ONE reduction launch; db_i[n_out_i] (+)= column sums of dy_i ride along (NULL = not wanted).  bf16 operands
+ * (MMAE_ESUPPORT otherwise), widths and leading dimensions multiples of 8, dw contiguous.  Every product is cut into the
+ * same number of row slices -- as many as fill the chip once (split_k = 0), at least 16 x 32 rows each -- whose f32 partials
+ * go through the caller's workspace (mmae_gemm_dw_group_ws_elems) and are summed in a fixed order (deterministic).
+ * ------------------------------------------------------------------------- */
+typedef struct mmae_dw_problem {
+    const void* dy; int64_t ldy;
+    const void* x; int64_t ldx;
+    float* dw; float* db;
+    int32_t n_out, k_in;
+} mmae_dw_problem;
+
+typedef struct mmae_dw_group_desc {
+    int32_t n, rows, ab_dtype, accumulate, split_k;
+    mmae_dw_problem p[8];
+    float* ws; int64_t ws_elems;
+} mmae_dw_group_desc;
+
+int64_t mmae_gemm_dw_group_ws_elems(const mmae_dw_group_desc* d);
+int mmae_gemm_dw_group(const mmae_dw_group_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * LayerNorm (biased variance, eps inside rsqrt), rows of width D.

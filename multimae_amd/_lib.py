@@ -80,6 +80,16 @@ class AdapterDesc(ctypes.Structure):
                 + [('ws_main', _P), ('ws_main_elems', _L), ('ws_side', _P), ('ws_side_elems', _L)])
 
 
+class DwProblem(ctypes.Structure):
+    """mirror of mmae_dw_problem"""
+    _fields_ = [('dy', _P), ('ldy', _L), ('x', _P), ('ldx', _L), ('dw', _P), ('db', _P), ('n_out', _I), ('k_in', _I)]
+
+
+class DwGroupDesc(ctypes.Structure):
+    """mirror of mmae_dw_group_desc"""
+    _fields_ = [('n', _I), ('rows', _I), ('ab_dtype', _I), ('accumulate', _I), ('split_k', _I), ('p', DwProblem * 8), ('ws', _P), ('ws_elems', _L)]
+
+
 class OptDesc(ctypes.Structure):
     """mirror of mmae_opt_desc"""
     _fields_ = [('p', _P), ('g', _P), ('m', _P), ('v', _P), ('n', _L), ('shadow', _P), ('shadow_dtype', _I),
@@ -151,7 +161,7 @@ def load() -> ctypes.CDLL:
         fn.argtypes = argtypes
     if lib.mmae_abi_version() != 2:
         raise RuntimeError('libmmae_hip.so ABI version mismatch')
-    for which, cls in enumerate((GemmDesc, BlockDesc, StackDesc, AdapterDesc, OptDesc, PatchSrc)):
+    for which, cls in enumerate((GemmDesc, BlockDesc, StackDesc, AdapterDesc, OptDesc, PatchSrc, DwGroupDesc)):
         if lib.mmae_struct_size(which) != ctypes.sizeof(cls):
             raise RuntimeError(f'{cls.__name__}: ctypes mirror ({ctypes.sizeof(cls)} B) != library struct ({lib.mmae_struct_size(which)} B)')
     _lib = lib

@@ -7,6 +7,7 @@
 // the host needed 20-33 ms per step and paced the four output adapters' backward passes.  With one call per stack / adapter a
 // step is ~40 library calls.
 #include <math.h>
+#include <stdlib.h>
 #include <mutex>
 #include "gemm_common.h"
 
@@ -130,6 +131,35 @@ int lin_dw(const Ctx& c, const void* dy, int64_t ldy, const void* x, float* dw, 
     }
     return 0;
 }
+
+// weight gradients of one block collected into ONE grouped launch (mmae_gemm_dw_group); bf16 only.  MMAE_DW_GROUP=0 restores
+// one split-K launch (+ reduce) per product.
+bool dw_group_enabled() {
+    static const bool on = !(getenv("MMAE_DW_GROUP") && atoi(getenv("MMAE_DW_GROUP")) == 0);
+    return on;
+}
+struct DwGroup {
+    mmae_dw_group_desc g;
+    bool on;
+    DwGroup(const Ctx& c, int rows) : g{}, on(c.act_dtype == MMAE_BF16 && dw_group_enabled()) {
+        g.rows = rows; g.ab_dtype = MMAE_BF16; g.accumulate = c.grad_acc;
+    }
+    // queue dw (+ db); returns false if this product must be issued on its own (group off / full / no weight gradient wanted)
+    bool add(const void* dy, int64_t ldy, const void* x, int64_t ldx, float* dw, float* db, int n_out, int k_in) {
+        if (!on || !dw || g.n >= 8 || (n_out % 8) || (k_in % 8) || (ldy % 8) || (ldx % 8)) return false;
+        mmae_dw_problem& q = g.p[g.n++];
+        q.dy = dy; q.ldy = ldy; q.x = x; q.ldx = ldx; q.dw = dw; q.db = db; q.n_out = n_out; q.k_in = k_in;
+        return true;
+    }
+    int flush(const Ctx& c, hipStream_t st) {
+        if (g.n == 0) return 0;
+        g.ws = c.ws_side; g.ws_elems = c.ws_side_elems;
+        if (mmae_gemm_dw_group_ws_elems(&g) > c.ws_side_elems) { mmae_set_error("composite: ws_side too small for the grouped weight gradients"); return MMAE_EINVAL; }
+        const int rc = mmae_gemm_dw_group(&g, st);
+        g.n = 0;
+        return rc;
+    }
+};
 
 // column sums of part [rows][nseg * seg_w] scattered into up to 8 gradient destinations (NULL = dropped)
 int scatter(const Ctx& c, const float* part, int rows, int seg_w, float* const* dsts, int nseg, hipStream_t st) {
@@ -374,11 +404,15 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
         dm_act = d->dxs_act;
     }
     float* part_h = d->g_fc1_b ? d->part_h : nullptr;
+    DwGroup grp(c, R);                                               // the block's four weight gradients: one launch at the end
+    if (d->dp1 || d->dp2) grp.on = false;                           // stochastic depth re-uses dxs_act between the two branches
     if ((rc = lin_dx(c, dm_act, D, d->fc2_w, d->d_hpre, act, R, D, Hd, d->hpre, MMAE_EPI_DGELU, part_h, st))) return rc;
     if ((rc = fork_to(st, sd))) return rc;                          // dx_act, d_hpre ready for the weight-gradient stream
-    if ((rc = lin_dw(c, dm_act, D, d->hact, d->g_fc2_w, d->fc2_b_done ? nullptr : d->g_fc2_b, R, D, Hd, sd))) return rc;
+    if (!grp.add(dm_act, D, d->hact, Hd, d->g_fc2_w, d->fc2_b_done ? nullptr : d->g_fc2_b, D, Hd) &&
+        (rc = lin_dw(c, dm_act, D, d->hact, d->g_fc2_w, d->fc2_b_done ? nullptr : d->g_fc2_b, R, D, Hd, sd))) return rc;
     if ((rc = lin_dx(c, d->d_hpre, Hd, d->fc1_w, d->d_ln2, act, R, Hd, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
-    if ((rc = lin_dw(c, d->d_hpre, Hd, d->ln2, d->g_fc1_w, nullptr, R, Hd, D, sd))) return rc;
+    if (!grp.add(d->d_hpre, Hd, d->ln2, D, d->g_fc1_w, nullptr, Hd, D) &&
+        (rc = lin_dw(c, d->d_hpre, Hd, d->ln2, d->g_fc1_w, nullptr, R, Hd, D, sd))) return rc;
     if (part_h) {
         float* dst[1] = {d->g_fc1_b};
         if ((rc = scatter(c, part_h, hrows, Hd, dst, 1, sd))) return rc;
@@ -396,7 +430,8 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
     if ((rc = fork_to(st, sd))) return rc;                          // part2, dx1_act
     // proj's bias gradient: colsum(dx1) from the LayerNorm partials, or colsum of the rescaled copy under stochastic depth
     if ((rc = scatter3(c, d->part2, nblk, D, d->g_n2_w, d->g_n2_b, d->dp1 ? nullptr : d->g_proj_b, sd))) return rc;
-    if ((rc = lin_dw(c, da_act, D, d->ao, d->g_proj_w, d->dp1 ? d->g_proj_b : nullptr, R, D, D, sd))) return rc;
+    if (!grp.add(da_act, D, d->ao, D, d->g_proj_w, d->dp1 ? d->g_proj_b : nullptr, D, D) &&
+        (rc = lin_dw(c, da_act, D, d->ao, d->g_proj_w, d->dp1 ? d->g_proj_b : nullptr, R, D, D, sd))) return rc;
     {
         const size_t es = act == MMAE_BF16 ? 2 : 4;
         const char* qkv = (const char*)d->qkv;
@@ -409,7 +444,9 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
     }
     if ((rc = lin_dx(c, d->d_qkv, 3 * D, d->qkv_w, d->d_ln1, act, R, 3 * D, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
     if ((rc = fork_to(st, sd))) return rc;                          // d_qkv
-    if ((rc = lin_dw(c, d->d_qkv, 3 * D, d->ln1, d->g_qkv_w, d->g_qkv_b, R, 3 * D, D, sd))) return rc;
+    if (!grp.add(d->d_qkv, 3 * D, d->ln1, D, d->g_qkv_w, d->g_qkv_b, 3 * D, D) &&
+        (rc = lin_dw(c, d->d_qkv, 3 * D, d->ln1, d->g_qkv_w, d->g_qkv_b, R, 3 * D, D, sd))) return rc;
+    if ((rc = grp.flush(c, sd))) return rc;
     void* dx0_act = act == MMAE_F32 ? nullptr : d->dx0_act;
     if ((rc = mmae_layernorm_bwd(d->d_ln1, act, d->x0, d->n1_w, d->mean1, d->rstd1, d->dx1, d->dx0, dx0_act, act, d->part1, R, D, st))) return rc;
     if ((rc = fork_to(st, sd))) return rc;                          // part1
@@ -720,8 +757,11 @@ int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream
         d_pat = t.d_pat;
     }
     MMAE_REQUIRE(ldp >= KP && ldp % 4 == 0, "adapter_bwd: bad ld_pat");
+    // the adapter's own weight gradients: two grouped launches at the end (products over the B * n_q query rows / over the
+    // B * NC context rows); whatever a group cannot take (f32 activations, odd widths) is issued on its own right away
+    DwGroup grp_q(c, Rq), grp_c(c, Rc);
     if ((rc = fork_to(st, sd))) return rc;
-    if ((rc = lin_dw(c, d_pat, ldp, h_act, gtail[0], gtail[1], Rq, KP, D, sd))) return rc;
+    if (!grp_q.add(d_pat, ldp, h_act, D, gtail[0], gtail[1], KP, D) && (rc = lin_dw(c, d_pat, ldp, h_act, gtail[0], gtail[1], Rq, KP, D, sd))) return rc;
     if ((rc = lin_dx(c, d_pat, ldp, ow, t.dh_act, act, Rq, KP, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
     const float* dh = (const float*)t.dh_act;
     if (bf) { if ((rc = mmae_cast_bf16_to_f32(t.dh_act, t.dh, (int64_t)Rq * D, st))) return rc; dh = t.dh; }
@@ -740,9 +780,10 @@ int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream
     // ---- x1 = x + mlp(out_norm(x))
     if ((rc = lin_dx(c, dh_act, D, f2w, t.d_hpre, act, Rq, D, Hd, a.hpre, MMAE_EPI_DGELU, gb[13] ? t.part_h : nullptr, st))) return rc;
     if ((rc = fork_to(st, sd))) return rc;
-    if ((rc = lin_dw(c, dh_act, D, a.hact, gb[14], fc2_done ? nullptr : gb[15], Rq, D, Hd, sd))) return rc;
+    if (!grp_q.add(dh_act, D, a.hact, Hd, gb[14], fc2_done ? nullptr : gb[15], D, Hd) &&
+        (rc = lin_dw(c, dh_act, D, a.hact, gb[14], fc2_done ? nullptr : gb[15], Rq, D, Hd, sd))) return rc;
     if ((rc = lin_dx(c, t.d_hpre, Hd, f1w, t.d_on, act, Rq, Hd, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
-    if ((rc = lin_dw(c, t.d_hpre, Hd, a.on, gb[12], nullptr, Rq, Hd, D, sd))) return rc;
+    if (!grp_q.add(t.d_hpre, Hd, a.on, D, gb[12], nullptr, Hd, D) && (rc = lin_dw(c, t.d_hpre, Hd, a.on, gb[12], nullptr, Rq, Hd, D, sd))) return rc;
     if (gb[13]) { float* dst[1] = {gb[13]}; if ((rc = scatter(c, t.part_h, (Rq + 63) / 64, Hd, dst, 1, sd))) return rc; }
     if ((rc = mmae_layernorm_bwd(t.d_on, act, a.x, onw, a.omean, a.orstd, dh, t.dx, bf ? t.dx_act : nullptr, act, t.part_o, Rq, D, st))) return rc;
     const void* dx_act = bf ? (const void*)t.dx_act : (const void*)t.dx;
@@ -750,7 +791,7 @@ int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream
     if ((rc = lin_dx(c, dx_act, D, pw, t.d_xo, act, Rq, D, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
     if ((rc = fork_to(st, sd))) return rc;
     if ((rc = scatter3(c, t.part_o, mmae_layernorm_bwd_nblk(Rq), D, gb[10], gb[11], gb[5], sd))) return rc;      // outn_w, outn_b, proj_b
-    if ((rc = lin_dw(c, dx_act, D, a.xo, gb[4], nullptr, Rq, D, D, sd))) return rc;
+    if (!grp_q.add(dx_act, D, a.xo, D, gb[4], nullptr, D, D) && (rc = lin_dw(c, dx_act, D, a.xo, gb[4], nullptr, Rq, D, D, sd))) return rc;
     {
         auto fn = bf ? mmae_attn_bwd : mmae_attn_bwd_f32x3;
         const char* kv = (const char*)a.kv; char* dkv = (char*)t.d_kv;
@@ -761,8 +802,8 @@ int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream
     if ((rc = lin_dx(c, t.d_q, D, qw, t.d_qn, act, Rq, D, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
     if ((rc = lin_dx(c, t.d_kv, 2 * D, kvw, t.d_cn, act, Rc, 2 * D, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
     if ((rc = fork_to(st, sd))) return rc;
-    if ((rc = lin_dw(c, t.d_q, D, a.qn, gb[0], gb[1], Rq, D, D, sd))) return rc;
-    if ((rc = lin_dw(c, t.d_kv, 2 * D, a.cn, gb[2], gb[3], Rc, 2 * D, D, sd))) return rc;
+    if (!grp_q.add(t.d_q, D, a.qn, D, gb[0], gb[1], D, D) && (rc = lin_dw(c, t.d_q, D, a.qn, gb[0], gb[1], Rq, D, D, sd))) return rc;
+    if (!grp_c.add(t.d_kv, 2 * D, a.cn, D, gb[2], gb[3], 2 * D, D) && (rc = lin_dw(c, t.d_kv, 2 * D, a.cn, gb[2], gb[3], Rc, 2 * D, D, sd))) return rc;
     if ((rc = mmae_layernorm_bwd(t.d_qn, act, a.queries, qnw, a.qmean, a.qrstd, nullptr, t.d_queries, nullptr, MMAE_F32, t.part_q, Rq, D, st))) return rc;
     if ((rc = mmae_layernorm_bwd(t.d_cn, act, a.context, cnw, a.cmean, a.crstd, nullptr, t.d_context, nullptr, MMAE_F32, t.part_c, Rc, D, st))) return rc;
     if ((rc = mmae_decoder_build_bwd(t.d_queries, t.d_context, d->ids_keep, d->ids_restore, d->task_offsets_host, T, d->q_task, B, NC - d->G, d->G, D,
@@ -778,7 +819,10 @@ int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream
         dst[T] = g_mask;
         if ((rc = scatter(c, t.part_b, mmae_decoder_build_bwd_nblk(B), D, dst, T + 1, sd))) return rc;
     }
-    if ((rc = lin_dw(c, d_ctx_act, D, enc_act, gtail[2], gtail[3], Rc, D, d->Denc, sd))) return rc;
+    if (!grp_c.add(d_ctx_act, D, enc_act, d->Denc, gtail[2], gtail[3], D, d->Denc) &&
+        (rc = lin_dw(c, d_ctx_act, D, enc_act, gtail[2], gtail[3], Rc, D, d->Denc, sd))) return rc;
+    if ((rc = grp_q.flush(c, sd))) return rc;
+    if ((rc = grp_c.flush(c, sd))) return rc;
     return lin_dx(c, d_ctx_act, D, pcw, d->d_enc, MMAE_F32, Rc, D, d->Denc, nullptr, MMAE_EPI_NONE, nullptr, st);
 }
 

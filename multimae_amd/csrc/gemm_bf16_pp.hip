@@ -60,8 +60,10 @@ __device__ __forceinline__ void wg_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// v0 / vstep: first output tile of this workgroup and the stride of its walk over the tile list (the plain kernel: its block
+// index and grid size; the grouped weight-gradient kernel: one tile per workgroup).  blockIdx.y = batch slice, blockIdx.z = K slice.
 template <int TM, bool AKS, bool BKS>
-__global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
+__device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const int vstep) {
     constexpr int WMR = TM * 32;                         // output rows per wave
     constexpr int BM = 2 * WMR, BN = 256, NW = 8;
     constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
@@ -89,7 +91,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bz, 0, 0x80000000, 0x00020000);
 
     // lane p of DMA piece s fills LDS slot p of that 1-KiB segment: find the chunk living there.
-    // Persistent workgroups: blockIdx.x walks the tile list in steps of gridDim.x; set_tile() re-targets the DMA offsets.
+    // Persistent workgroups: v walks the tile list from v0 in steps of vstep; set_tile() re-targets the DMA offsets.
     unsigned a_off[LA], b_off[LB];
     int a_kq[LA], b_kq[LB];
     int m0 = 0, n0 = 0;
@@ -129,7 +131,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
             }
         }
     };
-    set_tile(blockIdx.x, m0, n0);
+    set_tile(v0, m0, n0);
     const unsigned a_step = AKS ? (unsigned)(g.lda * BK * 2) : (unsigned)(BK * 2);
     const unsigned b_step = BKS ? (unsigned)(g.ldb * BK * 2) : (unsigned)(BK * 2);
 
@@ -219,7 +221,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
     // tiles while this tile's results are written out (the DMA latency and most of the prologue hide under the epilogue)
     char* stage = smem + 2 * STAGE + wave * 8192;
     static_assert(2 * STAGE >= 8 * 8192, "staging must fit in ring slots 2-3");
-    for (int v = blockIdx.x; v < g.tiles_total; v += gridDim.x) {
+    for (int v = v0; v < g.tiles_total; v += vstep) {
         asm volatile("" : "+v"(lane));
         derive();
 #pragma unroll
@@ -269,10 +271,10 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
         __syncthreads();                                     // every wave is out of the ring
 
         const int mw = m0 + wm * WMR, nw = n0 + wn * 64;
-        const bool has_next = v + (int)gridDim.x < g.tiles_total;
+        const bool has_next = v + vstep < g.tiles_total;
         if (has_next) {                                      // next tile: K tiles 0, 1 -> slots 0, 1 (in flight during the epilogue)
             asm volatile("" : "+v"(lane));
-            set_tile(v + gridDim.x, m0, n0);
+            set_tile(v + vstep, m0, n0);
             dma_first(0); dma_second(0);
             dma_first(1); dma_second(1);
         }
@@ -297,6 +299,55 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
             dma_first(2);
         }
     }
+}
+
+template <int TM, bool AKS, bool BKS>
+__global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
+    pp_body<TM, AKS, BKS>(g, blockIdx.x, gridDim.x);
+}
+
+// Grouped weight-gradient launch: up to 8 dW[N_out][K_in] = dY^T X products that share the reduction length (the rows of the
+// batch) and the number of K slices, in ONE grid -- blockIdx.x walks the concatenated tile lists, blockIdx.z is the K slice.
+// Every workgroup computes one 256 x 256 tile over its slice of the rows: the four weight gradients of a transformer block fill
+// the chip with 2 slices (216 workgroups at ViT-B) instead of 7-28 slices per product, i.e. 1/4-1/14 of the partial-slab
+// traffic, K loops 4-14x longer, and one reduction launch per block instead of four (+ the bias reductions).
+struct DwProblem {
+    const void* A; const void* B; float* ws; float* acs;
+    int M, N;                    // M = N_out (columns of dY), N = K_in (columns of X)
+    long long lda, ldb;
+    int tiles_n, tile_begin;
+};
+struct DwGroupArgs {
+    int n, K, splitk, kt_per_split;
+    DwProblem p[8];
+};
+
+__global__ void __launch_bounds__(512) gemm_bf16_pp_dwgroup_kernel(const DwGroupArgs ga) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) pi += (i < ga.n && (int)blockIdx.x >= ga.p[i].tile_begin) ? 1 : 0;
+    pi = __builtin_amdgcn_readfirstlane(pi);
+    const DwProblem& pr = ga.p[pi];
+    GemmArgs g;
+    g.A = pr.A; g.B = pr.B; g.C = nullptr;
+    g.M = pr.M; g.N = pr.N; g.K = ga.K;
+    g.lda = pr.lda; g.ldb = pr.ldb; g.ldc = pr.N;
+    g.nb_inner = 1;
+    g.sAo = g.sAi = g.sBo = g.sBi = g.sCo = g.sCi = 0;
+    g.bias = nullptr; g.resid = nullptr; g.ldr = 0; g.aux = nullptr; g.ldaux = 0;
+    g.c_f32 = 1; g.aux_f32 = 0; g.epi = MMAE_EPI_NONE; g.accumulate = 0; g.vec = 1;
+    g.alpha = 1.0f;
+    g.tiles_n = pr.tiles_n;
+    const int local = (int)blockIdx.x - pr.tile_begin;
+    g.tiles_total = local + 1;                            // exactly one tile for this workgroup
+    g.splitk = 2;                                         // always through the partial slabs (slice z -> ws[z][M][N]); > 1 only selects that epilogue
+    g.kt_per_split = ga.kt_per_split;
+    g.ws = pr.ws;
+    g.xcd_swizzle = 0;
+    g.acs = pr.acs;
+    g.colpart = nullptr;
+    g.wide_st = 0;
+    pp_body<4, true, true>(g, local, 1 << 30);
 }
 
 template <int TM, bool AKS, bool BKS>
@@ -333,4 +384,119 @@ int mmae_gemm_bf16_pp_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code,
     if (!aks && bks) return launch<4, false, true>(g, d->batch, st);
     if (aks && !bks) return launch<4, true, false>(g, d->batch, st);
     return launch<4, true, true>(g, d->batch, st);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// grouped weight gradients (mmae_gemm_dw_group)
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct DwReduceProblem { const float* ws; float* C; const float* acs; float* bias; long long mn; int M; long long begin4; };
+struct DwReduceArgs { int n, splits, accumulate; long long total4; DwReduceProblem p[8]; };
+
+// C_p (+)= sum_z ws_p[z] (fixed order: deterministic); bias_p (+)= sum_z acs_p[z]
+__global__ void __launch_bounds__(256) dw_group_reduce_kernel(const DwReduceArgs ra) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < ra.total4; i += (long long)gridDim.x * 256) {
+        int pi = 0;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) pi += (k < ra.n && i >= ra.p[k].begin4) ? 1 : 0;
+        const DwReduceProblem& pr = ra.p[pi];
+        const long long e = (i - pr.begin4) * 4;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (ra.accumulate) a = ld4(pr.C + e);
+        for (int z = 0; z < ra.splits; ++z) {
+            const f32x4 v = ld4(pr.ws + z * pr.mn + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] += v[j];
+        }
+        st4(pr.C + e, a);
+    }
+    if (blockIdx.x == 0) {
+        for (int pi = 0; pi < ra.n; ++pi) {
+            const DwReduceProblem& pr = ra.p[pi];
+            if (!pr.bias) continue;
+            for (int m = threadIdx.x; m < pr.M; m += 256) {
+                float a = ra.accumulate ? pr.bias[m] : 0.f;
+                for (int z = 0; z < ra.splits; ++z) a += pr.acs[(long long)z * pr.M + m];
+                pr.bias[m] = a;
+            }
+        }
+    }
+}
+
+int dw_group_splits(const mmae_dw_group_desc* d, long long* tiles_out) {
+    static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    long long tiles = 0;
+    for (int i = 0; i < d->n; ++i) tiles += (long long)((d->p[i].n_out + 255) / 256) * ((d->p[i].k_in + 255) / 256);
+    int s = d->split_k > 0 ? d->split_k : (int)(n_cu / (tiles > 0 ? tiles : 1));
+    const int nkt = (d->rows + 31) / 32;                      // 32-wide K tiles
+    if (s > nkt / 16) s = nkt / 16;                            // >= 16 K tiles per slice
+    if (s < 1) s = 1;
+    const int kt_per = (nkt + s - 1) / s;
+    s = (nkt + kt_per - 1) / kt_per;
+    if (tiles_out) *tiles_out = tiles;
+    return s;
+}
+
+}  // namespace
+
+extern "C" int64_t mmae_gemm_dw_group_ws_elems(const mmae_dw_group_desc* d) {
+    if (!d || d->n < 1 || d->n > 8 || d->rows <= 0) return -1;
+    const int s = dw_group_splits(d, nullptr);
+    long long elems = 0;
+    for (int i = 0; i < d->n; ++i) elems += (long long)s * ((long long)d->p[i].n_out * d->p[i].k_in + d->p[i].n_out);
+    return elems;
+}
+
+extern "C" int mmae_gemm_dw_group(const mmae_dw_group_desc* d, void* stream) {
+    MMAE_REQUIRE(d && d->n >= 1 && d->n <= 8 && d->rows > 0, "dw_group: bad descriptor");
+    if (d->ab_dtype != MMAE_BF16) { mmae_set_error("dw_group: bf16 operands only"); return MMAE_ESUPPORT; }
+    for (int i = 0; i < d->n; ++i) {
+        const mmae_dw_problem& q = d->p[i];
+        MMAE_REQUIRE(q.dy && q.x && q.dw && q.n_out > 0 && q.k_in > 0, "dw_group: null / empty problem");
+        if ((q.n_out % 8) || (q.k_in % 8) || (q.ldy % 8) || (q.ldx % 8) || ((uintptr_t)q.dy % 16) || ((uintptr_t)q.x % 16) || ((uintptr_t)q.dw % 16) ||
+            (q.db && ((uintptr_t)q.db % 4))) { mmae_set_error("dw_group: widths / leading dimensions must be multiples of 8, bases 16-byte aligned"); return MMAE_ESUPPORT; }
+    }
+    long long tiles = 0;
+    const int s = dw_group_splits(d, &tiles);
+    const int nkt = (d->rows + 31) / 32;
+    const int kt_per = (nkt + s - 1) / s;
+    MMAE_REQUIRE(d->ws && ((uintptr_t)d->ws % 16) == 0, "dw_group: workspace missing / unaligned");
+    MMAE_REQUIRE(d->ws_elems >= mmae_gemm_dw_group_ws_elems(d), "dw_group: workspace too small (mmae_gemm_dw_group_ws_elems)");
+    DwGroupArgs ga = {};
+    DwReduceArgs ra = {};
+    ga.n = d->n; ga.K = d->rows; ga.splitk = s; ga.kt_per_split = kt_per;
+    ra.n = d->n; ra.splits = s; ra.accumulate = d->accumulate;
+    float* w = d->ws;
+    int tb = 0;
+    long long b4 = 0;
+    for (int i = 0; i < d->n; ++i) {
+        const mmae_dw_problem& q = d->p[i];
+        const long long mn = (long long)q.n_out * q.k_in;
+        DwProblem& p = ga.p[i];
+        p.A = q.dy; p.B = q.x; p.ws = w; p.acs = q.db ? w + (long long)s * mn : nullptr;
+        p.M = q.n_out; p.N = q.k_in; p.lda = q.ldy; p.ldb = q.ldx;
+        p.tiles_n = (q.k_in + 255) / 256; p.tile_begin = tb;
+        tb += ((q.n_out + 255) / 256) * p.tiles_n;
+        DwReduceProblem& r = ra.p[i];
+        r.ws = w; r.C = q.dw; r.acs = p.acs; r.bias = q.db; r.mn = mn; r.M = q.n_out; r.begin4 = b4;
+        b4 += mn / 4;
+        w += (long long)s * (mn + q.n_out);      // n_out, k_in multiples of 8: every slab base stays 16-byte aligned
+    }
+    ra.total4 = b4;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)4 * (256 + 256) * 64 + 1024;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_dwgroup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_pp_dwgroup_kernel, dim3(tb, 1, s), dim3(512), lds, st, ga);
+    int rc = mmae_check_launch("gemm_bf16_pp_dwgroup");
+    if (rc) return rc;
+    long long nb = (b4 + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(dw_group_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, ra);
+    return mmae_check_launch("dw_group_reduce");
 }

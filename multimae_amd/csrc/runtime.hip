@@ -91,6 +91,7 @@ int mmae_struct_size(int which) {
         case 3: return (int)sizeof(mmae_adapter_desc);
         case 4: return (int)sizeof(mmae_opt_desc);
         case 5: return (int)sizeof(mmae_patch_src);
+        case 6: return (int)sizeof(mmae_dw_group_desc);
         default: return -1;
     }
 }

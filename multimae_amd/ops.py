@@ -14,7 +14,7 @@ import torch
 from . import _lib
 import contextlib
 
-from ._lib import BF16, F32, F32X3, EPI_NONE, EPI_GELU, EPI_DGELU, AdapterDesc, BlockDesc, GemmDesc, OptDesc, PatchSrc, StackDesc, check
+from ._lib import BF16, F32, F32X3, EPI_NONE, EPI_GELU, EPI_DGELU, AdapterDesc, BlockDesc, DwGroupDesc, GemmDesc, OptDesc, PatchSrc, StackDesc, check
 
 Tensor = torch.Tensor
 
@@ -152,6 +152,23 @@ def linear_dx(dy: Tensor, w: Tensor, out: Tensor, *, aux: Optional[Tensor] = Non
     return out
 
 
+def gemm_dw_group(problems: Sequence[tuple], accumulate: bool, split_k: int = 0) -> None:
+    """Up to 8 weight gradients in one launch (mmae_gemm_dw_group).  problems: (dy [rows, n_out] bf16, x [rows, k_in] bf16,
+    dw f32 [n_out, k_in] contiguous, db f32 [n_out] or None); all share `rows`."""
+    d = DwGroupDesc()
+    d.n, d.rows, d.ab_dtype, d.accumulate, d.split_k = len(problems), problems[0][0].shape[0], BF16, int(accumulate), split_k
+    for i, (dy, x, dw, db) in enumerate(problems):
+        assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32 and dw.is_contiguous()
+        assert dy.shape[0] == d.rows and x.shape[0] == d.rows and dw.shape == (dy.shape[1], x.shape[1])
+        q = d.p[i]
+        q.dy, q.ldy, q.x, q.ldx, q.dw, q.db, q.n_out, q.k_in = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), _p(db), dy.shape[1], x.shape[1]
+    lib = _lib.load()
+    n_ws = lib.mmae_gemm_dw_group_ws_elems(ctypes.byref(d))
+    ws = torch.empty((max(n_ws, 4),), device=problems[0][0].device, dtype=torch.float32)
+    d.ws, d.ws_elems = ws.data_ptr(), ws.numel()
+    check(lib.mmae_gemm_dw_group(ctypes.byref(d), _stream()), 'gemm_dw_group')
+
+
 def dx_colsum_part_shape(M: int, K: int):
     return ((M + 63) // 64, K)
 
@@ -287,6 +304,7 @@ def block_bwd_composite(dx: Tensor, dx_act: Tensor, fc2b_done: bool, saved, P: S
 
 # ------------------------------------------------ per-stack / per-adapter composites --
 _STACK = [_os.environ.get('MMAE_STACK_COMPOSITE', '1') != '0']
+_ADAPTER = [_os.environ.get('MMAE_ADAPTER_COMPOSITE', '1') != '0']
 
 
 def set_stack_composites(flag: bool) -> None:
@@ -411,7 +429,7 @@ class AdapterState:
 
 def adapter_composite_ok(enc: Tensor, act: torch.dtype, heads: int, D: int, n_q: int, NC: int, depth: int, T: int, KP: int) -> bool:
     hd = D // heads
-    if not (_STACK[0] and _COMPOSITE[0] and _FUSED_ATTN[0] and enc.is_cuda and hd in (32, 64) and n_q <= 256 and NC <= 256 and depth <= 8
+    if not (_STACK[0] and _ADAPTER[0] and _COMPOSITE[0] and _FUSED_ATTN[0] and enc.is_cuda and hd in (32, 64) and n_q <= 256 and NC <= 256 and depth <= 8
             and T <= 7 and D % 8 == 0 and enc.shape[-1] % 8 == 0 and KP % 4 == 0):
         return False
     if act == torch.bfloat16:

@@ -41,6 +41,8 @@ class FusedAdamW:
         self._istate = torch.zeros(4, device=a.device, dtype=torch.int32)
         self._ws = torch.empty(1024, device=a.device, dtype=torch.float32)
         self.grad_norm = self._state[1:2]
+        self.max_steps_in_flight = 2      # the host may enqueue at most this many steps ahead of the GPU (see step())
+        self._step_events = []
 
     # Adam's t.  Reading it synchronises with the device: checkpoints and tests only, never inside the step.
     @property
@@ -88,6 +90,14 @@ class FusedAdamW:
                      grad_prescale=self.grad_prescale, lrwd_dev=lrwd, loss_dev=loss, shadow=shadow)
         if shadow is not None:
             a.mark_shadow_fresh()
+        if cap is None and a.param.is_cuda and self.max_steps_in_flight:
+            # bound the host's lead: nothing in the step synchronises, so without this the host runs as far ahead as the launch
+            # queues allow and every step's activation slabs (tens of GB) stay allocated at once
+            ev = torch.cuda.Event()
+            ev.record()
+            self._step_events.append(ev)
+            if len(self._step_events) > self.max_steps_in_flight:
+                self._step_events.pop(0).synchronize()
         return self.grad_norm
 
     def state_dict(self):

@@ -507,3 +507,44 @@ def test_linear_dw_fused_bias_grad(shape, acc):
     base_w, base_b = (1.5, 0.25) if acc else (0.0, 0.0)
     assert rel_err(dw, base_w + dy.double().t() @ x.double()) < 2e-6
     assert rel_err(db, base_b + dy.double().sum(0)) < 2e-6
+
+
+@pytest.mark.parametrize('acc', [False, True])
+@pytest.mark.parametrize('case', ['block', 'ragged', 'single_slice'])
+def test_gemm_dw_group_vs_fp32_reference(case, acc):
+    """mmae_gemm_dw_group: several dW = dY^T X products (+ bias column sums) in one grid.  'block': the four weight gradients of
+    a small transformer block geometry over 5 000 rows (K not a multiple of the 32-row tile; 3 K slices forced); 'ragged': widths
+    that are not multiples of the 256 tile (partial tiles in both directions) with the automatic slice count; 'single_slice':
+    enough tiles to fill the chip without splitting."""
+    from multimae_amd import ops
+    g = torch.Generator().manual_seed(7)
+    if case == 'block':
+        rows, shapes, split = 5000, [(256, 1024, False), (1024, 256, False), (256, 256, True), (768, 256, True)], 3
+    elif case == 'ragged':
+        rows, shapes, split = 3001, [(264, 136, True), (520, 72, False), (8, 264, True)], 0
+    else:
+        rows, shapes, split = 700, [(2048, 1024, True), (1024, 2048, False), (2304, 768, True), (768, 3072, False), (3072, 768, True)], 0
+    probs, refs = [], []
+    for n_out, k_in, want_db in shapes:
+        dy = (torch.randn(rows, n_out, generator=g) * 0.5).to(DEV).to(torch.bfloat16)
+        x = torch.randn(rows, k_in, generator=g).to(DEV).to(torch.bfloat16)
+        dw0 = torch.randn(n_out, k_in, generator=g).to(DEV)
+        db0 = torch.randn(n_out, generator=g).to(DEV) if want_db else None
+        dw, db = dw0.clone(), (db0.clone() if want_db else None)
+        probs.append((dy, x, dw, db))
+        rw = dy.float().t() @ x.float() + (dw0 if acc else 0)
+        rb = (dy.float().sum(0) + (db0 if acc else 0)) if want_db else None
+        refs.append((rw, rb))
+    ops.gemm_dw_group(probs, acc, split)
+    torch.cuda.synchronize()
+    for (dy, x, dw, db), (rw, rb) in zip(probs, refs):
+        assert rel_err(dw, rw) < 2e-5, (case, dw.shape, rel_err(dw, rw))
+        if rb is not None:
+            assert rel_err(db, rb) < 2e-5, (case, rel_err(db, rb))
+    # determinism: fixed summation order
+    probs2 = [(dy, x, (torch.zeros_like(dw) if not acc else dw.clone()), (None if db is None else db.clone())) for dy, x, dw, db in probs]
+    if not acc:
+        ops.gemm_dw_group(probs2, False, split)
+        torch.cuda.synchronize()
+        for (_, _, a, _), (_, _, b, _) in zip(probs, probs2):
+            assert torch.equal(a, b)
