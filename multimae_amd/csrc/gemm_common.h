@@ -20,6 +20,8 @@ struct GemmArgs {
     float* acs;                   // optional [splitk][M] partial column sums of the k-strided A operand (ping-pong kernel)
     float* colpart;               // optional [ceil(M/64)][N] column sums of the epilogue output (dGELU flavour)
     int wide_st;                  // bf16 epilogues with 8-column (16-byte) lanes (store_tile64_bf16x8); env MMAE_EPI_WIDE=0 turns it off
+    int dbg;                      // epilogue dissection for profiling (env MMAE_EPI_DBG, GELU flavour only): 1 = no GELU arithmetic, 2 = no pre-activation store,
+                                  // 3 = arithmetic but no stores, 4 = nothing.  0 in production.
 };
 
 // XCD-aware tile order (MI355X: workgroup b runs on XCD b % 8, each XCD has its own 4 MiB L2): hand every XCD a
@@ -259,7 +261,7 @@ __device__ __forceinline__ i32x4 pack8_bf16(const f32x4 a, const f32x4 b) {
     i32x4 r; r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
     return r;
 }
-template <bool BIAS, int EPI, bool COLSUM>
+template <bool BIAS, int EPI, bool COLSUM, int DBG = 0>
 __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cbase, char* wave_lds, int lane, const f32x16 (&acc)[2][2],
                                                     int m_base, int n_base, int ntm) {
     constexpr unsigned OOB_OFF = 0x80000000u;
@@ -298,9 +300,11 @@ __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cba
                     for (int j = 0; j < 4; ++j) { v0[j] += b0[j]; v1[j] += b1[j]; }
                 }
                 if (EPI == MMAE_EPI_GELU) {
-                    __builtin_amdgcn_raw_buffer_store_b128(pack8_bf16(v0, v1), rsAux, voff(gi, g.ldaux), 0, 0);
+                    if (DBG != 2 && DBG != 3) __builtin_amdgcn_raw_buffer_store_b128(pack8_bf16(v0, v1), rsAux, voff(gi, g.ldaux), 0, 0);
+                    if (DBG != 1) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { v0[j] = gelu_erf(v0[j]); v1[j] = gelu_erf(v1[j]); }
+                        for (int j = 0; j < 4; ++j) { v0[j] = gelu_erf(v0[j]); v1[j] = gelu_erf(v1[j]); }
+                    }
                 } else if (EPI == MMAE_EPI_DGELU) {
                     const i32x4 pa = pre_aux[gi % PD];
                     i32x2 lo2, hi2; lo2[0] = pa[0]; lo2[1] = pa[1]; hi2[0] = pa[2]; hi2[1] = pa[3];
@@ -313,7 +317,8 @@ __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cba
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { cs0[j] += ok ? v0[j] : 0.f; cs1[j] += ok ? v1[j] : 0.f; }
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(pack8_bf16(v0, v1), rsC, voff(gi, g.ldc), 0, 0);
+                if (DBG != 3) __builtin_amdgcn_raw_buffer_store_b128(pack8_bf16(v0, v1), rsC, voff(gi, g.ldc), 0, 0);
+                else if (v0[0] == 1234.5678f) __builtin_amdgcn_raw_buffer_store_b128(pack8_bf16(v0, v1), rsC, voff(gi, g.ldc), 0, 0);   // keeps the arithmetic alive
             }
         }
     }
@@ -357,7 +362,13 @@ __device__ __forceinline__ void gemm_store_tile64(const GemmArgs& g, char* Cz, c
                     else store_tile64_bf16x8<false, MMAE_EPI_NONE, false>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
                     return;
                 }
-                if (g.epi == MMAE_EPI_GELU && bias) { store_tile64_bf16x8<true, MMAE_EPI_GELU, false>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm); return; }
+                if (g.epi == MMAE_EPI_GELU && bias) {
+                    if (g.dbg == 0) { store_tile64_bf16x8<true, MMAE_EPI_GELU, false>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm); return; }
+                    if (g.dbg == 1) { store_tile64_bf16x8<true, MMAE_EPI_GELU, false, 1>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm); return; }
+                    if (g.dbg == 2) { store_tile64_bf16x8<true, MMAE_EPI_GELU, false, 2>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm); return; }
+                    if (g.dbg == 3) { store_tile64_bf16x8<true, MMAE_EPI_GELU, false, 3>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm); return; }
+                    return;
+                }
                 if (g.epi == MMAE_EPI_DGELU && !bias) {
                     if (g.colpart) store_tile64_bf16x8<false, MMAE_EPI_DGELU, true>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
                     else store_tile64_bf16x8<false, MMAE_EPI_DGELU, false>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);

@@ -123,6 +123,8 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     g.xcd_swizzle = env_swz;
     static const int env_wide = getenv("MMAE_EPI_WIDE") ? atoi(getenv("MMAE_EPI_WIDE")) : 1;
     g.wide_st = env_wide;
+    static const int env_dbg = getenv("MMAE_EPI_DBG") ? atoi(getenv("MMAE_EPI_DBG")) : 0;
+    g.dbg = env_dbg;
     MMAE_REQUIRE(!d->colsum_part || (d->epi == MMAE_EPI_DGELU && !d->bias && !d->resid && !d->accumulate && d->batch == 1 && d->split_k <= 1 &&
                                      d->alpha == 1.0f && d->N % 4 == 0) ,
                  "gemm: colsum_part is only supported with the plain dGELU epilogue");

@@ -196,3 +196,29 @@ def test_oracle_cfg2_bench_geometry_vs_reference_golden():
     sum(losses.values()).backward()
     worst = max((rel_err_vs(z, f'cfg2/grad/{n}', t.grad), n) for n, t in sd.items() if t.requires_grad)
     assert worst[0] < 2e-4, worst
+
+
+def test_oracle_curve_matches_reference_curve_cfg1():
+    """First 4 AdamW steps of the cfg1 loss-curve recipe: the oracle (+ oracle AdamW) reproduces the curve the REFERENCE produced
+    with torch.optim.AdamW (tests/golden/curve_cfg1.json) -- the chain the GPU loss-curve tests compare the engine with."""
+    import json
+    import os
+    from helpers import GOLD
+    gold = json.load(open(os.path.join(GOLD, 'curve_cfg1.json')))['reference_fp32']
+    model, sd0, x = _seeded_engine_state(['rgb'], 8, 64, 4, enc=(192, 12, 3), posemb=224)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    sd = {k: v.detach().clone() for k, v in sd0.items()}
+    cfg = orc.standard_config(['rgb'], patch_size=8, image_size=224, dim_tokens=192, depth=12, num_heads=3)
+    mo = {n: torch.zeros_like(sd[n]) for n in names}
+    vo = {n: torch.zeros_like(sd[n]) for n in names}
+    for step in range(1, 5):
+        torch.manual_seed(1000 + step)
+        dist, tn, an = orc.draw_mask_randoms(4, [64], 1.0)
+        spt = orc.samples_per_task_from_dirichlet(dist, 49)
+        mask_all, ik, ir = orc.masks_from_noise(spt, tn, an, 49)
+        sdo = {k: (v.clone().requires_grad_(True) if k in mo else v) for k, v in sd.items()}
+        lo = sum(orc.pretrain_losses(orc.multimae_forward(x, sdo, cfg, ik, ir), x, mask_all, cfg, {'rgb': 64}).values())
+        lo.backward()
+        assert abs(float(lo.detach()) - gold[step - 1]) < 2e-5, (step, float(lo.detach()), gold[step - 1])
+        with torch.no_grad():
+            orc.adamw_step({n: sd[n] for n in names}, {n: sdo[n].grad for n in names}, mo, vo, step, 1.5e-4, 0.05)
