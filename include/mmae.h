@@ -399,6 +399,8 @@ typedef struct mmae_patch_src {
     const void* data;
     const float* emb;
     int32_t kind, C, H, W, ph, pw, k_off;
+    int32_t n_cls;               /* kind 1: rows of emb; class ids outside [0, n_cls) embed as zeros and receive no gradient
+                                    (nn.Embedding raises a device assert there); 0 = unchecked */
 } mmae_patch_src;
 
 int mmae_patch_rows(const mmae_patch_src* srcs_host, const int32_t* task_offsets_host, int T, const int64_t* sel,
@@ -478,6 +480,22 @@ int mmae_masked_ce_fwd(const float* logits, const int64_t* target, const int64_t
 int mmae_masked_ce_bwd(const float* logits, const int64_t* target, const int64_t* mask, int B, int C, int H, int W,
                        int patch, const float* lse, const float* per_sample, const float* loss, const float* upstream,
                        float* d_logits, void* stream);
+
+/* The same losses evaluated on the adapters' patch rows pat f32 [B*nh*nw][C*patch*patch] (column order c, i, j -- out_proj's
+ * output, output_adapters.py:274, before the rearrangement of :277-280): identical arithmetic per pixel, but the gradient is
+ * written straight back as patch rows d_pat (act dtype, row stride ld_pat >= C*patch*patch, pad columns zeroed) for
+ * mmae_adapter_bwd -- no f32 image-domain gradient and no patchify pass.  target / mask / stats / per_sample / loss as above;
+ * lse_pat f32 [B*nh*nw][patch*patch].  CE needs patch*patch a power of two <= 64 (MMAE_ESUPPORT otherwise). */
+int mmae_masked_pixel_loss_pat_fwd(const float* pat, const float* target, const int64_t* mask, int kind, int norm_pix, int B, int C, int H,
+                                   int W, int patch, float* stats, float* partial, float* per_sample, float* loss, void* stream);
+int mmae_masked_pixel_loss_pat_bwd(const float* pat, const float* target, const int64_t* mask, int kind, int norm_pix, int B, int C, int H,
+                                   int W, int patch, const float* stats, const float* per_sample, const float* loss, const float* upstream,
+                                   void* d_pat, int d_pat_dtype, int64_t ld_pat, void* stream);
+int mmae_masked_ce_pat_fwd(const float* pat, const int64_t* target, const int64_t* mask, int B, int C, int H, int W, int patch,
+                           float* lse_pat, float* partial, float* per_sample, float* loss, void* stream);
+int mmae_masked_ce_pat_bwd(const float* pat, const int64_t* target, const int64_t* mask, int B, int C, int H, int W, int patch,
+                           const float* lse_pat, const float* per_sample, const float* loss, const float* upstream, void* d_pat,
+                           int d_pat_dtype, int64_t ld_pat, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Optimiser step on flat arenas.  Replaces get_grad_norm_ / clip_grad_norm_

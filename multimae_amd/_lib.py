@@ -103,7 +103,7 @@ class PatchSrc(ctypes.Structure):
     _fields_ = [
         ('data', ctypes.c_void_p), ('emb', ctypes.c_void_p),
         ('kind', ctypes.c_int32), ('C', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32),
-        ('ph', ctypes.c_int32), ('pw', ctypes.c_int32), ('k_off', ctypes.c_int32),
+        ('ph', ctypes.c_int32), ('pw', ctypes.c_int32), ('k_off', ctypes.c_int32), ('n_cls', ctypes.c_int32),
     ]
 
 

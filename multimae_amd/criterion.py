@@ -14,7 +14,18 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from .functions import MaskedCEFn, MaskedPixelLossFn
+from .functions import MaskedCEFn, MaskedCEPatFn, MaskedPixelLossFn, MaskedPixelLossPatFn
+
+
+def _pat_handle(x: torch.Tensor, patch: int, ce: bool = False):
+    """The adapter's patch rows behind prediction x (functions.PatHandle), if x is exactly what an output adapter returned
+    (``preds[task].float()`` of an f32 tensor is the same object) and the loss's patch grid is the adapter's."""
+    h = getattr(x, '_mmae_pat', None)
+    if h is None or not h.matches(x, patch):
+        return None
+    if ce and (patch * patch > 64 or (patch * patch) & (patch * patch - 1)):
+        return None
+    return h
 
 
 def _ones_mask(x: torch.Tensor, scale: int) -> torch.Tensor:
@@ -37,6 +48,9 @@ class MaskedCrossEntropyLoss(nn.Module):
     def forward(self, input, target, mask=None):
         if mask is None:
             mask = _ones_mask(input, self.scale_factor)      # plain mean == masked mean with an all-ones mask
+        h = _pat_handle(input, self.scale_factor, ce=True)
+        if h is not None:
+            return MaskedCEPatFn.apply(h.token, h, target, mask, self.scale_factor)
         return MaskedCEFn.apply(input, target, mask, self.scale_factor)
 
 
@@ -53,6 +67,9 @@ class _MaskedPixelLoss(nn.Module):
     def forward(self, input, target, mask=None):
         if mask is None:
             mask = _ones_mask(input, self.scale_factor)
+        h = _pat_handle(input, self.scale_factor)
+        if h is not None:
+            return MaskedPixelLossPatFn.apply(h.token, h, target, mask, self.kind, bool(self.norm_pix), self.scale_factor)
         return MaskedPixelLossFn.apply(input, target, mask, self.kind, bool(self.norm_pix), self.scale_factor)
 
 

@@ -211,6 +211,177 @@ __global__ void __launch_bounds__(256) ce_bwd4_kernel(const float* __restrict__ 
     st4(d_logits + i, g);
 }
 
+// ---- the same losses in the PATCH domain ----------------------------------------------------------------------------
+// The output adapters produce their prediction as patch rows pat[b * np + p][(c, i, j)] (out_proj, output_adapters.py:274) and
+// only rearrange them into an image for the API (:277-280).  These kernels take the loss straight from the rows and write the
+// gradient straight back as rows in the adapter's activation dtype: no f32 image-domain gradient, no patchify pass
+// (criterion.py does the identical arithmetic per pixel).
+__global__ void __launch_bounds__(256) pixel_loss_pat_fwd_kernel(const float* __restrict__ pat, const float* __restrict__ target,
+                                                                 const long long* __restrict__ mask, int kind, int norm_pix, int C, int H,
+                                                                 int W, int P, float* __restrict__ stats, float* __restrict__ partial) {
+    const int b = blockIdx.y, nh = H / P, nw = W / P, np = nh * nw;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int npix = P * P, nval = npix * C;
+    float acc = 0.f;
+    for (int p = blockIdx.x * 4 + w; p < np; p += LSPLIT * 4) {
+        if (mask[(long long)b * np + p] == 0) continue;
+        const int py = p / nw, px = p % nw;
+        const float* prow = pat + ((long long)b * np + p) * nval;
+        float mu = 0.f, rs = 1.f;
+        if (norm_pix) {
+            float s = 0.f;
+            for (int e = lane; e < nval; e += 64) {
+                const int c = e / npix, ij = e % npix;
+                s += target[(((long long)b * C + c) * H + py * P + ij / P) * W + px * P + ij % P];
+            }
+            mu = wave_sum(s) / (float)nval;
+            float q = 0.f;
+            for (int e = lane; e < nval; e += 64) {
+                const int c = e / npix, ij = e % npix;
+                const float d = target[(((long long)b * C + c) * H + py * P + ij / P) * W + px * P + ij % P] - mu;
+                q += d * d;
+            }
+            const float var = wave_sum(q) / (float)(nval - 1);     // unbiased (criterion.py:92)
+            rs = 1.0f / sqrtf(var + 1e-6f);
+            if (lane == 0) { stats[((long long)b * np + p) * 2] = mu; stats[((long long)b * np + p) * 2 + 1] = rs; }
+        }
+        float s = 0.f;
+        for (int e = lane; e < nval; e += 64) {
+            const int c = e / npix, ij = e % npix;
+            const float t = (target[(((long long)b * C + c) * H + py * P + ij / P) * W + px * P + ij % P] - mu) * rs;
+            const float d = prow[e] - t;
+            s += kind == 0 ? d * d : fabsf(d);
+        }
+        s = wave_sum(s);
+        if (lane == 0) acc += s;
+    }
+    float dummy = 0.f;
+    block_sum2(acc, dummy);
+    if (threadIdx.x == 0) partial[(long long)b * LSPLIT + blockIdx.x] = acc / (float)C;
+}
+
+// one wave per patch row; 4 consecutive (c, i, j) elements per lane (P % 4 == 0: they share c, i and lie in one target row)
+template <typename DT>
+__global__ void __launch_bounds__(256) pixel_loss_pat_bwd_kernel(const float* __restrict__ pat, const float* __restrict__ target,
+                                                                 const long long* __restrict__ mask, int kind, int norm_pix, int C, int H,
+                                                                 int W, int P, const float* __restrict__ stats, const float* __restrict__ per_sample,
+                                                                 const float* __restrict__ loss, const float* __restrict__ upstream,
+                                                                 DT* __restrict__ d_pat, long long ld, long long n_rows) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int nw = W / P, np = (H / P) * nw, npix = P * P, nval = npix * C;
+    const long long b = row / np;
+    const int p = (int)(row % np), py = p / nw, px = p % nw;
+    const bool on = mask[row] != 0;
+    float mu = 0.f, rs = 1.f, wgt = 0.f;
+    if (on) {
+        if (norm_pix) { mu = stats[row * 2]; rs = stats[row * 2 + 1]; }
+        wgt = upstream[0] / (loss[1] * per_sample[b * 2 + 1] * (float)C);
+    }
+    const float* prow = pat + row * nval;
+    DT* drow = d_pat + row * ld;
+    if ((P & 3) == 0 && (W & 3) == 0 && (ld & 3) == 0) {
+        for (int e = lane * 4; e < (int)ld; e += 256) {
+            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+            if (on && e < nval) {
+                const int c = e / npix, ij = e % npix;
+                const f32x4 pr = ld4(prow + e);
+                const f32x4 tg = ld4(target + (((long long)b * C + c) * H + py * P + ij / P) * W + px * P + ij % P);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = pr[j] - (tg[j] - mu) * rs;
+                    g[j] = wgt * (kind == 0 ? 2.f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)));
+                }
+            }
+            st4(drow + e, g);
+        }
+    } else {
+        for (int e = lane; e < (int)ld; e += 64) {
+            float g = 0.f;
+            if (on && e < nval) {
+                const int c = e / npix, ij = e % npix;
+                const float d = prow[e] - (target[(((long long)b * C + c) * H + py * P + ij / P) * W + px * P + ij % P] - mu) * rs;
+                g = wgt * (kind == 0 ? 2.f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)));
+            }
+            ActT<DT>::st(drow + e, g);
+        }
+    }
+}
+
+// cross entropy on patch rows; npix = P * P <= 64, a power of two: lane = (class slot, pixel), 64 / npix class slots per pixel,
+// element index of iteration k = k * 64 + lane (perfectly coalesced).  lse_pat f32 [B * np][npix].
+__global__ void __launch_bounds__(256) ce_pat_fwd_kernel(const float* __restrict__ pat, const long long* __restrict__ target,
+                                                         const long long* __restrict__ mask, int C, int H, int W, int P,
+                                                         float* __restrict__ lse_pat, float* __restrict__ partial) {
+    const int b = blockIdx.y, nw = W / P, np = (H / P) * nw, npix = P * P, nval = npix * C;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int pix = lane % npix, slot = lane / npix, nslot = 64 / npix;
+    float acc = 0.f;
+    for (int p = blockIdx.x * 4 + w; p < np; p += LSPLIT * 4) {
+        if (mask[(long long)b * np + p] == 0) continue;
+        const int py = p / nw, px = p % nw;
+        const long long row = (long long)b * np + p;
+        const float* prow = pat + row * nval;
+        const long long t = target[((long long)b * H + py * P + pix / P) * W + px * P + pix % P];
+        float mx = -3.0e38f, s = 0.f, lt = 0.f;
+        int c = slot;
+        for (int e = lane; e < nval; e += 64, c += nslot) {
+            const float v = prow[e];
+            if (v > mx) { s *= expf(mx - v); mx = v; }
+            s += expf(v - mx);
+            if ((long long)c == t) lt = v;
+        }
+        // combine the class slots of a pixel (lanes pix, pix + npix, ...)
+        for (int o = npix; o < 64; o <<= 1) {
+            const float om = __shfl_xor(mx, o, 64), os = __shfl_xor(s, o, 64);
+            lt += __shfl_xor(lt, o, 64);
+            const float nm = fmaxf(mx, om);
+            s = s * expf(mx - nm) + os * expf(om - nm);
+            mx = nm;
+        }
+        const float ls = mx + logf(s);
+        if (slot == 0) { lse_pat[row * npix + pix] = ls; }
+        float contrib = slot == 0 ? ls - lt : 0.f;
+        contrib = wave_sum(contrib);
+        if (lane == 0) acc += contrib;
+    }
+    float dummy = 0.f;
+    block_sum2(acc, dummy);
+    if (threadIdx.x == 0) partial[(long long)b * LSPLIT + blockIdx.x] = acc;
+}
+
+template <typename DT>
+__global__ void __launch_bounds__(256) ce_pat_bwd_kernel(const float* __restrict__ pat, const long long* __restrict__ target,
+                                                         const long long* __restrict__ mask, int C, int H, int W, int P,
+                                                         const float* __restrict__ lse_pat, const float* __restrict__ per_sample,
+                                                         const float* __restrict__ loss, const float* __restrict__ upstream,
+                                                         DT* __restrict__ d_pat, long long ld, long long n_rows) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int nw = W / P, np = (H / P) * nw, npix = P * P, nval = npix * C;
+    const long long b = row / np;
+    const int p = (int)(row % np), py = p / nw, px = p % nw;
+    const int pix = lane % npix, slot = lane / npix, nslot = 64 / npix;
+    const bool on = mask[row] != 0;
+    DT* drow = d_pat + row * ld;
+    if (!on) {
+        for (int e = lane; e < (int)ld; e += 64) ActT<DT>::st(drow + e, 0.f);
+        return;
+    }
+    const float wgt = upstream[0] / (loss[1] * per_sample[b * 2 + 1]);
+    const float ls = lse_pat[row * npix + pix];
+    const long long t = target[((long long)b * H + py * P + pix / P) * W + px * P + pix % P];
+    const float* prow = pat + row * nval;
+    int c = slot;
+    for (int e = lane; e < (int)ld; e += 64, c += nslot) {
+        float g = 0.f;
+        if (e < nval) g = wgt * (expf(prow[e] - ls) - ((long long)c == t ? 1.f : 0.f));
+        ActT<DT>::st(drow + e, g);
+    }
+}
+
 // ---- optimiser ----------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) sumsq_stage1(const float* __restrict__ x, long long n, float* __restrict__ ws) {
     float s = 0.f, d = 0.f;
@@ -347,6 +518,73 @@ int mmae_masked_ce_bwd(const float* logits, const int64_t* target, const int64_t
     hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, logits, (const long long*)target,
                        (const long long*)mask, C, H, W, patch, lse, per_sample, loss, upstream, d_logits, total);
     return mmae_check_launch("ce_bwd");
+}
+
+int mmae_masked_pixel_loss_pat_fwd(const float* pat, const float* target, const int64_t* mask, int kind, int norm_pix, int B, int C, int H,
+                                   int W, int patch, float* stats, float* partial, float* per_sample, float* loss, void* stream) {
+    MMAE_REQUIRE(pat && target && mask && partial && per_sample && loss, "pixel_loss_pat_fwd: null pointer");
+    MMAE_REQUIRE(!norm_pix || stats, "pixel_loss_pat_fwd: norm_pix needs stats");
+    MMAE_REQUIRE(patch > 0 && H % patch == 0 && W % patch == 0 && (kind == 0 || kind == 1), "pixel_loss_pat_fwd: bad geometry");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pixel_loss_pat_fwd_kernel, dim3(LSPLIT, B), dim3(256), 0, st, pat, target, (const long long*)mask, kind, norm_pix, C, H, W,
+                       patch, stats, partial);
+    int rc = mmae_check_launch("pixel_loss_pat_fwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, partial, (const long long*)mask, B, (H / patch) * (W / patch),
+                       patch * patch, per_sample, loss);
+    return mmae_check_launch("loss_finalize");
+}
+
+int mmae_masked_pixel_loss_pat_bwd(const float* pat, const float* target, const int64_t* mask, int kind, int norm_pix, int B, int C, int H,
+                                   int W, int patch, const float* stats, const float* per_sample, const float* loss, const float* upstream,
+                                   void* d_pat, int d_pat_dtype, int64_t ld_pat, void* stream) {
+    MMAE_REQUIRE(pat && target && mask && per_sample && loss && upstream && d_pat, "pixel_loss_pat_bwd: null pointer");
+    MMAE_REQUIRE(patch > 0 && H % patch == 0 && W % patch == 0 && ld_pat >= (int64_t)C * patch * patch, "pixel_loss_pat_bwd: bad geometry");
+    MMAE_REQUIRE(!norm_pix || stats, "pixel_loss_pat_bwd: norm_pix needs stats");
+    MMAE_REQUIRE(((uintptr_t)pat % 16 == 0) && ((uintptr_t)target % 16 == 0) && ((uintptr_t)d_pat % 16 == 0), "pixel_loss_pat_bwd: unaligned");
+    const long long rows = (long long)B * (H / patch) * (W / patch);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (d_pat_dtype == MMAE_BF16)
+        hipLaunchKernelGGL((pixel_loss_pat_bwd_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, pat, target, (const long long*)mask, kind,
+                           norm_pix, C, H, W, patch, stats, per_sample, loss, upstream, (uint16_t*)d_pat, (long long)ld_pat, rows);
+    else
+        hipLaunchKernelGGL((pixel_loss_pat_bwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, pat, target, (const long long*)mask, kind,
+                           norm_pix, C, H, W, patch, stats, per_sample, loss, upstream, (float*)d_pat, (long long)ld_pat, rows);
+    return mmae_check_launch("pixel_loss_pat_bwd");
+}
+
+int mmae_masked_ce_pat_fwd(const float* pat, const int64_t* target, const int64_t* mask, int B, int C, int H, int W, int patch,
+                           float* lse_pat, float* partial, float* per_sample, float* loss, void* stream) {
+    MMAE_REQUIRE(pat && target && mask && lse_pat && partial && per_sample && loss, "ce_pat_fwd: null pointer");
+    MMAE_REQUIRE(patch > 0 && H % patch == 0 && W % patch == 0, "ce_pat_fwd: bad geometry");
+    const int npix = patch * patch;
+    if (npix > 64 || (npix & (npix - 1))) { mmae_set_error("ce_pat_fwd: patch_size^2 must be a power of two <= 64"); return MMAE_ESUPPORT; }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ce_pat_fwd_kernel, dim3(LSPLIT, B), dim3(256), 0, st, pat, (const long long*)target, (const long long*)mask, C, H, W, patch,
+                       lse_pat, partial);
+    int rc = mmae_check_launch("ce_pat_fwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, partial, (const long long*)mask, B, (H / patch) * (W / patch),
+                       patch * patch, per_sample, loss);
+    return mmae_check_launch("loss_finalize");
+}
+
+int mmae_masked_ce_pat_bwd(const float* pat, const int64_t* target, const int64_t* mask, int B, int C, int H, int W, int patch,
+                           const float* lse_pat, const float* per_sample, const float* loss, const float* upstream, void* d_pat,
+                           int d_pat_dtype, int64_t ld_pat, void* stream) {
+    MMAE_REQUIRE(pat && target && mask && lse_pat && per_sample && loss && upstream && d_pat, "ce_pat_bwd: null pointer");
+    MMAE_REQUIRE(patch > 0 && H % patch == 0 && W % patch == 0 && ld_pat >= (int64_t)C * patch * patch, "ce_pat_bwd: bad geometry");
+    const int npix = patch * patch;
+    if (npix > 64 || (npix & (npix - 1))) { mmae_set_error("ce_pat_bwd: patch_size^2 must be a power of two <= 64"); return MMAE_ESUPPORT; }
+    const long long rows = (long long)B * (H / patch) * (W / patch);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (d_pat_dtype == MMAE_BF16)
+        hipLaunchKernelGGL((ce_pat_bwd_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, pat, (const long long*)target, (const long long*)mask,
+                           C, H, W, patch, lse_pat, per_sample, loss, upstream, (uint16_t*)d_pat, (long long)ld_pat, rows);
+    else
+        hipLaunchKernelGGL((ce_pat_bwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, pat, (const long long*)target, (const long long*)mask,
+                           C, H, W, patch, lse_pat, per_sample, loss, upstream, (float*)d_pat, (long long)ld_pat, rows);
+    return mmae_check_launch("ce_pat_bwd");
 }
 
 int mmae_loss_split(void) { return LSPLIT; }

@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) mask_sample_kernel(const long long* __res
 struct PatchSrc {
     const void* data;      // f32 [B][C][H][W]  or  int64 [B][H][W] (semseg)
     const float* emb;      // semseg: f32 [n_cls][C]
-    int kind, C, H, W, ph, pw, k_off, k_len;
+    int kind, C, H, W, ph, pw, k_off, k_len, n_cls;
 };
 struct PatchSrcs { PatchSrc s[MAX_TASKS]; };
 
@@ -87,7 +87,10 @@ __global__ void __launch_bounds__(256) patch_rows_kernel(const PatchSrcs src, co
             const int c = kk / (s.ph * s.pw), ij = kk % (s.ph * s.pw), i = ij / s.pw, j = ij % s.pw;
             const int y = py * s.ph + i, x = px * s.pw + j;
             if (s.kind == 0) v = ((const float*)s.data)[(((long long)b * s.C + c) * s.H + y) * s.W + x];
-            else { const long long cls = ((const long long*)s.data)[((long long)b * s.H + y) * s.W + x]; v = s.emb[cls * s.C + c]; }
+            else {
+                const long long cls = ((const long long*)s.data)[((long long)b * s.H + y) * s.W + x];
+                v = (s.n_cls > 0 && (cls < 0 || cls >= s.n_cls)) ? 0.f : s.emb[cls * s.C + c];      // out-of-range ids (e.g. an ignore label) embed as zeros
+            }
         }
         ActT<RT>::st(out + k, v);
     }
@@ -111,7 +114,7 @@ __global__ void __launch_bounds__(256) semseg_emb_bwd_kernel(const RT* __restric
         for (int k = threadIdx.x; k < klen; k += 256) {
             const int e = k / (ph * pw), ij = k % (ph * pw), i = ij / pw, j = ij % pw;
             const long long c = cls[((long long)b * H + py * ph + i) * W + px * pw + j];
-            atomicAdd(&tab[c * E + e], ActT<RT>::ld(d_rows + row * ld + k_off + k));
+            if (c >= 0 && c < n_cls) atomicAdd(&tab[c * E + e], ActT<RT>::ld(d_rows + row * ld + k_off + k));
         }
     }
     __syncthreads();
@@ -474,7 +477,7 @@ int mmae_patch_rows(const mmae_patch_src* srcs, const int32_t* task_offsets_host
         MMAE_REQUIRE(s.data && s.ph > 0 && s.pw > 0 && s.H % s.ph == 0 && s.W % s.pw == 0, "patch_rows: bad source");
         MMAE_REQUIRE(s.kind == 0 || s.emb, "patch_rows: semseg source needs the class embedding");
         MMAE_REQUIRE((s.H / s.ph) * (s.W / s.pw) == tt.off[(t < T ? t : 0) + 1] - tt.off[t < T ? t : 0], "patch_rows: patch count != task tokens");
-        ps.s[t] = PatchSrc{s.data, s.emb, s.kind, s.C, s.H, s.W, s.ph, s.pw, s.k_off, s.C * s.ph * s.pw};
+        ps.s[t] = PatchSrc{s.data, s.emb, s.kind, s.C, s.H, s.W, s.ph, s.pw, s.k_off, s.C * s.ph * s.pw, s.n_cls};
     }
     const long long n_rows = (long long)B * n_sel;
     hipStream_t st = (hipStream_t)stream;

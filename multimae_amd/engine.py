@@ -29,6 +29,7 @@ _state = {
     'adapter_streams': False,
     'wgrad_stream': False,           # direct-grad mode: weight-gradient GEMMs / bias column sums on a side stream per compute stream        # run the independent output adapters on separate HIP streams
     'fp32_adapter_gemm': 'x3',       # GEMMs of fp32_output_adapters in bf16 speed mode: 'x3' (split bf16) | 'exact'
+    'patch_domain_loss': __import__('os').environ.get('MMAE_PATCH_LOSS', '1') != '0',
 }
 
 
@@ -52,6 +53,16 @@ def precision(mode: str):
         yield
     finally:
         _state['act_dtype'] = old
+
+
+def patch_domain_loss() -> bool:
+    return _state['patch_domain_loss']
+
+
+def set_patch_domain_loss(flag: bool) -> None:
+    """Masked losses applied to an output adapter's prediction read the adapter's patch rows and hand their gradient back as
+    patch rows (no f32 image-domain gradient, no patchify pass); the image is still materialised for the API.  Default on."""
+    _state['patch_domain_loss'] = bool(flag)
 
 
 def adapter_streams() -> bool:

@@ -476,6 +476,25 @@ def _lin_fwd(x, w, b, wc, out_dtype, **kw):
     return ops.linear_fwd(x, wc(w), b, torch.empty((x.shape[0], w.shape[0]), device=x.device, dtype=out_dtype), **kw)
 
 
+class PatHandle:
+    """Side channel between an output adapter and a masked loss evaluated on its prediction (patch-domain loss): the adapter's
+    patch rows `pat` (f32 [B*n_q, C*ph*pw], out_proj's output before the image rearrangement), the geometry, the autograd
+    `token` that links the loss node to the adapter node, and -- filled in by the loss's backward -- the gradient rows `d_pat`
+    in the adapter's activation dtype."""
+    __slots__ = ('pat', 'token', 'C', 'nh', 'nw', 'ph', 'pw', 'act', 'd_pat')
+
+    def __init__(self, pat, C, nh, nw, ph, pw, act):
+        self.pat, self.C, self.nh, self.nw, self.ph, self.pw, self.act = pat, C, nh, nw, ph, pw, act
+        self.token, self.d_pat = None, None
+
+    def matches(self, img: Tensor, patch: int) -> bool:
+        return (self.pat is not None and self.token is not None and self.ph == patch and self.pw == patch
+                and tuple(img.shape) == (self.pat.shape[0] // (self.nh * self.nw), self.C, self.nh * self.ph, self.nw * self.pw))
+
+    def ld(self) -> int:
+        return ops.round_up(self.C * self.ph * self.pw, 8)
+
+
 class SpatialAdapterFn(torch.autograd.Function):
     """forward(cfg, enc[B,NC,Denc] f32, ids_keep, ids_restore, *params)
 
@@ -488,11 +507,20 @@ class SpatialAdapterFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg: _Cfg, enc: Tensor, ids_keep: Tensor, ids_restore: Tensor, *params):
+        """returns (img, token): token is a 1-element tensor whose only purpose is to connect a patch-domain loss node to this
+        node in the autograd graph (see PatHandle); cfg.handle is set when the patch rows are available."""
+        ctx.set_materialize_grads(False)
+        cfg.handle = None
         with ops.f32_gemm_mode(getattr(cfg, 'f32_gemm', 'exact')):
-            return SpatialAdapterFn._forward(ctx, cfg, enc, ids_keep, ids_restore, *params)
+            img = SpatialAdapterFn._forward(ctx, cfg, enc, ids_keep, ids_restore, *params)
+        token = img.new_empty(1)
+        if cfg.handle is not None:
+            cfg.handle.token = token
+        ctx.handle = cfg.handle
+        return img, token
 
     @staticmethod
-    def backward(ctx, d_img: Tensor):
+    def backward(ctx, d_img: Optional[Tensor], d_token: Optional[Tensor] = None):
         with ops.f32_gemm_mode(getattr(ctx.cfg, 'f32_gemm', 'exact')):
             return SpatialAdapterFn._backward(ctx, d_img)
 
@@ -529,6 +557,8 @@ class SpatialAdapterFn(torch.autograd.Function):
             ctx.comp = state if save else None
             ctx.cfg, ctx.params, ctx.ids = cfg, params, (ids_keep, ids_restore)
             ctx.dims = (B, NC, Denc, n_keep, n_q, T)
+            if save and engine.patch_domain_loss():
+                cfg.handle = PatHandle(state.pat, cfg.C, cfg.nh, cfg.nw, cfg.ph, cfg.pw, act)
             return img
         if enc_act is None:
             enc_act = ops.cast(enc2, act)
@@ -577,7 +607,17 @@ class SpatialAdapterFn(torch.autograd.Function):
             sink = GradSink(engine.direct_grads())
             dsts, acc = _grad_targets(sink, params)
             use_side = sink.side is not None and acc
-            d_enc, keep = ops.adapter_bwd(ctx.comp, d_img, None, [None if t is None else t.view(-1) for t in dsts], acc,
+            h = getattr(ctx, 'handle', None)
+            d_pat = h.d_pat if h is not None else None
+            if d_pat is not None:
+                if d_img is not None:
+                    raise NotImplementedError('this prediction received gradient both through a patch-domain loss and through the image '
+                                              'tensor; turn the patch-domain losses off (engine.set_patch_domain_loss(False))')
+                d_pat.record_stream(torch.cuda.current_stream())     # produced by the loss's backward on another stream
+                h.d_pat, h.pat = None, None
+            elif d_img is None:                                      # nothing reached this adapter
+                d_img = torch.zeros((B, cfg.C, cfg.nh * cfg.ph, cfg.nw * cfg.pw), device=params[0].device, dtype=torch.float32)
+            d_enc, keep = ops.adapter_bwd(ctx.comp, d_img, d_pat, [None if t is None else t.view(-1) for t in dsts], acc,
                                           sink.side.cuda_stream if use_side else None)
             ctx.comp = None
             if use_side:
@@ -588,6 +628,8 @@ class SpatialAdapterFn(torch.autograd.Function):
             return (None, d_enc, None, None, *([None] * len(params) if acc else dsts))
         (enc_act, queries, context, qn, qmean, qrstd, cn, cmean, crstd, q, kv, Pm, xo, x, on, omean, orstd, hpre, hact, h_act,
          bsaved) = ctx.saved
+        if d_img is None:
+            d_img = torch.zeros((B, cfg.C, cfg.nh * cfg.ph, cfg.nw * cfg.pw), device=params[0].device, dtype=torch.float32)
         mask_token = params[0]
         temb = params[1:1 + T]
         (qw, qb, kvw, kvb, pw_, pb, cnw, cnb, qnw, qnb, onw, onb, f1w, f1b, f2w, f2b) = params[1 + T:17 + T]
@@ -811,14 +853,17 @@ class MaskedPixelLossFn(torch.autograd.Function):
         ops.check(_lib.load().mmae_masked_pixel_loss_fwd(pred.data_ptr(), target.data_ptr(), mask.data_ptr(), kind, int(norm_pix), B, C, H,
                                                          W, patch, ops._p(stats), partial.data_ptr(), per_sample.data_ptr(),
                                                          loss.data_ptr(), ops._stream()), 'masked_pixel_loss_fwd')
-        ctx.saved = (pred, target, mask, stats, per_sample, loss)
+        ctx.saved = (pred, target, mask, stats, per_sample, loss, (pred._version, target._version, mask._version))
         ctx.args = (kind, norm_pix, patch)
         return loss[0].clone()
 
     @staticmethod
     def backward(ctx, g: Tensor):
         from . import _lib
-        pred, target, mask, stats, per_sample, loss = ctx.saved
+        pred, target, mask, stats, per_sample, loss, versions = ctx.saved
+        ctx.saved = None
+        if (pred._version, target._version, mask._version) != versions:      # what ctx.save_for_backward would have caught
+            raise RuntimeError('a tensor saved for the masked-loss backward was modified in place')
         kind, norm_pix, patch = ctx.args
         B, C, H, W = pred.shape
         d_pred = torch.empty_like(pred)
@@ -844,14 +889,17 @@ class MaskedCEFn(torch.autograd.Function):
         lse = torch.empty((B, H, W), device=logits.device, dtype=torch.float32)
         ops.check(_lib.load().mmae_masked_ce_fwd(logits.data_ptr(), target.data_ptr(), mask.data_ptr(), B, C, H, W, patch, lse.data_ptr(),
                                                  partial.data_ptr(), per_sample.data_ptr(), loss.data_ptr(), ops._stream()), 'masked_ce_fwd')
-        ctx.saved = (logits, target, mask, lse, per_sample, loss)
+        ctx.saved = (logits, target, mask, lse, per_sample, loss, (logits._version, target._version, mask._version))
         ctx.patch = patch
         return loss[0].clone()
 
     @staticmethod
     def backward(ctx, g: Tensor):
         from . import _lib
-        logits, target, mask, lse, per_sample, loss = ctx.saved
+        logits, target, mask, lse, per_sample, loss, versions = ctx.saved
+        ctx.saved = None
+        if (logits._version, target._version, mask._version) != versions:
+            raise RuntimeError('a tensor saved for the masked-loss backward was modified in place')
         B, C, H, W = logits.shape
         d = torch.empty_like(logits)
         up = g.contiguous().float().reshape(1)
@@ -859,3 +907,76 @@ class MaskedCEFn(torch.autograd.Function):
                                                  lse.data_ptr(), per_sample.data_ptr(), loss.data_ptr(), up.data_ptr(), d.data_ptr(),
                                                  ops._stream()), 'masked_ce_bwd')
         return d, None, None, None
+
+
+class MaskedPixelLossPatFn(torch.autograd.Function):
+    """MaskedMSELoss / MaskedL1Loss on an output adapter's patch rows (PatHandle): same per-pixel arithmetic as
+    MaskedPixelLossFn, gradient handed to the adapter as patch rows in its activation dtype."""
+
+    @staticmethod
+    def forward(ctx, token: Tensor, h: PatHandle, target: Tensor, mask: Tensor, kind: int, norm_pix: bool, patch: int):
+        from . import _lib
+        pat = h.pat
+        target = target.contiguous().float()
+        mask = mask.contiguous().long()
+        B, C, H, W = target.shape[0], h.C, h.nh * h.ph, h.nw * h.pw
+        partial, per_sample, loss = _loss_bufs(B, pat.device)
+        stats = torch.empty((B, h.nh * h.nw, 2), device=pat.device, dtype=torch.float32) if norm_pix else None
+        ops.check(_lib.load().mmae_masked_pixel_loss_pat_fwd(pat.data_ptr(), target.data_ptr(), mask.data_ptr(), kind, int(norm_pix), B, C, H, W,
+                                                             patch, ops._p(stats), partial.data_ptr(), per_sample.data_ptr(), loss.data_ptr(),
+                                                             ops._stream()), 'masked_pixel_loss_pat_fwd')
+        ctx.saved = (h, target, mask, stats, per_sample, loss, (target._version, mask._version))
+        ctx.args = (kind, norm_pix, patch, B, C, H, W)
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        from . import _lib
+        h, target, mask, stats, per_sample, loss, versions = ctx.saved
+        ctx.saved = None
+        kind, norm_pix, patch, B, C, H, W = ctx.args
+        if (target._version, mask._version) != versions:
+            raise RuntimeError('a tensor saved for the masked-loss backward was modified in place')
+        d_pat = torch.empty((h.pat.shape[0], h.ld()), device=h.pat.device, dtype=h.act)
+        up = g.contiguous().float().reshape(1)
+        ops.check(_lib.load().mmae_masked_pixel_loss_pat_bwd(h.pat.data_ptr(), target.data_ptr(), mask.data_ptr(), kind, int(norm_pix), B, C, H, W,
+                                                             patch, ops._p(stats), per_sample.data_ptr(), loss.data_ptr(), up.data_ptr(),
+                                                             d_pat.data_ptr(), ops.dcode(h.act), d_pat.stride(0), ops._stream()),
+                  'masked_pixel_loss_pat_bwd')
+        h.d_pat = d_pat if h.d_pat is None else h.d_pat.add_(d_pat)        # several losses on one prediction: their gradients add
+        return up.new_empty(1), None, None, None, None, None, None
+
+
+class MaskedCEPatFn(torch.autograd.Function):
+    """MaskedCrossEntropyLoss on an output adapter's patch rows (label_smoothing = 0)."""
+
+    @staticmethod
+    def forward(ctx, token: Tensor, h: PatHandle, target: Tensor, mask: Tensor, patch: int):
+        from . import _lib
+        pat = h.pat
+        target = target.contiguous().long()
+        mask = mask.contiguous().long()
+        B, C, H, W = target.shape[0], h.C, h.nh * h.ph, h.nw * h.pw
+        partial, per_sample, loss = _loss_bufs(B, pat.device)
+        lse = torch.empty((pat.shape[0], patch * patch), device=pat.device, dtype=torch.float32)
+        ops.check(_lib.load().mmae_masked_ce_pat_fwd(pat.data_ptr(), target.data_ptr(), mask.data_ptr(), B, C, H, W, patch, lse.data_ptr(),
+                                                     partial.data_ptr(), per_sample.data_ptr(), loss.data_ptr(), ops._stream()), 'masked_ce_pat_fwd')
+        ctx.saved = (h, target, mask, lse, per_sample, loss, (target._version, mask._version))
+        ctx.args = (patch, B, C, H, W)
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        from . import _lib
+        h, target, mask, lse, per_sample, loss, versions = ctx.saved
+        ctx.saved = None
+        patch, B, C, H, W = ctx.args
+        if (target._version, mask._version) != versions:
+            raise RuntimeError('a tensor saved for the masked-loss backward was modified in place')
+        d_pat = torch.empty((h.pat.shape[0], h.ld()), device=h.pat.device, dtype=h.act)
+        up = g.contiguous().float().reshape(1)
+        ops.check(_lib.load().mmae_masked_ce_pat_bwd(h.pat.data_ptr(), target.data_ptr(), mask.data_ptr(), B, C, H, W, patch, lse.data_ptr(),
+                                                     per_sample.data_ptr(), loss.data_ptr(), up.data_ptr(), d_pat.data_ptr(), ops.dcode(h.act),
+                                                     d_pat.stride(0), ops._stream()), 'masked_ce_pat_bwd')
+        h.d_pat = d_pat if h.d_pat is None else h.d_pat.add_(d_pat)
+        return up.new_empty(1), None, None, None, None

@@ -756,6 +756,7 @@ def patch_rows(srcs: Sequence[dict], task_offsets: Sequence[int], sel: Tensor, B
         arr[i].emb = _p(s.get('emb'))
         arr[i].kind, arr[i].C, arr[i].H, arr[i].W = s['kind'], s['C'], s['H'], s['W']
         arr[i].ph, arr[i].pw, arr[i].k_off = s['ph'], s['pw'], s['k_off']
+        arr[i].n_cls = s['emb'].shape[0] if s.get('emb') is not None else 0
     rows = torch.empty((B * n_sel, Ktot), device=sel.device, dtype=dtype)
     check(_lib.load().mmae_patch_rows(ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(_i32_array(task_offsets), ctypes.c_void_p),
                                       T, sel.data_ptr(), rows.data_ptr(), dcode(dtype), B, n_sel, Ktot, _stream()), 'patch_rows')

@@ -161,7 +161,10 @@ class SpatialOutputAdapter(nn.Module):
                    q_task=in_tasks.index(self.task), G=G, D=self.dim_tokens, pos=self._pos_tokens(nh, nw), depth=self.depth,
                    C=self.num_channels, nh=nh, nw=nw, ph=self.P_H, pw=self.P_W, on_done=on_done, f32_gemm=f32_gemm,
                    enc_act=encoder_tokens_act)
-        return SpatialAdapterFn.apply(cfg, encoder_tokens, ids_keep.contiguous(), ids_restore.contiguous(), *self._params(in_tasks))
+        img, token = SpatialAdapterFn.apply(cfg, encoder_tokens, ids_keep.contiguous(), ids_restore.contiguous(), *self._params(in_tasks))
+        if cfg.handle is not None:
+            img._mmae_pat = cfg.handle       # a masked loss applied to exactly this tensor works on the patch rows (criterion.py)
+        return img
 
 
 class LinearOutputAdapter(nn.Module):

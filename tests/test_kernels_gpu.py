@@ -548,3 +548,45 @@ def test_gemm_dw_group_vs_fp32_reference(case, acc):
         torch.cuda.synchronize()
         for (_, _, a, _), (_, _, b, _) in zip(probs, probs2):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('act', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', [('mse', 3, 32, 8), ('mse_norm', 3, 32, 8), ('l1', 1, 24, 4), ('mse', 3, 12, 2), ('ce', 133, 8, 2), ('ce', 133, 16, 4), ('ce', 7, 16, 8)])
+def test_patch_domain_losses_equal_image_domain(case, act):
+    """mmae_masked_*_pat_fwd / _bwd: the masked losses evaluated on patch rows (what out_proj produces) equal the image-domain
+    kernels on the rearranged image -- same value, and the gradient rows equal patchify(image-domain gradient) (in the
+    adapter's activation dtype, pad columns zero).  Includes a sample without masked tokens and non-multiple-of-8 row widths."""
+    from multimae_amd import ops
+    from multimae_amd.functions import MaskedCEFn, MaskedCEPatFn, MaskedPixelLossFn, MaskedPixelLossPatFn, PatHandle
+    kind_name, C, S, P = case
+    B, nh = 3, S // P
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(B, C, S, S, generator=g).to(DEV).requires_grad_(True)
+    mask = (torch.rand(B, nh * nh, generator=g) < 0.6).long().to(DEV)
+    mask[1] = 0                                                   # a sample with no masked token
+    if kind_name == 'ce':
+        target = torch.randint(0, C, (B, S, S), generator=g).to(DEV)
+        ref = MaskedCEFn.apply(img, target, mask, P)
+    else:
+        target = torch.randn(B, C, S, S, generator=g).to(DEV)
+        kind, norm = (1 if kind_name == 'l1' else 0), kind_name.endswith('norm')
+        ref = MaskedPixelLossFn.apply(img, target, mask, kind, norm, P)
+    ref.backward()
+    d_img = img.grad
+    pat = ops.patchify(img.detach(), C, nh, nh, P, P, torch.float32).contiguous()
+    h = PatHandle(pat, C, nh, nh, P, P, act)
+    h.token = torch.zeros(1, device=DEV, requires_grad=True)
+    if kind_name == 'ce':
+        out = MaskedCEPatFn.apply(h.token, h, target, mask, P)
+    else:
+        out = MaskedPixelLossPatFn.apply(h.token, h, target, mask, kind, norm, P)
+    assert abs(float(out) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref))), (float(out), float(ref))
+    out.backward()
+    torch.cuda.synchronize()
+    KP = C * P * P
+    d_ref = ops.patchify(d_img, C, nh, nh, P, P, torch.float32)
+    assert h.d_pat.dtype == act and h.d_pat.shape == (B * nh * nh, (KP + 7) // 8 * 8)
+    got = h.d_pat.float()
+    assert rel_err(got[:, :KP], d_ref) < (1e-6 if act == torch.float32 else 4e-3), rel_err(got[:, :KP], d_ref)
+    assert float(got[:, KP:].abs().sum()) == 0.0
+    assert float(got.view(B, nh * nh, -1)[1].abs().sum()) == 0.0  # the sample without masked tokens: zero gradient
