@@ -353,10 +353,15 @@ def main():
         log(f'step captured as one hipGraph ({run.n_host_inputs} host inputs refreshed per replay)')
     sync()
     log('warmup done; timing')
+    opt.host_wait_s = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
-    host_ms = (time.perf_counter() - t0) / args.steps * 1e3        # launch-side time per step (before the final sync)
+    host_total = time.perf_counter() - t0
+    # launch-side WORK per step: loop time before the final sync minus the time the host sat in FusedAdamW's run-ahead bound
+    # (it may lead the GPU by at most 2 steps, so its loop time alone would just mirror the GPU's)
+    host_ms = (host_total - opt.host_wait_s) / args.steps * 1e3
+    host_wait_ms = opt.host_wait_s / args.steps * 1e3
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -367,7 +372,7 @@ def main():
     img_s = B * world * args.steps / dt
     final_loss = float(last['loss'].detach())
     counters = opt.counters()
-    log(f'timed region done: {ms_per_step:.2f} ms/step, {img_s:.1f} img/s, loss {final_loss:.4f} (host enqueue {host_ms:.2f} ms/step)')
+    log(f'timed region done: {ms_per_step:.2f} ms/step, {img_s:.1f} img/s, loss {final_loss:.4f} (host enqueue work {host_ms:.2f} ms/step + {host_wait_ms:.2f} ms waiting in the 2-step run-ahead bound)')
 
     # per-kernel timing pass (outside the timed region): HIP events around every MFMA GEMM launch.  The pass runs with the
     # multi-stream options OFF, so every launch is alone on the GPU and on the stream the events are recorded on: a launch's
@@ -447,7 +452,7 @@ def main():
                                    + ('fp32 semseg adapter, ' if 'semseg' in doms else '') + 'AdamW; fwd+losses+bwd+optimizer',
                        'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}'},
             'final_loss': round(final_loss, 5), 'launch': 'hipGraph replay of the captured step' if use_graph else 'eager, one library call per encoder stack / output adapter / loss / optimiser step',
-            'host_enqueue_ms_per_step': round(host_ms, 3), 'optimizer_counters': counters,
+            'host_enqueue_ms_per_step': round(host_ms, 3), 'host_throttle_wait_ms_per_step': round(host_wait_ms, 3), 'optimizer_counters': counters,
             'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(out))

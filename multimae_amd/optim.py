@@ -12,6 +12,7 @@ reference's per-iteration cosine tables (run_pretraining_multimae.py:474-480) pl
 from __future__ import annotations
 
 import math
+import time
 from typing import Optional, Tuple
 
 import torch
@@ -43,6 +44,7 @@ class FusedAdamW:
         self.grad_norm = self._state[1:2]
         self.max_steps_in_flight = 2      # the host may enqueue at most this many steps ahead of the GPU (see step())
         self._step_events = []
+        self.host_wait_s = 0.0            # time the host spent blocked by that bound (not launch work; bench.py subtracts it)
 
     # Adam's t.  Reading it synchronises with the device: checkpoints and tests only, never inside the step.
     @property
@@ -97,7 +99,9 @@ class FusedAdamW:
             ev.record()
             self._step_events.append(ev)
             if len(self._step_events) > self.max_steps_in_flight:
+                t0 = time.perf_counter()
                 self._step_events.pop(0).synchronize()
+                self.host_wait_s += time.perf_counter() - t0
         return self.grad_norm
 
     def state_dict(self):
