@@ -1,0 +1,43 @@
+// bf16 MFMA ping-pong GEMM: instantiations with the epilogue flavour fixed at compile time (gemm_common.h, gemm_flavour()).
+// Only the flavours the MultiMAE step actually launches: forward Linear layers (bias -> bf16 / bias + GELU -> bf16 x 2 / bias
+// [+ residual] -> f32) and their dX products (bf16, bf16 x dGELU [+ column sums], f32).  Anything else returns MMAE_ESUPPORT
+// and the caller launches the generic kernel.
+#include "gemm_pp_body.h"
+
+int mmae_gemm_bf16_pp_fl_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, int fl, hipStream_t st) {
+    const bool bks = d->b_trans != 0;
+    const bool t10 = code == 10 && !d->colsum_part;
+    if (d->a_trans) return MMAE_ESUPPORT;
+    if (!bks) {                                   // forward products: A [M][K], W [N][K]
+        if (t10) {
+            switch (fl) {
+                case FL_BF16_BIAS: return launch<5, false, false, FL_BF16_BIAS>(g, d->batch, st);
+                case FL_BF16_BIAS_GELU: return launch<5, false, false, FL_BF16_BIAS_GELU>(g, d->batch, st);
+                case FL_F32_BIAS_RESID: return launch<5, false, false, FL_F32_BIAS_RESID>(g, d->batch, st);
+                case FL_F32_BIAS: return launch<5, false, false, FL_F32_BIAS>(g, d->batch, st);
+                default: return MMAE_ESUPPORT;
+            }
+        }
+        switch (fl) {
+            case FL_BF16_BIAS: return launch<4, false, false, FL_BF16_BIAS>(g, d->batch, st);
+            case FL_BF16_BIAS_GELU: return launch<4, false, false, FL_BF16_BIAS_GELU>(g, d->batch, st);
+            case FL_F32_BIAS_RESID: return launch<4, false, false, FL_F32_BIAS_RESID>(g, d->batch, st);
+            case FL_F32_BIAS: return launch<4, false, false, FL_F32_BIAS>(g, d->batch, st);
+            default: return MMAE_ESUPPORT;
+        }
+    }
+    if (t10) {                                    // dX products: dY [M][N], W [N][K] read through the transposing LDS path
+        switch (fl) {
+            case FL_BF16: return launch<5, false, true, FL_BF16>(g, d->batch, st);
+            case FL_F32: return launch<5, false, true, FL_F32>(g, d->batch, st);
+            default: return MMAE_ESUPPORT;
+        }
+    }
+    switch (fl) {
+        case FL_BF16: return launch<4, false, true, FL_BF16>(g, d->batch, st);
+        case FL_BF16_DGELU_CS: return launch<4, false, true, FL_BF16_DGELU_CS>(g, d->batch, st);
+        case FL_BF16_DGELU: return launch<4, false, true, FL_BF16_DGELU>(g, d->batch, st);
+        case FL_F32: return launch<4, false, true, FL_F32>(g, d->batch, st);
+        default: return MMAE_ESUPPORT;
+    }
+}

@@ -261,7 +261,7 @@ __device__ __forceinline__ i32x4 pack8_bf16(const f32x4 a, const f32x4 b) {
     i32x4 r; r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
     return r;
 }
-template <bool BIAS, int EPI, bool COLSUM, int DBG = 0>
+template <bool BIAS, int EPI, bool COLSUM, int DBG = 0, int PDEPTH = 4>
 __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cbase, char* wave_lds, int lane, const f32x16 (&acc)[2][2],
                                                     int m_base, int n_base, int ntm) {
     constexpr unsigned OOB_OFF = 0x80000000u;
@@ -279,7 +279,7 @@ __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cba
         return (n_ok && r < rows_left) ? (int)((r * ld + n) * 2) : (int)OOB_OFF;
     };
     const int nsteps = ntm * 4;
-    constexpr int PD = 4;                                // dGELU: pre-activation rows prefetched 4 steps (32 rows) ahead
+    constexpr int PD = PDEPTH;                           // dGELU: pre-activation rows prefetched PD steps (8 rows each) ahead; 8 = the whole 64-row tile up front
     i32x4 pre_aux[PD];
     if (EPI == MMAE_EPI_DGELU) {
 #pragma unroll
@@ -407,3 +407,50 @@ __device__ __forceinline__ void gemm_store_tile64(const GemmArgs& g, char* Cz, c
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue flavour fixed at COMPILE time (ping-pong kernel): the instantiation then contains one store routine instead of all
+// of them -- the generic 320-row kernels hold 256 VGPRs and spill ~38 more, reloading them at the top of every output tile
+// behind a full s_waitcnt vmcnt(0) (which also drains the next tile's prefetched K tiles); with one flavour they fit.
+// gemm_flavour() applies exactly the conditions gemm_store_tile64 tests at run time; 0 = keep the generic kernel.
+// ------------------------------------------------------------------------------------------------
+enum { FL_GENERIC = 0, FL_BF16_BIAS = 1, FL_F32_BIAS_RESID = 2, FL_BF16_BIAS_GELU = 3, FL_BF16 = 4, FL_BF16_DGELU_CS = 5, FL_F32_BIAS = 6, FL_F32 = 7,
+       FL_BF16_DGELU = 8 };
+
+static inline int gemm_flavour(const GemmArgs& g, int batch) {
+    if (batch != 1 || g.splitk > 1 || !g.vec || (g.N & 3) || g.alpha != 1.0f || g.accumulate || g.dbg) return FL_GENERIC;
+    const bool bias = g.bias != nullptr, resid = g.resid != nullptr;
+    if (g.c_f32) {
+        if (g.epi != MMAE_EPI_NONE) return FL_GENERIC;
+        if (bias && resid) return FL_F32_BIAS_RESID;
+        if (bias && !resid) return FL_F32_BIAS;
+        if (!bias && !resid) return FL_F32;
+        return FL_GENERIC;
+    }
+    if (resid) return FL_GENERIC;
+    // the 8-column (dwordx4) bf16 routines
+    const bool wide = g.wide_st && (g.N & 7) == 0 && (g.ldc & 7) == 0 && ((uintptr_t)g.C & 15) == 0 &&
+                      (g.epi == MMAE_EPI_NONE || (!g.aux_f32 && (g.ldaux & 7) == 0 && ((uintptr_t)g.aux & 15) == 0)) &&
+                      (!bias || ((uintptr_t)g.bias & 15) == 0);
+    if (!wide) return FL_GENERIC;
+    if (g.epi == MMAE_EPI_NONE) return bias ? FL_BF16_BIAS : FL_BF16;
+    if (g.epi == MMAE_EPI_GELU && bias) return FL_BF16_BIAS_GELU;
+    if (g.epi == MMAE_EPI_DGELU && !bias) return g.colpart ? FL_BF16_DGELU_CS : FL_BF16_DGELU;
+    return FL_GENERIC;
+}
+
+template <int FL>
+__device__ __forceinline__ void gemm_store_tile64_fl(const GemmArgs& g, char* Cz, char* wave_lds, int lane, f32x16 (&acc)[2][2], int m_base, int n_base,
+                                                     int ntm = 2) {
+    if (FL == FL_BF16_BIAS) store_tile64_bf16x8<true, MMAE_EPI_NONE, false>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
+    else if (FL == FL_BF16) store_tile64_bf16x8<false, MMAE_EPI_NONE, false>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
+    else if (FL == FL_BF16_BIAS_GELU) store_tile64_bf16x8<true, MMAE_EPI_GELU, false>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
+    // (with one flavour per instantiation there are registers to spare: all 8 pre-activation loads of a 64-row tile go out before its first use)
+    else if (FL == FL_BF16_DGELU_CS) store_tile64_bf16x8<false, MMAE_EPI_DGELU, true, 0, 4>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
+    else if (FL == FL_BF16_DGELU) store_tile64_bf16x8<false, MMAE_EPI_DGELU, false, 0, 8>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
+    else if (FL == FL_F32_BIAS_RESID) store_tile64_fast<true, 0, true, true, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm);
+    else if (FL == FL_F32_BIAS) store_tile64_fast<true, 0, false, true, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm);
+    else if (FL == FL_F32) store_tile64_fast<false, 0, false, true, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm);
+    else gemm_store_tile64(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
+}
+
