@@ -94,7 +94,7 @@ typedef struct mmae_gemm_desc {
                                     never allocates: ask mmae_gemm_auto_splitk() and pass a workspace. */
     void* ws;                    /* f32 workspace of ws_elems >= split_k * M * N elements (split_k > 1) */
     int64_t ws_elems;
-    float* colsum_part;          /* optional f32 [ceil(M/64)][N]: per-64-row-block column sums of the epilogue output
+    float* colsum_part;          /* optional f32 [ceil(M/32)][N]: per-32-row-block column sums of the epilogue output
                                     (bias gradient of the next Linear for free); dGELU epilogue only, else must be NULL */
     float* a_colsum;             /* optional f32 [M]: receives sum_k A[k][m] -- for a dW product (A = dy, k-strided) that is the
                                     bias gradient, taken from the operand tiles already in LDS instead of a second pass over dy.
@@ -231,7 +231,7 @@ typedef struct mmae_block_desc {
     const float* dx; const void* dx_act;         /* backward in: d(x2) f32 and its act-dtype copy (== dx when act is f32) */
     float* dx0; void* dx0_act;                   /* backward out: d(x0) (dx0_act NULL when act is f32) */
     void *d_hpre, *d_ln2, *d_ao, *d_qkv, *d_ln1; float* dx1; void* dx1_act;     /* backward temporaries */
-    float *part_h, *part1, *part2;               /* [ceil(R/64)][Hd], [nblk][3D], [nblk][3D]; nblk = mmae_layernorm_bwd_nblk(R) */
+    float *part_h, *part1, *part2;               /* [ceil(R/32)][Hd], [nblk][3D], [nblk][3D]; nblk = mmae_layernorm_bwd_nblk(R) */
     float *g_n1_w, *g_n1_b, *g_qkv_w, *g_qkv_b, *g_proj_w, *g_proj_b, *g_n2_w, *g_n2_b, *g_fc1_w, *g_fc1_b, *g_fc2_w, *g_fc2_b;
     float* g_cs;                                 /* NULL or f32 [D]: receives colsum(dx0), the bias gradient of the Linear that produced x0 */
     int32_t grad_acc;                            /* gradients are added to (1) or stored into (0) their destinations */

@@ -242,7 +242,7 @@ BlockTmp carve_block_tmp(Carver& cv, int B, int N, int D, int Hd, size_t es, boo
     t.dx1_act = bf ? cv.take(R * D * es) : nullptr;
     t.dx0_act = bf ? cv.take(R * D * es) : nullptr;
     t.dxs_act = dp ? cv.take(R * D * es) : nullptr;
-    t.part_h = cv.takeT<float>((R + 63) / 64 * Hd);
+    t.part_h = cv.takeT<float>((R + 31) / 32 * Hd);
     t.part1 = cv.takeT<float>((int64_t)nblk * 3 * D); t.part2 = cv.takeT<float>((int64_t)nblk * 3 * D);
     return t;
 }
@@ -396,7 +396,7 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
     const Ctx c = ctx_of(d);
     const int R = d->B * d->N, D = d->D, Hd = d->Hd, N = d->N, hd = D / d->heads;
     const int nblk = mmae_layernorm_bwd_nblk(R);
-    const int hrows = (R + 63) / 64;
+    const int hrows = (R + 31) / 32;
     // ---- MLP: x2 = x1 + dp2 * mlp(norm2(x1))
     const void* dm_act = d->dx_act;                                  // gradient of the MLP branch output, act dtype
     if (d->dp2) {
@@ -604,7 +604,7 @@ AdapterTmp carve_adapter_tmp(Carver& cv, const mmae_adapter_desc* d) {
     t.dh_act = cv.take(Rq * D * es);
     t.dh = bf ? cv.takeT<float>(Rq * D) : nullptr;
     for (int l = 0; l < d->depth; ++l) t.blocks[l] = carve_block_tmp(cv, d->B, d->n_q, D, d->Hd, es, bf, false);
-    t.part_h = cv.takeT<float>((Rq + 63) / 64 * d->Hd);
+    t.part_h = cv.takeT<float>((Rq + 31) / 32 * d->Hd);
     t.d_hpre = cv.take(Rq * d->Hd * es); t.d_on = cv.take(Rq * D * es);
     t.dx = cv.takeT<float>(Rq * D); t.dx_act = bf ? cv.take(Rq * D * es) : nullptr;
     t.part_o = cv.takeT<float>((int64_t)mmae_layernorm_bwd_nblk(Rq) * 3 * D);
@@ -784,7 +784,7 @@ int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream
         (rc = lin_dw(c, dh_act, D, a.hact, gb[14], fc2_done ? nullptr : gb[15], Rq, D, Hd, sd))) return rc;
     if ((rc = lin_dx(c, t.d_hpre, Hd, f1w, t.d_on, act, Rq, Hd, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
     if (!grp_q.add(t.d_hpre, Hd, a.on, D, gb[12], nullptr, Hd, D) && (rc = lin_dw(c, t.d_hpre, Hd, a.on, gb[12], nullptr, Rq, Hd, D, sd))) return rc;
-    if (gb[13]) { float* dst[1] = {gb[13]}; if ((rc = scatter(c, t.part_h, (Rq + 63) / 64, Hd, dst, 1, sd))) return rc; }
+    if (gb[13]) { float* dst[1] = {gb[13]}; if ((rc = scatter(c, t.part_h, (Rq + 31) / 32, Hd, dst, 1, sd))) return rc; }
     if ((rc = mmae_layernorm_bwd(t.d_on, act, a.x, onw, a.omean, a.orstd, dh, t.dx, bf ? t.dx_act : nullptr, act, t.part_o, Rq, D, st))) return rc;
     const void* dx_act = bf ? (const void*)t.dx_act : (const void*)t.dx;
     // ---- x = proj(attn(q, k, v))

@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_dwgroup_kernel(const DwGroup
 
 int mmae_gemm_bf16_pp_fl_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, int fl, hipStream_t st);
 
-// tile codes: 9 = 256 x 256 (TM = 4), 10 = 320 x 256 (TM = 5; k-contiguous A only, no column-sum epilogue)
+// tile codes: 9 = 256 x 256 (TM = 4), 10 = 320 x 256 (TM = 5; k-contiguous A only)
 int mmae_gemm_bf16_pp_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hipStream_t st) {
     const bool aks = d->a_trans != 0, bks = d->b_trans != 0;
     // epilogue flavour known before the launch: use the instantiation that contains only that epilogue (fewer live registers:
@@ -70,7 +70,7 @@ int mmae_gemm_bf16_pp_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code,
             if (rc != MMAE_ESUPPORT) return rc;
         }
     }
-    if (code == 10 && !aks && !d->colsum_part) {
+    if (code == 10 && !aks) {
         return bks ? launch<5, false, true>(g, d->batch, st) : launch<5, false, false>(g, d->batch, st);
     }
     if (!aks && !bks) return launch<4, false, false>(g, d->batch, st);

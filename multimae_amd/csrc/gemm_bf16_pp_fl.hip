@@ -6,7 +6,7 @@
 
 int mmae_gemm_bf16_pp_fl_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, int fl, hipStream_t st) {
     const bool bks = d->b_trans != 0;
-    const bool t10 = code == 10 && !d->colsum_part;
+    const bool t10 = code == 10;
     if (d->a_trans) return MMAE_ESUPPORT;
     if (!bks) {                                   // forward products: A [M][K], W [N][K]
         if (t10) {
@@ -29,6 +29,8 @@ int mmae_gemm_bf16_pp_fl_impl(const mmae_gemm_desc* d, const GemmArgs& g, int co
     if (t10) {                                    // dX products: dY [M][N], W [N][K] read through the transposing LDS path
         switch (fl) {
             case FL_BF16: return launch<5, false, true, FL_BF16>(g, d->batch, st);
+            case FL_BF16_DGELU_CS: return launch<5, false, true, FL_BF16_DGELU_CS>(g, d->batch, st);
+            case FL_BF16_DGELU: return launch<5, false, true, FL_BF16_DGELU>(g, d->batch, st);
             case FL_F32: return launch<5, false, true, FL_F32>(g, d->batch, st);
             default: return MMAE_ESUPPORT;
         }

@@ -18,7 +18,7 @@ struct GemmArgs {
     float* ws;
     int xcd_swizzle;
     float* acs;                   // optional [splitk][M] partial column sums of the k-strided A operand (ping-pong kernel)
-    float* colpart;               // optional [ceil(M/64)][N] column sums of the epilogue output (dGELU flavour)
+    float* colpart;               // optional [ceil(M/32)][N] column sums of the epilogue output per 32-row block (dGELU flavour)
     int wide_st;                  // bf16 epilogues with 8-column (16-byte) lanes (store_tile64_bf16x8); env MMAE_EPI_WIDE=0 turns it off
     int dbg;                      // epilogue dissection for profiling (env MMAE_EPI_DBG, GELU flavour only): 1 = no GELU arithmetic, 2 = no pre-activation store,
                                   // 3 = arithmetic but no stores, 4 = nothing.  0 in production.
@@ -241,12 +241,13 @@ __device__ __forceinline__ void store_tile64_fast(const GemmArgs& g, char* Cbase
                     __builtin_amdgcn_raw_buffer_store_b64(pack4_bf16(v), rsC, voff(tm, it, ldc, C_ESZ), 0, 0);
                 }
             }
-        }
-    }
-    if (COLSUM) {       // the 4 lanes that share a column group (rsub = 0..3) -> one 64-row partial per column
+            if (COLSUM) {       // the 4 lanes that share a column group (rsub = 0..3) -> one partial per column and 32-row block
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { cs[j] += __shfl_xor(cs[j], 16, 64); cs[j] += __shfl_xor(cs[j], 32, 64); }
-        if (rsub == 0 && n_ok && m_base < g.M) st4(g.colpart + (long long)(m_base >> 6) * g.N + n, cs);
+                for (int j = 0; j < 4; ++j) { cs[j] += __shfl_xor(cs[j], 16, 64); cs[j] += __shfl_xor(cs[j], 32, 64); }
+                if (rsub == 0 && n_ok && m_base + tm * 32 < g.M) st4(g.colpart + (long long)((m_base + tm * 32) >> 5) * g.N + n, cs);
+                cs = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
     }
 }
 
@@ -320,17 +321,18 @@ __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cba
                 if (DBG != 3) __builtin_amdgcn_raw_buffer_store_b128(pack8_bf16(v0, v1), rsC, voff(gi, g.ldc), 0, 0);
                 else if (v0[0] == 1234.5678f) __builtin_amdgcn_raw_buffer_store_b128(pack8_bf16(v0, v1), rsC, voff(gi, g.ldc), 0, 0);   // keeps the arithmetic alive
             }
-        }
-    }
-    if (COLSUM) {       // the 8 lanes that share a column group (r8 = 0..7) -> one 64-row partial per column
+            if (COLSUM) {       // the 8 lanes that share a column group (r8 = 0..7) -> one partial per column and 32-row block
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            cs0[j] += __shfl_xor(cs0[j], 8, 64); cs0[j] += __shfl_xor(cs0[j], 16, 64); cs0[j] += __shfl_xor(cs0[j], 32, 64);
-            cs1[j] += __shfl_xor(cs1[j], 8, 64); cs1[j] += __shfl_xor(cs1[j], 16, 64); cs1[j] += __shfl_xor(cs1[j], 32, 64);
-        }
-        if (r8 == 0 && n_ok && m_base < g.M) {
-            float* cp = g.colpart + (long long)(m_base >> 6) * g.N + n;
-            st4(cp, cs0); st4(cp + 4, cs1);
+                for (int j = 0; j < 4; ++j) {
+                    cs0[j] += __shfl_xor(cs0[j], 8, 64); cs0[j] += __shfl_xor(cs0[j], 16, 64); cs0[j] += __shfl_xor(cs0[j], 32, 64);
+                    cs1[j] += __shfl_xor(cs1[j], 8, 64); cs1[j] += __shfl_xor(cs1[j], 16, 64); cs1[j] += __shfl_xor(cs1[j], 32, 64);
+                }
+                if (r8 == 0 && n_ok && m_base + tm * 32 < g.M) {
+                    float* cp = g.colpart + (long long)((m_base + tm * 32) >> 5) * g.N + n;
+                    st4(cp, cs0); st4(cp + 4, cs1);
+                }
+                cs0 = f32x4{0.f, 0.f, 0.f, 0.f}; cs1 = cs0;
+            }
         }
     }
 }

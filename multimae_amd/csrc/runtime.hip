@@ -51,7 +51,8 @@ void gemm_plan(const mmae_gemm_desc* d, int* tile_out, int* split_out) {
             if (d->M >= 2048 && d->N >= 192 && d->K >= env_min_k) {
                 // whole rounds of 256 workgroups x rows per tile: 320-row tiles when they waste less of the last round
                 const long long c4 = ((t4 + 255) / 256) * 256, c5 = ((t5 + 255) / 256) * 320;
-                tile = (c5 <= c4 && !d->a_trans && !d->colsum_part) ? 10 : 9;
+                static const int env_t10cs = getenv("MMAE_GEMM_T10_CS") ? atoi(getenv("MMAE_GEMM_T10_CS")) : 1;     // 0: 256-row tiles for the column-sum epilogue (A/B)
+                tile = (c5 <= c4 && !d->a_trans && (env_t10cs || !d->colsum_part)) ? 10 : 9;
             } else if (t4 >= 4 && can_split && d->K >= 4096) {
                 tile = 9;                                   // dW-shaped: few tiles, split along K below
             }

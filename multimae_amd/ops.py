@@ -139,7 +139,7 @@ def linear_dx(dy: Tensor, w: Tensor, out: Tensor, *, aux: Optional[Tensor] = Non
     """out[M,K] = dy[M,N] @ w[N,K]   (w read through the transposing LDS path).
     dGELU epilogue only -- the column sums of `out` (= the bias gradient of the Linear whose pre-activation gradient `out`
     is) collected in the GEMM epilogue instead of a separate pass over out:
-      colsum_part (f32 [ceil(M/64), K]): receives the per-64-row partial sums (caller reduces them, see GradSink.colsums);
+      colsum_part (f32 [ceil(M/32), K]): receives the per-32-row partial sums (caller reduces them, see GradSink.colsums);
       colsum_out  (f32 [K]): receives the reduced sums."""
     M, N = dy.shape
     K = w.shape[1]
@@ -170,7 +170,7 @@ def gemm_dw_group(problems: Sequence[tuple], accumulate: bool, split_k: int = 0)
 
 
 def dx_colsum_part_shape(M: int, K: int):
-    return ((M + 63) // 64, K)
+    return ((M + 31) // 32, K)
 
 
 def linear_dw(dy: Tensor, x: Tensor, dw: Tensor, accumulate: bool, *, db: Optional[Tensor] = None, db_accumulate: bool = False,
@@ -275,7 +275,7 @@ def block_bwd_composite(dx: Tensor, dx_act: Tensor, fc2b_done: bool, saved, P: S
     dx1_act = e((R, D), act) if bf else None
     dx0_act = e((R, D), act) if bf else None
     nblk = lib.mmae_layernorm_bwd_nblk(R)
-    part = e((2 * nblk * 3 * D + ((R + 63) // 64) * Hd,), f)
+    part = e((2 * nblk * 3 * D + ((R + 31) // 32) * Hd,), f)
     d = _block_desc(P, wts, heads, 0.0, act, B, N, D)
     d.x0, d.ln1, d.mean1, d.rstd1, d.qkv, d.lse, d.ao, d.x1 = (x0.data_ptr(), ln1.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(),
                                                                qkv.data_ptr(), Pm[1].data_ptr(), ao.data_ptr(), x1.data_ptr())

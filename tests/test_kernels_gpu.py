@@ -590,3 +590,28 @@ def test_patch_domain_losses_equal_image_domain(case, act):
     assert rel_err(got[:, :KP], d_ref) < (1e-6 if act == torch.float32 else 4e-3), rel_err(got[:, :KP], d_ref)
     assert float(got[:, KP:].abs().sum()) == 0.0
     assert float(got.view(B, nh * nh, -1)[1].abs().sum()) == 0.0  # the sample without masked tokens: zero gradient
+
+
+@pytest.mark.parametrize('tile', [9, 10])
+@pytest.mark.parametrize('M', [2500, 4160])
+def test_pingpong_dgelu_colsum_epilogue(tile, M):
+    """dX product with the dGELU epilogue and its fused column sums on the ping-pong kernel (256- and 320-row tiles, the
+    compile-time-flavoured instantiations): per-32-row-block partials [ceil(M/32)][N], M not a multiple of 32 / of the tile."""
+    from multimae_amd import ops
+    from multimae_amd._lib import EPI_DGELU
+    g = torch.Generator().manual_seed(3)
+    Nn, K = 520, 264                                    # out[M, Nn] = dy[M, K] @ w[K, Nn]
+    dy = bf(torch.randn(M, K, generator=g) * 0.3)
+    w = bf(torch.randn(K, Nn, generator=g) * 0.2)
+    pre = bf(torch.randn(M, Nn, generator=g))
+    out = torch.empty(M, Nn, device=DEV, dtype=torch.bfloat16)
+    part = torch.full(ops.dx_colsum_part_shape(M, Nn), float('nan'), device=DEV)
+    ops.gemm(dy.to(DEV), w.to(DEV), out, M, Nn, K, lda=K, ldb=Nn, ldc=Nn, b_trans=True, aux=pre.to(DEV), ldaux=Nn, epi=EPI_DGELU, tile=tile,
+             colsum_part=part)
+    torch.cuda.synchronize()
+    p = pre.float().clone().requires_grad_(True)
+    orc.gelu_erf(p).backward(dy.float() @ w.float())
+    assert rel_err(out.float(), p.grad) < 4e-3
+    assert part.shape[0] == (M + 31) // 32 and not torch.isnan(part).any()
+    ref_blocks = torch.stack([p.grad[i:i + 32].sum(0) for i in range(0, M, 32)])
+    assert rel_err(part.cpu(), ref_blocks) < 1e-4
