@@ -374,57 +374,46 @@ def main():
     counters = opt.counters()
     log(f'timed region done: {ms_per_step:.2f} ms/step, {img_s:.1f} img/s, loss {final_loss:.4f} (host enqueue work {host_ms:.2f} ms/step + {host_wait_ms:.2f} ms waiting in the 2-step run-ahead bound)')
 
-    # per-kernel timing pass (outside the timed region): HIP events around every MFMA GEMM launch.  The pass runs with the
-    # multi-stream options OFF, so every launch is alone on the GPU and on the stream the events are recorded on: a launch's
-    # event-bracketed time is then that kernel's own duration (with the adapters / weight-gradient GEMMs on other streams a
-    # bracketed launch also counts the time it shares the CUs with them).  rocprofv3 of
-    # `bench.py --adapter-streams 0 --wgrad-stream 0` gives the same per-kernel averages (profiles/*_serialized_*).
+    # per-kernel timing pass (outside the timed region): HIP events around every MFMA GEMM launch of the PRODUCTION path -- the
+    # library brackets each mmae_gemm / mmae_gemm_dw_group call on its launch stream (mmae_gemm_timing_*), also inside the
+    # composite per-stack / per-adapter calls.  The pass runs with the multi-stream options OFF, so every launch is alone on the
+    # GPU: a bracket is then that launch's own duration (with the adapters / weight-gradient GEMMs on other streams it would
+    # also contain the time the launch shares the CUs with them).  rocprofv3 of `bench.py --adapter-streams 0 --wgrad-stream 0`
+    # gives the same per-kernel averages (profiles/*_serialized*).
     roof = None
     if not args.no_kernel_timing:
+        import ctypes
+        from multimae_amd import _lib
+        lib = _lib.load()
         M.engine.set_adapter_streams(False)
         M.engine.set_wgrad_stream(False)
-        ops.set_composite_blocks(False)            # every GEMM through ops.gemm, where the events are
-        ops.set_stack_composites(False)
         step()
         torch.cuda.synchronize()
-        rec = []
-        orig = ops.gemm
-
-        def timed_gemm(A, Bm, C, Mm, N, K, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            orig(A, Bm, C, Mm, N, K, **kw)
-            e1.record()
-            rec.append((e0, e1, 2.0 * Mm * N * K * kw.get('batch', 1), A.dtype))
-        ops.gemm = timed_gemm
         # park the GPU for ~80 ms first, so the whole step is already queued when it starts executing: the events then
-        # bracket back-to-back kernels (with the GPU waiting for the host, a launch's bracket would include ~20 us of Python)
+        # bracket back-to-back kernels (with the GPU waiting for the host, a bracket would include host launch time)
         try:
             torch.cuda._sleep(int(0.08 * 2.0e9))
         except Exception:                      # noqa: BLE001 -- no spin kernel in this torch build: fill memory instead
             junk = torch.empty(1 << 30, device=device, dtype=torch.uint8)
             for _ in range(40):
                 junk.zero_()
+        lib.mmae_gemm_timing_enable(1)
         step()
         torch.cuda.synchronize()
-        ops.gemm = orig
-        ops.set_composite_blocks(True)
-        ops.set_stack_composites(True)
+        ms2, fl2, n2 = (ctypes.c_double * 2)(), (ctypes.c_double * 2)(), (ctypes.c_int64 * 2)()
+        lib.mmae_gemm_timing_read(ms2, fl2, n2)
+        lib.mmae_gemm_timing_enable(0)
         M.engine.set_adapter_streams(bool(args.adapter_streams))
         M.engine.set_wgrad_stream(bool(args.wgrad_stream))
         log('kernel timing pass done')
-        tot_ms = {torch.bfloat16: 0.0, torch.float32: 0.0}
-        tot_fl = {torch.bfloat16: 0.0, torch.float32: 0.0}
-        cnt = {torch.bfloat16: 0, torch.float32: 0}
-        for e0, e1, fl, dt_ in rec:
-            tot_ms[dt_] += e0.elapsed_time(e1)
-            tot_fl[dt_] += fl
-            cnt[dt_] += 1
+        tot_ms = {torch.bfloat16: ms2[0], torch.float32: ms2[1]}
+        tot_fl = {torch.bfloat16: fl2[0], torch.float32: fl2[1]}
+        cnt = {torch.bfloat16: int(n2[0]), torch.float32: int(n2[1])}
         dom = torch.bfloat16 if args.precision == 'bf16' else torch.float32
         peak = PEAK_BF16_TFLOPS if dom == torch.bfloat16 else 157.3
         ach = tot_fl[dom] / (tot_ms[dom] * 1e-3) / 1e12 if tot_ms[dom] > 0 else 0.0
         traffic, traffic_src = pmc_traffic(dom)
-        roof = {'bound': 'mfma', 'kernel': 'gemm_bf16_pp_kernel / gemm_bf16_kernel (all bf16 MFMA GEMM launches of one step, each timed alone on its stream)' if dom == torch.bfloat16 else 'gemm_f32_kernel',
+        roof = {'bound': 'mfma', 'kernel': 'gemm_bf16_pp_kernel (+ its grouped weight-gradient form gemm_bf16_pp_dwgroup_kernel) / gemm_bf16_kernel: all bf16 MFMA GEMM calls of one production step, each bracketed by HIP events on its launch stream inside the library, single-stream' if dom == torch.bfloat16 else 'gemm_f32_kernel',
                 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_source': traffic_src,
                 'launches_per_step': cnt[dom], 'gemm_ms_per_step': round(tot_ms[dom], 3),
                 'gemm_gflop_per_step': round(tot_fl[dom] / 1e9, 1),

@@ -112,6 +112,16 @@ int mmae_gemm_plan(const mmae_gemm_desc* d, int* tile, int* split_k);
 int mmae_gemm_auto_splitk(int M, int N, int K, int ab_dtype);
 
 /* ------------------------------------------------------------------------- *
+ * Launch timing of the MFMA GEMM entry points (mmae_gemm, mmae_gemm_dw_group -- also when they are reached through the
+ * composite calls): while enabled, every call is bracketed by two hipEvents recorded on ITS launch stream; mmae_gemm_timing_read
+ * waits for them and returns, per operand class (0: bf16, 1: f32 / split-bf16), the summed launch time [ms], the algorithmic
+ * FLOPs (2 M N K) and the number of calls.  For bench.py's roofline line (run the step single-stream while measuring: with
+ * other streams active a bracket also contains the time the launch shares the CUs).  Off by default; costs nothing then.
+ * ------------------------------------------------------------------------- */
+int mmae_gemm_timing_enable(int on);
+int mmae_gemm_timing_read(double* ms2, double* flop2, int64_t* calls2);
+
+/* ------------------------------------------------------------------------- *
  * Grouped weight gradients: up to 8 products dw_i[n_out_i][k_in_i] (+)= dy_i[rows][n_out_i]^T . x_i[rows][k_in_i] (the dW of
  * nn.Linear layers that saw the same rows, e.g. the four of a transformer block, multimae_utils.py:143-153,165-180) in ONE
  * MFMA launch + ONE reduction launch; db_i[n_out_i] (+)= column sums of dy_i ride along (NULL = not wanted).  bf16 operands
@@ -475,11 +485,12 @@ int mmae_masked_pixel_loss_fwd(const float* pred, const float* target, const int
 int mmae_masked_pixel_loss_bwd(const float* pred, const float* target, const int64_t* mask, int kind, int norm_pix,
                                int B, int C, int H, int W, int patch, const float* stats, const float* per_sample,
                                const float* loss, const float* upstream, float* d_pred, void* stream);
+/* label_smoothing as F.cross_entropy's (criterion.py:47): (1 - eps) * nll(target) + eps * mean over classes of -log p_c */
 int mmae_masked_ce_fwd(const float* logits, const int64_t* target, const int64_t* mask, int B, int C, int H, int W,
-                       int patch, float* lse, float* partial, float* per_sample, float* loss, void* stream);
+                       int patch, float label_smoothing, float* lse, float* partial, float* per_sample, float* loss, void* stream);
 int mmae_masked_ce_bwd(const float* logits, const int64_t* target, const int64_t* mask, int B, int C, int H, int W,
-                       int patch, const float* lse, const float* per_sample, const float* loss, const float* upstream,
-                       float* d_logits, void* stream);
+                       int patch, float label_smoothing, const float* lse, const float* per_sample, const float* loss,
+                       const float* upstream, float* d_logits, void* stream);
 
 /* The same losses evaluated on the adapters' patch rows pat f32 [B*nh*nw][C*patch*patch] (column order c, i, j -- out_proj's
  * output, output_adapters.py:274, before the rearrangement of :277-280): identical arithmetic per pixel, but the gradient is
@@ -492,10 +503,10 @@ int mmae_masked_pixel_loss_pat_bwd(const float* pat, const float* target, const 
                                    int W, int patch, const float* stats, const float* per_sample, const float* loss, const float* upstream,
                                    void* d_pat, int d_pat_dtype, int64_t ld_pat, void* stream);
 int mmae_masked_ce_pat_fwd(const float* pat, const int64_t* target, const int64_t* mask, int B, int C, int H, int W, int patch,
-                           float* lse_pat, float* partial, float* per_sample, float* loss, void* stream);
+                           float label_smoothing, float* lse_pat, float* partial, float* per_sample, float* loss, void* stream);
 int mmae_masked_ce_pat_bwd(const float* pat, const int64_t* target, const int64_t* mask, int B, int C, int H, int W, int patch,
-                           const float* lse_pat, const float* per_sample, const float* loss, const float* upstream, void* d_pat,
-                           int d_pat_dtype, int64_t ld_pat, void* stream);
+                           float label_smoothing, const float* lse_pat, const float* per_sample, const float* loss, const float* upstream,
+                           void* d_pat, int d_pat_dtype, int64_t ld_pat, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Optimiser step on flat arenas.  Replaces get_grad_norm_ / clip_grad_norm_

@@ -42,16 +42,14 @@ class MaskedCrossEntropyLoss(nn.Module):
         self.stride = stride
         self.scale_factor = patch_size // stride
         self.label_smoothing = label_smoothing
-        if label_smoothing != 0.0:
-            raise NotImplementedError('label_smoothing > 0 is not built (pre-training uses 0.0, run_pretraining_multimae.py:70)')
 
     def forward(self, input, target, mask=None):
         if mask is None:
             mask = _ones_mask(input, self.scale_factor)      # plain mean == masked mean with an all-ones mask
         h = _pat_handle(input, self.scale_factor, ce=True)
         if h is not None:
-            return MaskedCEPatFn.apply(h.token, h, target, mask, self.scale_factor)
-        return MaskedCEFn.apply(input, target, mask, self.scale_factor)
+            return MaskedCEPatFn.apply(h.token, h, target, mask, self.scale_factor, float(self.label_smoothing))
+        return MaskedCEFn.apply(input, target, mask, self.scale_factor, float(self.label_smoothing))
 
 
 class _MaskedPixelLoss(nn.Module):

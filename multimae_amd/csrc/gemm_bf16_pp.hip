@@ -56,6 +56,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_dwgroup_kernel(const DwGroup
 }  // namespace
 
 int mmae_gemm_bf16_pp_fl_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, int fl, hipStream_t st);
+hipEvent_t mmae_timing_begin(hipStream_t st);
+void mmae_timing_end(hipEvent_t a, hipStream_t st, double flop, int cls);
 
 // tile codes: 9 = 256 x 256 (TM = 4), 10 = 320 x 256 (TM = 5; k-contiguous A only)
 int mmae_gemm_bf16_pp_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hipStream_t st) {
@@ -188,12 +190,16 @@ extern "C" int mmae_gemm_dw_group(const mmae_dw_group_desc* d, void* stream) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_dwgroup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
+    double flop = 0.0;
+    for (int i = 0; i < d->n; ++i) flop += 2.0 * d->rows * d->p[i].n_out * d->p[i].k_in;
+    hipEvent_t t_ev = mmae_timing_begin(st);
     hipLaunchKernelGGL(gemm_bf16_pp_dwgroup_kernel, dim3(tb, 1, s), dim3(512), lds, st, ga);
     int rc = mmae_check_launch("gemm_bf16_pp_dwgroup");
-    if (rc) return rc;
+    if (rc) { mmae_timing_end(t_ev, st, flop, 0); return rc; }
     long long nb = (b4 + 255) / 256;
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(dw_group_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, ra);
+    mmae_timing_end(t_ev, st, flop, 0);
     return mmae_check_launch("dw_group_reduce");
 }

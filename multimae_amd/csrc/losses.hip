@@ -109,8 +109,9 @@ __global__ void pixel_loss_bwd_kernel(const float* __restrict__ pred, const floa
 }
 
 // cross entropy.  thread per pixel, channel planes strided by H*W (coalesced across pixels).
+// label smoothing eps (F.cross_entropy(label_smoothing=eps), criterion.py:47): (1 - eps) * nll(target) + eps * mean_c(-log p_c)
 __global__ void __launch_bounds__(256) ce_fwd_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
-                                                     const long long* __restrict__ mask, int C, int H, int W, int P,
+                                                     const long long* __restrict__ mask, int C, int H, int W, int P, float eps,
                                                      float* __restrict__ lse, float* __restrict__ partial) {
     const int b = blockIdx.y, HW = H * W, nw = W / P, np = (H / P) * nw;
     float acc = 0.f;
@@ -119,22 +120,25 @@ __global__ void __launch_bounds__(256) ce_fwd_kernel(const float* __restrict__ l
         if (mask[(long long)b * np + (y / P) * nw + x / P] == 0) continue;
         const float* l = logits + (long long)b * C * HW + px;
         // one pass over the C channel planes: running max + rescaled sum (the two-pass form read the logits twice)
-        float mx = l[0], s = 1.f;
+        float mx = l[0], s = 1.f, sx = l[0];
         int c = 1;
         for (; c + 4 <= C; c += 4) {
             const float v0 = l[(long long)c * HW], v1 = l[(long long)(c + 1) * HW], v2 = l[(long long)(c + 2) * HW], v3 = l[(long long)(c + 3) * HW];
             const float m4 = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
             if (m4 > mx) { s *= expf(mx - m4); mx = m4; }
             s += (expf(v0 - mx) + expf(v1 - mx)) + (expf(v2 - mx) + expf(v3 - mx));
+            sx += (v0 + v1) + (v2 + v3);
         }
         for (; c < C; ++c) {
             const float v = l[(long long)c * HW];
             if (v > mx) { s *= expf(mx - v); mx = v; }
             s += expf(v - mx);
+            sx += v;
         }
         const float ls = mx + logf(s);
         lse[(long long)b * HW + px] = ls;
-        acc += ls - l[target[(long long)b * HW + px] * HW];
+        const float nll = ls - l[target[(long long)b * HW + px] * HW];
+        acc += eps == 0.f ? nll : (1.f - eps) * nll + eps * (ls - sx / (float)C);
     }
     float dummy = 0.f;
     block_sum2(acc, dummy);
@@ -142,7 +146,7 @@ __global__ void __launch_bounds__(256) ce_fwd_kernel(const float* __restrict__ l
 }
 
 __global__ void ce_bwd_kernel(const float* __restrict__ logits, const long long* __restrict__ target, const long long* __restrict__ mask,
-                              int C, int H, int W, int P, const float* __restrict__ lse, const float* __restrict__ per_sample,
+                              int C, int H, int W, int P, float eps, const float* __restrict__ lse, const float* __restrict__ per_sample,
                               const float* __restrict__ loss, const float* __restrict__ upstream, float* __restrict__ d_logits,
                               long long total) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;    // over B*C*H*W
@@ -155,7 +159,7 @@ __global__ void ce_bwd_kernel(const float* __restrict__ logits, const long long*
     if (mask[b * np + (y / P) * nw + x / P] != 0) {
         const float wgt = upstream[0] / (loss[1] * per_sample[b * 2 + 1]);
         const float sm = expf(logits[i] - lse[b * HW + px]);
-        g = wgt * (sm - (target[b * HW + px] == c ? 1.f : 0.f));
+        g = wgt * (sm - ((target[b * HW + px] == c ? 1.f - eps : 0.f) + eps / (float)C));
     }
     d_logits[i] = g;
 }
@@ -190,7 +194,7 @@ __global__ void __launch_bounds__(256) pixel_loss_bwd4_kernel(const float* __res
 }
 
 __global__ void __launch_bounds__(256) ce_bwd4_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
-                                                      const long long* __restrict__ mask, int C, int H, int W, int P, const float* __restrict__ lse,
+                                                      const long long* __restrict__ mask, int C, int H, int W, int P, float eps, const float* __restrict__ lse,
                                                       const float* __restrict__ per_sample, const float* __restrict__ loss,
                                                       const float* __restrict__ upstream, float* __restrict__ d_logits, long long total4) {
     const long long i4 = (long long)blockIdx.x * 256 + threadIdx.x;          // over B*C*H*W / 4
@@ -206,7 +210,7 @@ __global__ void __launch_bounds__(256) ce_bwd4_kernel(const float* __restrict__ 
         const f32x4 lg = ld4(logits + i), ls = ld4(lse + b * HW + px);
         const long long* t = target + b * HW + px;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) g[j] = wgt * (expf(lg[j] - ls[j]) - (t[j] == c ? 1.f : 0.f));
+        for (int j = 0; j < 4; ++j) g[j] = wgt * (expf(lg[j] - ls[j]) - ((t[j] == c ? 1.f - eps : 0.f) + eps / (float)C));
     }
     st4(d_logits + i, g);
 }
@@ -312,7 +316,7 @@ __global__ void __launch_bounds__(256) pixel_loss_pat_bwd_kernel(const float* __
 // cross entropy on patch rows; npix = P * P <= 64, a power of two: lane = (class slot, pixel), 64 / npix class slots per pixel,
 // element index of iteration k = k * 64 + lane (perfectly coalesced).  lse_pat f32 [B * np][npix].
 __global__ void __launch_bounds__(256) ce_pat_fwd_kernel(const float* __restrict__ pat, const long long* __restrict__ target,
-                                                         const long long* __restrict__ mask, int C, int H, int W, int P,
+                                                         const long long* __restrict__ mask, int C, int H, int W, int P, float eps,
                                                          float* __restrict__ lse_pat, float* __restrict__ partial) {
     const int b = blockIdx.y, nw = W / P, np = (H / P) * nw, npix = P * P, nval = npix * C;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -324,25 +328,27 @@ __global__ void __launch_bounds__(256) ce_pat_fwd_kernel(const float* __restrict
         const long long row = (long long)b * np + p;
         const float* prow = pat + row * nval;
         const long long t = target[((long long)b * H + py * P + pix / P) * W + px * P + pix % P];
-        float mx = -3.0e38f, s = 0.f, lt = 0.f;
+        float mx = -3.0e38f, s = 0.f, lt = 0.f, sx = 0.f;
         int c = slot;
         for (int e = lane; e < nval; e += 64, c += nslot) {
             const float v = prow[e];
             if (v > mx) { s *= expf(mx - v); mx = v; }
             s += expf(v - mx);
+            sx += v;
             if ((long long)c == t) lt = v;
         }
         // combine the class slots of a pixel (lanes pix, pix + npix, ...)
         for (int o = npix; o < 64; o <<= 1) {
             const float om = __shfl_xor(mx, o, 64), os = __shfl_xor(s, o, 64);
             lt += __shfl_xor(lt, o, 64);
+            sx += __shfl_xor(sx, o, 64);
             const float nm = fmaxf(mx, om);
             s = s * expf(mx - nm) + os * expf(om - nm);
             mx = nm;
         }
         const float ls = mx + logf(s);
         if (slot == 0) { lse_pat[row * npix + pix] = ls; }
-        float contrib = slot == 0 ? ls - lt : 0.f;
+        float contrib = slot == 0 ? (eps == 0.f ? ls - lt : (1.f - eps) * (ls - lt) + eps * (ls - sx / (float)C)) : 0.f;
         contrib = wave_sum(contrib);
         if (lane == 0) acc += contrib;
     }
@@ -353,7 +359,7 @@ __global__ void __launch_bounds__(256) ce_pat_fwd_kernel(const float* __restrict
 
 template <typename DT>
 __global__ void __launch_bounds__(256) ce_pat_bwd_kernel(const float* __restrict__ pat, const long long* __restrict__ target,
-                                                         const long long* __restrict__ mask, int C, int H, int W, int P,
+                                                         const long long* __restrict__ mask, int C, int H, int W, int P, float eps,
                                                          const float* __restrict__ lse_pat, const float* __restrict__ per_sample,
                                                          const float* __restrict__ loss, const float* __restrict__ upstream,
                                                          DT* __restrict__ d_pat, long long ld, long long n_rows) {
@@ -377,7 +383,7 @@ __global__ void __launch_bounds__(256) ce_pat_bwd_kernel(const float* __restrict
     int c = slot;
     for (int e = lane; e < (int)ld; e += 64, c += nslot) {
         float g = 0.f;
-        if (e < nval) g = wgt * (expf(prow[e] - ls) - ((long long)c == t ? 1.f : 0.f));
+        if (e < nval) g = wgt * (expf(prow[e] - ls) - (((long long)c == t ? 1.f - eps : 0.f) + eps / (float)C));
         ActT<DT>::st(drow + e, g);
     }
 }
@@ -493,12 +499,13 @@ int mmae_masked_pixel_loss_bwd(const float* pred, const float* target, const int
 }
 
 int mmae_masked_ce_fwd(const float* logits, const int64_t* target, const int64_t* mask, int B, int C, int H, int W, int patch,
-                       float* lse, float* partial, float* per_sample, float* loss, void* stream) {
+                       float label_smoothing, float* lse, float* partial, float* per_sample, float* loss, void* stream) {
     MMAE_REQUIRE(logits && target && mask && lse && partial && per_sample && loss, "ce_fwd: null pointer");
     MMAE_REQUIRE(patch > 0 && H % patch == 0 && W % patch == 0, "ce_fwd: bad geometry");
     hipStream_t st = (hipStream_t)stream;
+    MMAE_REQUIRE(label_smoothing >= 0.f && label_smoothing <= 1.f, "ce_fwd: label_smoothing outside [0, 1]");
     hipLaunchKernelGGL(ce_fwd_kernel, dim3(LSPLIT, B), dim3(256), 0, st, logits, (const long long*)target, (const long long*)mask, C, H, W,
-                       patch, lse, partial);
+                       patch, label_smoothing, lse, partial);
     int rc = mmae_check_launch("ce_fwd");
     if (rc) return rc;
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, partial, (const long long*)mask, B, (H / patch) * (W / patch),
@@ -507,16 +514,16 @@ int mmae_masked_ce_fwd(const float* logits, const int64_t* target, const int64_t
 }
 
 int mmae_masked_ce_bwd(const float* logits, const int64_t* target, const int64_t* mask, int B, int C, int H, int W, int patch,
-                       const float* lse, const float* per_sample, const float* loss, const float* upstream, float* d_logits,
-                       void* stream) {
+                       float label_smoothing, const float* lse, const float* per_sample, const float* loss, const float* upstream,
+                       float* d_logits, void* stream) {
     MMAE_REQUIRE(logits && target && mask && lse && per_sample && loss && upstream && d_logits, "ce_bwd: null pointer");
     const long long total = (long long)B * C * H * W;
     if (W % 4 == 0 && patch % 4 == 0 && ((uintptr_t)logits % 16 == 0) && ((uintptr_t)lse % 16 == 0) && ((uintptr_t)d_logits % 16 == 0))
         hipLaunchKernelGGL(ce_bwd4_kernel, dim3((unsigned)cdiv64(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, logits,
-                           (const long long*)target, (const long long*)mask, C, H, W, patch, lse, per_sample, loss, upstream, d_logits, total / 4);
+                           (const long long*)target, (const long long*)mask, C, H, W, patch, label_smoothing, lse, per_sample, loss, upstream, d_logits, total / 4);
     else
     hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, logits, (const long long*)target,
-                       (const long long*)mask, C, H, W, patch, lse, per_sample, loss, upstream, d_logits, total);
+                       (const long long*)mask, C, H, W, patch, label_smoothing, lse, per_sample, loss, upstream, d_logits, total);
     return mmae_check_launch("ce_bwd");
 }
 
@@ -554,14 +561,14 @@ int mmae_masked_pixel_loss_pat_bwd(const float* pat, const float* target, const 
 }
 
 int mmae_masked_ce_pat_fwd(const float* pat, const int64_t* target, const int64_t* mask, int B, int C, int H, int W, int patch,
-                           float* lse_pat, float* partial, float* per_sample, float* loss, void* stream) {
+                           float label_smoothing, float* lse_pat, float* partial, float* per_sample, float* loss, void* stream) {
     MMAE_REQUIRE(pat && target && mask && lse_pat && partial && per_sample && loss, "ce_pat_fwd: null pointer");
     MMAE_REQUIRE(patch > 0 && H % patch == 0 && W % patch == 0, "ce_pat_fwd: bad geometry");
     const int npix = patch * patch;
     if (npix > 64 || (npix & (npix - 1))) { mmae_set_error("ce_pat_fwd: patch_size^2 must be a power of two <= 64"); return MMAE_ESUPPORT; }
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(ce_pat_fwd_kernel, dim3(LSPLIT, B), dim3(256), 0, st, pat, (const long long*)target, (const long long*)mask, C, H, W, patch,
-                       lse_pat, partial);
+                       label_smoothing, lse_pat, partial);
     int rc = mmae_check_launch("ce_pat_fwd");
     if (rc) return rc;
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, partial, (const long long*)mask, B, (H / patch) * (W / patch),
@@ -570,8 +577,8 @@ int mmae_masked_ce_pat_fwd(const float* pat, const int64_t* target, const int64_
 }
 
 int mmae_masked_ce_pat_bwd(const float* pat, const int64_t* target, const int64_t* mask, int B, int C, int H, int W, int patch,
-                           const float* lse_pat, const float* per_sample, const float* loss, const float* upstream, void* d_pat,
-                           int d_pat_dtype, int64_t ld_pat, void* stream) {
+                           float label_smoothing, const float* lse_pat, const float* per_sample, const float* loss, const float* upstream,
+                           void* d_pat, int d_pat_dtype, int64_t ld_pat, void* stream) {
     MMAE_REQUIRE(pat && target && mask && lse_pat && per_sample && loss && upstream && d_pat, "ce_pat_bwd: null pointer");
     MMAE_REQUIRE(patch > 0 && H % patch == 0 && W % patch == 0 && ld_pat >= (int64_t)C * patch * patch, "ce_pat_bwd: bad geometry");
     const int npix = patch * patch;
@@ -580,10 +587,10 @@ int mmae_masked_ce_pat_bwd(const float* pat, const int64_t* target, const int64_
     const dim3 grid((unsigned)((rows + 3) / 4));
     if (d_pat_dtype == MMAE_BF16)
         hipLaunchKernelGGL((ce_pat_bwd_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, pat, (const long long*)target, (const long long*)mask,
-                           C, H, W, patch, lse_pat, per_sample, loss, upstream, (uint16_t*)d_pat, (long long)ld_pat, rows);
+                           C, H, W, patch, label_smoothing, lse_pat, per_sample, loss, upstream, (uint16_t*)d_pat, (long long)ld_pat, rows);
     else
         hipLaunchKernelGGL((ce_pat_bwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, pat, (const long long*)target, (const long long*)mask,
-                           C, H, W, patch, lse_pat, per_sample, loss, upstream, (float*)d_pat, (long long)ld_pat, rows);
+                           C, H, W, patch, label_smoothing, lse_pat, per_sample, loss, upstream, (float*)d_pat, (long long)ld_pat, rows);
     return mmae_check_launch("ce_pat_bwd");
 }
 

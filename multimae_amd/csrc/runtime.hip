@@ -27,6 +27,32 @@ int mmae_gemm_f32x3_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t
 int mmae_splitk_reduce(const float* ws, float* C, int M, int N, long long ldc, int splits, int accumulate, hipStream_t st);
 int mmae_acs_reduce(const float* part, int splits, int M, float* out, int accumulate, hipStream_t st);
 
+// ---- optional launch timing (mmae_gemm_timing_*) ----------------------------------------------------------------------
+#include <mutex>
+#include <vector>
+namespace {
+struct TimedLaunch { hipEvent_t a, b; double flop; int cls; };
+std::mutex g_tmu;
+bool g_timing = false;
+std::vector<TimedLaunch> g_timed;
+}  // namespace
+
+hipEvent_t mmae_timing_begin(hipStream_t st) {
+    if (!g_timing) return nullptr;
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    (void)hipEventRecord(e, st);
+    return e;
+}
+void mmae_timing_end(hipEvent_t a, hipStream_t st, double flop, int cls) {
+    if (!a) return;
+    hipEvent_t b = nullptr;
+    if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return; }
+    (void)hipEventRecord(b, st);
+    std::lock_guard<std::mutex> lk(g_tmu);
+    g_timed.push_back({a, b, flop, cls});
+}
+
 namespace {
 
 bool split_eligible(const mmae_gemm_desc* d) {
@@ -138,6 +164,11 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     g.vec = vec ? 1 : 0;
     MMAE_REQUIRE(!d->colsum_part || (vec && ((uintptr_t)d->colsum_part % 16 == 0)), "gemm: colsum_part needs 4-element aligned C/aux");
     hipStream_t st = (hipStream_t)stream;
+    hipEvent_t t_ev = mmae_timing_begin(st);
+    struct TimingGuard {            // the bracket closes on every return path
+        hipEvent_t a; hipStream_t st; double flop; int cls;
+        ~TimingGuard() { mmae_timing_end(a, st, flop, cls); }
+    } t_guard{t_ev, st, 2.0 * d->M * d->N * d->K * d->batch, d->ab_dtype == MMAE_BF16 ? 0 : 1};
     // split-K: the dW-type products (small M x N, K = all rows of the batch) would otherwise occupy
     // a handful of the 256 CUs.  Each K slice writes a dense f32 partial slab into the caller's
     // workspace; a second launch sums the slabs into C in a fixed order (deterministic).
@@ -173,6 +204,27 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     }
     if (g.splitk <= 1) return 0;
     return mmae_splitk_reduce(g.ws, (float*)d->C, d->M, d->N, d->ldc, g.splitk, d->accumulate, st);
+}
+
+int mmae_gemm_timing_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_tmu);
+    for (auto& t : g_timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    g_timed.clear();
+    g_timing = on != 0;
+    return 0;
+}
+
+int mmae_gemm_timing_read(double* ms2, double* flop2, int64_t* calls2) {
+    MMAE_REQUIRE(ms2 && flop2 && calls2, "gemm_timing_read: null pointer");
+    std::lock_guard<std::mutex> lk(g_tmu);
+    for (int c = 0; c < 2; ++c) { ms2[c] = 0.0; flop2[c] = 0.0; calls2[c] = 0; }
+    for (auto& t : g_timed) {
+        if (hipEventSynchronize(t.b) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) != hipSuccess) continue;
+        ms2[t.cls] += ms; flop2[t.cls] += t.flop; calls2[t.cls] += 1;
+    }
+    return 0;
 }
 
 int mmae_gemm_plan(const mmae_gemm_desc* d, int* tile, int* split_k) {

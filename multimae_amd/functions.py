@@ -875,10 +875,10 @@ class MaskedPixelLossFn(torch.autograd.Function):
 
 
 class MaskedCEFn(torch.autograd.Function):
-    """MaskedCrossEntropyLoss (criterion.py:37-57), label_smoothing = 0."""
+    """MaskedCrossEntropyLoss (criterion.py:37-57)."""
 
     @staticmethod
-    def forward(ctx, logits: Tensor, target: Tensor, mask: Tensor, patch: int):
+    def forward(ctx, logits: Tensor, target: Tensor, mask: Tensor, patch: int, smooth: float = 0.0):
         from . import _lib
         ops._require_gpu(logits, 'loss input')
         logits = logits.contiguous().float()
@@ -887,10 +887,10 @@ class MaskedCEFn(torch.autograd.Function):
         B, C, H, W = logits.shape
         partial, per_sample, loss = _loss_bufs(B, logits.device)
         lse = torch.empty((B, H, W), device=logits.device, dtype=torch.float32)
-        ops.check(_lib.load().mmae_masked_ce_fwd(logits.data_ptr(), target.data_ptr(), mask.data_ptr(), B, C, H, W, patch, lse.data_ptr(),
+        ops.check(_lib.load().mmae_masked_ce_fwd(logits.data_ptr(), target.data_ptr(), mask.data_ptr(), B, C, H, W, patch, float(smooth), lse.data_ptr(),
                                                  partial.data_ptr(), per_sample.data_ptr(), loss.data_ptr(), ops._stream()), 'masked_ce_fwd')
         ctx.saved = (logits, target, mask, lse, per_sample, loss, (logits._version, target._version, mask._version))
-        ctx.patch = patch
+        ctx.patch, ctx.smooth = patch, float(smooth)
         return loss[0].clone()
 
     @staticmethod
@@ -903,10 +903,10 @@ class MaskedCEFn(torch.autograd.Function):
         B, C, H, W = logits.shape
         d = torch.empty_like(logits)
         up = g.contiguous().float().reshape(1)
-        ops.check(_lib.load().mmae_masked_ce_bwd(logits.data_ptr(), target.data_ptr(), mask.data_ptr(), B, C, H, W, ctx.patch,
+        ops.check(_lib.load().mmae_masked_ce_bwd(logits.data_ptr(), target.data_ptr(), mask.data_ptr(), B, C, H, W, ctx.patch, ctx.smooth,
                                                  lse.data_ptr(), per_sample.data_ptr(), loss.data_ptr(), up.data_ptr(), d.data_ptr(),
                                                  ops._stream()), 'masked_ce_bwd')
-        return d, None, None, None
+        return d, None, None, None, None
 
 
 class MaskedPixelLossPatFn(torch.autograd.Function):
@@ -948,10 +948,10 @@ class MaskedPixelLossPatFn(torch.autograd.Function):
 
 
 class MaskedCEPatFn(torch.autograd.Function):
-    """MaskedCrossEntropyLoss on an output adapter's patch rows (label_smoothing = 0)."""
+    """MaskedCrossEntropyLoss on an output adapter's patch rows."""
 
     @staticmethod
-    def forward(ctx, token: Tensor, h: PatHandle, target: Tensor, mask: Tensor, patch: int):
+    def forward(ctx, token: Tensor, h: PatHandle, target: Tensor, mask: Tensor, patch: int, smooth: float = 0.0):
         from . import _lib
         pat = h.pat
         target = target.contiguous().long()
@@ -959,10 +959,10 @@ class MaskedCEPatFn(torch.autograd.Function):
         B, C, H, W = target.shape[0], h.C, h.nh * h.ph, h.nw * h.pw
         partial, per_sample, loss = _loss_bufs(B, pat.device)
         lse = torch.empty((pat.shape[0], patch * patch), device=pat.device, dtype=torch.float32)
-        ops.check(_lib.load().mmae_masked_ce_pat_fwd(pat.data_ptr(), target.data_ptr(), mask.data_ptr(), B, C, H, W, patch, lse.data_ptr(),
+        ops.check(_lib.load().mmae_masked_ce_pat_fwd(pat.data_ptr(), target.data_ptr(), mask.data_ptr(), B, C, H, W, patch, float(smooth), lse.data_ptr(),
                                                      partial.data_ptr(), per_sample.data_ptr(), loss.data_ptr(), ops._stream()), 'masked_ce_pat_fwd')
         ctx.saved = (h, target, mask, lse, per_sample, loss, (target._version, mask._version))
-        ctx.args = (patch, B, C, H, W)
+        ctx.args = (patch, B, C, H, W, float(smooth))
         return loss[0].clone()
 
     @staticmethod
@@ -970,13 +970,13 @@ class MaskedCEPatFn(torch.autograd.Function):
         from . import _lib
         h, target, mask, lse, per_sample, loss, versions = ctx.saved
         ctx.saved = None
-        patch, B, C, H, W = ctx.args
+        patch, B, C, H, W, smooth = ctx.args
         if (target._version, mask._version) != versions:
             raise RuntimeError('a tensor saved for the masked-loss backward was modified in place')
         d_pat = torch.empty((h.pat.shape[0], h.ld()), device=h.pat.device, dtype=h.act)
         up = g.contiguous().float().reshape(1)
-        ops.check(_lib.load().mmae_masked_ce_pat_bwd(h.pat.data_ptr(), target.data_ptr(), mask.data_ptr(), B, C, H, W, patch, lse.data_ptr(),
+        ops.check(_lib.load().mmae_masked_ce_pat_bwd(h.pat.data_ptr(), target.data_ptr(), mask.data_ptr(), B, C, H, W, patch, smooth, lse.data_ptr(),
                                                      per_sample.data_ptr(), loss.data_ptr(), up.data_ptr(), d_pat.data_ptr(), ops.dcode(h.act),
                                                      d_pat.stride(0), ops._stream()), 'masked_ce_pat_bwd')
         h.d_pat = d_pat if h.d_pat is None else h.d_pat.add_(d_pat)
-        return up.new_empty(1), None, None, None, None
+        return up.new_empty(1), None, None, None, None, None

@@ -381,11 +381,15 @@ def masked_l1(pred: Tensor, target: Tensor, mask: Optional[Tensor], patch_size: 
     return _masked_reduce(err.mean(1), mask, scale)
 
 
-def masked_ce(logits: Tensor, target: Tensor, mask: Optional[Tensor], patch_size: int, stride: int = 1) -> Tensor:
-    """MaskedCrossEntropyLoss.forward, criterion.py:37-57 (label_smoothing = 0)."""
+def masked_ce(logits: Tensor, target: Tensor, mask: Optional[Tensor], patch_size: int, stride: int = 1,
+              label_smoothing: float = 0.0) -> Tensor:
+    """MaskedCrossEntropyLoss.forward, criterion.py:37-57.  label_smoothing as F.cross_entropy defines it (:47):
+    (1 - eps) * nll(target) + eps * mean over the C classes of -log_softmax."""
     scale = patch_size // stride
     lse = torch.logsumexp(logits, dim=1)
     nll = lse - torch.gather(logits, 1, target[:, None]).squeeze(1)
+    if label_smoothing:
+        nll = (1.0 - label_smoothing) * nll + label_smoothing * (lse - logits.mean(dim=1))
     return _masked_reduce(nll, mask, scale)
 
 

@@ -615,3 +615,34 @@ def test_pingpong_dgelu_colsum_epilogue(tile, M):
     assert part.shape[0] == (M + 31) // 32 and not torch.isnan(part).any()
     ref_blocks = torch.stack([p.grad[i:i + 32].sum(0) for i in range(0, M, 32)])
     assert rel_err(part.cpu(), ref_blocks) < 1e-4
+
+
+@pytest.mark.parametrize('domain', ['image', 'patch'])
+@pytest.mark.parametrize('eps', [0.1, 0.3])
+def test_masked_cross_entropy_label_smoothing(eps, domain):
+    """label_smoothing > 0 (criterion.py:47, F.cross_entropy semantics) in the image-domain and the patch-domain CE kernels
+    against the oracle (whose formula is checked against F.cross_entropy on the CPU side)."""
+    import multimae_amd as M
+    from multimae_amd import ops
+    from multimae_amd.functions import MaskedCEPatFn, PatHandle
+    torch.manual_seed(9)
+    B, C, S, P = 3, 133, 16, 4
+    logits, tgt = torch.randn(B, C, S, S) * 2, torch.randint(0, C, (B, S, S))
+    mask = (torch.rand(B, 16) < 0.6).long()
+    lr = logits.clone().requires_grad_(True)
+    ref = orc.masked_ce(lr, tgt, mask, 16, 4, label_smoothing=eps)
+    ref.backward()
+    if domain == 'image':
+        ld = logits.to(DEV).requires_grad_(True)
+        out = M.MaskedCrossEntropyLoss(16, 4, label_smoothing=eps)(ld, tgt.to(DEV), mask=mask.to(DEV))
+        out.backward()
+        got = ld.grad
+    else:
+        pat = ops.patchify(logits.to(DEV), C, 4, 4, P, P, torch.float32).contiguous()
+        h = PatHandle(pat, C, 4, 4, P, P, torch.float32)
+        h.token = torch.zeros(1, device=DEV, requires_grad=True)
+        out = MaskedCEPatFn.apply(h.token, h, tgt.to(DEV), mask.to(DEV), P, eps)
+        out.backward()
+        got = ops.unpatchify(h.d_pat[:, :C * P * P].contiguous(), B, C, 4, 4, P, P)
+    assert abs(float(out) - float(ref)) < 5e-6
+    assert rel_err(got, lr.grad) < 1e-5

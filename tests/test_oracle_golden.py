@@ -222,3 +222,15 @@ def test_oracle_curve_matches_reference_curve_cfg1():
         assert abs(float(lo.detach()) - gold[step - 1]) < 2e-5, (step, float(lo.detach()), gold[step - 1])
         with torch.no_grad():
             orc.adamw_step({n: sd[n] for n in names}, {n: sdo[n].grad for n in names}, mo, vo, step, 1.5e-4, 0.05)
+
+
+def test_oracle_label_smoothing_is_torch_cross_entropy():
+    """oracle.masked_ce(label_smoothing=eps) per pixel == F.cross_entropy(..., label_smoothing=eps) (what criterion.py:47 calls)."""
+    import torch.nn.functional as F
+    torch.manual_seed(2)
+    logits, tgt = torch.randn(2, 11, 8, 8), torch.randint(0, 11, (2, 8, 8))
+    for eps in (0.0, 0.1, 0.35):
+        ref = F.cross_entropy(logits, tgt, reduction='none', label_smoothing=eps)
+        # all-ones mask: masked mean over every pixel, then mean over samples
+        got = orc.masked_ce(logits, tgt, torch.ones(2, 4, dtype=torch.long), 4, 1, label_smoothing=eps)
+        assert abs(float(got) - float(ref.mean(dim=(1, 2)).mean())) < 1e-6
