@@ -17,7 +17,7 @@ from typing import Dict, List, Tuple
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_PKG), 'include', 'mmae.h')
-LIB_PATH = os.path.join(_PKG, 'libmmae_hip.so')
+LIB_PATH = os.environ.get('MMAE_LIB') or os.path.join(_PKG, 'libmmae_hip.so')      # MMAE_LIB: an alternative build of the same ABI (A/B experiments)
 
 F32, BF16, F32X3 = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2

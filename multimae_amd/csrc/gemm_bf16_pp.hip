@@ -21,6 +21,7 @@ struct DwGroupArgs {
     DwProblem p[8];
 };
 
+template <bool KF>
 __global__ void __launch_bounds__(512) gemm_bf16_pp_dwgroup_kernel(const DwGroupArgs ga) {
     // XCD-aware order (workgroup b runs on XCD b % 8): every XCD takes a contiguous range of the concatenated tile lists, so the
     // tiles resident on one XCD share dY / X column panels in its L2 instead of every XCD streaming every panel
@@ -50,7 +51,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_dwgroup_kernel(const DwGroup
     g.colpart = nullptr;
     g.wide_st = 0;
     g.dbg = 0;
-    pp_body<4, true, true>(g, local, 1 << 30);
+    pp_body<4, true, true, 0, KF>(g, local, 1 << 30);
 }
 
 }  // namespace
@@ -187,13 +188,20 @@ extern "C" int mmae_gemm_dw_group(const mmae_dw_group_desc* d, void* stream) {
     const size_t lds = (size_t)4 * (256 + 256) * 64 + 1024;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_dwgroup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_dwgroup_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_dwgroup_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
+#ifdef MMAE_NO_KF
+    static const int env_kf = 0;
+#else
+    static const int env_kf = getenv("MMAE_PP_KF") ? atoi(getenv("MMAE_PP_KF")) : 1;
+#endif
     double flop = 0.0;
     for (int i = 0; i < d->n; ++i) flop += 2.0 * d->rows * d->p[i].n_out * d->p[i].k_in;
     hipEvent_t t_ev = mmae_timing_begin(st);
-    hipLaunchKernelGGL(gemm_bf16_pp_dwgroup_kernel, dim3(tb, 1, s), dim3(512), lds, st, ga);
+    if (env_kf && (d->rows & 31) == 0) hipLaunchKernelGGL(gemm_bf16_pp_dwgroup_kernel<true>, dim3(tb, 1, s), dim3(512), lds, st, ga);
+    else hipLaunchKernelGGL(gemm_bf16_pp_dwgroup_kernel<false>, dim3(tb, 1, s), dim3(512), lds, st, ga);
     int rc = mmae_check_launch("gemm_bf16_pp_dwgroup");
     if (rc) { mmae_timing_end(t_ev, st, flop, 0); return rc; }
     long long nb = (b4 + 255) / 256;

@@ -4,42 +4,49 @@
 // and the caller launches the generic kernel.
 #include "gemm_pp_body.h"
 
+// -DMMAE_NO_KF builds the same flavours on the general address walk (A/B library: make NOKF=1, MMAE_LIB=...)
+#ifdef MMAE_NO_KF
+constexpr bool KFV = false;
+#else
+constexpr bool KFV = true;
+#endif
+
 int mmae_gemm_bf16_pp_fl_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, int fl, hipStream_t st) {
     const bool bks = d->b_trans != 0;
     const bool t10 = code == 10;
-    if (d->a_trans) return MMAE_ESUPPORT;
+    if (d->a_trans || (KFV && (g.K & 31))) return MMAE_ESUPPORT;       // these instantiations carry the K % 32 == 0 address walk (KF)
     if (!bks) {                                   // forward products: A [M][K], W [N][K]
         if (t10) {
             switch (fl) {
-                case FL_BF16_BIAS: return launch<5, false, false, FL_BF16_BIAS>(g, d->batch, st);
-                case FL_BF16_BIAS_GELU: return launch<5, false, false, FL_BF16_BIAS_GELU>(g, d->batch, st);
-                case FL_F32_BIAS_RESID: return launch<5, false, false, FL_F32_BIAS_RESID>(g, d->batch, st);
-                case FL_F32_BIAS: return launch<5, false, false, FL_F32_BIAS>(g, d->batch, st);
+                case FL_BF16_BIAS: return launch<5, false, false, FL_BF16_BIAS, KFV>(g, d->batch, st);
+                case FL_BF16_BIAS_GELU: return launch<5, false, false, FL_BF16_BIAS_GELU, KFV>(g, d->batch, st);
+                case FL_F32_BIAS_RESID: return launch<5, false, false, FL_F32_BIAS_RESID, KFV>(g, d->batch, st);
+                case FL_F32_BIAS: return launch<5, false, false, FL_F32_BIAS, KFV>(g, d->batch, st);
                 default: return MMAE_ESUPPORT;
             }
         }
         switch (fl) {
-            case FL_BF16_BIAS: return launch<4, false, false, FL_BF16_BIAS>(g, d->batch, st);
-            case FL_BF16_BIAS_GELU: return launch<4, false, false, FL_BF16_BIAS_GELU>(g, d->batch, st);
-            case FL_F32_BIAS_RESID: return launch<4, false, false, FL_F32_BIAS_RESID>(g, d->batch, st);
-            case FL_F32_BIAS: return launch<4, false, false, FL_F32_BIAS>(g, d->batch, st);
+            case FL_BF16_BIAS: return launch<4, false, false, FL_BF16_BIAS, KFV>(g, d->batch, st);
+            case FL_BF16_BIAS_GELU: return launch<4, false, false, FL_BF16_BIAS_GELU, KFV>(g, d->batch, st);
+            case FL_F32_BIAS_RESID: return launch<4, false, false, FL_F32_BIAS_RESID, KFV>(g, d->batch, st);
+            case FL_F32_BIAS: return launch<4, false, false, FL_F32_BIAS, KFV>(g, d->batch, st);
             default: return MMAE_ESUPPORT;
         }
     }
     if (t10) {                                    // dX products: dY [M][N], W [N][K] read through the transposing LDS path
         switch (fl) {
-            case FL_BF16: return launch<5, false, true, FL_BF16>(g, d->batch, st);
-            case FL_BF16_DGELU_CS: return launch<5, false, true, FL_BF16_DGELU_CS>(g, d->batch, st);
-            case FL_BF16_DGELU: return launch<5, false, true, FL_BF16_DGELU>(g, d->batch, st);
-            case FL_F32: return launch<5, false, true, FL_F32>(g, d->batch, st);
+            case FL_BF16: return launch<5, false, true, FL_BF16, KFV>(g, d->batch, st);
+            case FL_BF16_DGELU_CS: return launch<5, false, true, FL_BF16_DGELU_CS, KFV>(g, d->batch, st);
+            case FL_BF16_DGELU: return launch<5, false, true, FL_BF16_DGELU, KFV>(g, d->batch, st);
+            case FL_F32: return launch<5, false, true, FL_F32, KFV>(g, d->batch, st);
             default: return MMAE_ESUPPORT;
         }
     }
     switch (fl) {
-        case FL_BF16: return launch<4, false, true, FL_BF16>(g, d->batch, st);
-        case FL_BF16_DGELU_CS: return launch<4, false, true, FL_BF16_DGELU_CS>(g, d->batch, st);
-        case FL_BF16_DGELU: return launch<4, false, true, FL_BF16_DGELU>(g, d->batch, st);
-        case FL_F32: return launch<4, false, true, FL_F32>(g, d->batch, st);
+        case FL_BF16: return launch<4, false, true, FL_BF16, KFV>(g, d->batch, st);
+        case FL_BF16_DGELU_CS: return launch<4, false, true, FL_BF16_DGELU_CS, KFV>(g, d->batch, st);
+        case FL_BF16_DGELU: return launch<4, false, true, FL_BF16_DGELU, KFV>(g, d->batch, st);
+        case FL_F32: return launch<4, false, true, FL_F32, KFV>(g, d->batch, st);
         default: return MMAE_ESUPPORT;
     }
 }

@@ -64,7 +64,11 @@ __device__ __forceinline__ void wg_barrier() {
 
 // v0 / vstep: first output tile of this workgroup and the stride of its walk over the tile list (the plain kernel: its block
 // index and grid size; the grouped weight-gradient kernel: one tile per workgroup).  blockIdx.y = batch slice, blockIdx.z = K slice.
-template <int TM, bool AKS, bool BKS, int FL = 0>
+// KF: K is a multiple of the 32-wide K tile (every ViT product): the DMA pieces then walk running byte offsets -- one v_or
+// (out-of-range mask of the prefetch overrun past the K slice) and one add per piece and K tile instead of the compare / select
+// chains of the general path.  The memory half-phase, not the MFMA half-phase, paces the loop (MFMA pipe 46 % busy at 2.08 GHz on
+// the best product, profiles/r02_pmc_mfma.txt), so every instruction taken out of it counts.
+template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false>
 __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const int vstep) {
     constexpr int WMR = TM * 32;                         // output rows per wave
     constexpr int BM = 2 * WMR, BN = 256, NW = 8;
@@ -94,7 +98,14 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
 
     // lane p of DMA piece s fills LDS slot p of that 1-KiB segment: find the chunk living there.
     // Persistent workgroups: v walks the tile list from v0 in steps of vstep; set_tile() re-targets the DMA offsets.
+    const int nkt_all = (g.K + BK - 1) / BK;
+    const int kt_begin = blockIdx.z * g.kt_per_split;
+    const int kt_end = (kt_begin + g.kt_per_split < nkt_all) ? kt_begin + g.kt_per_split : nkt_all;
+    const int T = kt_end - kt_begin;
+    const unsigned a_step = AKS ? (unsigned)(g.lda * BK * 2) : (unsigned)(BK * 2);
+    const unsigned b_step = BKS ? (unsigned)(g.ldb * BK * 2) : (unsigned)(BK * 2);
     unsigned a_off[LA], b_off[LB];
+    unsigned a_cur[LA], b_cur[LB];                       // KF: byte offset each piece fetches next (invalid rows keep the out-of-range bit)
     int a_kq[LA], b_kq[LB];
     int m0 = 0, n0 = 0;
     auto set_tile = [&](int v, int& tm0, int& tn0) {
@@ -116,6 +127,7 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
                 a_kq[i] = krow;
                 a_off[i] = (seg < PA && tm0 + ch * 8 < g.M) ? (unsigned)((((long long)krow) * g.lda + tm0 + ch * 8) * 2) : OOB;
             }
+            if (KF) a_cur[i] = a_off[i] == OOB ? OOB : a_off[i] + (unsigned)kt_begin * a_step;
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
@@ -131,29 +143,36 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
                 b_kq[i] = krow;
                 b_off[i] = (tn0 + ch * 8 < g.N) ? (unsigned)((((long long)krow) * g.ldb + tn0 + ch * 8) * 2) : OOB;
             }
+            if (KF) b_cur[i] = b_off[i] == OOB ? OOB : b_off[i] + (unsigned)kt_begin * b_step;
         }
     };
     set_tile(v0, m0, n0);
-    const unsigned a_step = AKS ? (unsigned)(g.lda * BK * 2) : (unsigned)(BK * 2);
-    const unsigned b_step = BKS ? (unsigned)(g.ldb * BK * 2) : (unsigned)(BK * 2);
 
-    const int nkt_all = (g.K + BK - 1) / BK;
-    const int kt_begin = blockIdx.z * g.kt_per_split;
-    const int kt_end = (kt_begin + g.kt_per_split < nkt_all) ? kt_begin + g.kt_per_split : nkt_all;
-    const int T = kt_end - kt_begin;
 
     // Every call issues the same number of DMA instructions (the vmcnt arithmetic depends on it): tiles past the end of
     // this K slice and the padding pieces load from the out-of-range sentinel (zeros, no memory traffic).
     auto dma_a = [&](int u, int i) {                     // u = K tile relative to kt_begin
         const int kt = kt_begin + u;
-        const bool ok = (a_off[i] != OOB) & (kt < kt_end) & (kt * BK + a_kq[i] < g.K);
         char* dst = (i * NW + wave < PA) ? smem + (u & (NST - 1)) * STAGE + (i * NW + wave) * 1024 : smem + DUMP;
+        if (KF) {                                        // pieces are issued once per K tile, in tile order: a running offset suffices
+            const unsigned tail = kt < kt_end ? 0u : OOB;                    // wave-uniform
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)dst, 16, (int)(a_cur[i] | tail), 0, 0, 0);
+            a_cur[i] += a_step;
+            return;
+        }
+        const bool ok = (a_off[i] != OOB) & (kt < kt_end) & (kt * BK + a_kq[i] < g.K);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)dst, 16, (int)(ok ? a_off[i] + (unsigned)kt * a_step : OOB), 0, 0, 0);
     };
     auto dma_b = [&](int u, int i) {
         const int kt = kt_begin + u;
-        const bool ok = (b_off[i] != OOB) & (kt < kt_end) & (kt * BK + b_kq[i] < g.K);
         char* dst = smem + (u & (NST - 1)) * STAGE + A_BYTES + (i * NW + wave) * 1024;
+        if (KF) {
+            const unsigned tail = kt < kt_end ? 0u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)dst, 16, (int)(b_cur[i] | tail), 0, 0, 0);
+            b_cur[i] += b_step;
+            return;
+        }
+        const bool ok = (b_off[i] != OOB) & (kt < kt_end) & (kt * BK + b_kq[i] < g.K);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)dst, 16, (int)(ok ? b_off[i] + (unsigned)kt * b_step : OOB), 0, 0, 0);
     };
     auto dma_first = [&](int u) { dma_a(u, 0); dma_a(u, 1); };                                  // 2 pieces
@@ -303,12 +322,12 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
     }
 }
 
-template <int TM, bool AKS, bool BKS, int FL = 0>
+template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false>
 __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
-    pp_body<TM, AKS, BKS, FL>(g, blockIdx.x, gridDim.x);
+    pp_body<TM, AKS, BKS, FL, KF>(g, blockIdx.x, gridDim.x);
 }
 
-template <int TM, bool AKS, bool BKS, int FL = 0>
+template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false>
 int launch(const GemmArgs& g, int batch, hipStream_t st) {
     constexpr int BM = TM * 64, BN = 256;
     const int tiles_m = (g.M + BM - 1) / BM;
@@ -323,10 +342,10 @@ int launch(const GemmArgs& g, int batch, hipStream_t st) {
     const size_t lds = (size_t)4 * (BM + BN) * 64 + 1024;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<TM, AKS, BKS, FL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<TM, AKS, BKS, FL, KF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_pp_kernel<TM, AKS, BKS, FL>), grid, block, lds, st, a);
+    hipLaunchKernelGGL((gemm_bf16_pp_kernel<TM, AKS, BKS, FL, KF>), grid, block, lds, st, a);
     return mmae_check_launch("gemm_bf16_pp");
 }
 

@@ -1,0 +1,24 @@
+#!/bin/bash
+# GPU visit I: running-offset address walk (KF) A/B against the same build without it (libmmae_hip_nokf.so), + GEMM tests + chunked stack bwd test.
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+R=$PWD
+: > gpurun_out/summary.txt
+timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py tests/test_parity_geometry_gpu.py -m gpu -q -p no:cacheprovider 2>&1 | tail -6 >> gpurun_out/summary.txt
+B="python bench.py --no-cpu-baseline --no-kernel-timing --steps 20 --warmup 5"
+run() { label=$1; shift; ( env "$@" > gpurun_out/x.log 2> gpurun_out/x.err ); echo "$label: $(grep 'timed region' gpurun_out/x.err | sed 's/.*done: //' | cut -c1-60)" >> gpurun_out/summary.txt; }
+for v in "KF=1" "MMAE_LIB=$R/multimae_amd/libmmae_hip_nokf.so" "KF=1" "MMAE_LIB=$R/multimae_amd/libmmae_hip_nokf.so"; do
+  run "$v default-streams" $v timeout 300 $B
+  run "$v serialized" $v timeout 300 $B --adapter-streams 0 --wgrad-stream 0
+done
+for v in "KF=1" "MMAE_LIB=$R/multimae_amd/libmmae_hip_nokf.so"; do
+  rm -rf gpurun_out/encg
+  (cd /tmp && env $v timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/encg -o p --output-format csv -- python $R/tools/encoder_gemms.py > $R/gpurun_out/encg.log 2>&1)
+  echo "== encoder_gemms $v" >> gpurun_out/summary.txt
+  python tools/encoder_gemms.py --parse gpurun_out/encg >> gpurun_out/summary.txt 2>&1
+done
+rm -rf gpurun_out/encg
+echo "== encoder step KF / noKF" >> gpurun_out/summary.txt
+timeout 300 python tools/encoder_step.py >> gpurun_out/summary.txt 2> gpurun_out/encoder_step.err
+MMAE_LIB=$R/multimae_amd/libmmae_hip_nokf.so timeout 300 python tools/encoder_step.py >> gpurun_out/summary.txt 2>> gpurun_out/encoder_step.err
+cat gpurun_out/summary.txt
