@@ -44,6 +44,7 @@ __device__ __forceinline__ int ks_off(int krow, int chunk) {
 
 template <int N> __device__ __forceinline__ void wait_vm();
 template <> __device__ __forceinline__ void wait_vm<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vm<5>() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vm<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vm<7>() { asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
 
@@ -68,7 +69,10 @@ __device__ __forceinline__ void wg_barrier() {
 // (out-of-range mask of the prefetch overrun past the K slice) and one add per piece and K tile instead of the compare / select
 // chains of the general path.  The memory half-phase, not the MFMA half-phase, paces the loop (MFMA pipe 46 % busy at 2.08 GHz on
 // the best product, profiles/r02_pmc_mfma.txt), so every instruction taken out of it counts.
-template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false>
+// UNR: the K loop unrolled over the NST ring slots (slot-dependent LDS addresses and M0 values become immediates: 29 fewer
+// instructions per K tile in the memory half-phases); off where the extra address registers would spill (generic flavours,
+// 320-row k-strided B).
+template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false, bool UNR = false>
 __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const int vstep) {
     constexpr int WMR = TM * 32;                         // output rows per wave
     constexpr int BM = 2 * WMR, BN = 256, NW = 8;
@@ -151,9 +155,11 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
 
     // Every call issues the same number of DMA instructions (the vmcnt arithmetic depends on it): tiles past the end of
     // this K slice and the padding pieces load from the out-of-range sentinel (zeros, no memory traffic).
-    auto dma_a = [&](int u, int i) {                     // u = K tile relative to kt_begin
+    // slot: ring slot of K tile u (= u mod NST) -- passed as a compile-time constant by the 4x-unrolled K loop so that LDS
+    // addresses and M0 values are immediates instead of per-phase scalar arithmetic
+    auto dma_a = [&](int u, int i, int slot) {           // u = K tile relative to kt_begin
         const int kt = kt_begin + u;
-        char* dst = (i * NW + wave < PA) ? smem + (u & (NST - 1)) * STAGE + (i * NW + wave) * 1024 : smem + DUMP;
+        char* dst = (i * NW + wave < PA) ? smem + slot * STAGE + (i * NW + wave) * 1024 : smem + DUMP;
         if (KF) {                                        // pieces are issued once per K tile, in tile order: a running offset suffices
             const unsigned tail = kt < kt_end ? 0u : OOB;                    // wave-uniform
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)dst, 16, (int)(a_cur[i] | tail), 0, 0, 0);
@@ -163,9 +169,9 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
         const bool ok = (a_off[i] != OOB) & (kt < kt_end) & (kt * BK + a_kq[i] < g.K);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)dst, 16, (int)(ok ? a_off[i] + (unsigned)kt * a_step : OOB), 0, 0, 0);
     };
-    auto dma_b = [&](int u, int i) {
+    auto dma_b = [&](int u, int i, int slot) {
         const int kt = kt_begin + u;
-        char* dst = smem + (u & (NST - 1)) * STAGE + A_BYTES + (i * NW + wave) * 1024;
+        char* dst = smem + slot * STAGE + A_BYTES + (i * NW + wave) * 1024;
         if (KF) {
             const unsigned tail = kt < kt_end ? 0u : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)dst, 16, (int)(b_cur[i] | tail), 0, 0, 0);
@@ -175,8 +181,12 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
         const bool ok = (b_off[i] != OOB) & (kt < kt_end) & (kt * BK + b_kq[i] < g.K);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)dst, 16, (int)(ok ? b_off[i] + (unsigned)kt * b_step : OOB), 0, 0, 0);
     };
-    auto dma_first = [&](int u) { dma_a(u, 0); dma_a(u, 1); };                                  // 2 pieces
-    auto dma_second = [&](int u) { dma_b(u, 0); dma_b(u, 1); if (LA == 3) dma_a(u, 2); };       // LA + LB - 2 pieces
+    auto dma_first = [&](int u, int slot) { dma_a(u, 0, slot); dma_a(u, 1, slot); };                                  // 2 pieces
+    // third A piece (320-row tiles: 20 pieces for 8 waves): only the waves that own a real one issue it -- a padding piece costs
+    // its wave a full LDS-DMA issue slot (60-180 cycles) per K tile for nothing; their counted waits are one lower
+    const bool has3 = LA == 3 && 2 * NW + wave < PA;
+    auto dma_second = [&](int u, int slot) { dma_b(u, 0, slot); dma_b(u, 1, slot); if (LA == 3 && has3) dma_a(u, 2, slot); };  // LA + LB - 2 pieces
+    auto wait_tile = [&]() { if (LA == 3 && !has3) wait_vm<W - 1>(); else wait_vm<W>(); };
 
     f32x16 acc[2][TM];
 
@@ -202,14 +212,14 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
     // workgroups add up the A fragments they hold anyway (v_dot2c with a vector of ones, in the shadow of the MFMAs)
     bool do_acs = false;
     float acs[TM];
-    auto mem_phase = [&](int u, int kk) {
-        const char* sa = smem + (u & (NST - 1)) * STAGE;
+    auto mem_phase = [&](int u, int kk, int slot) {
+        const char* sa = smem + slot * STAGE;
         const char* sb = sa + A_BYTES;
 #pragma unroll
         for (int t = 0; t < 2; ++t) bf[t] = BKS ? frag_ks(sb, wn * 64 + t * 32, kk) : frag_kc(sb, wn * 64 + t * 32, kk);
 #pragma unroll
         for (int t = 0; t < TM; ++t) af[t] = AKS ? frag_ks(sa, wm * WMR + t * 32, kk) : frag_kc(sa, wm * WMR + t * 32, kk);
-        if (kk == 0) dma_second(u + 2); else dma_first(u + 3);
+        if (kk == 0) dma_second(u + 2, (slot + 2) & (NST - 1)); else dma_first(u + 3, (slot + 3) & (NST - 1));
     };
     // (Issuing all, or one, of the phase's DMA pieces between the MFMAs instead -- an LDS-DMA issue stalls its wave 60-180
     // cycles -- measured 0-10 % slower than keeping them in the memory half-phase.)
@@ -232,10 +242,10 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
     };
 
     // prologue of the first tile: K tiles 0, 1 and the first half of K tile 2
-    dma_first(0); dma_second(0);
-    dma_first(1); dma_second(1);
-    dma_first(2);
-    wait_vm<W>();                                        // K tile 0 has landed (this wave's share)
+    dma_first(0, 0); dma_second(0, 0);
+    dma_first(1, 1); dma_second(1, 1);
+    dma_first(2, 2);
+    wait_tile();                                        // K tile 0 has landed (this wave's share)
     wg_barrier();
 
     // epilogue staging lives in ring slots 2-3 so that slots 0-1 can already receive the NEXT output tile's first two K
@@ -255,27 +265,66 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
 #pragma unroll
         for (int t = 0; t < TM; ++t) acs[t] = 0.f;
 
-        if (wm == 0) {
+        if (UNR) {
+            // the K loop unrolled over the NST ring slots: slot = u mod NST is a constant in every copy of the body
+            if (wm == 0) {
+                for (int u0 = 0; u0 < T; u0 += NST) {
+#pragma unroll
+                    for (int j = 0; j < NST; ++j) {
+                        const int u = u0 + j;
+                        if (u < T) {
+                            mem_phase(u, 0, j);
+                            wg_barrier();
+                            mfma_phase();
+                            wg_barrier();
+                            mem_phase(u, 1, j);
+                            wg_barrier();
+                            mfma_phase();
+                            wait_tile();                    // K tile u + 1
+                            wg_barrier();
+                        }
+                    }
+                }
+            } else {
+                for (int u0 = 0; u0 < T; u0 += NST) {
+#pragma unroll
+                    for (int j = 0; j < NST; ++j) {
+                        const int u = u0 + j;
+                        if (u < T) {
+                            wg_barrier();
+                            mem_phase(u, 0, j);
+                            wg_barrier();
+                            mfma_phase();
+                            wg_barrier();
+                            mem_phase(u, 1, j);
+                            wait_tile();                    // K tile u + 1
+                            wg_barrier();
+                            mfma_phase();
+                        }
+                    }
+                }
+            }
+        } else if (wm == 0) {
             for (int u = 0; u < T; ++u) {
-                mem_phase(u, 0);
+                mem_phase(u, 0, u & (NST - 1));
                 wg_barrier();
                 mfma_phase();
                 wg_barrier();
-                mem_phase(u, 1);
+                mem_phase(u, 1, u & (NST - 1));
                 wg_barrier();
                 mfma_phase();
-                wait_vm<W>();                                // K tile u + 1
+                wait_tile();                                // K tile u + 1
                 wg_barrier();
             }
         } else {
             for (int u = 0; u < T; ++u) {
                 wg_barrier();
-                mem_phase(u, 0);
+                mem_phase(u, 0, u & (NST - 1));
                 wg_barrier();
                 mfma_phase();
                 wg_barrier();
-                mem_phase(u, 1);
-                wait_vm<W>();                                // K tile u + 1
+                mem_phase(u, 1, u & (NST - 1));
+                wait_tile();                                // K tile u + 1
                 wg_barrier();
                 mfma_phase();
             }
@@ -296,8 +345,8 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
         if (has_next) {                                      // next tile: K tiles 0, 1 -> slots 0, 1 (in flight during the epilogue)
             asm volatile("" : "+v"(lane));
             set_tile(v + vstep, m0, n0);
-            dma_first(0); dma_second(0);
-            dma_first(1); dma_second(1);
+            dma_first(0, 0); dma_second(0, 0);
+            dma_first(1, 1); dma_second(1, 1);
         }
         {
             f32x16 sub[2][2] = {{acc[0][0], acc[0][1]}, {acc[1][0], acc[1][1]}};
@@ -317,14 +366,15 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
             // slots 2-3 back to the DMA ring
             wait_vm<0>();
             __syncthreads();
-            dma_first(2);
+            dma_first(2, 2);
         }
     }
 }
 
 template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false>
 __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
-    pp_body<TM, AKS, BKS, FL, KF>(g, blockIdx.x, gridDim.x);
+    // unrolled wherever the flavoured instantiation has the registers for it (measured: no scratch)
+    pp_body<TM, AKS, BKS, FL, KF, (FL != 0 && KF && !(TM == 5 && BKS))>(g, blockIdx.x, gridDim.x);
 }
 
 template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false>
