@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_dwgroup_kernel(const DwGroup
     g.acs = pr.acs;
     g.colpart = nullptr;
     g.wide_st = 0;
-    g.dbg = 0;
+    g.dbg = 0; g.dephase = 0;
     pp_body<4, true, true, 0, KF, KF>(g, local, 1 << 30);
 }
 

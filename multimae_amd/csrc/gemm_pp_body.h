@@ -241,6 +241,9 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
         }
     };
 
+    if (g.dephase && (blockIdx.x & 1)) {                 // experiment: half of the CUs run out of phase with the other half
+        for (int i = 0; i < g.dephase; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     // prologue of the first tile: K tiles 0, 1 and the first half of K tile 2
     dma_first(0, 0); dma_second(0, 0);
     dma_first(1, 1); dma_second(1, 1);

@@ -152,6 +152,8 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     g.wide_st = env_wide;
     static const int env_dbg = getenv("MMAE_EPI_DBG") ? atoi(getenv("MMAE_EPI_DBG")) : 0;
     g.dbg = env_dbg;
+    static const int env_dephase = getenv("MMAE_PP_DEPHASE") ? atoi(getenv("MMAE_PP_DEPHASE")) : 0;
+    g.dephase = env_dephase;
     MMAE_REQUIRE(!d->colsum_part || (d->epi == MMAE_EPI_DGELU && !d->bias && !d->resid && !d->accumulate && d->batch == 1 && d->split_k <= 1 &&
                                      d->alpha == 1.0f && d->N % 4 == 0) ,
                  "gemm: colsum_part is only supported with the plain dGELU epilogue");
