@@ -27,12 +27,14 @@
 extern "C" {
 #endif
 
-#define MMAE_ABI_VERSION 2
+#define MMAE_ABI_VERSION 3
 
 #define MMAE_F32  0
 #define MMAE_BF16 1
 #define MMAE_F32X3 2   /* GEMM only: f32 operands in memory, multiplied as split bf16 (hi+lo) on the bf16 MFMA:
                         a.b ~= ah.bh + ah.bl + al.bh, fp32 accumulate (~16 operand mantissa bits, > TF32) */
+#define MMAE_MXFP8 4   /* GEMM only: OCP MX operands -- e4m3 elements [rows][K] plus one E8M0 scale per 32 consecutive K elements in the
+                          packed layout of mmae_mx_quant (a_scale / b_scale of the descriptor); block-scaled MFMA, fp32 accumulation */
 
 #define MMAE_EINVAL   (-1)   /* bad argument (shape / alignment / dtype)        */
 #define MMAE_ELAUNCH  (-2)   /* hipLaunchKernel reported an error               */
@@ -70,7 +72,7 @@ const char* mmae_last_error(void);
 
 typedef struct mmae_gemm_desc {
     const void* A; const void* B; void* C;
-    int32_t ab_dtype;            /* MMAE_F32 | MMAE_BF16 | MMAE_F32X3 */
+    int32_t ab_dtype;            /* MMAE_F32 | MMAE_BF16 | MMAE_F32X3 | MMAE_MXFP8 */
     int32_t c_dtype;             /* MMAE_F32 | MMAE_BF16 */
     int32_t M, N, K;
     int32_t a_trans, b_trans;
@@ -101,6 +103,11 @@ typedef struct mmae_gemm_desc {
                                     Only for bf16, a_trans = 1, batch = 1 products that mmae_gemm_plan maps to tile 9; needs
                                     max(split_k, 1) * M extra workspace floats after the split-K slabs. */
     int32_t a_colsum_acc;        /* a_colsum += (else =) */
+    const void* a_scale;         /* MMAE_MXFP8 only: packed E8M0 scales of A ([M] rows) and B ([N] rows) as mmae_mx_quant writes them. */
+    const void* b_scale;         /* Such a product needs a_trans = b_trans = 0 (both operands [rows][K], K contiguous: quantise the
+                                    transposed copy of a weight for its dX product, mmae_mx_quant_t), K % 256 == 0, batch = 1, no split_k,
+                                    and one of the epilogue combinations of the training step (bias -> bf16, bias + GELU, bias
+                                    [+ residual] -> f32, plain bf16 / f32, dGELU [+ colsum_part]); MMAE_ESUPPORT otherwise. */
 } mmae_gemm_desc;
 
 int mmae_gemm(const mmae_gemm_desc* d, void* stream);
@@ -110,6 +117,26 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream);
 int mmae_gemm_plan(const mmae_gemm_desc* d, int* tile, int* split_k);
 /* suggested number of K slices for a dW-shaped (both operands k-strided) [M,N,K] product (1 = do not split) */
 int mmae_gemm_auto_splitk(int M, int N, int K, int ab_dtype);
+
+/* ------------------------------------------------------------------------- *
+ * MX-fp8 operands (BASELINE.json configs[4], "fp8 MFMA path"; OCP Microscaling v1.0: e4m3 elements, one power-of-two E8M0
+ * scale per 32 consecutive elements along the contraction, shared exponent = floor(log2(max|x|)) - 8, elements rounded to
+ * nearest even and saturated at +-448).  The reference has no such path (it trains under fp16 autocast,
+ * run_pretraining_multimae.py:514-516); these entry points replace the casts autocast inserts in front of nn.Linear.
+ *   scales: uint32 S[ceil(cols/256)][rows][2]; byte j of S[g][r][h] = biased exponent of the block cols 256g + 64j + 32h .. +32
+ *           of row r (exponent 0 for blocks past the last column) -- the layout the 32x32x64 scaled MFMA consumes with one dword
+ *           load per lane and four K tiles (lane l < 32 supplies the scale of K 0-31 of row l, lane l + 32 that of K 32-63).  mmae_mx_scale_bytes(rows, cols) bytes.
+ *   mmae_mx_quant:   x [rows][cols] (f32 / bf16, row stride ldx) -> q [rows][cols] e4m3 (row stride ldq) + scales.  cols % 32 == 0.
+ *   mmae_mx_quant_t: w [n][k] -> q [k][n] e4m3 with the blocks along n (+ scales for k rows, n cols): the operand of the dX
+ *                    product dx[m][k] = sum_n dy[m][n] w[n][k].  n % 32 == 0.
+ *   mmae_probe_mx_mfma: one v_mfma_scale_f32_32x32x64_f8f6f4 on caller-supplied registers (8 operand dwords and one scale dword
+ *                    per lane, op_sel byte selectors) -- the test-suite pins the lane layout the kernels assume with it.
+ * ------------------------------------------------------------------------- */
+int64_t mmae_mx_scale_bytes(int rows, int cols);
+int mmae_mx_quant(const void* x, int x_dtype, int64_t ldx, int rows, int cols, void* q, int64_t ldq, void* scales, void* stream);
+int mmae_mx_quant_t(const void* w, int w_dtype, int64_t ldw, int n, int k, void* q, int64_t ldq, void* scales, void* stream);
+int mmae_probe_mx_mfma(const int32_t* a_64x8, const int32_t* b_64x8, const int32_t* scale_a_64, const int32_t* scale_b_64, int opsel_a, int opsel_b,
+                       float* out_64x16, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Launch timing of the MFMA GEMM entry points (mmae_gemm, mmae_gemm_dw_group -- also when they are reached through the

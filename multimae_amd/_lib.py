@@ -20,6 +20,7 @@ HEADER = os.path.join(os.path.dirname(_PKG), 'include', 'mmae.h')
 LIB_PATH = os.environ.get('MMAE_LIB') or os.path.join(_PKG, 'libmmae_hip.so')      # MMAE_LIB: an alternative build of the same ABI (A/B experiments)
 
 F32, BF16, F32X3 = 0, 1, 2
+MXFP8 = 4
 EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
 
 
@@ -41,6 +42,7 @@ class GemmDesc(ctypes.Structure):
         ('alpha', ctypes.c_float), ('tile', ctypes.c_int32), ('split_k', ctypes.c_int32),
         ('ws', ctypes.c_void_p), ('ws_elems', ctypes.c_int64), ('colsum_part', ctypes.c_void_p),
         ('a_colsum', ctypes.c_void_p), ('a_colsum_acc', ctypes.c_int32),
+        ('a_scale', ctypes.c_void_p), ('b_scale', ctypes.c_void_p),
     ]
 
 
@@ -159,7 +161,7 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = ret
         fn.argtypes = argtypes
-    if lib.mmae_abi_version() != 2:
+    if lib.mmae_abi_version() != 3:
         raise RuntimeError('libmmae_hip.so ABI version mismatch')
     for which, cls in enumerate((GemmDesc, BlockDesc, StackDesc, AdapterDesc, OptDesc, PatchSrc, DwGroupDesc)):
         if lib.mmae_struct_size(which) != ctypes.sizeof(cls):

@@ -21,6 +21,7 @@ struct GemmArgs {
     float* colpart;               // optional [ceil(M/32)][N] column sums of the epilogue output per 32-row block (dGELU flavour)
     int wide_st;                  // bf16 epilogues with 8-column (16-byte) lanes (store_tile64_bf16x8); env MMAE_EPI_WIDE=0 turns it off
     int dephase;                  // experiment (env MMAE_PP_DEPHASE = n): odd workgroups of the ping-pong kernel start n x ~4 us late
+    const void* scA; const void* scB;   // MX-fp8 products: packed E8M0 scales of the two operands (mxfp8.hip)
     int dbg;                      // epilogue dissection for profiling (env MMAE_EPI_DBG, GELU flavour only): 1 = no GELU arithmetic, 2 = no pre-activation store,
                                   // 3 = arithmetic but no stores, 4 = nothing.  0 in production.
 };

@@ -24,6 +24,7 @@ int mmae_check_launch(const char* what) {
 int mmae_gemm_bf16_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hipStream_t st);
 int mmae_gemm_f32_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st);
 int mmae_gemm_f32x3_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st);
+int mmae_gemm_mxfp8_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st);
 int mmae_splitk_reduce(const float* ws, float* C, int M, int N, long long ldc, int splits, int accumulate, hipStream_t st);
 int mmae_acs_reduce(const float* part, int splits, int M, float* out, int accumulate, hipStream_t st);
 
@@ -128,7 +129,7 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     MMAE_REQUIRE(d && d->A && d->B && d->C, "gemm: null operand");
     MMAE_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: empty problem");
     MMAE_REQUIRE(d->batch >= 1 && d->batch <= 65535 && d->batch_inner >= 1, "gemm: bad batch");
-    MMAE_REQUIRE(d->ab_dtype == MMAE_F32 || d->ab_dtype == MMAE_BF16 || d->ab_dtype == MMAE_F32X3, "gemm: bad ab_dtype");
+    MMAE_REQUIRE(d->ab_dtype == MMAE_F32 || d->ab_dtype == MMAE_BF16 || d->ab_dtype == MMAE_F32X3 || d->ab_dtype == MMAE_MXFP8, "gemm: bad ab_dtype");
     MMAE_REQUIRE(d->c_dtype == MMAE_F32 || d->c_dtype == MMAE_BF16, "gemm: bad c_dtype");
     MMAE_REQUIRE(!(d->accumulate && d->c_dtype != MMAE_F32), "gemm: accumulate needs f32 C");
     MMAE_REQUIRE(!(d->epi != MMAE_EPI_NONE && !d->aux), "gemm: epilogue needs aux");
@@ -154,6 +155,7 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     g.dbg = env_dbg;
     static const int env_dephase = getenv("MMAE_PP_DEPHASE") ? atoi(getenv("MMAE_PP_DEPHASE")) : 0;
     g.dephase = env_dephase;
+    g.scA = d->a_scale; g.scB = d->b_scale;
     MMAE_REQUIRE(!d->colsum_part || (d->epi == MMAE_EPI_DGELU && !d->bias && !d->resid && !d->accumulate && d->batch == 1 && d->split_k <= 1 &&
                                      d->alpha == 1.0f && d->N % 4 == 0) ,
                  "gemm: colsum_part is only supported with the plain dGELU epilogue");
@@ -170,7 +172,7 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     struct TimingGuard {            // the bracket closes on every return path
         hipEvent_t a; hipStream_t st; double flop; int cls;
         ~TimingGuard() { mmae_timing_end(a, st, flop, cls); }
-    } t_guard{t_ev, st, 2.0 * d->M * d->N * d->K * d->batch, d->ab_dtype == MMAE_BF16 ? 0 : 1};
+    } t_guard{t_ev, st, 2.0 * d->M * d->N * d->K * d->batch, (d->ab_dtype == MMAE_BF16 || d->ab_dtype == MMAE_MXFP8) ? 0 : 1};
     // split-K: the dW-type products (small M x N, K = all rows of the batch) would otherwise occupy
     // a handful of the 256 CUs.  Each K slice writes a dense f32 partial slab into the caller's
     // workspace; a second launch sums the slabs into C in a fixed order (deterministic).
@@ -196,6 +198,11 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
         const int64_t slab = g.splitk > 1 ? (int64_t)g.splitk * d->M * d->N : 0;
         MMAE_REQUIRE(d->ws && d->ws_elems >= slab + (int64_t)g.splitk * d->M, "gemm: a_colsum workspace too small");
         g.acs = (float*)d->ws + slab;
+    }
+    if (d->ab_dtype == MMAE_MXFP8) {
+        MMAE_REQUIRE(splitk == 1 && !d->a_colsum, "gemm(mxfp8): no split_k / a_colsum");
+        g.splitk = 1;
+        return mmae_gemm_mxfp8_impl(d, g, st);
     }
     int rc = (d->ab_dtype == MMAE_BF16) ? mmae_gemm_bf16_impl(d, g, code, st)
            : (d->ab_dtype == MMAE_F32X3 ? mmae_gemm_f32x3_impl(d, g, st) : mmae_gemm_f32_impl(d, g, st));

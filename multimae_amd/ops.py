@@ -14,7 +14,7 @@ import torch
 from . import _lib
 import contextlib
 
-from ._lib import BF16, F32, F32X3, EPI_NONE, EPI_GELU, EPI_DGELU, AdapterDesc, BlockDesc, DwGroupDesc, GemmDesc, OptDesc, PatchSrc, StackDesc, check
+from ._lib import BF16, F32, F32X3, MXFP8, EPI_NONE, EPI_GELU, EPI_DGELU, AdapterDesc, BlockDesc, DwGroupDesc, GemmDesc, OptDesc, PatchSrc, StackDesc, check
 
 Tensor = torch.Tensor
 
@@ -123,6 +123,65 @@ def gemm(A: Tensor, B: Tensor, C: Tensor, M: int, N: int, K: int, *, lda: int, l
         assert resid.dtype == torch.float32
     check(lib.mmae_gemm(ctypes.byref(d), _stream()), 'mmae_gemm')
     return fused_cs
+
+
+# ------------------------------------------------------------------------- MX-fp8 --
+class MxTensor:
+    """An OCP MX-fp8 operand: e4m3 bytes [rows, cols] (blocks of 32 along cols) + the packed E8M0 scales of mmae_mx_quant."""
+    __slots__ = ('q', 'scales', 'rows', 'cols')
+
+    def __init__(self, q: Tensor, scales: Tensor, rows: int, cols: int):
+        self.q, self.scales, self.rows, self.cols = q, scales, rows, cols
+
+
+def mx_scale_bytes(rows: int, cols: int) -> int:
+    return int(_lib.load().mmae_mx_scale_bytes(rows, cols))
+
+
+def mx_quant(x: Tensor, out: Optional[MxTensor] = None) -> MxTensor:
+    """x [rows, cols] (f32 / bf16, contiguous) -> MX-fp8 with the blocks along cols (mmae_mx_quant)."""
+    _require_gpu(x, 'mx_quant input')
+    rows, cols = x.shape
+    if out is None:
+        out = MxTensor(torch.empty((rows, cols), device=x.device, dtype=torch.uint8),
+                       torch.empty((mx_scale_bytes(rows, cols),), device=x.device, dtype=torch.uint8), rows, cols)
+    check(_lib.load().mmae_mx_quant(x.data_ptr(), dcode(x.dtype), x.stride(0), rows, cols, out.q.data_ptr(), cols, out.scales.data_ptr(),
+                                    _stream()), 'mmae_mx_quant')
+    return out
+
+
+def mx_quant_t(w: Tensor, out: Optional[MxTensor] = None) -> MxTensor:
+    """w [n, k] -> MX-fp8 of w^T: bytes [k, n], blocks along n (the weight operand of a dX product; mmae_mx_quant_t)."""
+    _require_gpu(w, 'mx_quant_t input')
+    n, k = w.shape
+    if out is None:
+        out = MxTensor(torch.empty((k, n), device=w.device, dtype=torch.uint8),
+                       torch.empty((mx_scale_bytes(k, n),), device=w.device, dtype=torch.uint8), k, n)
+    check(_lib.load().mmae_mx_quant_t(w.data_ptr(), dcode(w.dtype), w.stride(0), n, k, out.q.data_ptr(), n, out.scales.data_ptr(),
+                                      _stream()), 'mmae_mx_quant_t')
+    return out
+
+
+def gemm_mx(a: MxTensor, b: MxTensor, C: Tensor, *, bias: Optional[Tensor] = None, resid: Optional[Tensor] = None,
+            aux: Optional[Tensor] = None, epi: int = EPI_NONE, colsum_part: Optional[Tensor] = None) -> Tensor:
+    """C[M, N] = a[M, K] . b[N, K]^T on the block-scaled MFMA, with the fused epilogues of mmae_gemm."""
+    assert a.cols == b.cols, (a.cols, b.cols)
+    M, N, K = a.rows, b.rows, a.cols
+    d = GemmDesc()
+    d.A, d.B, d.C = a.q.data_ptr(), b.q.data_ptr(), C.data_ptr()
+    d.a_scale, d.b_scale = a.scales.data_ptr(), b.scales.data_ptr()
+    d.ab_dtype, d.c_dtype = MXFP8, dcode(C.dtype)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = K, K, N
+    d.batch = d.batch_inner = 1
+    d.bias = _p(bias)
+    d.resid, d.ldr = _p(resid), N
+    d.aux, d.ldaux = _p(aux), N
+    d.aux_dtype = dcode(aux.dtype) if aux is not None else F32
+    d.epi, d.alpha, d.split_k = epi, 1.0, 1
+    d.colsum_part = _p(colsum_part)
+    check(_lib.load().mmae_gemm(ctypes.byref(d), _stream()), 'mmae_gemm(mxfp8)')
+    return C
 
 
 def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], out: Tensor, *, resid: Optional[Tensor] = None,

@@ -1,0 +1,150 @@
+"""MX-fp8 path (BASELINE.json configs[4]): the scaled MFMA's lane layout, the quantiser (bit-exact against the spec oracle) and
+the GEMM with the training step's epilogues (against the oracle's dequantised float64 product)."""
+import numpy as np
+import pytest
+import torch
+
+from multimae_amd import _lib, ops
+from oracle import multimae_oracle as orc
+from oracle import mx_oracle as mx
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _rand_e4m3_bytes(rng, shape):
+    # exactly representable small values: sign, exponent fields 5..9 (2^-2 .. 2^2), any mantissa
+    return (rng.integers(0, 2, shape) << 7 | rng.integers(5, 10, shape) << 3 | rng.integers(0, 8, shape)).astype(np.uint8)
+
+
+@pytest.mark.parametrize('opsel', [(0, 0), (2, 1), (3, 3)])
+def test_probe_scaled_mfma_lane_layout(opsel):
+    """Measured layout (tools/mx_probe_discover.py) the GEMM kernel relies on: lane l of either operand holds row (l & 31);
+    its bytes 0-15 are K 16 (l >> 5) .. + 16 and its bytes 16-31 are K 32 + 16 (l >> 5) .. + 16; byte op_sel of the scale dword of
+    lane l scales K block (l >> 5) of row (l & 31); D[i][j]: i = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), j = lane & 31."""
+    rng = np.random.default_rng(11)
+    table = mx.e4m3_decode_table().astype(np.float64)
+    a = _rand_e4m3_bytes(rng, (64, 32)); b = _rand_e4m3_bytes(rng, (64, 32))
+    sa = rng.integers(120, 135, (64, 4)).astype(np.uint8); sb = rng.integers(120, 135, (64, 4)).astype(np.uint8)
+    out = torch.empty((64, 16), device=DEV, dtype=torch.float32)
+    t = lambda x: torch.from_numpy(x.copy()).to(DEV)
+    a_d, b_d, sa_d, sb_d = t(a), t(b), t(sa), t(sb)
+    _lib.check(_lib.load().mmae_probe_mx_mfma(a_d.data_ptr(), b_d.data_ptr(), sa_d.data_ptr(), sb_d.data_ptr(), opsel[0], opsel[1],
+                                              out.data_ptr(), ops._stream()), 'probe')
+    got = out.cpu().numpy().astype(np.float64)
+    A = np.zeros((32, 64)); B = np.zeros((32, 64))
+    for l in range(64):
+        r, h = l & 31, l >> 5
+        for half16 in range(2):
+            k0 = 32 * half16 + 16 * h
+            A[r, k0:k0 + 16] = table[a[l, 16 * half16:16 * half16 + 16]]
+            B[r, k0:k0 + 16] = table[b[l, 16 * half16:16 * half16 + 16]]
+    for l in range(64):
+        r, h = l & 31, l >> 5
+        A[r, 32 * h:32 * h + 32] *= 2.0 ** (int(sa[l, opsel[0]]) - 127)
+        B[r, 32 * h:32 * h + 32] *= 2.0 ** (int(sb[l, opsel[1]]) - 127)
+    D = A @ B.T
+    exp = np.zeros((64, 16))
+    for l in range(64):
+        for r in range(16):
+            exp[l, r] = D[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31]
+    # the MFMA's internal summation order / width is not documented: not bit-exact against float64, but a wrong layout is off by O(1)
+    err = np.abs(got - exp)
+    assert err.max() <= 2e-5 * np.abs(exp).max(), (err.max(), np.abs(exp).max(), np.argwhere(err > 2e-5 * np.abs(exp).max())[:8].tolist())
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('shape', [(37, 256), (128, 768), (5, 96)])
+def test_mx_quant_bit_exact_vs_oracle(dtype, shape):
+    g = torch.Generator().manual_seed(shape[0])
+    x = torch.randn(shape, generator=g) * torch.exp2(torch.randint(-20, 12, (shape[0], shape[1] // 32), generator=g).float()).repeat_interleave(32, 1)
+    x[0, :32] = 0.0                                        # an empty block
+    x[1, 0] = 500.0; x[1, 1:32] = 0.25                     # an element in (448, 512) x scale saturates
+    x = x.to(dtype)
+    q = ops.mx_quant(x.to(DEV))
+    q_ref, e_ref = mx.mx_quantize(x.float().numpy())
+    assert np.array_equal(q.q.cpu().numpy(), q_ref)
+    assert np.array_equal(q.scales.cpu().numpy(), mx.pack_scales(e_ref))
+
+
+def test_mx_quant_t_bit_exact_vs_oracle():
+    g = torch.Generator().manual_seed(3)
+    w = (torch.randn(96, 80, generator=g) * 0.05).bfloat16()
+    q = ops.mx_quant_t(w.to(DEV))
+    q_ref, e_ref = mx.mx_quantize(w.float().numpy().T.copy())
+    assert np.array_equal(q.q.cpu().numpy(), q_ref)
+    assert np.array_equal(q.scales.cpu().numpy(), mx.pack_scales(e_ref))
+
+
+def _mx_ref(a, b):
+    return torch.from_numpy(mx.mx_matmul(a.float().numpy(), b.float().numpy()))
+
+
+@pytest.mark.parametrize('M,N,K', [(512, 256, 256), (700, 768, 1024), (1234, 520, 512)])
+def test_mx_gemm_epilogues_vs_oracle(M, N, K):
+    g = torch.Generator().manual_seed(M + N)
+    a = (torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-3, 4, (M, 1), generator=g).float())).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    ref = _mx_ref(a, w)                                    # float64, exact product of the quantised operands (the MFMA sums in ~f32: 2e-5 measured)
+    qa, qw = ops.mx_quant(a.to(DEV)), ops.mx_quant(w.to(DEV))
+    scale = ref.abs().max().item()
+
+    def close(got, want, tol):
+        err = (got.double().cpu() - want).abs().max().item()
+        assert err <= tol * max(1.0, want.abs().max().item()), (err, want.abs().max().item())
+
+    # bias + residual -> f32 (proj / fc2 forward)
+    out = torch.empty((M, N), device=DEV, dtype=torch.float32)
+    ops.gemm_mx(qa, qw, out, bias=bias.to(DEV), resid=resid.to(DEV))
+    close(out, ref + bias.double() + resid.double(), 5e-5)
+    # plain f32 (dX into the residual stream) and bias -> f32
+    ops.gemm_mx(qa, qw, out)
+    close(out, ref, 5e-5)
+    ops.gemm_mx(qa, qw, out, bias=bias.to(DEV))
+    close(out, ref + bias.double(), 5e-5)
+    # bias -> bf16 (qkv forward), plain bf16 (dX)
+    outb = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+    ops.gemm_mx(qa, qw, outb, bias=bias.to(DEV))
+    close(outb, ref + bias.double(), 4e-3)
+    ops.gemm_mx(qa, qw, outb)
+    close(outb, ref, 4e-3)
+    # bias + GELU with the pre-activation saved (fc1 forward)
+    aux = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+    ops.gemm_mx(qa, qw, outb, bias=bias.to(DEV), aux=aux, epi=ops.EPI_GELU)
+    pre = ref + bias.double()
+    close(aux, pre, 4e-3)
+    close(outb, orc.gelu_erf(pre.float()).double(), 4e-3 + 1e-2 * 0)
+    # dGELU against a saved pre-activation (+ column sums per 32 rows) (fc2 dX)
+    hpre = torch.randn(M, N, generator=g).bfloat16()
+    hp = hpre.float().double().requires_grad_(True)
+    (gg,) = torch.autograd.grad(torch.nn.functional.gelu(hp).sum(), hp)
+    want = ref * gg
+    ops.gemm_mx(qa, qw, outb, aux=hpre.to(DEV), epi=ops.EPI_DGELU)
+    close(outb, want, 4e-3)
+    part = torch.zeros(((M + 31) // 32, N), device=DEV, dtype=torch.float32)
+    ops.gemm_mx(qa, qw, outb, aux=hpre.to(DEV), epi=ops.EPI_DGELU, colsum_part=part)
+    close(outb, want, 4e-3)
+    got_cs = part.sum(0).double().cpu()
+    assert (got_cs - want.sum(0)).abs().max().item() <= 2e-2 * max(1.0, want.sum(0).abs().max().item())
+
+
+def test_mx_gemm_rejects_what_it_cannot_do():
+    a = ops.mx_quant(torch.randn(64, 128, device=DEV).bfloat16())
+    b = ops.mx_quant(torch.randn(64, 128, device=DEV).bfloat16())
+    out = torch.empty((64, 64), device=DEV, dtype=torch.float32)
+    with pytest.raises(_lib.KernelError):
+        ops.gemm_mx(a, b, out)                             # K % 256 != 0
+
+
+def test_mx_gemm_quantisation_error_is_fp8_class():
+    """against the UNquantised product the MX result deviates by the e4m3 rounding of both operands: ~2-3 % of the row norms"""
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(1024, 1024, generator=g).bfloat16()
+    w = (torch.randn(768, 1024, generator=g) * 0.03).bfloat16()
+    out = torch.empty((1024, 768), device=DEV, dtype=torch.float32)
+    ops.gemm_mx(ops.mx_quant(a.to(DEV)), ops.mx_quant(w.to(DEV)), out)
+    exact = a.double() @ w.double().T
+    rel = ((out.double().cpu() - exact).norm() / exact.norm()).item()
+    assert 5e-3 < rel < 5e-2, rel

@@ -234,3 +234,55 @@ def test_oracle_label_smoothing_is_torch_cross_entropy():
         # all-ones mask: masked mean over every pixel, then mean over samples
         got = orc.masked_ce(logits, tgt, torch.ones(2, 4, dtype=torch.long), 4, 1, label_smoothing=eps)
         assert abs(float(got) - float(ref.mean(dim=(1, 2)).mean())) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# MX-fp8 oracle (oracle/mx_oracle.py): pinned against PyTorch's float8_e4m3fn cast and the OCP MX v1.0 tables
+# ---------------------------------------------------------------------------------------------------------------------
+def test_mx_e4m3_codec_matches_torch_float8():
+    from oracle import mx_oracle as mx
+    table = mx.e4m3_decode_table()
+    ref = torch.arange(256, dtype=torch.uint8).view(torch.float8_e4m3fn).to(torch.float32).numpy()
+    ok = ~np.isnan(ref)
+    assert np.array_equal(table[ok], ref[ok]) and np.isnan(table[~ok]).all()
+    assert table[0x7e] == 448.0 and table[0x08] == 2.0 ** -6 and table[0x01] == 2.0 ** -9      # spec table 1: max normal, min normal, min subnormal
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(200000, generator=g) * torch.exp2(torch.randint(-12, 9, (200000,), generator=g).float())).clamp(-448, 448)
+    x = torch.cat([x, torch.tensor([0.0, -0.0, 448.0, -448.0, 2.0 ** -10, 3 * 2.0 ** -10, 2.0 ** -9, 0.0009765625 * 1.5, 17.0, 19.0, 464.0, 1e9, -1e9])])
+    mine = mx.e4m3_encode(x.numpy())
+    theirs = x.clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    assert np.array_equal(mine, theirs)
+    # ties go to even mantissas: 17 -> 16, 19 -> 20; 2^-10 (half the smallest subnormal) -> 0
+    assert table[mx.e4m3_encode(np.float32([17.0, 19.0, 2.0 ** -10]))].tolist() == [16.0, 20.0, 0.0]
+
+
+def test_mx_block_quantisation_spec_vectors():
+    from oracle import mx_oracle as mx
+    x = np.zeros((2, 64), dtype=np.float32)
+    x[0, :32] = np.linspace(-1.0, 1.0, 32)              # amax 1.0 -> shared exponent 0 - 8 -> scale 2^-8, elements up to 256
+    x[0, 32:] = 0.0                                      # empty block -> exponent byte 0, all-zero elements
+    x[1, :32] = 1000.0 * np.cos(np.arange(32))           # amax ~1000 -> floor(log2) = 9 -> scale 2^1
+    x[1, 32:] = 3e-5 * np.sin(np.arange(32))
+    q, e = mx.mx_quantize(x)
+    assert e[0, 0] == 127 - 8 and e[0, 1] == 0 and e[1, 0] == 127 + 1
+    assert not q[0, 32:].any()
+    back = mx.mx_dequantize(q, e)
+    # relative error of an element against its block's amax is bounded by the e4m3 quantum at the top binade: 2^-4 of 2^floor(log2 amax)
+    for r in range(2):
+        for b in range(2):
+            blk = x[r, b * 32:(b + 1) * 32]
+            if np.abs(blk).max() == 0:
+                continue
+            top = 2.0 ** np.floor(np.log2(np.abs(blk).max()))
+            # ... except above 1.75 x top = 448 x scale, where the spec's floor-based exponent makes the element saturate
+            err = np.abs(back[r, b * 32:(b + 1) * 32] - blk)
+            bound = np.maximum(top / 16, np.abs(blk) - 1.75 * top) + 1e-30
+            assert (err <= bound).all()
+    # a value in (448, 512) x scale saturates instead of overflowing to NaN
+    y = np.zeros((1, 32), dtype=np.float32); y[0, 0] = 500.0; y[0, 1] = 1.0
+    q, e = mx.mx_quantize(y)
+    assert e[0, 0] == 127 and q[0, 0] == 0x7e
+    # packed scale layout: byte j of dword (g, r, h) is block 8 g + 2 j + h
+    ex = np.arange(3 * 12, dtype=np.uint8).reshape(3, 12)
+    p = mx.pack_scales(ex).reshape(2, 3, 2, 4)
+    assert p[0, 1, 1, 2] == ex[1, 2 * 2 + 1] and p[1, 2, 0, 1] == ex[2, 8 + 2] and p[1, 0, 1, 2] == 0
