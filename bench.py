@@ -249,7 +249,8 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default 256; 128 for cfg5)')
     ap.add_argument('--config', default='cfg3', choices=['cfg3', 'cfg2', 'cfg5'],
                     help='cfg3 = BASELINE.json configs[2] (the metric), cfg2 = configs[1] (RGB-only), cfg5 = configs[4] geometry (ViT-L, 196 visible tokens; bf16 -- the MX-fp8 path is not built)')
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32', 'mxfp8'],
+                    help="'mxfp8': encoder forward / dX products on OCP MX-fp8 operands (block-scaled MFMA), everything else as bf16")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-batch', type=int, default=16)
     ap.add_argument('--cpu-threads', type=int, default=0, help='0: best of an 8/16/32/64 sweep')
@@ -400,7 +401,7 @@ def main():
         lib.mmae_gemm_timing_enable(1)
         step()
         torch.cuda.synchronize()
-        ms2, fl2, n2 = (ctypes.c_double * 2)(), (ctypes.c_double * 2)(), (ctypes.c_int64 * 2)()
+        ms2, fl2, n2 = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 3)()
         lib.mmae_gemm_timing_read(ms2, fl2, n2)
         lib.mmae_gemm_timing_enable(0)
         M.engine.set_adapter_streams(bool(args.adapter_streams))
@@ -409,7 +410,7 @@ def main():
         tot_ms = {torch.bfloat16: ms2[0], torch.float32: ms2[1]}
         tot_fl = {torch.bfloat16: fl2[0], torch.float32: fl2[1]}
         cnt = {torch.bfloat16: int(n2[0]), torch.float32: int(n2[1])}
-        dom = torch.bfloat16 if args.precision == 'bf16' else torch.float32
+        dom = torch.float32 if args.precision == 'fp32' else torch.bfloat16
         peak = PEAK_BF16_TFLOPS if dom == torch.bfloat16 else 157.3
         ach = tot_fl[dom] / (tot_ms[dom] * 1e-3) / 1e12 if tot_ms[dom] > 0 else 0.0
         traffic, traffic_src = pmc_traffic(dom)
@@ -420,6 +421,11 @@ def main():
                 'f32_adapter_gemm_ms_per_step': round(tot_ms[torch.float32], 3) if dom == torch.bfloat16 else None,
                 'f32_adapter_gemm_tflops': round(tot_fl[torch.float32] / max(tot_ms[torch.float32], 1e-9) / 1e9, 2) if dom == torch.bfloat16 else None,
                 'whole_step_frac_of_peak': round(ALG_GFLOP_PER_IMG[args.config] * 1e9 * B / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+        if args.precision == 'mxfp8':                       # the MX products have their own line: 5 PFLOP/s dense MX-fp8 peak
+            roof['mxfp8'] = {'kernel': 'gemm_mxfp8_kernel (v_mfma_scale_f32_32x32x64_f8f6f4): encoder forward + dX products', 'launches_per_step': int(n2[2]),
+                             'gemm_ms_per_step': round(ms2[2], 3), 'gemm_gflop_per_step': round(fl2[2] / 1e9, 1),
+                             'achieved': round(fl2[2] / max(ms2[2], 1e-9) / 1e9, 2), 'peak': 5000.0, 'unit': 'TFLOP/s',
+                             'frac': round(fl2[2] / max(ms2[2], 1e-9) / 1e9 / 5000.0, 4)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config != 'cfg5':      # the CPU leg is sized for the ViT-B configs
@@ -433,9 +439,9 @@ def main():
                        'cfg5': 'pre-train images/sec (whole node), ViT-L RGB+D+S 224^2 196-vis-tok'}[args.config],
             'value': round(img_s, 1), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': args.precision if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
+            'dtype': {'bf16': 'bf16', 'fp32': 'f32', 'mxfp8': 'mxfp8 (e4m3 + E8M0/32) encoder forward and dX products, bf16 everywhere else'}[args.precision], 'data': 'synthetic',
             'config': {'workload': f'BASELINE.json configs[{ {"cfg3": 2, "cfg2": 1, "cfg5": 4}[args.config] }]: '
-                                   + ('ViT-L (bf16; the MX-fp8 path is not built), ' if args.config == 'cfg5' else 'ViT-B, ')
+                                   + (('ViT-L (MX-fp8 encoder products), ' if args.precision == 'mxfp8' else 'ViT-L (bf16 run of the fp8 config), ') if args.config == 'cfg5' else 'ViT-B, ')
                                    + ('RGB-only' if args.config == 'cfg2' else 'RGB+depth+semseg')
                                    + f', 224^2, Dirichlet alpha=1.0, {n_vis} visible tokens, {len(doms) + 1} cross-attention decoders (dim 256, depth 2), '
                                    + ('fp32 semseg adapter, ' if 'semseg' in doms else '') + 'AdamW; fwd+losses+bwd+optimizer',

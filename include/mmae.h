@@ -120,8 +120,9 @@ int mmae_gemm_auto_splitk(int M, int N, int K, int ab_dtype);
 
 /* ------------------------------------------------------------------------- *
  * MX-fp8 operands (BASELINE.json configs[4], "fp8 MFMA path"; OCP Microscaling v1.0: e4m3 elements, one power-of-two E8M0
- * scale per 32 consecutive elements along the contraction, shared exponent = floor(log2(max|x|)) - 8, elements rounded to
- * nearest even and saturated at +-448).  The reference has no such path (it trains under fp16 autocast,
+ * scale per 32 consecutive elements along the contraction, elements rounded to nearest even; shared exponent =
+ * floor(log2(max|x|)) - 8, plus one when max|x| / 2^floor(log2 max|x|) > 1.75 so that no element saturates -- the
+ * specification's plain floor rule clips the largest element of such blocks by up to 12.5 %).  The reference has no such path (it trains under fp16 autocast,
  * run_pretraining_multimae.py:514-516); these entry points replace the casts autocast inserts in front of nn.Linear.
  *   scales: uint32 S[ceil(cols/256)][rows][2]; byte j of S[g][r][h] = biased exponent of the block cols 256g + 64j + 32h .. +32
  *           of row r (exponent 0 for blocks past the last column) -- the layout the 32x32x64 scaled MFMA consumes with one dword
@@ -135,18 +136,25 @@ int mmae_gemm_auto_splitk(int M, int N, int K, int ab_dtype);
 int64_t mmae_mx_scale_bytes(int rows, int cols);
 int mmae_mx_quant(const void* x, int x_dtype, int64_t ldx, int rows, int cols, void* q, int64_t ldq, void* scales, void* stream);
 int mmae_mx_quant_t(const void* w, int w_dtype, int64_t ldw, int n, int k, void* q, int64_t ldq, void* scales, void* stream);
+/* scratch a composite call needs to quantise one [rows][cols] activation operand (bytes + scales, 256-byte aligned parts) */
+int64_t mmae_mx_tmp_bytes(int rows, int cols);
+/* Quantise n weights w[i] = [n_out[i]][k_in[i]] (f32 / bf16, contiguous) for both products that read them: dst[4 i] e4m3
+ * [n_out][k_in] + dst[4 i + 1] its scales (forward: contraction over k_in), dst[4 i + 2] e4m3 of the transpose [k_in][n_out] +
+ * dst[4 i + 3] its scales (dX: contraction over n_out).  Sizes: n_out * k_in bytes and mmae_mx_scale_bytes(n_out, k_in) /
+ * mmae_mx_scale_bytes(k_in, n_out).  Once per optimiser step. */
+int mmae_mx_prepare_weights(int n, const void* const* w, int w_dtype, const int32_t* n_out, const int32_t* k_in, void* const* dst, void* stream);
 int mmae_probe_mx_mfma(const int32_t* a_64x8, const int32_t* b_64x8, const int32_t* scale_a_64, const int32_t* scale_b_64, int opsel_a, int opsel_b,
                        float* out_64x16, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Launch timing of the MFMA GEMM entry points (mmae_gemm, mmae_gemm_dw_group -- also when they are reached through the
  * composite calls): while enabled, every call is bracketed by two hipEvents recorded on ITS launch stream; mmae_gemm_timing_read
- * waits for them and returns, per operand class (0: bf16, 1: f32 / split-bf16), the summed launch time [ms], the algorithmic
- * FLOPs (2 M N K) and the number of calls.  For bench.py's roofline line (run the step single-stream while measuring: with
+ * waits for them and returns, per operand class (0: bf16, 1: f32 / split-bf16, 2: MX-fp8 -- arrays of THREE entries), the summed
+ * launch time [ms], the algorithmic FLOPs (2 M N K) and the number of calls.  For bench.py's roofline line (run the step single-stream while measuring: with
  * other streams active a bracket also contains the time the launch shares the CUs).  Off by default; costs nothing then.
  * ------------------------------------------------------------------------- */
 int mmae_gemm_timing_enable(int on);
-int mmae_gemm_timing_read(double* ms2, double* flop2, int64_t* calls2);
+int mmae_gemm_timing_read(double* ms3, double* flop3, int64_t* calls3);
 
 /* ------------------------------------------------------------------------- *
  * Grouped weight gradients: up to 8 products dw_i[n_out_i][k_in_i] (+)= dy_i[rows][n_out_i]^T . x_i[rows][k_in_i] (the dW of
@@ -281,6 +289,12 @@ typedef struct mmae_block_desc {
      * are scratch the caller provides. */
     const float* dp1; const float* dp2;
     float* branch; void* dxs_act;
+    /* MX-fp8 products (optional; bf16 activations only): mx_w = host array of 16 device pointers, for qkv, proj, fc1, fc2 in turn
+     * {e4m3 [n_out][k_in], its scales, e4m3 of the transpose [k_in][n_out], its scales} as mmae_mx_prepare_weights writes them.
+     * The four forward products and the four dX products then run on the block-scaled MFMA: their activation operand is
+     * quantised into mx_tmp (mmae_mx_tmp_bytes(B * N, max(Hd, 3 D)) bytes) right before each product; weight gradients stay
+     * bf16.  D, 3 D and Hd must be multiples of 256.  NULL = bf16 products. */
+    const void* const* mx_w; void* mx_tmp; int64_t mx_tmp_bytes;
 } mmae_block_desc;
 
 int mmae_block_fwd(const mmae_block_desc* d, void* stream);
@@ -323,6 +337,8 @@ typedef struct mmae_stack_desc {
     int32_t l_begin, l_end;
     float* ws_main; int64_t ws_main_elems;
     float* ws_side; int64_t ws_side_elems;
+    const void* const* mx_w;     /* optional host array [16 L]: mmae_block_desc.mx_w of every block (NULL = bf16 products).  Set it
+                                    BEFORE asking for the slab sizes: the quantisation scratch is carved from act (forward) / tmp (backward) */
 } mmae_stack_desc;
 
 int64_t mmae_stack_act_bytes(const mmae_stack_desc* d);

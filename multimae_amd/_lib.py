@@ -61,7 +61,8 @@ class BlockDesc(ctypes.Structure):
                                      'g_n1_w', 'g_n1_b', 'g_qkv_w', 'g_qkv_b', 'g_proj_w', 'g_proj_b', 'g_n2_w', 'g_n2_b',
                                      'g_fc1_w', 'g_fc1_b', 'g_fc2_w', 'g_fc2_b', 'g_cs')]
                 + [('grad_acc', _I), ('fc2_b_done', _I), ('ws_main', _P), ('ws_main_elems', _L), ('ws_side', _P), ('ws_side_elems', _L)]
-                + [(n, _P) for n in ('dp1', 'dp2', 'branch', 'dxs_act')])
+                + [(n, _P) for n in ('dp1', 'dp2', 'branch', 'dxs_act')]
+                + [('mx_w', _P), ('mx_tmp', _P), ('mx_tmp_bytes', _L)])
 
 
 class StackDesc(ctypes.Structure):
@@ -69,7 +70,7 @@ class StackDesc(ctypes.Structure):
     _fields_ = ([(n, _I) for n in ('L', 'B', 'N', 'D', 'heads', 'Hd', 'act_dtype', 'f32_gemm')] + [('eps', _F), ('grad_acc', _I)]
                 + [(n, _P) for n in ('w', 'p', 'dp', 'x', 'act')] + [('act_bytes', _L)]
                 + [(n, _P) for n in ('g', 'd_out', 'dx', 'tmp')] + [('tmp_bytes', _L), ('l_begin', _I), ('l_end', _I)]
-                + [('ws_main', _P), ('ws_main_elems', _L), ('ws_side', _P), ('ws_side_elems', _L)])
+                + [('ws_main', _P), ('ws_main_elems', _L), ('ws_side', _P), ('ws_side_elems', _L), ('mx_w', _P)])
 
 
 class AdapterDesc(ctypes.Structure):

@@ -18,11 +18,24 @@ struct Ctx {
     int act_dtype, f32_gemm, grad_acc;
     float* ws_main; int64_t ws_main_elems;
     float* ws_side; int64_t ws_side_elems;
+    void* mx_tmp = nullptr; int64_t mx_tmp_bytes = 0;      // scratch of the MX-fp8 activation operands (main stream only)
     int ab() const { return act_dtype == MMAE_BF16 ? MMAE_BF16 : f32_gemm; }
     size_t es() const { return act_dtype == MMAE_BF16 ? 2 : 4; }
 };
 
-Ctx ctx_of(const mmae_block_desc* d) { return {d->act_dtype, d->f32_gemm, d->grad_acc, d->ws_main, d->ws_main_elems, d->ws_side, d->ws_side_elems}; }
+Ctx ctx_of(const mmae_block_desc* d) {
+    Ctx c{d->act_dtype, d->f32_gemm, d->grad_acc, d->ws_main, d->ws_main_elems, d->ws_side, d->ws_side_elems};
+    c.mx_tmp = d->mx_tmp; c.mx_tmp_bytes = d->mx_tmp_bytes;
+    return c;
+}
+
+// quantise the activation operand of an MX-fp8 product into the call's scratch: *q e4m3 [M][K] dense, *s its packed scales
+int mx_operand(const Ctx& c, const void* x, int64_t ldx, int M, int K, const void** q, const void** s, hipStream_t st) {
+    const int64_t qb = ((int64_t)M * K + 255) / 256 * 256;
+    if (!c.mx_tmp || qb + mmae_mx_scale_bytes(M, K) > c.mx_tmp_bytes) { mmae_set_error("composite: mx_tmp too small"); return MMAE_EINVAL; }
+    *q = c.mx_tmp; *s = (const char*)c.mx_tmp + qb;
+    return mmae_mx_quant(x, c.act_dtype, ldx, M, K, c.mx_tmp, K, (char*)c.mx_tmp + qb, st);
+}
 
 // events that order one stream behind another.  A wait captures the event's state when it is enqueued, so a ring entry only
 // has to outlive the hipStreamWaitEvent call that consumes it.  Two rings: `fork` entries are consumed immediately; `held`
@@ -51,8 +64,9 @@ int fork_to(hipStream_t from, hipStream_t to) {      // `to` continues after eve
 }
 
 // out[M,N] = x[M,K] w[N,K]^T (+ bias, epilogue, residual) -- ops.linear_fwd
+// mxw: {e4m3 weight [N][K], its scales, ...} of mmae_mx_prepare_weights, or NULL for the act-dtype product
 int lin_fwd(const Ctx& c, const void* x, const void* w, const float* bias, void* out, int out_dtype, int M, int N, int K,
-            const float* resid, void* aux, int epi, hipStream_t st) {
+            const float* resid, void* aux, int epi, hipStream_t st, const void* const* mxw = nullptr) {
     mmae_gemm_desc g = {};
     g.A = x; g.B = w; g.C = out;
     g.ab_dtype = c.ab();
@@ -63,6 +77,12 @@ int lin_fwd(const Ctx& c, const void* x, const void* w, const float* bias, void*
     g.bias = bias; g.resid = resid; g.ldr = N;
     g.aux = aux; g.ldaux = N; g.aux_dtype = c.act_dtype;
     g.epi = epi; g.alpha = 1.0f;
+    if (mxw) {
+        int rc = mx_operand(c, x, K, M, K, &g.A, &g.a_scale, st);
+        if (rc) return rc;
+        g.B = mxw[0]; g.b_scale = mxw[1]; g.ab_dtype = MMAE_MXFP8; g.split_k = 1;
+        return mmae_gemm(&g, st);
+    }
     int tile = 0, split = 1;
     int rc = mmae_gemm_plan(&g, &tile, &split);
     if (rc) return rc;
@@ -76,7 +96,7 @@ int lin_fwd(const Ctx& c, const void* x, const void* w, const float* bias, void*
 
 // out[M,K] = dy[M,N] w[N,K] (+ dGELU epilogue with column-sum partials) -- ops.linear_dx.  ldy: row stride of dy.
 int lin_dx(const Ctx& c, const void* dy, int64_t ldy, const void* w, void* out, int out_dtype, int M, int N, int K, void* aux, int epi,
-           float* colsum_part, hipStream_t st) {
+           float* colsum_part, hipStream_t st, const void* const* mxw = nullptr) {
     mmae_gemm_desc g = {};
     g.A = dy; g.B = w; g.C = out;
     g.ab_dtype = c.ab();
@@ -88,6 +108,12 @@ int lin_dx(const Ctx& c, const void* dy, int64_t ldy, const void* w, void* out, 
     g.aux = aux; g.ldaux = K; g.aux_dtype = c.act_dtype;
     g.epi = epi; g.alpha = 1.0f;
     g.colsum_part = colsum_part;
+    if (mxw) {                                            // dy quantised along n; the weight's transposed copy [K][N], blocks along n
+        int rc = mx_operand(c, dy, ldy, M, N, &g.A, &g.a_scale, st);
+        if (rc) return rc;
+        g.lda = N; g.B = mxw[2]; g.b_scale = mxw[3]; g.ldb = N; g.b_trans = 0; g.ab_dtype = MMAE_MXFP8; g.split_k = 1;
+        return mmae_gemm(&g, st);
+    }
     int tile = 0, split = 1;
     int rc = mmae_gemm_plan(&g, &tile, &split);
     if (rc) return rc;
@@ -189,6 +215,13 @@ int check_desc(const mmae_block_desc* d) {
                  d->fc1_b && d->fc2_b, "block: null parameter");
     MMAE_REQUIRE(d->x0 && d->ln1 && d->mean1 && d->rstd1 && d->qkv && d->lse && d->ao && d->x1 && d->ln2 && d->mean2 && d->rstd2 &&
                  d->hpre && d->hact, "block: null activation buffer");
+    if (d->mx_w) {
+        MMAE_REQUIRE(d->act_dtype == MMAE_BF16, "block: MX-fp8 products need bf16 activations");
+        if (d->D % 256 || d->Hd % 256) { mmae_set_error("block: MX-fp8 products need D and Hd to be multiples of 256"); return MMAE_ESUPPORT; }
+        const int wide = d->Hd > 3 * d->D ? d->Hd : 3 * d->D;
+        MMAE_REQUIRE(d->mx_tmp && d->mx_tmp_bytes >= mmae_mx_tmp_bytes(d->B * d->N, wide), "block: mx_tmp too small");
+        for (int i = 0; i < 16; ++i) MMAE_REQUIRE(d->mx_w[i], "block: null MX weight pointer");
+    }
     return 0;
 }
 
@@ -249,6 +282,10 @@ BlockTmp carve_block_tmp(Carver& cv, int B, int N, int D, int Hd, size_t es, boo
 
 constexpr int NSET = 3;      // backward temporary sets of a stack (block l uses set l % NSET)
 
+int64_t stack_mx_tmp_bytes(const mmae_stack_desc* d) {
+    return mmae_mx_tmp_bytes(d->B * d->N, d->Hd > 3 * d->D ? d->Hd : 3 * d->D);
+}
+
 bool stack_has_dp(const mmae_stack_desc* d) {
     if (!d->dp) return false;
     for (int i = 0; i < 2 * d->L; ++i) if (d->dp[i]) return true;
@@ -263,6 +300,10 @@ int check_stack(const mmae_stack_desc* d) {
     const int hd = d->D / d->heads;
     if ((hd != 32 && hd != 64) || d->N > 256) { mmae_set_error("stack: geometry outside the fused attention kernel (head_dim 32/64, N <= 256)"); return MMAE_ESUPPORT; }
     MMAE_REQUIRE(d->w && d->p && d->x && d->act, "stack: null pointer");
+    if (d->mx_w) {
+        MMAE_REQUIRE(d->act_dtype == MMAE_BF16, "stack: MX-fp8 products need bf16 activations");
+        if (d->D % 256 || d->Hd % 256) { mmae_set_error("stack: MX-fp8 products need D and Hd to be multiples of 256"); return MMAE_ESUPPORT; }
+    }
     return 0;
 }
 
@@ -297,6 +338,7 @@ struct StackRun {
     const void* const* w; const float* const* p; const float* const* dp; float* const* g;
     const float* x_in; const BlockAct* acts; BlockTmp* tmps; int nset;
     float* ws_main; int64_t ws_main_elems; float* ws_side; int64_t ws_side_elems;
+    const void* const* mx_w = nullptr; void* mx_tmp = nullptr; int64_t mx_tmp_bytes = 0;
 };
 
 int run_blocks_bwd(const StackRun& s, int lo, int hi, const float* dx_top, const void* dx_top_act, bool top_in_sets, bool first_fc2_b_done,
@@ -337,6 +379,7 @@ int run_blocks_bwd(const StackRun& s, int lo, int hi, const float* dx_top, const
         b.g_cs = l > 0 ? ((below_clean && s.g) ? s.g[12 * (l - 1) + 11] : nullptr) : cs_first;
         b.grad_acc = s.grad_acc; b.fc2_b_done = fc2_done ? 1 : 0;
         b.ws_main = s.ws_main; b.ws_main_elems = s.ws_main_elems; b.ws_side = s.ws_side; b.ws_side_elems = s.ws_side_elems;
+        if (s.mx_w) { b.mx_w = s.mx_w + 16 * l; b.mx_tmp = s.mx_tmp; b.mx_tmp_bytes = s.mx_tmp_bytes; }
         if ((rc = mmae_block_bwd(&b, st, sd))) return rc;
         if (sd != st) {
             hipEvent_t e = g_held_ring.next();
@@ -364,21 +407,22 @@ int mmae_block_fwd(const mmae_block_desc* d, void* stream) {
     const Ctx c = ctx_of(d);
     const int R = d->B * d->N, D = d->D, Hd = d->Hd, act = d->act_dtype;
     if ((rc = mmae_layernorm_fwd(d->x0, d->n1_w, d->n1_b, d->ln1, act, d->mean1, d->rstd1, R, D, d->eps, st))) return rc;
-    if ((rc = lin_fwd(c, d->ln1, d->qkv_w, d->qkv_b, d->qkv, act, R, 3 * D, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;
+    const void* const* mx = (d->mx_w && act == MMAE_BF16) ? d->mx_w : nullptr;
+    if ((rc = lin_fwd(c, d->ln1, d->qkv_w, d->qkv_b, d->qkv, act, R, 3 * D, D, nullptr, nullptr, MMAE_EPI_NONE, st, mx))) return rc;
     if ((rc = attn_strides_fwd(d, st))) return rc;
     if (d->dp1) {
-        if ((rc = lin_fwd(c, d->ao, d->proj_w, d->proj_b, d->branch, MMAE_F32, R, D, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;
+        if ((rc = lin_fwd(c, d->ao, d->proj_w, d->proj_b, d->branch, MMAE_F32, R, D, D, nullptr, nullptr, MMAE_EPI_NONE, st, mx ? mx + 4 : nullptr))) return rc;
         if ((rc = mmae_rowscale_add(d->x0, d->branch, d->dp1, d->x1, R, d->N, D, st))) return rc;
     } else {
-        if ((rc = lin_fwd(c, d->ao, d->proj_w, d->proj_b, d->x1, MMAE_F32, R, D, D, d->x0, nullptr, MMAE_EPI_NONE, st))) return rc;
+        if ((rc = lin_fwd(c, d->ao, d->proj_w, d->proj_b, d->x1, MMAE_F32, R, D, D, d->x0, nullptr, MMAE_EPI_NONE, st, mx ? mx + 4 : nullptr))) return rc;
     }
     if ((rc = mmae_layernorm_fwd(d->x1, d->n2_w, d->n2_b, d->ln2, act, d->mean2, d->rstd2, R, D, d->eps, st))) return rc;
-    if ((rc = lin_fwd(c, d->ln2, d->fc1_w, d->fc1_b, d->hact, act, R, Hd, D, nullptr, d->hpre, MMAE_EPI_GELU, st))) return rc;
+    if ((rc = lin_fwd(c, d->ln2, d->fc1_w, d->fc1_b, d->hact, act, R, Hd, D, nullptr, d->hpre, MMAE_EPI_GELU, st, mx ? mx + 8 : nullptr))) return rc;
     if (d->dp2) {
-        if ((rc = lin_fwd(c, d->hact, d->fc2_w, d->fc2_b, d->branch, MMAE_F32, R, D, Hd, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;
+        if ((rc = lin_fwd(c, d->hact, d->fc2_w, d->fc2_b, d->branch, MMAE_F32, R, D, Hd, nullptr, nullptr, MMAE_EPI_NONE, st, mx ? mx + 12 : nullptr))) return rc;
         return mmae_rowscale_add(d->x1, d->branch, d->dp2, d->x2, R, d->N, D, st);
     }
-    return lin_fwd(c, d->hact, d->fc2_w, d->fc2_b, d->x2, MMAE_F32, R, D, Hd, d->x1, nullptr, MMAE_EPI_NONE, st);
+    return lin_fwd(c, d->hact, d->fc2_w, d->fc2_b, d->x2, MMAE_F32, R, D, Hd, d->x1, nullptr, MMAE_EPI_NONE, st, mx ? mx + 12 : nullptr);
 }
 
 int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
@@ -404,13 +448,14 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
         dm_act = d->dxs_act;
     }
     float* part_h = d->g_fc1_b ? d->part_h : nullptr;
+    const void* const* mx = (d->mx_w && act == MMAE_BF16) ? d->mx_w : nullptr;
     DwGroup grp(c, R);                                               // the block's four weight gradients: one launch at the end
     if (d->dp1 || d->dp2) grp.on = false;                           // stochastic depth re-uses dxs_act between the two branches
-    if ((rc = lin_dx(c, dm_act, D, d->fc2_w, d->d_hpre, act, R, D, Hd, d->hpre, MMAE_EPI_DGELU, part_h, st))) return rc;
+    if ((rc = lin_dx(c, dm_act, D, d->fc2_w, d->d_hpre, act, R, D, Hd, d->hpre, MMAE_EPI_DGELU, part_h, st, mx ? mx + 12 : nullptr))) return rc;
     if ((rc = fork_to(st, sd))) return rc;                          // dx_act, d_hpre ready for the weight-gradient stream
     if (!grp.add(dm_act, D, d->hact, Hd, d->g_fc2_w, d->fc2_b_done ? nullptr : d->g_fc2_b, D, Hd) &&
         (rc = lin_dw(c, dm_act, D, d->hact, d->g_fc2_w, d->fc2_b_done ? nullptr : d->g_fc2_b, R, D, Hd, sd))) return rc;
-    if ((rc = lin_dx(c, d->d_hpre, Hd, d->fc1_w, d->d_ln2, act, R, Hd, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
+    if ((rc = lin_dx(c, d->d_hpre, Hd, d->fc1_w, d->d_ln2, act, R, Hd, D, nullptr, MMAE_EPI_NONE, nullptr, st, mx ? mx + 8 : nullptr))) return rc;
     if (!grp.add(d->d_hpre, Hd, d->ln2, D, d->g_fc1_w, nullptr, Hd, D) &&
         (rc = lin_dw(c, d->d_hpre, Hd, d->ln2, d->g_fc1_w, nullptr, R, Hd, D, sd))) return rc;
     if (part_h) {
@@ -426,7 +471,7 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
         if ((rc = mmae_rowscale_cast(d->dx1, d->dp1, d->dxs_act, act, R, N, D, st))) return rc;
         da_act = d->dxs_act;
     }
-    if ((rc = lin_dx(c, da_act, D, d->proj_w, d->d_ao, act, R, D, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
+    if ((rc = lin_dx(c, da_act, D, d->proj_w, d->d_ao, act, R, D, D, nullptr, MMAE_EPI_NONE, nullptr, st, mx ? mx + 4 : nullptr))) return rc;
     if ((rc = fork_to(st, sd))) return rc;                          // part2, dx1_act
     // proj's bias gradient: colsum(dx1) from the LayerNorm partials, or colsum of the rescaled copy under stochastic depth
     if ((rc = scatter3(c, d->part2, nblk, D, d->g_n2_w, d->g_n2_b, d->dp1 ? nullptr : d->g_proj_b, sd))) return rc;
@@ -442,7 +487,7 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
                      d->B, d->heads, N, N, hd, sb3, 3 * D, sb3, 3 * D, sb3, 3 * D, sb1, D, sb3, 3 * D, sb3, 3 * D, sb3, 3 * D,
                      1.0f / sqrtf((float)hd), st))) return rc;
     }
-    if ((rc = lin_dx(c, d->d_qkv, 3 * D, d->qkv_w, d->d_ln1, act, R, 3 * D, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
+    if ((rc = lin_dx(c, d->d_qkv, 3 * D, d->qkv_w, d->d_ln1, act, R, 3 * D, D, nullptr, MMAE_EPI_NONE, nullptr, st, mx))) return rc;
     if ((rc = fork_to(st, sd))) return rc;                          // d_qkv
     if (!grp.add(d->d_qkv, 3 * D, d->ln1, D, d->g_qkv_w, d->g_qkv_b, 3 * D, D) &&
         (rc = lin_dw(c, d->d_qkv, 3 * D, d->ln1, d->g_qkv_w, d->g_qkv_b, R, 3 * D, D, sd))) return rc;
@@ -462,6 +507,7 @@ int64_t mmae_stack_act_bytes(const mmae_stack_desc* d) {
     const size_t es = d->act_dtype == MMAE_BF16 ? 2 : 4;
     for (int l = 0; l < d->L; ++l) (void)carve_block_act(cv, d->B, d->N, d->D, d->heads, d->Hd, es);
     if (stack_has_dp(d)) (void)cv.takeT<float>((int64_t)d->B * d->N * d->D);
+    if (d->mx_w) (void)cv.take(stack_mx_tmp_bytes(d));
     return cv.off;
 }
 
@@ -482,6 +528,7 @@ int64_t mmae_stack_tmp_bytes(const mmae_stack_desc* d) {
     const int nset = d->L < NSET ? d->L : NSET;
     for (int s = 0; s < nset; ++s) (void)carve_block_tmp(cv, d->B, d->N, d->D, d->Hd, es, bf, stack_has_dp(d));
     if (bf) (void)cv.take((int64_t)d->B * d->N * d->D * es);       // act-dtype copy of the incoming gradient
+    if (d->mx_w) (void)cv.take(stack_mx_tmp_bytes(d));
     return cv.off;
 }
 
@@ -497,12 +544,14 @@ int mmae_stack_fwd(const mmae_stack_desc* d, void* stream) {
     MMAE_REQUIRE(d->L <= 64, "stack: at most 64 blocks");
     for (int l = 0; l < d->L; ++l) acts[l] = carve_block_act(cv, d->B, d->N, d->D, d->heads, d->Hd, es);
     float* branch = stack_has_dp(d) ? cv.takeT<float>((int64_t)d->B * d->N * d->D) : nullptr;
+    void* mx_tmp = d->mx_w ? cv.take(stack_mx_tmp_bytes(d)) : nullptr;
     for (int l = 0; l < d->L; ++l) {
         mmae_block_desc b = {};
         fill_block_params(b, d->B, d->N, d->D, d->heads, d->Hd, d->act_dtype, d->f32_gemm, d->eps, d->w + 4 * l, d->p + 8 * l);
         fill_block_act(b, x, acts[l]);
         b.dp1 = d->dp ? d->dp[2 * l] : nullptr; b.dp2 = d->dp ? d->dp[2 * l + 1] : nullptr; b.branch = branch;
         b.ws_main = d->ws_main; b.ws_main_elems = d->ws_main_elems;
+        if (d->mx_w) { b.mx_w = d->mx_w + 16 * l; b.mx_tmp = mx_tmp; b.mx_tmp_bytes = stack_mx_tmp_bytes(d); }
         if ((rc = mmae_block_fwd(&b, st))) return rc;
         x = acts[l].x2;
     }
@@ -530,6 +579,7 @@ int mmae_stack_bwd(const mmae_stack_desc* d, void* stream, void* side_stream) {
     BlockTmp tmps[NSET];
     for (int s = 0; s < nset; ++s) tmps[s] = carve_block_tmp(ct, d->B, d->N, d->D, d->Hd, es, bf, stack_has_dp(d));
     void* top_act = bf ? ct.take(RD * es) : nullptr;
+    void* mx_tmp = d->mx_w ? ct.take(stack_mx_tmp_bytes(d)) : nullptr;
     // a continuation call (l_end < L) may overwrite temporaries that the previous call's side-stream work still reads
     if (d->l_end < d->L && (rc = fork_to(sd, st))) return rc;
     const float* dx; const void* dx_act;
@@ -551,6 +601,7 @@ int mmae_stack_bwd(const mmae_stack_desc* d, void* stream, void* side_stream) {
     }
     StackRun s = {d->B, d->N, d->D, d->heads, d->Hd, d->act_dtype, d->f32_gemm, d->grad_acc, d->w, d->p, d->dp, d->g, d->x, acts, tmps, nset,
                   d->ws_main, d->ws_main_elems, d->ws_side, d->ws_side_elems};
+    if (d->mx_w) { s.mx_w = d->mx_w; s.mx_tmp = mx_tmp; s.mx_tmp_bytes = stack_mx_tmp_bytes(d); }
     const float* o; const void* oa;
     return run_blocks_bwd(s, d->l_begin, d->l_end, dx, dx_act, d->l_end < d->L, fc2_done, d->d_out, nullptr, d->l_begin == 0 ? d->dx : nullptr, st, sd, &o, &oa);
 }

@@ -172,7 +172,7 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     struct TimingGuard {            // the bracket closes on every return path
         hipEvent_t a; hipStream_t st; double flop; int cls;
         ~TimingGuard() { mmae_timing_end(a, st, flop, cls); }
-    } t_guard{t_ev, st, 2.0 * d->M * d->N * d->K * d->batch, (d->ab_dtype == MMAE_BF16 || d->ab_dtype == MMAE_MXFP8) ? 0 : 1};
+    } t_guard{t_ev, st, 2.0 * d->M * d->N * d->K * d->batch, d->ab_dtype == MMAE_BF16 ? 0 : (d->ab_dtype == MMAE_MXFP8 ? 2 : 1)};
     // split-K: the dW-type products (small M x N, K = all rows of the batch) would otherwise occupy
     // a handful of the 256 CUs.  Each K slice writes a dense f32 partial slab into the caller's
     // workspace; a second launch sums the slabs into C in a fixed order (deterministic).
@@ -226,7 +226,7 @@ int mmae_gemm_timing_enable(int on) {
 int mmae_gemm_timing_read(double* ms2, double* flop2, int64_t* calls2) {
     MMAE_REQUIRE(ms2 && flop2 && calls2, "gemm_timing_read: null pointer");
     std::lock_guard<std::mutex> lk(g_tmu);
-    for (int c = 0; c < 2; ++c) { ms2[c] = 0.0; flop2[c] = 0.0; calls2[c] = 0; }
+    for (int c = 0; c < 3; ++c) { ms2[c] = 0.0; flop2[c] = 0.0; calls2[c] = 0; }
     for (auto& t : g_timed) {
         if (hipEventSynchronize(t.b) != hipSuccess) continue;
         float ms = 0.f;

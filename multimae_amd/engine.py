@@ -39,20 +39,33 @@ def act_dtype() -> torch.dtype:
 
 def set_precision(mode: str) -> None:
     """'bf16' (default): bf16 MFMA operands, fp32 accumulate/residual/softmax/LN/loss.
-    'fp32': every operand f32 on the exact-f32 MFMA path (parity mode, 1/16 the rate)."""
-    if mode not in ('bf16', 'fp32'):
+    'fp32': every operand f32 on the exact-f32 MFMA path (parity mode, 1/16 the rate).
+    'mxfp8': as 'bf16', but the forward and dX products of the encoder blocks run on the block-scaled MFMA with OCP MX-fp8
+    operands (e4m3 elements, one power-of-two scale per 32 contraction elements; BASELINE.json configs[4]); weight gradients,
+    attention, the adapters and everything else stay as in 'bf16'.  Needs dim_tokens and the MLP width to be multiples of 256
+    (ViT-B / ViT-L); other encoders silently keep their bf16 products."""
+    if mode not in ('bf16', 'fp32', 'mxfp8'):
         raise ValueError(mode)
-    _state['act_dtype'] = torch.bfloat16 if mode == 'bf16' else torch.float32
+    _state['act_dtype'] = torch.float32 if mode == 'fp32' else torch.bfloat16
+    _state['mx_encoder'] = mode == 'mxfp8'
+
+
+def mx_encoder() -> bool:
+    return _state.get('mx_encoder', False)
+
+
+def precision_mode() -> str:
+    return 'fp32' if _state['act_dtype'] == torch.float32 else ('mxfp8' if mx_encoder() else 'bf16')
 
 
 @contextlib.contextmanager
 def precision(mode: str):
-    old = _state['act_dtype']
+    old = precision_mode()
     set_precision(mode)
     try:
         yield
     finally:
-        _state['act_dtype'] = old
+        set_precision(old)
 
 
 def patch_domain_loss() -> bool:

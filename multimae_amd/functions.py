@@ -317,7 +317,7 @@ class EncoderStackFn(torch.autograd.Function):
         ctx.cfg, ctx.params, ctx.shape = cfg, params, (B, N, D)
         ctx.stack, ctx.saved = None, None
         if ops.stack_composites() and L <= 64 and ops.block_composite_ok(h, cfg.act, cfg.heads, N):
-            outs, state = ops.stack_fwd(h, params, cfg.wc, cfg.heads, cfg.eps, cfg.act, B, N, dp)
+            outs, state = ops.stack_fwd(h, params, cfg.wc, cfg.heads, cfg.eps, cfg.act, B, N, dp, mx=bool(getattr(cfg, 'mx', False)))
             ctx.stack = state if save else None
             if cfg.all_layers:
                 return tuple(o.view(B, N, D) for o in outs)

@@ -248,7 +248,7 @@ class MultiMAE(nn.Module):
                               on_done=self._embed_done_cb())
 
         encoder_tokens = run_blocks(self.encoder, tokens, root=self, on_layer_done=self._layer_done_cb(),
-                                    bwd_chunk=getattr(self, '_bwd_chunk_layers', 1))
+                                    bwd_chunk=getattr(self, '_bwd_chunk_layers', 1), mx=engine.mx_encoder())
 
         if self.output_adapters is None:
             return encoder_tokens, task_masks
@@ -353,7 +353,7 @@ class MultiViT(MultiMAE):
 
     def _forward_vit(self, x, return_all_layers):
         input_tokens, input_info = self.process_input(x)
-        encoder_tokens = run_blocks(self.encoder, input_tokens, root=self, all_layers=return_all_layers)
+        encoder_tokens = run_blocks(self.encoder, input_tokens, root=self, all_layers=return_all_layers, mx=engine.mx_encoder())
         if self.output_adapters is None:
             return encoder_tokens
         return {domain: self.output_adapters[domain](encoder_tokens=encoder_tokens, input_info=input_info)

@@ -250,7 +250,7 @@ def _stack_drop_path(blocks, batch: int, device):
     return dp
 
 
-def run_blocks(blocks, x, root=None, all_layers=False, on_layer_done=None, bwd_chunk: int = 1):
+def run_blocks(blocks, x, root=None, all_layers=False, on_layer_done=None, bwd_chunk: int = 1, mx: bool = False):
     """Run a sequence of Blocks as ONE autograd node (the encoder / decoder_transformer fast path), stochastic depth
     included: the per-sample scales are drawn here and folded into the blocks' residual adds."""
     blocks = list(blocks)
@@ -258,7 +258,7 @@ def run_blocks(blocks, x, root=None, all_layers=False, on_layer_done=None, bwd_c
         return [] if all_layers else x
     b0 = blocks[0]
     cfg = _cfg(b0 if root is None else root, heads=b0.attn.num_heads, eps=b0.norm1.eps, all_layers=all_layers,
-               on_layer_done=on_layer_done, dp=_stack_drop_path(blocks, x.shape[0], x.device), bwd_chunk=bwd_chunk)
+               on_layer_done=on_layer_done, dp=_stack_drop_path(blocks, x.shape[0], x.device), bwd_chunk=bwd_chunk, mx=mx)
     params = [p for b in blocks for p in block_params(b)]
     out = EncoderStackFn.apply(cfg, x, *params)
     return list(out) if all_layers else out

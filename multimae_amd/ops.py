@@ -410,10 +410,60 @@ class StackState:
     __slots__ = ('desc', 'act', 'keep', 'x', 'L', 'shape', 'act_dtype', 'dp')
 
 
+class MxStackWeights:
+    """MX-fp8 copies of the four Linear weights of every block of a stack (both orientations, mmae_mx_prepare_weights): one
+    byte buffer + the host pointer table mmae_stack_desc.mx_w wants.  refresh() re-quantises from the f32 master weights."""
+
+    def __init__(self, params: Sequence[Tensor]):
+        lib = _lib.load()
+        L = len(params) // 12
+        self.ws = [params[12 * l + i] for l in range(L) for i in (2, 4, 8, 10)]
+        dev = self.ws[0].device
+        offs, total = [], 0
+        for w in self.ws:
+            n, k = w.shape
+            for nb in (n * k, int(lib.mmae_mx_scale_bytes(n, k)), n * k, int(lib.mmae_mx_scale_bytes(k, n))):
+                offs.append(total)
+                total += round_up(nb, 256)
+        self.buf = torch.empty((total,), device=dev, dtype=torch.uint8)
+        base = self.buf.data_ptr()
+        self.dst = _ptr_arr([base + o for o in offs])
+        self.src = _ptr_arr([w.data_ptr() for w in self.ws])
+        self.n_out = (ctypes.c_int32 * len(self.ws))(*[w.shape[0] for w in self.ws])
+        self.k_in = (ctypes.c_int32 * len(self.ws))(*[w.shape[1] for w in self.ws])
+        self.probe = tuple(w.data_ptr() for w in self.ws[:1] + self.ws[-1:])
+
+    def matches(self, params: Sequence[Tensor]) -> bool:
+        return self.probe == (params[2].data_ptr(), params[-2].data_ptr()) and len(self.ws) * 3 == len(params)
+
+    def refresh(self) -> None:
+        check(_lib.load().mmae_mx_prepare_weights(len(self.ws), ctypes.cast(self.src, ctypes.c_void_p), F32, self.n_out, self.k_in,
+                                                  ctypes.cast(self.dst, ctypes.c_void_p), _stream()), 'mmae_mx_prepare_weights')
+
+
+_MX_STACKS = {}
+
+
+def mx_stack_weights(params: Sequence[Tensor]) -> MxStackWeights:
+    key = (id(params[2]), len(params))
+    m = _MX_STACKS.get(key)
+    if m is None or not m.matches(params):
+        if len(_MX_STACKS) > 8:
+            _MX_STACKS.clear()
+        m = MxStackWeights(params)
+        _MX_STACKS[key] = m
+    return m
+
+
+def mx_stack_ok(D: int, Hd: int, act: torch.dtype) -> bool:
+    return act == torch.bfloat16 and D % 256 == 0 and Hd % 256 == 0
+
+
 def stack_fwd(x: Tensor, params: Sequence[Tensor], wc, heads: int, eps: float, act: torch.dtype, B: int, N: int,
-              dp: Optional[Sequence[Optional[Tensor]]] = None):
+              dp: Optional[Sequence[Optional[Tensor]]] = None, mx: bool = False):
     """L = len(params) // 12 pre-LN blocks on x f32 [B*N, D] in one library call.
-    Returns ([output of every block as f32 [B*N, D] views of the slab], StackState)."""
+    Returns ([output of every block as f32 [B*N, D] views of the slab], StackState).
+    mx: forward / dX products on MX-fp8 operands (weights re-quantised here from their f32 masters, once per call)."""
     lib = _lib.load()
     R, D = x.shape
     L = len(params) // 12
@@ -432,6 +482,12 @@ def stack_fwd(x: Tensor, params: Sequence[Tensor], wc, heads: int, eps: float, a
         dp_arr = _ptr_arr([_p(t) for t in dp])
         d.dp = ctypes.cast(dp_arr, ctypes.c_void_p)
     d.x = x.data_ptr()
+    mxw = None
+    if mx and mx_stack_ok(D, Hd, act):
+        assert all(params[12 * l + i].dtype == torch.float32 for l in range(L) for i in (2, 4, 8, 10))
+        mxw = mx_stack_weights(params)
+        mxw.refresh()
+        d.mx_w = ctypes.cast(mxw.dst, ctypes.c_void_p)
     nbytes = lib.mmae_stack_act_bytes(ctypes.byref(d))
     slab = _slab(nbytes, x.device)
     d.act, d.act_bytes = slab.data_ptr(), slab.numel()
@@ -444,7 +500,7 @@ def stack_fwd(x: Tensor, params: Sequence[Tensor], wc, heads: int, eps: float, a
         off = lib.mmae_stack_out_offset(ctypes.byref(d), l)
         outs.append(slab[off:off + R * D * 4].view(torch.float32).view(R, D))
     s = StackState()
-    s.desc, s.act, s.keep, s.x, s.L, s.shape, s.act_dtype, s.dp = d, slab, (w_arr, p_arr, dp_arr, wts, dp), x, L, (B, N, D, Hd), act, dp
+    s.desc, s.act, s.keep, s.x, s.L, s.shape, s.act_dtype, s.dp = d, slab, (w_arr, p_arr, dp_arr, wts, dp, mxw), x, L, (B, N, D, Hd), act, dp
     return outs, s
 
 

@@ -263,25 +263,42 @@ def test_mx_block_quantisation_spec_vectors():
     x[0, 32:] = 0.0                                      # empty block -> exponent byte 0, all-zero elements
     x[1, :32] = 1000.0 * np.cos(np.arange(32))           # amax ~1000 -> floor(log2) = 9 -> scale 2^1
     x[1, 32:] = 3e-5 * np.sin(np.arange(32))
-    q, e = mx.mx_quantize(x)
+    q, e = mx.mx_quantize(x, round_up=False)               # the specification's rule
     assert e[0, 0] == 127 - 8 and e[0, 1] == 0 and e[1, 0] == 127 + 1
     assert not q[0, 32:].any()
     back = mx.mx_dequantize(q, e)
     # relative error of an element against its block's amax is bounded by the e4m3 quantum at the top binade: 2^-4 of 2^floor(log2 amax)
+    # ... except above 1.75 x top = 448 x scale, where the spec's floor-based exponent makes the element saturate
     for r in range(2):
         for b in range(2):
             blk = x[r, b * 32:(b + 1) * 32]
             if np.abs(blk).max() == 0:
                 continue
             top = 2.0 ** np.floor(np.log2(np.abs(blk).max()))
-            # ... except above 1.75 x top = 448 x scale, where the spec's floor-based exponent makes the element saturate
             err = np.abs(back[r, b * 32:(b + 1) * 32] - blk)
             bound = np.maximum(top / 16, np.abs(blk) - 1.75 * top) + 1e-30
             assert (err <= bound).all()
-    # a value in (448, 512) x scale saturates instead of overflowing to NaN
+    # a value in (448, 512) x scale saturates under the spec's rule instead of overflowing to NaN ...
     y = np.zeros((1, 32), dtype=np.float32); y[0, 0] = 500.0; y[0, 1] = 1.0
-    q, e = mx.mx_quantize(y)
+    q, e = mx.mx_quantize(y, round_up=False)
     assert e[0, 0] == 127 and q[0, 0] == 0x7e
+    # ... and is kept (one bit coarser) under the engine's round-up rule: nothing saturates, error <= amax / 16 everywhere
+    q, e = mx.mx_quantize(y)
+    assert e[0, 0] == 128
+    assert abs(mx.mx_dequantize(q, e)[0, 0] - 500.0) <= 500.0 / 16
+    q, e = mx.mx_quantize(x)
+    assert e[1, 0] == 127 + 2 and e[0, 0] == 127 - 8        # amax 1000 = 1.95 x 512 rounds up; amax 1.0 does not
+    back = mx.mx_dequantize(q, e)
+    for r in range(2):
+        for b in range(2):
+            blk = x[r, b * 32:(b + 1) * 32]
+            if np.abs(blk).max() > 0:
+                assert np.abs(back[r, b * 32:(b + 1) * 32] - blk).max() <= np.abs(blk).max() / 16
+    g = np.random.default_rng(0)
+    z = (g.standard_normal((64, 256)) * np.exp2(g.integers(-6, 6, (64, 1)))).astype(np.float32)
+    q, e = mx.mx_quantize(z)
+    zb = z.reshape(64, 8, 32)
+    assert (np.abs(zb).max(2) * np.exp2(127.0 - e) <= 448.0).all()           # no block needs saturation
     # packed scale layout: byte j of dword (g, r, h) is block 8 g + 2 j + h
     ex = np.arange(3 * 12, dtype=np.uint8).reshape(3, 12)
     p = mx.pack_scales(ex).reshape(2, 3, 2, 4)
