@@ -108,6 +108,10 @@ typedef struct mmae_gemm_desc {
                                     transposed copy of a weight for its dX product, mmae_mx_quant_t), K % 256 == 0, batch = 1, no split_k,
                                     and one of the epilogue combinations of the training step (bias -> bf16, bias + GELU, bias
                                     [+ residual] -> f32, plain bf16 / f32, dGELU [+ colsum_part]); MMAE_ESUPPORT otherwise. */
+    void* q_out; void* q_scale;  /* MMAE_MXFP8 products with a bf16 C and the bias + GELU or the dGELU epilogue: also write the MX-fp8 quantisation
+                                    of C (what mmae_mx_quant would produce from it: e4m3 [M][ldq] + packed scales for M rows, N cols) -- the
+                                    operand of the next MX product without a separate pass.  N % 32 == 0.  NULL = off. */
+    int64_t ldq;
 } mmae_gemm_desc;
 
 int mmae_gemm(const mmae_gemm_desc* d, void* stream);
@@ -136,6 +140,12 @@ int mmae_gemm_auto_splitk(int M, int N, int K, int ab_dtype);
 int64_t mmae_mx_scale_bytes(int rows, int cols);
 int mmae_mx_quant(const void* x, int x_dtype, int64_t ldx, int rows, int cols, void* q, int64_t ldq, void* scales, void* stream);
 int mmae_mx_quant_t(const void* w, int w_dtype, int64_t ldw, int n, int k, void* q, int64_t ldq, void* scales, void* stream);
+/* zero a packed scale array (only needed by producers that write the blocks of a width that is not a multiple of 256) */
+int mmae_mx_scale_clear(void* scales, int rows, int cols, void* stream);
+/* nn.LayerNorm forward (mmae_layernorm_fwd, bf16 y) that also emits the MX-fp8 quantisation of y -- bit-identical to
+ * mmae_mx_quant applied to y -- for the Linear that follows (multimae_utils.py:230-231).  D % 32 == 0. */
+int mmae_layernorm_fwd_mx(const float* x, const float* gamma, const float* beta, void* y_bf16, float* mean, float* rstd, int64_t R, int D,
+                          float eps, void* q, void* scales, void* stream);
 /* scratch a composite call needs to quantise one [rows][cols] activation operand (bytes + scales, 256-byte aligned parts) */
 int64_t mmae_mx_tmp_bytes(int rows, int cols);
 /* Quantise n weights w[i] = [n_out[i]][k_in[i]] (f32 / bf16, contiguous) for both products that read them: dst[4 i] e4m3
@@ -292,8 +302,9 @@ typedef struct mmae_block_desc {
     /* MX-fp8 products (optional; bf16 activations only): mx_w = host array of 16 device pointers, for qkv, proj, fc1, fc2 in turn
      * {e4m3 [n_out][k_in], its scales, e4m3 of the transpose [k_in][n_out], its scales} as mmae_mx_prepare_weights writes them.
      * The four forward products and the four dX products then run on the block-scaled MFMA: their activation operand is
-     * quantised into mx_tmp (mmae_mx_tmp_bytes(B * N, max(Hd, 3 D)) bytes) right before each product; weight gradients stay
-     * bf16.  D, 3 D and Hd must be multiples of 256.  NULL = bf16 products. */
+     * quantised into mx_tmp (two halves of mmae_mx_tmp_bytes(B * N, max(Hd, 3 D)) bytes each) right before each product -- or by
+     * the kernel that produces it: both LayerNorms and the GELU / dGELU epilogues emit the e4m3 copy themselves (env
+     * MMAE_MX_FUSE=0: separate passes everywhere); weight gradients stay bf16.  D, 3 D and Hd must be multiples of 256.  NULL = bf16 products. */
     const void* const* mx_w; void* mx_tmp; int64_t mx_tmp_bytes;
 } mmae_block_desc;
 

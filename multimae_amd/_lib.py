@@ -43,6 +43,7 @@ class GemmDesc(ctypes.Structure):
         ('ws', ctypes.c_void_p), ('ws_elems', ctypes.c_int64), ('colsum_part', ctypes.c_void_p),
         ('a_colsum', ctypes.c_void_p), ('a_colsum_acc', ctypes.c_int32),
         ('a_scale', ctypes.c_void_p), ('b_scale', ctypes.c_void_p),
+        ('q_out', ctypes.c_void_p), ('q_scale', ctypes.c_void_p), ('ldq', ctypes.c_int64),
     ]
 
 

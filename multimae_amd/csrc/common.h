@@ -73,6 +73,30 @@ __device__ __forceinline__ void gelu_cdf_exp(float x, float& cdf, float& e) {
 __device__ __forceinline__ float gelu_erf(float x) { float c, e; gelu_cdf_exp(x, c, e); return x * c; }
 __device__ __forceinline__ float gelu_erf_grad(float x) { float c, e; gelu_cdf_exp(x, c, e); return c + x * e * 0.39894228040143268f; }
 
+// ---- MX-fp8 quantisation helpers (mxfp8.hip, the ..._Q GEMM epilogue flavours, the LayerNorm kernels) ----------------
+// shared exponent of a block as a biased E8M0 byte, clamped at 0: floor(log2(amax)) - emax(e4m3 = 8) as OCP MX v1.0 section 6.3 has
+// it, PLUS ONE when that scale would push the block's largest element past 448 (amax's mantissa > 1.75): the specification's rule
+// saturates such elements -- up to 12.5 % off on exactly the largest value of the block, a systematic shrink that moved the
+// initial loss of the cfg1 recipe by 1.2 % -- rounding the scale up costs that block one bit instead (the choice of NVIDIA's
+// MX-fp8 pre-training recipe, arXiv 2506.08027 section 3)
+__device__ __forceinline__ int mx_shared_exp(float amax) {
+    const unsigned b = __float_as_uint(amax);
+    const int e = (int)((b >> 23) & 0xffu) - 8 + ((b & 0x7fffffu) > 0x600000u ? 1 : 0);
+    return e < 0 ? 0 : e;
+}
+__device__ __forceinline__ float mx_inv_scale(int e) { return __uint_as_float((unsigned)(254 - e) << 23); }   // 2^(127 - e)
+__device__ __forceinline__ float mx_clamp448(float v) { return __builtin_amdgcn_fmed3f(v, -448.0f, 448.0f); }
+__device__ __forceinline__ int mx_cvt4_e4m3(float a, float b, float c, float d) {
+    int r = 0;
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(mx_clamp448(a), mx_clamp448(b), r, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(mx_clamp448(c), mx_clamp448(d), r, true);
+    return r;
+}
+// byte address of block kb (32 elements) of row r in the packed scale array u32 S[ceil(K/256)][rows][2] (include/mmae.h)
+__device__ __forceinline__ long long mx_scale_addr(long long rows, long long r, int kb) {
+    return (((long long)(kb >> 3) * rows + r) * 2 + (kb & 1)) * 4 + ((kb >> 1) & 3);
+}
+
 // ---- wave / block reductions ---------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -29,12 +29,31 @@ Ctx ctx_of(const mmae_block_desc* d) {
     return c;
 }
 
-// quantise the activation operand of an MX-fp8 product into the call's scratch: *q e4m3 [M][K] dense, *s its packed scales
-int mx_operand(const Ctx& c, const void* x, int64_t ldx, int M, int K, const void** q, const void** s, hipStream_t st) {
-    const int64_t qb = ((int64_t)M * K + 255) / 256 * 256;
-    if (!c.mx_tmp || qb + mmae_mx_scale_bytes(M, K) > c.mx_tmp_bytes) { mmae_set_error("composite: mx_tmp too small"); return MMAE_EINVAL; }
-    *q = c.mx_tmp; *s = (const char*)c.mx_tmp + qb;
-    return mmae_mx_quant(x, c.act_dtype, ldx, M, K, c.mx_tmp, K, (char*)c.mx_tmp + qb, st);
+// The MX scratch is two halves: a product reads its quantised activation operand from one while its epilogue (fc1 forward,
+// fc2 dX) may already write the next product's operand into the other.
+// mx_slot: where the e4m3 bytes [M][K] and the packed scales of an operand live in half `which`
+int mx_slot(const Ctx& c, int which, int M, int K, void** q, void** s) {
+    const int64_t half = c.mx_tmp_bytes / 2 / 256 * 256, qb = ((int64_t)M * K + 255) / 256 * 256;
+    if (!c.mx_tmp || qb + mmae_mx_scale_bytes(M, K) > half) { mmae_set_error("composite: mx_tmp too small"); return MMAE_EINVAL; }
+    *q = (char*)c.mx_tmp + which * half; *s = (char*)*q + qb;
+    return 0;
+}
+// quantise the activation operand of an MX-fp8 product into half `which`
+int mx_operand(const Ctx& c, const void* x, int64_t ldx, int M, int K, int which, const void** q, const void** s, hipStream_t st) {
+    void *qq, *ss;
+    int rc = mx_slot(c, which, M, K, &qq, &ss);
+    if (rc) return rc;
+    *q = qq; *s = ss;
+    return mmae_mx_quant(x, c.act_dtype, ldx, M, K, qq, K, ss, st);
+}
+// operand of an MX product: already quantised in half mx_in (by the producing kernel), or quantised here into the half the
+// epilogue does not write
+int mx_in_operand(const Ctx& c, const void* x, int64_t ldx, int M, int K, int mx_in, int mx_out, const void** q, const void** s, hipStream_t st) {
+    if (mx_in < 0) return mx_operand(c, x, ldx, M, K, mx_out == 0 ? 1 : 0, q, s, st);
+    void *qq, *ss;
+    int rc = mx_slot(c, mx_in, M, K, &qq, &ss);
+    *q = qq; *s = ss;
+    return rc;
 }
 
 // events that order one stream behind another.  A wait captures the event's state when it is enqueued, so a ring entry only
@@ -64,9 +83,10 @@ int fork_to(hipStream_t from, hipStream_t to) {      // `to` continues after eve
 }
 
 // out[M,N] = x[M,K] w[N,K]^T (+ bias, epilogue, residual) -- ops.linear_fwd
-// mxw: {e4m3 weight [N][K], its scales, ...} of mmae_mx_prepare_weights, or NULL for the act-dtype product
+// mxw: {e4m3 weight [N][K], its scales, ...} of mmae_mx_prepare_weights, or NULL for the act-dtype product.  mx_in >= 0: x is
+// already quantised in that half of the MX scratch; mx_out >= 0: the epilogue also leaves the quantised output there.
 int lin_fwd(const Ctx& c, const void* x, const void* w, const float* bias, void* out, int out_dtype, int M, int N, int K,
-            const float* resid, void* aux, int epi, hipStream_t st, const void* const* mxw = nullptr) {
+            const float* resid, void* aux, int epi, hipStream_t st, const void* const* mxw = nullptr, int mx_in = -1, int mx_out = -1) {
     mmae_gemm_desc g = {};
     g.A = x; g.B = w; g.C = out;
     g.ab_dtype = c.ab();
@@ -78,8 +98,9 @@ int lin_fwd(const Ctx& c, const void* x, const void* w, const float* bias, void*
     g.aux = aux; g.ldaux = N; g.aux_dtype = c.act_dtype;
     g.epi = epi; g.alpha = 1.0f;
     if (mxw) {
-        int rc = mx_operand(c, x, K, M, K, &g.A, &g.a_scale, st);
+        int rc = mx_in_operand(c, x, K, M, K, mx_in, mx_out, &g.A, &g.a_scale, st);
         if (rc) return rc;
+        if (mx_out >= 0) { if ((rc = mx_slot(c, mx_out, M, N, &g.q_out, &g.q_scale))) return rc; g.ldq = N; }
         g.B = mxw[0]; g.b_scale = mxw[1]; g.ab_dtype = MMAE_MXFP8; g.split_k = 1;
         return mmae_gemm(&g, st);
     }
@@ -96,7 +117,7 @@ int lin_fwd(const Ctx& c, const void* x, const void* w, const float* bias, void*
 
 // out[M,K] = dy[M,N] w[N,K] (+ dGELU epilogue with column-sum partials) -- ops.linear_dx.  ldy: row stride of dy.
 int lin_dx(const Ctx& c, const void* dy, int64_t ldy, const void* w, void* out, int out_dtype, int M, int N, int K, void* aux, int epi,
-           float* colsum_part, hipStream_t st, const void* const* mxw = nullptr) {
+           float* colsum_part, hipStream_t st, const void* const* mxw = nullptr, int mx_in = -1, int mx_out = -1) {
     mmae_gemm_desc g = {};
     g.A = dy; g.B = w; g.C = out;
     g.ab_dtype = c.ab();
@@ -109,8 +130,9 @@ int lin_dx(const Ctx& c, const void* dy, int64_t ldy, const void* w, void* out, 
     g.epi = epi; g.alpha = 1.0f;
     g.colsum_part = colsum_part;
     if (mxw) {                                            // dy quantised along n; the weight's transposed copy [K][N], blocks along n
-        int rc = mx_operand(c, dy, ldy, M, N, &g.A, &g.a_scale, st);
+        int rc = mx_in_operand(c, dy, ldy, M, N, mx_in, mx_out, &g.A, &g.a_scale, st);
         if (rc) return rc;
+        if (mx_out >= 0) { if ((rc = mx_slot(c, mx_out, M, K, &g.q_out, &g.q_scale))) return rc; g.ldq = K; }
         g.lda = N; g.B = mxw[2]; g.b_scale = mxw[3]; g.ldb = N; g.b_trans = 0; g.ab_dtype = MMAE_MXFP8; g.split_k = 1;
         return mmae_gemm(&g, st);
     }
@@ -219,7 +241,7 @@ int check_desc(const mmae_block_desc* d) {
         MMAE_REQUIRE(d->act_dtype == MMAE_BF16, "block: MX-fp8 products need bf16 activations");
         if (d->D % 256 || d->Hd % 256) { mmae_set_error("block: MX-fp8 products need D and Hd to be multiples of 256"); return MMAE_ESUPPORT; }
         const int wide = d->Hd > 3 * d->D ? d->Hd : 3 * d->D;
-        MMAE_REQUIRE(d->mx_tmp && d->mx_tmp_bytes >= mmae_mx_tmp_bytes(d->B * d->N, wide), "block: mx_tmp too small");
+        MMAE_REQUIRE(d->mx_tmp && d->mx_tmp_bytes >= 2 * mmae_mx_tmp_bytes(d->B * d->N, wide), "block: mx_tmp too small");
         for (int i = 0; i < 16; ++i) MMAE_REQUIRE(d->mx_w[i], "block: null MX weight pointer");
     }
     return 0;
@@ -283,7 +305,7 @@ BlockTmp carve_block_tmp(Carver& cv, int B, int N, int D, int Hd, size_t es, boo
 constexpr int NSET = 3;      // backward temporary sets of a stack (block l uses set l % NSET)
 
 int64_t stack_mx_tmp_bytes(const mmae_stack_desc* d) {
-    return mmae_mx_tmp_bytes(d->B * d->N, d->Hd > 3 * d->D ? d->Hd : 3 * d->D);
+    return 2 * mmae_mx_tmp_bytes(d->B * d->N, d->Hd > 3 * d->D ? d->Hd : 3 * d->D);
 }
 
 bool stack_has_dp(const mmae_stack_desc* d) {
@@ -406,9 +428,19 @@ int mmae_block_fwd(const mmae_block_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const Ctx c = ctx_of(d);
     const int R = d->B * d->N, D = d->D, Hd = d->Hd, act = d->act_dtype;
-    if ((rc = mmae_layernorm_fwd(d->x0, d->n1_w, d->n1_b, d->ln1, act, d->mean1, d->rstd1, R, D, d->eps, st))) return rc;
     const void* const* mx = (d->mx_w && act == MMAE_BF16) ? d->mx_w : nullptr;
-    if ((rc = lin_fwd(c, d->ln1, d->qkv_w, d->qkv_b, d->qkv, act, R, 3 * D, D, nullptr, nullptr, MMAE_EPI_NONE, st, mx))) return rc;
+    // MX mode: the LayerNorms leave the quantised copy of their output in half 0 of the scratch; fc1's epilogue leaves the
+    // quantised GELU output in half 1 (the separate passes cost 7 % of the step, profiles/r02_mxfp8_*)
+    static const bool mx_fuse = !(getenv("MMAE_MX_FUSE") && atoi(getenv("MMAE_MX_FUSE")) == 0);
+    const int pre = (mx && mx_fuse) ? 0 : -1;
+    auto ln = [&](const float* x, const float* w, const float* b, void* y, float* mu, float* rs) -> int {
+        if (pre < 0) return mmae_layernorm_fwd(x, w, b, y, act, mu, rs, R, D, d->eps, st);
+        void *q, *s;
+        const int r0 = mx_slot(c, 0, R, D, &q, &s);
+        return r0 ? r0 : mmae_layernorm_fwd_mx(x, w, b, y, mu, rs, R, D, d->eps, q, s, st);
+    };
+    if ((rc = ln(d->x0, d->n1_w, d->n1_b, d->ln1, d->mean1, d->rstd1))) return rc;
+    if ((rc = lin_fwd(c, d->ln1, d->qkv_w, d->qkv_b, d->qkv, act, R, 3 * D, D, nullptr, nullptr, MMAE_EPI_NONE, st, mx, pre))) return rc;
     if ((rc = attn_strides_fwd(d, st))) return rc;
     if (d->dp1) {
         if ((rc = lin_fwd(c, d->ao, d->proj_w, d->proj_b, d->branch, MMAE_F32, R, D, D, nullptr, nullptr, MMAE_EPI_NONE, st, mx ? mx + 4 : nullptr))) return rc;
@@ -416,13 +448,14 @@ int mmae_block_fwd(const mmae_block_desc* d, void* stream) {
     } else {
         if ((rc = lin_fwd(c, d->ao, d->proj_w, d->proj_b, d->x1, MMAE_F32, R, D, D, d->x0, nullptr, MMAE_EPI_NONE, st, mx ? mx + 4 : nullptr))) return rc;
     }
-    if ((rc = mmae_layernorm_fwd(d->x1, d->n2_w, d->n2_b, d->ln2, act, d->mean2, d->rstd2, R, D, d->eps, st))) return rc;
-    if ((rc = lin_fwd(c, d->ln2, d->fc1_w, d->fc1_b, d->hact, act, R, Hd, D, nullptr, d->hpre, MMAE_EPI_GELU, st, mx ? mx + 8 : nullptr))) return rc;
+    if ((rc = ln(d->x1, d->n2_w, d->n2_b, d->ln2, d->mean2, d->rstd2))) return rc;
+    const int hq = pre < 0 ? -1 : 1;                     // quantised GELU output: half 1
+    if ((rc = lin_fwd(c, d->ln2, d->fc1_w, d->fc1_b, d->hact, act, R, Hd, D, nullptr, d->hpre, MMAE_EPI_GELU, st, mx ? mx + 8 : nullptr, pre, hq))) return rc;
     if (d->dp2) {
-        if ((rc = lin_fwd(c, d->hact, d->fc2_w, d->fc2_b, d->branch, MMAE_F32, R, D, Hd, nullptr, nullptr, MMAE_EPI_NONE, st, mx ? mx + 12 : nullptr))) return rc;
+        if ((rc = lin_fwd(c, d->hact, d->fc2_w, d->fc2_b, d->branch, MMAE_F32, R, D, Hd, nullptr, nullptr, MMAE_EPI_NONE, st, mx ? mx + 12 : nullptr, hq))) return rc;
         return mmae_rowscale_add(d->x1, d->branch, d->dp2, d->x2, R, d->N, D, st);
     }
-    return lin_fwd(c, d->hact, d->fc2_w, d->fc2_b, d->x2, MMAE_F32, R, D, Hd, d->x1, nullptr, MMAE_EPI_NONE, st, mx ? mx + 12 : nullptr);
+    return lin_fwd(c, d->hact, d->fc2_w, d->fc2_b, d->x2, MMAE_F32, R, D, Hd, d->x1, nullptr, MMAE_EPI_NONE, st, mx ? mx + 12 : nullptr, hq);
 }
 
 int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
@@ -451,11 +484,13 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
     const void* const* mx = (d->mx_w && act == MMAE_BF16) ? d->mx_w : nullptr;
     DwGroup grp(c, R);                                               // the block's four weight gradients: one launch at the end
     if (d->dp1 || d->dp2) grp.on = false;                           // stochastic depth re-uses dxs_act between the two branches
-    if ((rc = lin_dx(c, dm_act, D, d->fc2_w, d->d_hpre, act, R, D, Hd, d->hpre, MMAE_EPI_DGELU, part_h, st, mx ? mx + 12 : nullptr))) return rc;
+    static const bool mx_fuse = !(getenv("MMAE_MX_FUSE") && atoi(getenv("MMAE_MX_FUSE")) == 0);
+    const int hq = (mx && mx_fuse) ? 1 : -1;                 // fc2's dX epilogue leaves the quantised d_hpre in half 1 for fc1's dX
+    if ((rc = lin_dx(c, dm_act, D, d->fc2_w, d->d_hpre, act, R, D, Hd, d->hpre, MMAE_EPI_DGELU, part_h, st, mx ? mx + 12 : nullptr, -1, hq))) return rc;
     if ((rc = fork_to(st, sd))) return rc;                          // dx_act, d_hpre ready for the weight-gradient stream
     if (!grp.add(dm_act, D, d->hact, Hd, d->g_fc2_w, d->fc2_b_done ? nullptr : d->g_fc2_b, D, Hd) &&
         (rc = lin_dw(c, dm_act, D, d->hact, d->g_fc2_w, d->fc2_b_done ? nullptr : d->g_fc2_b, R, D, Hd, sd))) return rc;
-    if ((rc = lin_dx(c, d->d_hpre, Hd, d->fc1_w, d->d_ln2, act, R, Hd, D, nullptr, MMAE_EPI_NONE, nullptr, st, mx ? mx + 8 : nullptr))) return rc;
+    if ((rc = lin_dx(c, d->d_hpre, Hd, d->fc1_w, d->d_ln2, act, R, Hd, D, nullptr, MMAE_EPI_NONE, nullptr, st, mx ? mx + 8 : nullptr, hq))) return rc;
     if (!grp.add(d->d_hpre, Hd, d->ln2, D, d->g_fc1_w, nullptr, Hd, D) &&
         (rc = lin_dw(c, d->d_hpre, Hd, d->ln2, d->g_fc1_w, nullptr, R, Hd, D, sd))) return rc;
     if (part_h) {

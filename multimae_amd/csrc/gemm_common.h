@@ -22,6 +22,7 @@ struct GemmArgs {
     int wide_st;                  // bf16 epilogues with 8-column (16-byte) lanes (store_tile64_bf16x8); env MMAE_EPI_WIDE=0 turns it off
     int dephase;                  // experiment (env MMAE_PP_DEPHASE = n): odd workgroups of the ping-pong kernel start n x ~4 us late
     const void* scA; const void* scB;   // MX-fp8 products: packed E8M0 scales of the two operands (mxfp8.hip)
+    unsigned char* qout; unsigned char* qsc; long long ldq;   // ..._Q flavours: also emit the MX-fp8 quantisation of the bf16 output C ([M][ldq] bytes + packed scales)
     int dbg;                      // epilogue dissection for profiling (env MMAE_EPI_DBG, GELU flavour only): 1 = no GELU arithmetic, 2 = no pre-activation store,
                                   // 3 = arithmetic but no stores, 4 = nothing.  0 in production.
 };
@@ -264,7 +265,8 @@ __device__ __forceinline__ i32x4 pack8_bf16(const f32x4 a, const f32x4 b) {
     i32x4 r; r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
     return r;
 }
-template <bool BIAS, int EPI, bool COLSUM, int DBG = 0, int PDEPTH = 4>
+// MXQ: additionally write the MX-fp8 quantisation of the (bf16-rounded) output -- a 32-column block is four adjacent lanes
+template <bool BIAS, int EPI, bool COLSUM, int DBG = 0, int PDEPTH = 4, bool MXQ = false>
 __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cbase, char* wave_lds, int lane, const f32x16 (&acc)[2][2],
                                                     int m_base, int n_base, int ntm) {
     constexpr unsigned OOB_OFF = 0x80000000u;
@@ -320,6 +322,28 @@ __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cba
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { cs0[j] += ok ? v0[j] : 0.f; cs1[j] += ok ? v1[j] : 0.f; }
                 }
+                if (MXQ) {
+                    const i32x4 pk = pack8_bf16(v0, v1);
+                    __builtin_amdgcn_raw_buffer_store_b128(pk, rsC, voff(gi, g.ldc), 0, 0);
+                    float w[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { w[2 * j] = __uint_as_float(((unsigned)pk[j]) << 16); w[2 * j + 1] = __uint_as_float(((unsigned)pk[j]) & 0xffff0000u); }
+                    float am = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) am = fmaxf(am, fabsf(w[j]));
+                    am = fmaxf(am, __shfl_xor(am, 1, 64));
+                    am = fmaxf(am, __shfl_xor(am, 2, 64));
+                    const int e = mx_shared_exp(am);
+                    const float inv = mx_inv_scale(e);
+                    i32x2 o;
+                    o[0] = mx_cvt4_e4m3(w[0] * inv, w[1] * inv, w[2] * inv, w[3] * inv);
+                    o[1] = mx_cvt4_e4m3(w[4] * inv, w[5] * inv, w[6] * inv, w[7] * inv);
+                    if (ok) {
+                        const long long grow = m_base + tm * 32 + r;
+                        *reinterpret_cast<i32x2*>(g.qout + grow * g.ldq + n) = o;
+                        if ((c8 & 3) == 0) g.qsc[mx_scale_addr(g.M, grow, n >> 5)] = (unsigned char)e;
+                    }
+                } else
                 if (DBG != 3) __builtin_amdgcn_raw_buffer_store_b128(pack8_bf16(v0, v1), rsC, voff(gi, g.ldc), 0, 0);
                 else if (v0[0] == 1234.5678f) __builtin_amdgcn_raw_buffer_store_b128(pack8_bf16(v0, v1), rsC, voff(gi, g.ldc), 0, 0);   // keeps the arithmetic alive
             }
@@ -419,7 +443,8 @@ __device__ __forceinline__ void gemm_store_tile64(const GemmArgs& g, char* Cz, c
 // gemm_flavour() applies exactly the conditions gemm_store_tile64 tests at run time; 0 = keep the generic kernel.
 // ------------------------------------------------------------------------------------------------
 enum { FL_GENERIC = 0, FL_BF16_BIAS = 1, FL_F32_BIAS_RESID = 2, FL_BF16_BIAS_GELU = 3, FL_BF16 = 4, FL_BF16_DGELU_CS = 5, FL_F32_BIAS = 6, FL_F32 = 7,
-       FL_BF16_DGELU = 8 };
+       FL_BF16_DGELU = 8,
+       FL_BF16_BIAS_GELU_Q = 9, FL_BF16_DGELU_CS_Q = 10, FL_BF16_DGELU_Q = 11 };      // + MX-fp8 copy of the output (mxfp8.hip only)
 
 static inline int gemm_flavour(const GemmArgs& g, int batch) {
     if (batch != 1 || g.splitk > 1 || !g.vec || (g.N & 3) || g.alpha != 1.0f || g.accumulate || g.dbg) return FL_GENERIC;
@@ -452,6 +477,9 @@ __device__ __forceinline__ void gemm_store_tile64_fl(const GemmArgs& g, char* Cz
     // (with one flavour per instantiation there are registers to spare: all 8 pre-activation loads of a 64-row tile go out before its first use)
     else if (FL == FL_BF16_DGELU_CS) store_tile64_bf16x8<false, MMAE_EPI_DGELU, true, 0, 4>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
     else if (FL == FL_BF16_DGELU) store_tile64_bf16x8<false, MMAE_EPI_DGELU, false, 0, 8>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
+    else if (FL == FL_BF16_BIAS_GELU_Q) store_tile64_bf16x8<true, MMAE_EPI_GELU, false, 0, 4, true>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
+    else if (FL == FL_BF16_DGELU_CS_Q) store_tile64_bf16x8<false, MMAE_EPI_DGELU, true, 0, 4, true>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
+    else if (FL == FL_BF16_DGELU_Q) store_tile64_bf16x8<false, MMAE_EPI_DGELU, false, 0, 8, true>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
     else if (FL == FL_F32_BIAS_RESID) store_tile64_fast<true, 0, true, true, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm);
     else if (FL == FL_F32_BIAS) store_tile64_fast<true, 0, false, true, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm);
     else if (FL == FL_F32) store_tile64_fast<false, 0, false, true, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm);

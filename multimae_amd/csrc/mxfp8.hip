@@ -32,28 +32,8 @@ constexpr unsigned OOB = 0x80000000u;
 // ---------------------------------------------------------------------------------------------------------------------------
 // quantisation
 // ---------------------------------------------------------------------------------------------------------------------------
-// shared exponent of a block as a biased E8M0 byte, clamped at 0: floor(log2(amax)) - emax(e4m3 = 8) as OCP MX v1.0 section 6.3 has
-// it, PLUS ONE when that scale would push the block's largest element past 448 (amax's mantissa > 1.75): the specification's rule
-// saturates such elements -- up to 12.5 % off on exactly the largest value of the block, a systematic shrink that moved the
-// initial loss of the cfg1 recipe by 1.2 % -- rounding the scale up costs that block one bit instead (the choice of NVIDIA's
-// MX-fp8 pre-training recipe, arXiv 2506.08027 section 3)
-__device__ __forceinline__ int mx_shared_exp(float amax) {
-    const unsigned b = __float_as_uint(amax);
-    const int e = (int)((b >> 23) & 0xffu) - 8 + ((b & 0x7fffffu) > 0x600000u ? 1 : 0);
-    return e < 0 ? 0 : e;
-}
-__device__ __forceinline__ float mx_inv_scale(int e) { return __uint_as_float((unsigned)(254 - e) << 23); }   // 2^(127 - e)
-__device__ __forceinline__ float clamp448(float v) { return __builtin_amdgcn_fmed3f(v, -448.0f, 448.0f); }
-__device__ __forceinline__ int cvt4_e4m3(float a, float b, float c, float d) {
-    int r = 0;
-    r = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(a), clamp448(b), r, false);
-    r = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(c), clamp448(d), r, true);
-    return r;
-}
-// byte address of block kb (32 elements) of row r in the packed scale array
-__device__ __forceinline__ long long mx_scale_addr(long long rows, long long r, int kb) {
-    return (((long long)(kb >> 3) * rows + r) * 2 + (kb & 1)) * 4 + ((kb >> 1) & 3);
-}
+// (mx_shared_exp, mx_inv_scale, mx_cvt4_e4m3, mx_scale_addr: gemm_common.h)
+__device__ __forceinline__ int cvt4_e4m3(float a, float b, float c, float d) { return mx_cvt4_e4m3(a, b, c, d); }
 
 // 4 lanes per 32-element block (8 elements = 16 B of bf16 per lane): coalesced 1-KiB reads per wave instruction
 template <typename T>
@@ -432,6 +412,9 @@ int launch_mx_fl(const GemmArgs& g, int fl, hipStream_t st) {
         case FL_BF16_DGELU_CS: return launch_mx<TM, FL_BF16_DGELU_CS>(g, st);
         case FL_BF16_DGELU: return launch_mx<TM, FL_BF16_DGELU>(g, st);
         case FL_F32: return launch_mx<TM, FL_F32>(g, st);
+        case FL_BF16_BIAS_GELU_Q: return launch_mx<TM, FL_BF16_BIAS_GELU_Q>(g, st);
+        case FL_BF16_DGELU_CS_Q: return launch_mx<TM, FL_BF16_DGELU_CS_Q>(g, st);
+        case FL_BF16_DGELU_Q: return launch_mx<TM, FL_BF16_DGELU_Q>(g, st);
         default: mmae_set_error("gemm(mxfp8): epilogue combination without a compiled flavour (see gemm_flavour())"); return MMAE_ESUPPORT;
     }
 }
@@ -447,12 +430,18 @@ int mmae_gemm_mxfp8_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t
     MMAE_REQUIRE(d->lda % 16 == 0 && d->ldb % 16 == 0 && (uintptr_t)d->A % 16 == 0 && (uintptr_t)d->B % 16 == 0, "gemm(mxfp8): operand rows must be 16-byte aligned");
     MMAE_REQUIRE((long long)d->M * d->lda < 0x7fffffffLL && (long long)d->N * d->ldb < 0x7fffffffLL, "gemm(mxfp8): operand larger than a 2 GiB buffer window");
     MMAE_REQUIRE((long long)(d->K / 256) * d->M * 8 < 0x7fffffffLL && (long long)(d->K / 256) * d->N * 8 < 0x7fffffffLL, "gemm(mxfp8): scale array too large");
-    const int fl = gemm_flavour(g, d->batch);
+    int fl = gemm_flavour(g, d->batch);
+    if (d->q_out) {                                       // fused quantisation of the output for the next MX product
+        MMAE_REQUIRE(d->q_scale && d->N % 32 == 0 && d->ldq % 8 == 0 && (uintptr_t)d->q_out % 8 == 0, "gemm(mxfp8): q_out needs q_scale, N % 32 == 0 and 8-byte aligned rows");
+        fl = fl == FL_BF16_BIAS_GELU ? FL_BF16_BIAS_GELU_Q : fl == FL_BF16_DGELU_CS ? FL_BF16_DGELU_CS_Q : fl == FL_BF16_DGELU ? FL_BF16_DGELU_Q : -1;
+        if (fl < 0) { mmae_set_error("gemm(mxfp8): q_out is implemented for the bias + GELU and the dGELU epilogues only"); return MMAE_ESUPPORT; }
+    }
     const long long nt = (d->N + 255) / 256;
     const long long t4 = ((d->M + 255) / 256) * nt, t5 = ((d->M + 319) / 320) * nt;
     const long long c4 = ((t4 + 255) / 256) * 256, c5 = ((t5 + 255) / 256) * 320;
     static const int env_tm = getenv("MMAE_MX_TM") ? atoi(getenv("MMAE_MX_TM")) : 0;
-    const bool five = env_tm ? env_tm == 5 : c5 < c4;
+    (void)c4; (void)c5;                                   // 320-row tiles spill ~35 registers in this body and measured 14 % slower: opt-in only
+    const bool five = env_tm == 5;
     return five ? launch_mx_fl<5>(g, fl, st) : launch_mx_fl<4>(g, fl, st);
 }
 
@@ -494,6 +483,13 @@ int mmae_mx_quant_t(const void* w, int w_dtype, int64_t ldw, int n, int k, void*
     else
         hipLaunchKernelGGL(mx_quant_t_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)w, (long long)ldw, n, k, (unsigned char*)q, (long long)ldq, (unsigned char*)scales);
     return mmae_check_launch("mx_quant_t");
+}
+
+int mmae_mx_scale_clear(void* scales, int rows, int cols, void* stream) {
+    MMAE_REQUIRE(scales && rows > 0 && cols > 0, "mx_scale_clear: bad argument");
+    const long long n = mmae_mx_scale_bytes(rows, cols) / 4;
+    hipLaunchKernelGGL(mx_scale_clear_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)stream, (unsigned*)scales, n);
+    return mmae_check_launch("mx_scale_clear");
 }
 
 int64_t mmae_mx_tmp_bytes(int rows, int cols) {

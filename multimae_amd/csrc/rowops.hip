@@ -9,11 +9,14 @@ namespace {
 // LayerNorm forward.  x f32 [R][D] -> y act [R][D], mean/rstd f32 [R].  D % 4 == 0, D <= 1024.
 // lane l owns float4 chunks l, l+64, l+128, l+192 of the row (NV chunks).
 // ------------------------------------------------------------------------------------------
-template <int NV, typename YT>
+// MXQ (bf16 y, D % 32 == 0): also write the MX-fp8 quantisation of the bf16 row (what mmae_mx_quant would make of y): a
+// 32-element block is the 8 adjacent lanes of one chunk round
+template <int NV, typename YT, bool MXQ = false>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, YT* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
-                                                     long long R, int D, float eps) {
+                                                     long long R, int D, float eps, unsigned char* __restrict__ qy = nullptr,
+                                                     unsigned char* __restrict__ sc = nullptr) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= R) return;
@@ -49,6 +52,17 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
             st4(yr + c, o);
+            if (MXQ) {
+                float w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = bf16_bits_to_f32(f32_to_bf16_bits(o[j]));
+                float am = fmaxf(fmaxf(fabsf(w[0]), fabsf(w[1])), fmaxf(fabsf(w[2]), fabsf(w[3])));
+                am = fmaxf(am, __shfl_xor(am, 1, 64)); am = fmaxf(am, __shfl_xor(am, 2, 64)); am = fmaxf(am, __shfl_xor(am, 4, 64));
+                const int e = mx_shared_exp(am);
+                const float inv = mx_inv_scale(e);
+                *reinterpret_cast<int*>(qy + row * D + c) = mx_cvt4_e4m3(w[0] * inv, w[1] * inv, w[2] * inv, w[3] * inv);
+                if ((lane & 7) == 0) sc[mx_scale_addr(R, row, c >> 5)] = (unsigned char)e;
+            }
         }
     }
 }
@@ -475,6 +489,25 @@ int mmae_layernorm_fwd(const float* x, const float* gamma, const float* beta, vo
     switch (nv) { case 1: LN_FWD(1) break; case 2: LN_FWD(2) break; case 3: LN_FWD(3) break; default: LN_FWD(4) break; }
 #undef LN_FWD
     return mmae_check_launch("layernorm_fwd");
+}
+
+int mmae_layernorm_fwd_mx(const float* x, const float* gamma, const float* beta, void* y_bf16, float* mean, float* rstd, int64_t R, int D,
+                          float eps, void* q, void* scales, void* stream) {
+    MMAE_REQUIRE(x && gamma && beta && y_bf16 && mean && rstd && q && scales, "layernorm_fwd_mx: null pointer");
+    MMAE_REQUIRE(D % 32 == 0 && D >= 32 && D <= 1024, "layernorm_fwd_mx: D must be a multiple of 32 in [32,1024]");
+    if (R <= 0) return 0;
+    const int nv = (D + 255) / 256;
+    dim3 grid((unsigned)cdiv64(R, 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (D % 256) {                                        // exponent bytes of the blocks past the last column
+        const int rc = mmae_mx_scale_clear(scales, R, D, stream);
+        if (rc) return rc;
+    }
+#define LN_FWD_MX(NV) hipLaunchKernelGGL((ln_fwd_kernel<NV, uint16_t, true>), grid, block, 0, st, x, gamma, beta, (uint16_t*)y_bf16, mean, rstd, \
+                                         (long long)R, D, eps, (unsigned char*)q, (unsigned char*)scales);
+    switch (nv) { case 1: LN_FWD_MX(1) break; case 2: LN_FWD_MX(2) break; case 3: LN_FWD_MX(3) break; default: LN_FWD_MX(4) break; }
+#undef LN_FWD_MX
+    return mmae_check_launch("layernorm_fwd_mx");
 }
 
 // workgroups (= rows of the partial block): 4 rows per workgroup pass, capped at 1 024 -- 2 048 for the long, narrow decoder

@@ -156,6 +156,8 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     static const int env_dephase = getenv("MMAE_PP_DEPHASE") ? atoi(getenv("MMAE_PP_DEPHASE")) : 0;
     g.dephase = env_dephase;
     g.scA = d->a_scale; g.scB = d->b_scale;
+    g.qout = (unsigned char*)d->q_out; g.qsc = (unsigned char*)d->q_scale; g.ldq = d->ldq;
+    MMAE_REQUIRE(!d->q_out || d->ab_dtype == MMAE_MXFP8, "gemm: q_out is an MX-fp8 product option");
     MMAE_REQUIRE(!d->colsum_part || (d->epi == MMAE_EPI_DGELU && !d->bias && !d->resid && !d->accumulate && d->batch == 1 && d->split_k <= 1 &&
                                      d->alpha == 1.0f && d->N % 4 == 0) ,
                  "gemm: colsum_part is only supported with the plain dGELU epilogue");

@@ -150,6 +150,25 @@ def mx_quant(x: Tensor, out: Optional[MxTensor] = None) -> MxTensor:
     return out
 
 
+def mx_empty(rows: int, cols: int, device) -> MxTensor:
+    return MxTensor(torch.empty((rows, cols), device=device, dtype=torch.uint8),
+                    torch.zeros((mx_scale_bytes(rows, cols),), device=device, dtype=torch.uint8), rows, cols)
+
+
+def layernorm_fwd_mx(x: Tensor, w: Tensor, b: Tensor, eps: float):
+    """LayerNorm forward with bf16 output that also emits the MX-fp8 quantisation of that output (mmae_layernorm_fwd_mx).
+    Returns (y bf16, mean, rstd, MxTensor)."""
+    _require_gpu(x, 'layernorm input')
+    R, D = x.shape
+    y = torch.empty((R, D), device=x.device, dtype=torch.bfloat16)
+    mean = torch.empty((R,), device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    q = mx_empty(R, D, x.device)
+    check(_lib.load().mmae_layernorm_fwd_mx(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), R, D, eps,
+                                            q.q.data_ptr(), q.scales.data_ptr(), _stream()), 'mmae_layernorm_fwd_mx')
+    return y, mean, rstd, q
+
+
 def mx_quant_t(w: Tensor, out: Optional[MxTensor] = None) -> MxTensor:
     """w [n, k] -> MX-fp8 of w^T: bytes [k, n], blocks along n (the weight operand of a dX product; mmae_mx_quant_t)."""
     _require_gpu(w, 'mx_quant_t input')
@@ -163,8 +182,10 @@ def mx_quant_t(w: Tensor, out: Optional[MxTensor] = None) -> MxTensor:
 
 
 def gemm_mx(a: MxTensor, b: MxTensor, C: Tensor, *, bias: Optional[Tensor] = None, resid: Optional[Tensor] = None,
-            aux: Optional[Tensor] = None, epi: int = EPI_NONE, colsum_part: Optional[Tensor] = None) -> Tensor:
-    """C[M, N] = a[M, K] . b[N, K]^T on the block-scaled MFMA, with the fused epilogues of mmae_gemm."""
+            aux: Optional[Tensor] = None, epi: int = EPI_NONE, colsum_part: Optional[Tensor] = None,
+            q_out: Optional[MxTensor] = None) -> Tensor:
+    """C[M, N] = a[M, K] . b[N, K]^T on the block-scaled MFMA, with the fused epilogues of mmae_gemm.
+    q_out (GELU / dGELU epilogues, bf16 C): also receives the MX-fp8 quantisation of C."""
     assert a.cols == b.cols, (a.cols, b.cols)
     M, N, K = a.rows, b.rows, a.cols
     d = GemmDesc()
@@ -180,6 +201,9 @@ def gemm_mx(a: MxTensor, b: MxTensor, C: Tensor, *, bias: Optional[Tensor] = Non
     d.aux_dtype = dcode(aux.dtype) if aux is not None else F32
     d.epi, d.alpha, d.split_k = epi, 1.0, 1
     d.colsum_part = _p(colsum_part)
+    if q_out is not None:
+        assert q_out.rows == M and q_out.cols == N
+        d.q_out, d.q_scale, d.ldq = q_out.q.data_ptr(), q_out.scales.data_ptr(), N
     check(_lib.load().mmae_gemm(ctypes.byref(d), _stream()), 'mmae_gemm(mxfp8)')
     return C
 

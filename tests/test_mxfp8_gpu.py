@@ -150,6 +150,46 @@ def test_mx_gemm_quantisation_error_is_fp8_class():
     assert 5e-3 < rel < 5e-2, rel
 
 
+def test_fused_quantisation_equals_the_separate_pass():
+    """Producers that emit the MX copy of their bf16 output themselves (LayerNorm forward; the bias + GELU and dGELU [+ column
+    sums] GEMM epilogues) must write exactly what mmae_mx_quant makes of that output: bytes and packed scales bit-identical."""
+    g = torch.Generator().manual_seed(21)
+    for R, D in ((300, 256), (77, 768), (130, 1024)):
+        x = (torch.randn(R, D, generator=g) * 3 + 0.5).to(DEV)
+        w, b = torch.randn(D, generator=g).to(DEV), torch.randn(D, generator=g).to(DEV)
+        y, mean, rstd, q = ops.layernorm_fwd_mx(x, w, b, 1e-6)
+        y_ref, mean_ref, rstd_ref = ops.layernorm_fwd(x, w, b, 1e-6, torch.bfloat16)
+        assert torch.equal(y, y_ref) and torch.equal(mean, mean_ref) and torch.equal(rstd, rstd_ref)
+        sep = ops.mx_quant(y)
+        assert torch.equal(q.q, sep.q) and torch.equal(q.scales, sep.scales)
+    M, N, K = 700, 512, 256
+    a = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    wgt = (torch.randn(N, K, generator=g) * 0.05).bfloat16().to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    qa, qw = ops.mx_quant(a), ops.mx_quant(wgt)
+    out = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+    aux = torch.empty_like(out)
+    qo = ops.mx_empty(M, N, DEV)
+    ops.gemm_mx(qa, qw, out, bias=bias, aux=aux, epi=ops.EPI_GELU, q_out=qo)
+    out2, aux2 = torch.empty_like(out), torch.empty_like(out)
+    ops.gemm_mx(qa, qw, out2, bias=bias, aux=aux2, epi=ops.EPI_GELU)
+    assert torch.equal(out, out2) and torch.equal(aux, aux2)
+    sep = ops.mx_quant(out)
+    assert torch.equal(qo.q, sep.q) and torch.equal(qo.scales, sep.scales)
+    hpre = torch.randn(M, N, generator=g).bfloat16().to(DEV)
+    for with_cs in (False, True):
+        part = torch.zeros(((M + 31) // 32, N), device=DEV) if with_cs else None
+        qo = ops.mx_empty(M, N, DEV)
+        ops.gemm_mx(qa, qw, out, aux=hpre, epi=ops.EPI_DGELU, colsum_part=part, q_out=qo)
+        part2 = torch.zeros_like(part) if with_cs else None
+        ops.gemm_mx(qa, qw, out2, aux=hpre, epi=ops.EPI_DGELU, colsum_part=part2)
+        assert torch.equal(out, out2) and (not with_cs or torch.equal(part, part2))
+        sep = ops.mx_quant(out)
+        assert torch.equal(qo.q, sep.q) and torch.equal(qo.scales, sep.scales)
+    with pytest.raises(_lib.KernelError):                  # not offered for the other epilogues
+        ops.gemm_mx(qa, qw, out, bias=bias, q_out=qo)
+
+
 def _rel(a, b):
     return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 

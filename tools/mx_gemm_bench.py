@@ -1,7 +1,8 @@
 """MX-fp8 vs bf16 GEMM on the transformer shapes of cfg5 (ViT-L, B=128 x 197 rows) and cfg3 (ViT-B, 256 x 99): HIP-event timing."""
 import sys
 import torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from multimae_amd import ops
 
 DEV = 'cuda'
