@@ -308,18 +308,33 @@ class ParamArena:
     # -- integrity -----------------------------------------------------------------
     def intact(self) -> bool:
         """False if someone re-materialised the parameters (e.g. module.to(...)) after the arena
-        was built."""
+        was built.  Called several times per step (arena_of): three sentinel parameters are compared every time -- a
+        re-materialisation moves them all -- and the full walk over the 351 tensors runs on every 64th call."""
+        base = self.param.data_ptr()
+        self._intact_calls = getattr(self, '_intact_calls', 0) + 1
+        if self._intact_calls % 64 != 1:
+            sent = getattr(self, '_sentinels', None)
+            if sent is None:
+                items = list(self._params.items())
+                sent = self._sentinels = [items[0], items[len(items) // 2], items[-1]] if items else []
+            return all(p.data_ptr() == base + 4 * self.offsets[n] for n, p in sent)
         for n, p in self._params.items():
-            if p.data_ptr() != self.param.data_ptr() + 4 * self.offsets[n]:
+            if p.data_ptr() != base + 4 * self.offsets[n]:
                 return False
         return True
 
     def rebind_grads(self) -> None:
-        """(re)point every p.grad at the gradient arena (after zero_grad(set_to_none=True))."""
-        for n, p in self._params.items():
-            if p.requires_grad:
-                o, s = self.offsets[n], self.sizes[n]
-                p.grad = self.grad[o:o + s].view(p.shape)
+        """(re)point every p.grad at the gradient arena (after zero_grad(set_to_none=True)).  The views are made once; a step
+        whose gradients are still bound costs one identity check per parameter."""
+        views = getattr(self, '_grad_views', None)
+        if views is None or self._grad_views_base != self.grad.data_ptr():
+            views = self._grad_views = {n: self.grad[self.offsets[n]:self.offsets[n] + self.sizes[n]].view(p.shape)
+                                        for n, p in self._params.items()}
+            self._grad_views_base = self.grad.data_ptr()
+        for n, v in views.items():
+            p = self._params[n]
+            if p.requires_grad and p.grad is not v:
+                p.grad = v
 
     def zero_grad(self) -> None:
         self.grad.zero_()

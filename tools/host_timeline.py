@@ -35,3 +35,12 @@ print(f'host {th / 8 * 1e3:.2f} ms/step, wall {tw / 8 * 1e3:.2f} ms/step')
 names = ['zero_grad', 'forward', 'losses', 'backward', 'opt.step']
 for i, t in enumerate(T):
     print(i, ' '.join(f'{n}={1e3 * (t[j + 1] - t[j]):6.2f}' for j, n in enumerate(names)), f' start@{1e3 * (t[0] - t0):7.2f}')
+
+# where the launching thread's own time goes (the run-ahead bound's waits show up as Event.synchronize)
+import cProfile, pstats
+torch.cuda.synchronize()
+pr = cProfile.Profile(); pr.enable()
+for _ in range(10): step()
+pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr); st.sort_stats('tottime').print_stats(45)
