@@ -328,12 +328,15 @@ class ParamArena:
         whose gradients are still bound costs one identity check per parameter."""
         views = getattr(self, '_grad_views', None)
         if views is None or self._grad_views_base != self.grad.data_ptr():
-            views = self._grad_views = {n: self.grad[self.offsets[n]:self.offsets[n] + self.sizes[n]].view(p.shape)
-                                        for n, p in self._params.items()}
+            views = self._grad_views = {}
             self._grad_views_base = self.grad.data_ptr()
-        for n, v in views.items():
-            p = self._params[n]
-            if p.requires_grad and p.grad is not v:
+        for n, p in self._params.items():
+            if not p.requires_grad:
+                continue
+            v = views.get(n)
+            if v is None:                # the gradient arena covers the trainable tensors only
+                v = views[n] = self.grad[self.offsets[n]:self.offsets[n] + self.sizes[n]].view(p.shape)
+            if p.grad is not v:
                 p.grad = v
 
     def zero_grad(self) -> None:
