@@ -273,7 +273,7 @@ def linear_dw(dy: Tensor, x: Tensor, dw: Tensor, accumulate: bool, *, db: Option
 # ------------------------------------------------------ composite transformer block --
 _COMPOSITE = [_os.environ.get('MMAE_COMPOSITE', '1') != '0']
 _WS = {}
-_WS_ELEMS = [40 << 20]          # f32 elements per stream workspace (160 MB: the largest split-K slab set of ViT-B / ViT-L is 17 M)
+_WS_ELEMS = [56 << 20]          # f32 elements per stream workspace (224 MB: ViT-L's grouped weight gradients in four row slices need 50.4 M)
 
 
 def _device_ok(t: Tensor) -> bool:
