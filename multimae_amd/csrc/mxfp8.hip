@@ -95,6 +95,72 @@ __global__ void __launch_bounds__(256) mx_quant_t_kernel(const T* __restrict__ w
     }
 }
 
+// up to 32 weights per launch (blockIdx.y = weight): the per-step refresh of a ViT-L encoder is 6 launches instead of 192
+struct MxWeightTab { const void* w[32]; unsigned char* q[32]; unsigned char* s[32]; int n[32]; int k[32]; };
+
+template <typename T>
+__global__ void __launch_bounds__(256) mx_quant_batch_kernel(const MxWeightTab tab) {
+    const int i = blockIdx.y;
+    const T* __restrict__ x = (const T*)tab.w[i];
+    unsigned char* __restrict__ q = tab.q[i];
+    unsigned char* __restrict__ sc = tab.s[i];
+    const int rows = tab.n[i], cols = tab.k[i], cpr = cols >> 3;
+    const long long total = (long long)rows * cpr;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long r = idx / cpr;
+        const int c8 = (int)(idx - r * cpr);
+        float v[8];
+        if (sizeof(T) == 2) {
+            const i32x4 raw = *reinterpret_cast<const i32x4*>((const uint16_t*)x + r * cols + c8 * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(((unsigned)raw[j]) << 16); v[2 * j + 1] = __uint_as_float(((unsigned)raw[j]) & 0xffff0000u); }
+        } else {
+            const f32x4 a = *reinterpret_cast<const f32x4*>((const float*)x + r * cols + c8 * 8);
+            const f32x4 b = *reinterpret_cast<const f32x4*>((const float*)x + r * cols + c8 * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+        }
+        float am = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) am = fmaxf(am, fabsf(v[j]));
+        am = fmaxf(am, __shfl_xor(am, 1, 64));
+        am = fmaxf(am, __shfl_xor(am, 2, 64));
+        const int e = mx_shared_exp(am);
+        const float inv = mx_inv_scale(e);
+        i32x2 o;
+        o[0] = cvt4_e4m3(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
+        o[1] = cvt4_e4m3(v[4] * inv, v[5] * inv, v[6] * inv, v[7] * inv);
+        *reinterpret_cast<i32x2*>(q + r * cols + c8 * 8) = o;
+        if ((c8 & 3) == 0) sc[mx_scale_addr(rows, r, c8 >> 2)] = (unsigned char)e;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) mx_quant_t_batch_kernel(const MxWeightTab tab) {
+    const int i = blockIdx.y;
+    const T* __restrict__ w = (const T*)tab.w[i];
+    unsigned char* __restrict__ q = tab.q[i];
+    unsigned char* __restrict__ sc = tab.s[i];
+    const int n = tab.n[i], k = tab.k[i], nb = n >> 5;
+    const long long total = (long long)nb * k;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int b = (int)(idx / k), kk = (int)(idx - (long long)b * k);
+        float v[32];
+        float am = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { v[j] = ActT<T>::ld(w + (long long)(b * 32 + j) * k + kk); am = fmaxf(am, fabsf(v[j])); }
+        const int e = mx_shared_exp(am);
+        const float inv = mx_inv_scale(e);
+        int o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = cvt4_e4m3(v[4 * j] * inv, v[4 * j + 1] * inv, v[4 * j + 2] * inv, v[4 * j + 3] * inv);
+        i32x4* dst = reinterpret_cast<i32x4*>(q + (long long)kk * n + b * 32);
+        dst[0] = i32x4{o[0], o[1], o[2], o[3]};
+        dst[1] = i32x4{o[4], o[5], o[6], o[7]};
+        sc[mx_scale_addr(k, kk, b)] = (unsigned char)e;
+    }
+}
+
 __global__ void mx_scale_clear_kernel(unsigned* __restrict__ s, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s[i] = 0u;
 }
@@ -498,14 +564,41 @@ int64_t mmae_mx_tmp_bytes(int rows, int cols) {
 
 int mmae_mx_prepare_weights(int n, const void* const* w, int w_dtype, const int32_t* n_out, const int32_t* k_in, void* const* dst, void* stream) {
     MMAE_REQUIRE(n >= 0 && (n == 0 || (w && n_out && k_in && dst)), "mx_prepare_weights: null argument");
+    MMAE_REQUIRE(w_dtype == MMAE_F32 || w_dtype == MMAE_BF16, "mx_prepare_weights: weights must be f32 or bf16");
+    hipStream_t st = (hipStream_t)stream;
+    bool batched = true;                                 // the batched kernels want whole scale groups in both orientations
     for (int i = 0; i < n; ++i) {
         MMAE_REQUIRE(w[i] && dst[4 * i] && dst[4 * i + 1] && dst[4 * i + 2] && dst[4 * i + 3], "mx_prepare_weights: null pointer");
-        int rc = mmae_mx_quant(w[i], w_dtype, k_in[i], n_out[i], k_in[i], dst[4 * i], k_in[i], dst[4 * i + 1], stream);
-        if (rc) return rc;
-        rc = mmae_mx_quant_t(w[i], w_dtype, k_in[i], n_out[i], k_in[i], dst[4 * i + 2], n_out[i], dst[4 * i + 3], stream);
-        if (rc) return rc;
+        MMAE_REQUIRE(n_out[i] > 0 && k_in[i] > 0 && n_out[i] % 32 == 0 && k_in[i] % 32 == 0, "mx_prepare_weights: widths must be multiples of 32");
+        batched = batched && n_out[i] % 256 == 0 && k_in[i] % 256 == 0 && (uintptr_t)w[i] % 16 == 0 && (uintptr_t)dst[4 * i] % 16 == 0 && (uintptr_t)dst[4 * i + 2] % 16 == 0;
     }
-    return 0;
+    if (!batched) {
+        for (int i = 0; i < n; ++i) {
+            int rc = mmae_mx_quant(w[i], w_dtype, k_in[i], n_out[i], k_in[i], dst[4 * i], k_in[i], dst[4 * i + 1], stream);
+            if (rc) return rc;
+            rc = mmae_mx_quant_t(w[i], w_dtype, k_in[i], n_out[i], k_in[i], dst[4 * i + 2], n_out[i], dst[4 * i + 3], stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    for (int i0 = 0; i0 < n; i0 += 32) {
+        const int m = n - i0 < 32 ? n - i0 : 32;
+        MxWeightTab a = {}, t = {};
+        for (int j = 0; j < m; ++j) {
+            const int i = i0 + j;
+            a.w[j] = t.w[j] = w[i]; a.n[j] = t.n[j] = n_out[i]; a.k[j] = t.k[j] = k_in[i];
+            a.q[j] = (unsigned char*)dst[4 * i]; a.s[j] = (unsigned char*)dst[4 * i + 1];
+            t.q[j] = (unsigned char*)dst[4 * i + 2]; t.s[j] = (unsigned char*)dst[4 * i + 3];
+        }
+        if (w_dtype == MMAE_BF16) {
+            hipLaunchKernelGGL(mx_quant_batch_kernel<uint16_t>, dim3(128, m), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(mx_quant_t_batch_kernel<uint16_t>, dim3(128, m), dim3(256), 0, st, t);
+        } else {
+            hipLaunchKernelGGL(mx_quant_batch_kernel<float>, dim3(128, m), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(mx_quant_t_batch_kernel<float>, dim3(128, m), dim3(256), 0, st, t);
+        }
+    }
+    return mmae_check_launch("mx_prepare_weights");
 }
 
 int mmae_probe_mx_mfma(const int32_t* a_64x8, const int32_t* b_64x8, const int32_t* scale_a_64, const int32_t* scale_b_64, int opsel_a, int opsel_b,

@@ -190,6 +190,30 @@ def test_fused_quantisation_equals_the_separate_pass():
         ops.gemm_mx(qa, qw, out, bias=bias, q_out=qo)
 
 
+def test_mx_prepare_weights_batched_equals_per_tensor():
+    """the per-step weight refresh (two batched launches per 32 weights) writes what mmae_mx_quant / mmae_mx_quant_t write"""
+    import ctypes
+    g = torch.Generator().manual_seed(4)
+    shapes = [(768, 256), (256, 256), (1024, 256), (256, 1024)] * 9            # 36 weights: two batches
+    ws = [(torch.randn(n, k, generator=g) * 0.04).to(DEV) for n, k in shapes]
+    lib = _lib.load()
+    bufs = []
+    for w in ws:
+        n, k = w.shape
+        bufs += [torch.empty(n * k, device=DEV, dtype=torch.uint8), torch.zeros(int(lib.mmae_mx_scale_bytes(n, k)), device=DEV, dtype=torch.uint8),
+                 torch.empty(n * k, device=DEV, dtype=torch.uint8), torch.zeros(int(lib.mmae_mx_scale_bytes(k, n)), device=DEV, dtype=torch.uint8)]
+    src = (ctypes.c_void_p * len(ws))(*[w.data_ptr() for w in ws])
+    dst = (ctypes.c_void_p * len(bufs))(*[b.data_ptr() for b in bufs])
+    n_out = (ctypes.c_int32 * len(ws))(*[w.shape[0] for w in ws])
+    k_in = (ctypes.c_int32 * len(ws))(*[w.shape[1] for w in ws])
+    _lib.check(lib.mmae_mx_prepare_weights(len(ws), ctypes.cast(src, ctypes.c_void_p), _lib.F32, n_out, k_in, ctypes.cast(dst, ctypes.c_void_p),
+                                           ops._stream()), 'prepare')
+    for i, w in enumerate(ws):
+        a, t = ops.mx_quant(w), ops.mx_quant_t(w)
+        assert torch.equal(bufs[4 * i], a.q.view(-1)) and torch.equal(bufs[4 * i + 1], a.scales), i
+        assert torch.equal(bufs[4 * i + 2], t.q.view(-1)) and torch.equal(bufs[4 * i + 3], t.scales), i
+
+
 def _rel(a, b):
     return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 
