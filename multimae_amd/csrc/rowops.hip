@@ -1,6 +1,7 @@
 // HBM-bound row kernels: LayerNorm fwd/bwd, row softmax fwd/bwd, column sums, casts.
 // One 64-lane wavefront per row, 16-byte vector accesses, shuffle reductions (no LDS on the
 // per-row critical path).  Roofline for all of them is HBM bytes / 8 TB/s.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -78,8 +79,10 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const DT* __restrict__ dy, 
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ dx_in,
                                                      float* __restrict__ dx_out, AT* __restrict__ dx_act,
-                                                     float* __restrict__ part, long long R, int D) {
-    __shared__ float red[4][3][1024];
+                                                     float* __restrict__ part, long long R, int D, int part_rows) {
+    // cross-wave combine of the column partials in two rounds through a [2][3][D] buffer (18 KB at D = 768): with the former
+    // [4][3][1024] (48 KB) only three workgroups fitted a CU, so the 1 024-workgroup grid ran as 1.33 rounds of the chip
+    __shared__ float red[2][3][NV * 256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     f32x4 g[NV], dg[NV], db[NV], dxs[NV];
 #pragma unroll
@@ -153,19 +156,36 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const DT* __restrict__ dy, 
             }
         }
     }
+    if (w < 2) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (c < D) {
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < D) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { red[w][0][c + j] = dg[i][j]; red[w][1][c + j] = db[i][j]; red[w][2][c + j] = dxs[i][j]; }
+                for (int j = 0; j < 4; ++j) { red[w][0][c + j] = dg[i][j]; red[w][1][c + j] = db[i][j]; red[w][2][c + j] = dxs[i][j]; }
+            }
+        }
+    }
+    __syncthreads();
+    if (w >= 2) {                                            // waves 2, 3 add onto the rows of waves 0, 1 (each lane its own columns)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < D) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { red[w - 2][0][c + j] += dg[i][j]; red[w - 2][1][c + j] += db[i][j]; red[w - 2][2][c + j] += dxs[i][j]; }
+            }
         }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < 3 * D; c += 256) {
         const int k = c / D, cc = c % D;
-        part[((long long)blockIdx.x * 3 + k) * D + cc] = (red[0][k][cc] + red[1][k][cc]) + (red[2][k][cc] + red[3][k][cc]);
+        part[((long long)blockIdx.x * 3 + k) * D + cc] = red[0][k][cc] + red[1][k][cc];
     }
+    // the caller's partial block has part_rows rows (mmae_layernorm_bwd_nblk); the grid may be smaller (one resident round of
+    // the chip): the rows nobody owns are zeros
+    for (long long r = (long long)blockIdx.x + gridDim.x; r < part_rows; r += gridDim.x)
+        for (int c = threadIdx.x; c < 3 * D; c += 256) part[r * 3 * D + c] = 0.f;
 }
 
 // Up to 8 destination segments for a column-sum result: column c goes to dst[c / seg_w][c % seg_w] (a null segment is
@@ -521,12 +541,21 @@ int mmae_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float
     MMAE_REQUIRE(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm_bwd: D must be a multiple of 4 in [4,1024]");
     MMAE_REQUIRE(R > 0, "layernorm_bwd: empty");
     const int nv = (D + 255) / 256;
-    dim3 grid(mmae_layernorm_bwd_nblk(R)), block(256);
+    // The kernel's registers (83 / 127 / 168 / 209 VGPRs for D <= 256 / 512 / 768 / 1024) allow 5 / 4 / 3 / 2 waves per SIMD =
+    // workgroups per CU: a 1 024-workgroup grid at D = 768 ran as 1.33 rounds of the chip (768 resident).  Launch what is
+    // resident at once -- every workgroup walks rows block-stride, so fewer workgroups just take more rows each.  (Measured: -0.1 ms
+    // per cfg3 step, i.e. close to nothing -- the kernel is HBM-bound either way; MMAE_LN_BWD_RESIDENT=0 restores the full grid.)
+    static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    static const int env_res = getenv("MMAE_LN_BWD_RESIDENT") ? atoi(getenv("MMAE_LN_BWD_RESIDENT")) : 1;
+    const int part_rows = mmae_layernorm_bwd_nblk(R);
+    const int per_cu = nv == 1 ? 5 : (nv == 2 ? 4 : (nv == 3 ? 3 : 2));
+    const int resident = env_res ? n_cu * per_cu : part_rows;
+    dim3 grid(part_rows < resident ? part_rows : resident), block(256);
     hipStream_t st = (hipStream_t)stream;
     const bool dyb = dy_dtype == MMAE_BF16, axb = dx_act_dtype == MMAE_BF16;
 #define LN_BWD(NV, DT, AT)                                                                                                \
     hipLaunchKernelGGL((ln_bwd_kernel<NV, DT, AT>), grid, block, 0, st, (const DT*)dy, x, gamma, mean, rstd, dx_in, dx_out, \
-                       (AT*)dx_act, part, (long long)R, D)
+                       (AT*)dx_act, part, (long long)R, D, part_rows)
 #define LN_BWD_T(NV)                                                                                                      \
     if (dyb && axb) LN_BWD(NV, uint16_t, uint16_t); else if (dyb) LN_BWD(NV, uint16_t, float);                           \
     else if (axb) LN_BWD(NV, float, uint16_t); else LN_BWD(NV, float, float);
