@@ -260,6 +260,7 @@ def main():
     ap.add_argument('--adapter-streams', type=int, default=1, help='1: output adapters on separate HIP streams')
     ap.add_argument('--wgrad-stream', type=int, default=1, help='1: weight-gradient GEMMs on a side stream')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for --gpus > 1 ('nccl' = RCCL; 'gloo' for functional tests)")
+    ap.add_argument('--force-dist', type=int, default=0, help='1: run the data-parallel path (process group, bucketed all-reduce overlapped with backward, chunked encoder backward) even at world size 1 -- exercises RCCL and the reducer\'s stream logic on a single GPU')
     ap.add_argument('--share-device', type=int, default=0, help='1: every rank uses cuda:0 (functional test of the multi-process path on one GPU; use with --backend gloo)')
     ap.add_argument('--graph', type=int, default=-1, help='1: capture the step once as a hipGraph and replay it (multimae_amd.graph.StepGraph; 1 GPU only). Default 0: on ROCm 7.2 the replay of this ~1 100-node, 10-stream graph measured 46.2 ms/step against 44.1 ms eager')
     args = ap.parse_args()
@@ -275,7 +276,10 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if args.share_device:
         local = 0
-    if args.gpus > 1 or world > 1:
+    use_dist = world > 1 or bool(args.force_dist)
+    if args.force_dist and 'MASTER_ADDR' not in os.environ:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    if args.gpus > 1 or use_dist:
         assert world == args.gpus, f'launch with torch.distributed.run --nproc-per-node {args.gpus}'
         torch.cuda.set_device(local)
         if args.backend == 'nccl':
@@ -290,7 +294,7 @@ def main():
     model.to(device)
     arena = model.build_arena()
     reducer = None
-    if world > 1:
+    if use_dist:
         broadcast_parameters(arena)
         reducer = GradAllReducer.for_arena(arena)
     M.engine.set_precision(args.precision)
@@ -333,7 +337,7 @@ def main():
         last['loss'] = loss
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -365,7 +369,7 @@ def main():
     host_wait_ms = opt.host_wait_s / args.steps * 1e3
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -451,7 +455,7 @@ def main():
             'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
