@@ -619,6 +619,11 @@ int mmae_opt_step(const mmae_opt_desc* d, void* stream);
 int mmae_depth_standardize(const float* x, float* y, int B, int n, int lo, int hi, float eps, void* stream);
 
 /* hardware probes used by tests/ to pin instruction semantics the kernels rely on */
+/* Gradient of LEARNABLE positional embeddings (PatchedInputAdapter / SemSegInputAdapter with learnable_pos_emb=True,
+ * input_adapters.py:75-78,183-186): d_pos[sel[b][j]][:] += d_tok[b][j][:] over the selected tokens (d_tok f32 [B][n_sel + G][D] as
+ * mmae_tokens_assemble lays tokens out; sel as given to it; d_pos f32 [n_pos][D], all tasks' position tables stacked in task order,
+ * zeroed by the caller).  The resize of the parameter to the token grid (F.interpolate) stays with the caller. */
+int mmae_pos_emb_bwd(const float* d_tok, const int64_t* sel, float* d_pos, int B, int n_sel, int G, int D, int n_pos, void* stream);
 int mmae_probe_tr16(const uint16_t* lds_image_1024, const uint32_t* lane_byte_addr_64, uint16_t* out_64x4,
                     void* stream);
 

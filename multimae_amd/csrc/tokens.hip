@@ -431,6 +431,23 @@ __global__ void __launch_bounds__(256) patch_tile_kernel(const float* __restrict
 inline int patch_tile_cb(int ph, int W) { int cb = 8192 / (ph * W); return cb < 1 ? 0 : (cb > 16 ? 16 : cb); }
 
 // hardware probe: what does ds_read_b64_tr_b16 return for a given LDS image / lane addresses
+// Gradient of learnable positional embeddings (input_adapters.py:75-78 with learnable_pos_emb=True): token (b, j) carries the
+// embedding of position sel[b][j] (task offsets included), so d_pos[sel[b][j]] += d_tok[b][j].  One wave per selected token,
+// float atomics (order-dependent in the last bit, like semseg_emb_bwd).
+__global__ void pos_emb_bwd_kernel(const float* __restrict__ d_tok, const long long* __restrict__ sel, float* __restrict__ d_pos,
+                                   int n_sel, int G, int D, int n_pos) {
+    const int row = blockIdx.x, b = row / n_sel, j = row - b * n_sel;
+    const long long p = sel[row];
+    if (p < 0 || p >= n_pos) return;
+    const float* src = d_tok + ((long long)b * (n_sel + G) + j) * D;
+    float* dst = d_pos + p * D;
+    for (int c = threadIdx.x * 4; c < D; c += 256) {
+        const f32x4 v = ld4(src + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(dst + c + k, v[k]);
+    }
+}
+
 __global__ void probe_tr16_kernel(const uint16_t* __restrict__ image, const uint32_t* __restrict__ addr, uint16_t* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint16_t lds[1024];
     for (int i = threadIdx.x; i < 1024; i += 64) lds[i] = image[i];
@@ -604,6 +621,12 @@ int mmae_patchify(const float* img, void* patches, int patches_dtype, int64_t ld
     if (patches_dtype == MMAE_BF16) hipLaunchKernelGGL((patchify_kernel<uint16_t>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, img, (uint16_t*)patches, (long long)ld, C, nh, nw, ph, pw, total);
     else hipLaunchKernelGGL((patchify_kernel<float>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, img, (float*)patches, (long long)ld, C, nh, nw, ph, pw, total);
     return mmae_check_launch("patchify");
+}
+
+int mmae_pos_emb_bwd(const float* d_tok, const int64_t* sel, float* d_pos, int B, int n_sel, int G, int D, int n_pos, void* stream) {
+    MMAE_REQUIRE(d_tok && sel && d_pos && B > 0 && n_sel > 0 && G >= 0 && D > 0 && D % 4 == 0 && n_pos > 0, "pos_emb_bwd: bad argument");
+    hipLaunchKernelGGL(pos_emb_bwd_kernel, dim3((unsigned)(B * n_sel)), dim3(64), 0, (hipStream_t)stream, d_tok, (const long long*)sel, d_pos, n_sel, G, D, n_pos);
+    return mmae_check_launch("pos_emb_bwd");
 }
 
 int mmae_probe_tr16(const uint16_t* lds_image_1024, const uint32_t* lane_byte_addr_64, uint16_t* out_64x4, void* stream) {

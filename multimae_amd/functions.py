@@ -401,7 +401,10 @@ class EncoderStackFn(torch.autograd.Function):
 # gather-first patch embedding (input adapters + token select + global tokens)
 # ------------------------------------------------------------------------------------------
 class EmbedFn(torch.autograd.Function):
-    """forward(cfg, sel[B,n_sel] int64, global_tokens|None, *per task: data, proj.weight, proj.bias, class_emb|None)
+    """forward(cfg, sel[B,n_sel] int64, global_tokens|None, *per task: data, proj.weight, proj.bias, class_emb|None, pos)
+
+    pos: the task's position table [n_patches, D] f32 (the adapter's pos_emb resized to the token grid); it receives a gradient
+    only when the adapter was built with learnable_pos_emb=True.
 
     cfg.tasks: list of dicts (kind, C, H, W, ph, pw, k_off, K, n_patches, pos [n_patches, D] f32)
     cfg.task_offsets, cfg.D, cfg.G, cfg.wc, cfg.act
@@ -412,7 +415,7 @@ class EmbedFn(torch.autograd.Function):
         T = len(cfg.tasks)
         B, n_sel = sel.shape
         D, G, act, wc = cfg.D, cfg.G, cfg.act, cfg.wc
-        data, ws, bs, embs = tens[0::4], tens[1::4], tens[2::4], tens[3::4]
+        data, ws, bs, embs, poss = tens[0::5], tens[1::5], tens[2::5], tens[3::5], tens[4::5]
         Ktot = sum(t['K'] for t in cfg.tasks)
         if act == torch.bfloat16 and any(t['K'] % 8 for t in cfg.tasks):
             raise NotImplementedError('bf16 patch embedding needs C*P_H*P_W to be a multiple of 8 for every modality')
@@ -428,7 +431,7 @@ class EmbedFn(torch.autograd.Function):
             ops.gemm(rows, wc(w).view(D, t['K']), proj, B * n_sel, D, t['K'], lda=Ktot, ldb=t['K'], ldc=D, a_off=t['k_off'],
                      accumulate=(i > 0))
         gt = global_tokens.detach().reshape(G, D) if G > 0 else None
-        tok = ops.tokens_assemble(proj, [b.detach() for b in bs], [t['pos'] for t in cfg.tasks], cfg.task_offsets, sel, gt,
+        tok = ops.tokens_assemble(proj, [b.detach() for b in bs], [p.detach() for p in poss], cfg.task_offsets, sel, gt,
                                   B, n_sel, G, D)
         ctx.cfg, ctx.sel, ctx.rows = cfg, sel, rows
         ctx.tens, ctx.gt = tens, global_tokens
@@ -446,10 +449,13 @@ class EmbedFn(torch.autograd.Function):
         d_proj, part = ops.tokens_assemble_bwd(d_tok.contiguous(), cfg.task_offsets, sel, B, n_sel, G, D, act, raw=True)
         # one reduction of the per-workgroup partials feeds every projection bias and the global tokens
         gt_p = ctx.gt if (G > 0 and ctx.gt is not None) else None
-        g_small = sink.colsums(part, D, [tens[4 * i + 2] for i in range(T)] + [(gt_p, g) for g in range(G)])
+        g_small = sink.colsums(part, D, [tens[5 * i + 2] for i in range(T)] + [(gt_p, g) for g in range(G)])
+        d_pos = None
+        if any(tens[5 * i + 4].requires_grad for i in range(T)):          # learnable positional embeddings
+            d_pos = ops.pos_emb_bwd(d_tok.contiguous(), sel, cfg.task_offsets[-1], B, n_sel, G, D)
         out: List[Optional[Tensor]] = []
         for i, t in enumerate(cfg.tasks):
-            w, b, emb = tens[4 * i + 1], tens[4 * i + 2], tens[4 * i + 3]
+            w, b, emb = tens[5 * i + 1], tens[5 * i + 2], tens[5 * i + 3]
             gw = sink.weight(w, d_proj, rows, x_off=t['k_off'], ldx=Ktot, K=t['K'])
             if gw is not None:
                 gw = gw.view(w.shape)
@@ -462,7 +468,8 @@ class EmbedFn(torch.autograd.Function):
                 ops.semseg_emb_bwd(d_rows, s['data'], sel, ge_buf, B=B, H=t['H'], W=t['W'], E=t['C'], ph=t['ph'], pw=t['pw'],
                                    n_sel=n_sel, k_off=0, tok_off=cfg.task_offsets[i], n_patches=t['n_patches'], n_cls=emb.shape[0])
                 ge = sink.vec(emb, ge_buf)
-            out += [None, gw, gb, ge]
+            gp = d_pos[cfg.task_offsets[i]:cfg.task_offsets[i + 1]] if (d_pos is not None and tens[5 * i + 4].requires_grad) else None
+            out += [None, gw, gb, ge, gp]
         g_glob = g_small[T] if G > 0 else None
         if getattr(cfg, 'on_done', None) is not None:
             cfg.on_done()

@@ -27,6 +27,9 @@ class _PosEmbMixin:
 
     def pos_tokens(self, nh: int, nw: int) -> torch.Tensor:
         p = self.pos_emb
+        if p.requires_grad and torch.is_grad_enabled():      # learnable: resize inside autograd, every forward
+            mode = dict(mode='bicubic', align_corners=False) if self._interp_mode == 'bicubic' else dict(mode='bilinear')
+            return F.interpolate(p, size=(nh, nw), **mode)[0].flatten(1).t().contiguous().float()
         key = (nh, nw, p._version, p.device, p.data_ptr())
         cache = self.__dict__.setdefault('_pos_cache', {})
         t = cache.get(key)
@@ -76,8 +79,6 @@ class PatchedInputAdapter(nn.Module, _PosEmbMixin):
         else:
             self.pos_emb = nn.Parameter(torch.zeros(1, self.dim_tokens, h_posemb, w_posemb))
             trunc_normal_(self.pos_emb, std=0.02)
-        if self.pos_emb.requires_grad:
-            raise NotImplementedError('learnable positional embeddings are not built in the HIP engine (pre-training uses fixed sin-cos)')
         # parameter container only (weight (D,C,P_H,P_W) / bias (D,)); never called as a conv
         self.proj = nn.Conv2d(in_channels=self.num_channels, out_channels=self.dim_tokens,
                               kernel_size=(self.P_H, self.P_W), stride=(self.P_H, self.P_W))
@@ -103,7 +104,7 @@ class PatchedInputAdapter(nn.Module, _PosEmbMixin):
         H, W = x.shape[-2:]
         desc = dict(kind=0, C=self.num_channels, H=H, W=W, ph=self.P_H, pw=self.P_W, K=self.num_channels * self.P_H * self.P_W,
                     n_patches=nh * nw, pos=self.pos_tokens(nh, nw))
-        return desc, (x.float(), self.proj.weight, self.proj.bias, None)
+        return desc, (x.float(), self.proj.weight, self.proj.bias, None, desc['pos'])
 
     def forward(self, x):
         """All tokens of this modality: (B, N_H*N_W, dim_tokens)  (input_adapters.py:97-119)."""
@@ -151,8 +152,6 @@ class SemSegInputAdapter(nn.Module, _PosEmbMixin):
         else:
             self.pos_emb = nn.Parameter(torch.zeros(1, self.dim_tokens, h_posemb, w_posemb))
             trunc_normal_(self.pos_emb, std=0.02)
-        if self.pos_emb.requires_grad:
-            raise NotImplementedError('learnable positional embeddings are not built in the HIP engine')
         self.class_emb = nn.Embedding(num_embeddings=self.num_classes, embedding_dim=self.dim_class_emb,
                                       padding_idx=self.emb_padding_idx)
         trunc_normal_(self.class_emb.weight, std=0.02)
@@ -175,7 +174,7 @@ class SemSegInputAdapter(nn.Module, _PosEmbMixin):
         H, W = x.shape[-2:]
         desc = dict(kind=1, C=self.dim_class_emb, H=H, W=W, ph=self.P_H, pw=self.P_W, K=self.dim_class_emb * self.P_H * self.P_W,
                     n_patches=nh * nw, pos=self.pos_tokens(nh, nw))
-        return desc, (x.long(), self.proj.weight, self.proj.bias, self.class_emb.weight)
+        return desc, (x.long(), self.proj.weight, self.proj.bias, self.class_emb.weight, desc['pos'])
 
     def forward(self, x):
         return _embed_all(self, x)

@@ -12,6 +12,7 @@ import math
 import warnings
 
 import torch
+from typing import Optional
 from torch import nn
 
 from . import engine
@@ -171,6 +172,8 @@ class Attention(nn.Module):
         head_dim = dim // num_heads
         self.scale = head_dim ** -0.5
         self.qkv = Linear(dim, dim * 3, bias=qkv_bias)
+        if not qkv_bias:          # the fused kernels always add a bias row: a frozen zero vector outside the state_dict stands in
+            self.register_buffer('_zero_qkv_bias', torch.zeros(dim * 3), persistent=False)
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj = Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
@@ -193,6 +196,9 @@ class CrossAttention(nn.Module):
         self.scale = head_dim ** -0.5
         self.q = Linear(dim, dim, bias=qkv_bias)
         self.kv = Linear(dim, dim * 2, bias=qkv_bias)
+        if not qkv_bias:
+            self.register_buffer('_zero_q_bias', torch.zeros(dim), persistent=False)
+            self.register_buffer('_zero_kv_bias', torch.zeros(dim * 2), persistent=False)
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj = Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
@@ -205,8 +211,14 @@ class CrossAttention(nn.Module):
         return self.proj(o)
 
 
+def bias_or_zero(lin: nn.Linear, zero: Optional[torch.Tensor]) -> torch.Tensor:
+    """the Linear's bias, or the owner's frozen zero vector when it was built with bias=False (qkv_bias=False)"""
+    return lin.bias if lin.bias is not None else zero
+
+
 def block_params(blk: 'Block'):
-    return [blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight, blk.attn.proj.bias,
+    return [blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, bias_or_zero(blk.attn.qkv, getattr(blk.attn, '_zero_qkv_bias', None)),
+            blk.attn.proj.weight, blk.attn.proj.bias,
             blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias]
 
 
@@ -220,8 +232,6 @@ class Block(nn.Module):
         self.norm2 = _as_hip_norm(norm_layer, dim)
         mlp_hidden_dim = int(dim * mlp_ratio)
         self.mlp = Mlp(in_features=dim, hidden_features=mlp_hidden_dim, act_layer=act_layer, drop=drop)
-        if not qkv_bias:
-            raise NotImplementedError('qkv_bias=False is not built (every reference factory uses True)')
 
     def forward(self, x):
         return run_blocks([self], x)

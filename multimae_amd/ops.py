@@ -913,6 +913,13 @@ def _ptr_array(ts: Sequence[Tensor]):
     return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
 
 
+def pos_emb_bwd(d_tok: Tensor, sel: Tensor, n_pos: int, B: int, n_sel: int, G: int, D: int) -> Tensor:
+    """d_pos f32 [n_pos, D]: the selected tokens' gradients summed per position (learnable positional embeddings)."""
+    d_pos = torch.zeros((n_pos, D), device=d_tok.device, dtype=torch.float32)
+    check(_lib.load().mmae_pos_emb_bwd(d_tok.data_ptr(), sel.data_ptr(), d_pos.data_ptr(), B, n_sel, G, D, n_pos, _stream()), 'mmae_pos_emb_bwd')
+    return d_pos
+
+
 def tokens_assemble(proj: Tensor, biases: Sequence[Tensor], poss: Sequence[Tensor], task_offsets: Sequence[int], sel: Tensor,
                     global_tok: Optional[Tensor], B: int, n_sel: int, G: int, D: int) -> Tensor:
     tok = torch.empty((B, n_sel + G, D), device=proj.device, dtype=torch.float32)

@@ -23,7 +23,7 @@ from torch import nn
 
 from . import engine
 from .functions import SpatialAdapterFn, TokenMeanFn
-from .multimae_utils import (Block, CrossAttention, LayerNorm, Linear, Mlp, _as_hip_norm, _cfg, block_params,
+from .multimae_utils import (Block, CrossAttention, LayerNorm, Linear, Mlp, _as_hip_norm, _cfg, bias_or_zero, block_params,
                              build_2d_sincos_posemb, pair, trunc_normal_)
 
 
@@ -126,7 +126,8 @@ class SpatialOutputAdapter(nn.Module):
             else:
                 te.append(None)
         d = self.decoder
-        ps = [self.mask_token, *te, d.q.weight, d.q.bias, d.kv.weight, d.kv.bias, d.proj.weight, d.proj.bias,
+        ps = [self.mask_token, *te, d.q.weight, bias_or_zero(d.q, getattr(d, '_zero_q_bias', None)), d.kv.weight,
+              bias_or_zero(d.kv, getattr(d, '_zero_kv_bias', None)), d.proj.weight, d.proj.bias,
               self.context_norm.weight, self.context_norm.bias, self.query_norm.weight, self.query_norm.bias,
               self.out_norm.weight, self.out_norm.bias, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight,
               self.mlp.fc2.bias]
