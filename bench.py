@@ -249,8 +249,9 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default 256; 128 for cfg5)')
     ap.add_argument('--config', default='cfg3', choices=['cfg3', 'cfg2', 'cfg5'],
                     help='cfg3 = BASELINE.json configs[2] (the metric), cfg2 = configs[1] (RGB-only), cfg5 = configs[4] geometry (ViT-L, 196 visible tokens; bf16 -- the MX-fp8 path is not built)')
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32', 'mxfp8'],
-                    help="'mxfp8': encoder forward / dX products on OCP MX-fp8 operands (block-scaled MFMA), everything else as bf16")
+    ap.add_argument('--precision', default=None, choices=['bf16', 'fp32', 'mxfp8'],
+                    help="'mxfp8': encoder forward / dX products on OCP MX-fp8 operands (block-scaled MFMA), everything else as bf16.  "
+                         "Default: bf16; mxfp8 for --config cfg5 (BASELINE.json configs[4] names the fp8 MFMA path)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-batch', type=int, default=16)
     ap.add_argument('--cpu-threads', type=int, default=0, help='0: best of an 8/16/32/64 sweep')
@@ -264,6 +265,8 @@ def main():
     ap.add_argument('--share-device', type=int, default=0, help='1: every rank uses cuda:0 (functional test of the multi-process path on one GPU; use with --backend gloo)')
     ap.add_argument('--graph', type=int, default=-1, help='1: capture the step once as a hipGraph and replay it (multimae_amd.graph.StepGraph; 1 GPU only). Default 0: on ROCm 7.2 the replay of this ~1 100-node, 10-stream graph measured 46.2 ms/step against 44.1 ms eager')
     args = ap.parse_args()
+    if args.precision is None:
+        args.precision = 'mxfp8' if args.config == 'cfg5' else 'bf16'
 
     import torch.distributed as dist
     import multimae_amd as M
@@ -425,12 +428,15 @@ def main():
                 'f32_adapter_gemm_ms_per_step': round(tot_ms[torch.float32], 3) if dom == torch.bfloat16 else None,
                 'f32_adapter_gemm_tflops': round(tot_fl[torch.float32] / max(tot_ms[torch.float32], 1e-9) / 1e9, 2) if dom == torch.bfloat16 else None,
                 'whole_step_frac_of_peak': round(ALG_GFLOP_PER_IMG[args.config] * 1e9 * B / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
-        if args.precision == 'mxfp8':                       # the MX products have their own line: 5 PFLOP/s dense MX-fp8 peak
-            roof['mxfp8'] = {'kernel': 'gemm_mxfp8_kernel (v_mfma_scale_f32_32x32x64_f8f6f4): encoder forward + dX products', 'launches_per_step': int(n2[2]),
-                             'gemm_ms_per_step': round(ms2[2], 3), 'gemm_gflop_per_step': round(fl2[2] / 1e9, 1),
-                             'achieved': round(fl2[2] / max(ms2[2], 1e-9) / 1e9, 2), 'peak': 5000.0, 'unit': 'TFLOP/s',
-                             'frac': round(fl2[2] / max(ms2[2], 1e-9) / 1e9 / 5000.0, 4)}
-
+        if args.precision == 'mxfp8':
+            # the dominant kernel of this mode is the MX-fp8 GEMM: ITS launches against the 5 PFLOP/s dense MX-fp8 peak are the
+            # roofline line; the bf16 launches of the same step (weight gradients, adapters) are kept beside it
+            mx_ach = fl2[2] / max(ms2[2], 1e-9) / 1e9
+            roof = {'bound': 'mfma', 'kernel': 'gemm_mxfp8_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3 x E8M0 / 32): the encoder forward + dX products of one production step, each launch bracketed by HIP events inside the library, single-stream',
+                    'achieved': round(mx_ach, 2), 'peak': 5000.0, 'unit': 'TFLOP/s', 'frac': round(mx_ach / 5000.0, 4),
+                    'traffic': None, 'traffic_source': 'PMC passes of this mode: profiles/r02_mxfp8_pmc_traffic.json (per kernel; not averaged into one figure)',
+                    'launches_per_step': int(n2[2]), 'gemm_ms_per_step': round(ms2[2], 3), 'gemm_gflop_per_step': round(fl2[2] / 1e9, 1),
+                    'bf16_products': roof}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config != 'cfg5':      # the CPU leg is sized for the ViT-B configs
         M.engine.set_direct_grads(False)

@@ -30,7 +30,7 @@ run "serialized (one stream)" timeout 300 $B --adapter-streams 0 --wgrad-stream 
 run "hipGraph replay" timeout 300 $B --graph 1
 echo "== other configs" >> gpurun_out/summary.txt
 run "cfg2 (RGB only) B=256" timeout 300 $B --config cfg2
-run "cfg5 geometry (ViT-L, bf16) B=128" timeout 600 $B --config cfg5 --steps 10 --warmup 3
+run "cfg5 geometry (ViT-L, bf16) B=128" timeout 600 $B --config cfg5 --precision bf16 --steps 10 --warmup 3
 run "cfg5 geometry (ViT-L, --precision mxfp8) B=128" timeout 600 $B --config cfg5 --precision mxfp8 --steps 10 --warmup 3
 run "cfg3, data-parallel path over RCCL at world size 1 (--force-dist 1)" timeout 300 $B --force-dist 1
 run "cfg3 B=128" timeout 300 $B --batch 128
