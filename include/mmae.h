@@ -306,6 +306,11 @@ typedef struct mmae_block_desc {
      * the kernel that produces it: both LayerNorms and the GELU / dGELU epilogues emit the e4m3 copy themselves (env
      * MMAE_MX_FUSE=0: separate passes everywhere); weight gradients stay bf16.  D, 3 D and Hd must be multiples of 256.  NULL = bf16 products. */
     const void* const* mx_w; void* mx_tmp; int64_t mx_tmp_bytes;
+    /* f32 activations with MMAE_F32X3 products: optional pre-split weights -- host array of x3_n triples {the f32 weight pointer
+     * as it appears above, its [n_out][3 k_in] copy, its [3 n_out][k_in] copy} (mmae_x3_prepare_weights) -- and a scratch of
+     * mmae_x3_tmp_bytes(B * N, max(Hd, 3 D)) bytes.  Forward and dX products whose contraction is a multiple of 32 then run as
+     * one bf16 product over 3 K on the ping-pong kernel; weight gradients keep the MMAE_F32X3 kernel.  NULL = off. */
+    const void* const* x3_w; int32_t x3_n; void* x3_tmp; int64_t x3_tmp_bytes;
 } mmae_block_desc;
 
 int mmae_block_fwd(const mmae_block_desc* d, void* stream);
@@ -400,6 +405,8 @@ typedef struct mmae_adapter_desc {
     void* tmp; int64_t tmp_bytes;
     float* ws_main; int64_t ws_main_elems;
     float* ws_side; int64_t ws_side_elems;
+    const void* const* x3_w; int32_t x3_n;       /* optional pre-split weights (triples, as mmae_block_desc.x3_w) of an f32 adapter; set them
+                                                    BEFORE asking for the slab sizes: the operand scratch is carved from act / tmp */
 } mmae_adapter_desc;
 
 int64_t mmae_adapter_act_bytes(const mmae_adapter_desc* d);
@@ -624,6 +631,20 @@ int mmae_depth_standardize(const float* x, float* y, int B, int n, int lo, int h
  * mmae_tokens_assemble lays tokens out; sel as given to it; d_pos f32 [n_pos][D], all tasks' position tables stacked in task order,
  * zeroed by the caller).  The resize of the parameter to the token grid (F.interpolate) stays with the caller. */
 int mmae_pos_emb_bwd(const float* d_tok, const int64_t* sel, float* d_pos, int B, int n_sel, int G, int D, int n_pos, void* stream);
+/* ------------------------------------------------------------------------- *
+ * Pre-split operands for the split-bf16 ("x3") products of fp32_output_adapters (multimae.py:367-377) in speed mode.
+ * a.b ~= a_hi.b_hi + a_hi.b_lo + a_lo.b_hi is ONE bf16 product over a contraction of 3 K when the operands are stored as
+ * A' = [hi | hi | lo] and B' = [hi | lo | hi]: it then runs on the ping-pong bf16 kernel (2-3x the rate of the MMAE_F32X3 kernel,
+ * which splits in registers).  mmae_x3_split writes such an operand: out bf16 [rows][out_ld], segment s (cols elements) at
+ * element offset s * seg_stride of the row (or, with seg_stride = rows * cols and out_ld = cols, stacked along the rows);
+ * segment lo_seg gets bf16(x - bf16(x)), the other two bf16(x).  mmae_x3_prepare_weights does both weight layouts:
+ * dst[2 i] = [n_out][3 k_in] = [hi | lo | hi] for the forward product, dst[2 i + 1] = [3 n_out][k_in] = [hi ; lo ; hi] for dX.
+ * The composite calls use them when the descriptor's x3_w table is set (mmae_adapter_desc / mmae_block_desc).
+ * ------------------------------------------------------------------------- */
+int mmae_x3_split(const float* x, int64_t ldx, int64_t rows, int cols, void* out, int64_t out_ld, int64_t seg_stride, int lo_seg, void* stream);
+int mmae_x3_prepare_weights(int n, const void* const* w, const int32_t* n_out, const int32_t* k_in, void* const* dst, void* stream);
+/* scratch for one pre-split activation operand [rows][3 cols] bf16 */
+int64_t mmae_x3_tmp_bytes(int64_t rows, int cols);
 int mmae_probe_tr16(const uint16_t* lds_image_1024, const uint32_t* lane_byte_addr_64, uint16_t* out_64x4,
                     void* stream);
 

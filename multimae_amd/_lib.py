@@ -63,7 +63,8 @@ class BlockDesc(ctypes.Structure):
                                      'g_fc1_w', 'g_fc1_b', 'g_fc2_w', 'g_fc2_b', 'g_cs')]
                 + [('grad_acc', _I), ('fc2_b_done', _I), ('ws_main', _P), ('ws_main_elems', _L), ('ws_side', _P), ('ws_side_elems', _L)]
                 + [(n, _P) for n in ('dp1', 'dp2', 'branch', 'dxs_act')]
-                + [('mx_w', _P), ('mx_tmp', _P), ('mx_tmp_bytes', _L)])
+                + [('mx_w', _P), ('mx_tmp', _P), ('mx_tmp_bytes', _L)]
+                + [('x3_w', _P), ('x3_n', _I), ('x3_tmp', _P), ('x3_tmp_bytes', _L)])
 
 
 class StackDesc(ctypes.Structure):
@@ -81,7 +82,8 @@ class AdapterDesc(ctypes.Structure):
                 + [(n, _P) for n in ('task_offsets_host', 'w', 'p', 'mask_token', 'task_emb', 'pos', 'enc', 'enc_act', 'ids_keep',
                                      'ids_restore', 'act')] + [('act_bytes', _L), ('img', _P)]
                 + [('d_img', _P), ('d_pat', _P), ('ld_pat', _L), ('g', _P), ('d_enc', _P), ('tmp', _P), ('tmp_bytes', _L)]
-                + [('ws_main', _P), ('ws_main_elems', _L), ('ws_side', _P), ('ws_side_elems', _L)])
+                + [('ws_main', _P), ('ws_main_elems', _L), ('ws_side', _P), ('ws_side_elems', _L)]
+                + [('x3_w', _P), ('x3_n', _I)])
 
 
 class DwProblem(ctypes.Structure):

@@ -16,6 +16,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 void mmae_set_error(const char* msg);
 int mmae_check_launch(const char* what);
+int mmae_gemm_ex(const mmae_gemm_desc* d, void* stream, int timing_cls, double flop_scale);   // runtime.hip
 
 #define MMAE_REQUIRE(cond, msg) do { if (!(cond)) { mmae_set_error(msg); return MMAE_EINVAL; } } while (0)
 

@@ -19,6 +19,8 @@ struct Ctx {
     float* ws_main; int64_t ws_main_elems;
     float* ws_side; int64_t ws_side_elems;
     void* mx_tmp = nullptr; int64_t mx_tmp_bytes = 0;      // scratch of the MX-fp8 activation operands (main stream only)
+    const void* const* x3_w = nullptr; int x3_n = 0;       // pre-split weights of an f32 call: triples {f32 weight, [n][3k], [3n][k]}
+    void* x3_tmp = nullptr; int64_t x3_tmp_bytes = 0;      // scratch of the pre-split activation operand (main stream only)
     int ab() const { return act_dtype == MMAE_BF16 ? MMAE_BF16 : f32_gemm; }
     size_t es() const { return act_dtype == MMAE_BF16 ? 2 : 4; }
 };
@@ -26,7 +28,22 @@ struct Ctx {
 Ctx ctx_of(const mmae_block_desc* d) {
     Ctx c{d->act_dtype, d->f32_gemm, d->grad_acc, d->ws_main, d->ws_main_elems, d->ws_side, d->ws_side_elems};
     c.mx_tmp = d->mx_tmp; c.mx_tmp_bytes = d->mx_tmp_bytes;
+    c.x3_w = d->x3_w; c.x3_n = d->x3_n; c.x3_tmp = d->x3_tmp; c.x3_tmp_bytes = d->x3_tmp_bytes;
     return c;
+}
+
+// Pre-split x3 product (mmae.h, mmae_x3_split): if this f32 call carries a pre-split copy of weight w and the contraction is a
+// multiple of 32, split the activation operand [M][kc] (row stride ldx) into the scratch and return the weight triple.
+const void* const* x3_operand(const Ctx& c, const void* x, int64_t ldx, const void* w, int M, int kc, const void** a3, hipStream_t st, int* rc) {
+    static const bool on = !(getenv("MMAE_X3_PRESPLIT") && atoi(getenv("MMAE_X3_PRESPLIT")) == 0);    // the host side only passes x3_w when asked to (ops.py)
+    *rc = 0;
+    if (!on || c.act_dtype != MMAE_F32 || c.f32_gemm != MMAE_F32X3 || !c.x3_w || !c.x3_tmp || (kc % 32) || (ldx % 4)) return nullptr;
+    const void* const* t3 = nullptr;
+    for (int i = 0; i < c.x3_n; ++i) if (c.x3_w[3 * i] == w) { t3 = c.x3_w + 3 * i; break; }
+    if (!t3 || mmae_x3_tmp_bytes(M, kc) > c.x3_tmp_bytes) return nullptr;
+    *rc = mmae_x3_split((const float*)x, ldx, M, kc, c.x3_tmp, 3LL * kc, kc, 2, st);
+    *a3 = c.x3_tmp;
+    return *rc ? nullptr : t3;
 }
 
 // The MX scratch is two halves: a product reads its quantised activation operand from one while its epilogue (fc1 forward,
@@ -97,6 +114,14 @@ int lin_fwd(const Ctx& c, const void* x, const void* w, const float* bias, void*
     g.bias = bias; g.resid = resid; g.ldr = N;
     g.aux = aux; g.ldaux = N; g.aux_dtype = c.act_dtype;
     g.epi = epi; g.alpha = 1.0f;
+    bool x3p = false;
+    if (!mxw) {
+        int rc3 = 0;
+        const void* a3 = nullptr;
+        const void* const* t3 = x3_operand(c, x, K, w, M, K, &a3, st, &rc3);
+        if (rc3) return rc3;
+        if (t3) { g.A = a3; g.B = t3[1]; g.K = 3 * K; g.lda = g.ldb = 3LL * K; g.ab_dtype = MMAE_BF16; x3p = true; }
+    }
     if (mxw) {
         int rc = mx_in_operand(c, x, K, M, K, mx_in, mx_out, &g.A, &g.a_scale, st);
         if (rc) return rc;
@@ -112,7 +137,7 @@ int lin_fwd(const Ctx& c, const void* x, const void* w, const float* bias, void*
         if ((int64_t)split * M * N > c.ws_main_elems) { mmae_set_error("composite: ws_main too small"); return MMAE_EINVAL; }
         g.ws = c.ws_main; g.ws_elems = c.ws_main_elems;
     }
-    return mmae_gemm(&g, st);
+    return x3p ? mmae_gemm_ex(&g, st, 1, 1.0 / 3.0) : mmae_gemm(&g, st);
 }
 
 // out[M,K] = dy[M,N] w[N,K] (+ dGELU epilogue with column-sum partials) -- ops.linear_dx.  ldy: row stride of dy.
@@ -129,6 +154,14 @@ int lin_dx(const Ctx& c, const void* dy, int64_t ldy, const void* w, void* out, 
     g.aux = aux; g.ldaux = K; g.aux_dtype = c.act_dtype;
     g.epi = epi; g.alpha = 1.0f;
     g.colsum_part = colsum_part;
+    bool x3p = false;
+    if (!mxw) {                                           // dy pre-split along n; the weight's [3 N][K] copy
+        int rc3 = 0;
+        const void* a3 = nullptr;
+        const void* const* t3 = x3_operand(c, dy, ldy, w, M, N, &a3, st, &rc3);
+        if (rc3) return rc3;
+        if (t3) { g.A = a3; g.lda = 3LL * N; g.B = t3[2]; g.K = 3 * N; g.ab_dtype = MMAE_BF16; x3p = true; }
+    }
     if (mxw) {                                            // dy quantised along n; the weight's transposed copy [K][N], blocks along n
         int rc = mx_in_operand(c, dy, ldy, M, N, mx_in, mx_out, &g.A, &g.a_scale, st);
         if (rc) return rc;
@@ -144,7 +177,7 @@ int lin_dx(const Ctx& c, const void* dy, int64_t ldy, const void* w, void* out, 
         if ((int64_t)split * M * K > c.ws_main_elems) { mmae_set_error("composite: ws_main too small"); return MMAE_EINVAL; }
         g.ws = c.ws_main; g.ws_elems = c.ws_main_elems;
     }
-    return mmae_gemm(&g, st);
+    return x3p ? mmae_gemm_ex(&g, st, 1, 1.0 / 3.0) : mmae_gemm(&g, st);
 }
 
 // dw[N,K] (+)= dy[M,N]^T x[M,K]; db[N] (+)= column sums of dy (inside the GEMM where the kernel can) -- ops.linear_dw
@@ -361,6 +394,7 @@ struct StackRun {
     const float* x_in; const BlockAct* acts; BlockTmp* tmps; int nset;
     float* ws_main; int64_t ws_main_elems; float* ws_side; int64_t ws_side_elems;
     const void* const* mx_w = nullptr; void* mx_tmp = nullptr; int64_t mx_tmp_bytes = 0;
+    const void* const* x3_w = nullptr; int x3_n = 0; void* x3_tmp = nullptr; int64_t x3_tmp_bytes = 0;
 };
 
 int run_blocks_bwd(const StackRun& s, int lo, int hi, const float* dx_top, const void* dx_top_act, bool top_in_sets, bool first_fc2_b_done,
@@ -402,6 +436,7 @@ int run_blocks_bwd(const StackRun& s, int lo, int hi, const float* dx_top, const
         b.grad_acc = s.grad_acc; b.fc2_b_done = fc2_done ? 1 : 0;
         b.ws_main = s.ws_main; b.ws_main_elems = s.ws_main_elems; b.ws_side = s.ws_side; b.ws_side_elems = s.ws_side_elems;
         if (s.mx_w) { b.mx_w = s.mx_w + 16 * l; b.mx_tmp = s.mx_tmp; b.mx_tmp_bytes = s.mx_tmp_bytes; }
+        b.x3_w = s.x3_w; b.x3_n = s.x3_n; b.x3_tmp = s.x3_tmp; b.x3_tmp_bytes = s.x3_tmp_bytes;
         if ((rc = mmae_block_bwd(&b, st, sd))) return rc;
         if (sd != st) {
             hipEvent_t e = g_held_ring.next();
@@ -650,8 +685,18 @@ struct AdapterAct {
     float *ctx_tok, *te, *queries, *context, *qmean, *qrstd, *cmean, *crstd, *lse, *x, *omean, *orstd, *x1, *pat;
     void *enc_act, *qn, *cn, *q, *kv, *xo, *on, *hpre, *hact, *h_act;
     BlockAct blocks[8];
+    void* x3_tmp;
 };
 int kp_of(const mmae_adapter_desc* d) { return d->C * d->ph * d->pw; }
+// scratch for the widest pre-split operand of an f32 adapter (rows: the B * n_q query rows; columns: the widest contraction)
+int64_t adapter_x3_bytes(const mmae_adapter_desc* d) {
+    if (!d->x3_w || d->act_dtype != MMAE_F32) return 0;
+    int wide = d->Hd > 3 * d->D ? d->Hd : 3 * d->D;
+    if (d->Denc > wide) wide = d->Denc;
+    if (kp_of(d) % 32 == 0 && kp_of(d) > wide) wide = kp_of(d);
+    const int64_t rq = (int64_t)d->B * d->n_q, rc = (int64_t)d->B * d->NC;
+    return mmae_x3_tmp_bytes(rq > rc ? rq : rc, wide);
+}
 
 AdapterAct carve_adapter_act(Carver& cv, const mmae_adapter_desc* d) {
     const size_t es = d->act_dtype == MMAE_BF16 ? 2 : 4;
@@ -670,6 +715,7 @@ AdapterAct carve_adapter_act(Carver& cv, const mmae_adapter_desc* d) {
     for (int l = 0; l < d->depth; ++l) a.blocks[l] = carve_block_act(cv, d->B, d->n_q, D, d->heads, d->Hd, es);
     a.h_act = d->act_dtype == MMAE_BF16 ? cv.take(Rq * D * es) : nullptr;
     a.pat = cv.takeT<float>(Rq * kp_of(d));
+    a.x3_tmp = adapter_x3_bytes(d) ? cv.take(adapter_x3_bytes(d)) : nullptr;
     return a;
 }
 
@@ -677,6 +723,7 @@ struct AdapterTmp {
     void *d_pat, *dh_act, *d_hpre, *d_on, *dx_act, *d_xo, *d_q, *d_kv, *d_qn, *d_cn, *d_ctx_act;
     float *dh, *part_h, *dx, *part_o, *d_queries, *part_q, *d_context, *part_c, *d_ctx, *part_b;
     BlockTmp blocks[8];
+    void* x3_tmp;
 };
 int64_t ldpat_of(const mmae_adapter_desc* d) { return (kp_of(d) + 7) / 8 * 8; }
 
@@ -700,6 +747,7 @@ AdapterTmp carve_adapter_tmp(Carver& cv, const mmae_adapter_desc* d) {
     t.d_context = cv.takeT<float>(Rc * D); t.part_c = cv.takeT<float>((int64_t)mmae_layernorm_bwd_nblk(Rc) * 3 * D);
     t.d_ctx = cv.takeT<float>(Rc * D); t.part_b = cv.takeT<float>((int64_t)mmae_decoder_build_bwd_nblk(d->B) * (d->T + 1) * D);
     t.d_ctx_act = bf ? cv.take(Rc * D * es) : nullptr;
+    t.x3_tmp = adapter_x3_bytes(d) ? cv.take(adapter_x3_bytes(d)) : nullptr;
     return t;
 }
 
@@ -724,7 +772,11 @@ int check_adapter(const mmae_adapter_desc* d) {
     return 0;
 }
 
-Ctx ctx_of(const mmae_adapter_desc* d) { return {d->act_dtype, d->f32_gemm, d->grad_acc, d->ws_main, d->ws_main_elems, d->ws_side, d->ws_side_elems}; }
+Ctx ctx_of(const mmae_adapter_desc* d, void* x3_tmp) {
+    Ctx c{d->act_dtype, d->f32_gemm, d->grad_acc, d->ws_main, d->ws_main_elems, d->ws_side, d->ws_side_elems};
+    if (x3_tmp) { c.x3_w = d->x3_w; c.x3_n = d->x3_n; c.x3_tmp = x3_tmp; c.x3_tmp_bytes = adapter_x3_bytes(d); }
+    return c;
+}
 
 }  // namespace
 
@@ -752,12 +804,12 @@ int mmae_adapter_fwd(const mmae_adapter_desc* d, void* stream) {
     if (rc) return rc;
     MMAE_REQUIRE(d->act_bytes >= mmae_adapter_act_bytes(d), "adapter_fwd: activation slab too small");
     hipStream_t st = (hipStream_t)stream;
-    const Ctx c = ctx_of(d);
     const int act = d->act_dtype, D = d->D, Hd = d->Hd, B = d->B, NC = d->NC, n_q = d->n_q, T = d->T, depth = d->depth;
     const int Rq = B * n_q, Rc = B * NC, hd = D / d->heads, KP = kp_of(d);
-    const size_t es = c.es();
     Carver cv(d->act);
     AdapterAct a = carve_adapter_act(cv, d);
+    const Ctx c = ctx_of(d, a.x3_tmp);
+    const size_t es = c.es();
     const void* const* w = d->w; const float* const* p = d->p;
     const void *qw = w[0], *kvw = w[1], *pw = w[2], *f1w = w[3], *f2w = w[4], *ow = w[5 + 4 * depth], *pcw = w[6 + 4 * depth];
     const float *qb = p[0], *kvb = p[1], *pb = p[2], *cnw = p[3], *cnb = p[4], *qnw = p[5], *qnb = p[6], *onw = p[7], *onb = p[8], *f1b = p[9],
@@ -795,6 +847,7 @@ int mmae_adapter_fwd(const mmae_adapter_desc* d, void* stream) {
         fill_block_params(b, B, n_q, D, d->heads, Hd, act, d->f32_gemm, d->eps, w + 5 + 4 * l, p + 11 + 8 * l);
         fill_block_act(b, h, a.blocks[l]);
         b.ws_main = d->ws_main; b.ws_main_elems = d->ws_main_elems;
+        b.x3_w = c.x3_w; b.x3_n = c.x3_n; b.x3_tmp = c.x3_tmp; b.x3_tmp_bytes = c.x3_tmp_bytes;
         if ((rc = mmae_block_fwd(&b, st))) return rc;
         h = a.blocks[l].x2;
     }
@@ -813,15 +866,15 @@ int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream
     MMAE_REQUIRE(d->g && d->d_enc, "adapter_bwd: null gradient destination table / d_enc");
     hipStream_t st = (hipStream_t)stream;
     hipStream_t sd = side_stream ? (hipStream_t)side_stream : st;
-    const Ctx c = ctx_of(d);
     const int act = d->act_dtype, D = d->D, Hd = d->Hd, B = d->B, NC = d->NC, n_q = d->n_q, T = d->T, depth = d->depth;
     const int Rq = B * n_q, Rc = B * NC, hd = D / d->heads, KP = kp_of(d);
-    const size_t es = c.es();
     const bool bf = act == MMAE_BF16;
     Carver ca(d->act);
     AdapterAct a = carve_adapter_act(ca, d);
     Carver ct(d->tmp);
     AdapterTmp t = carve_adapter_tmp(ct, d);
+    const Ctx c = ctx_of(d, t.x3_tmp);
+    const size_t es = c.es();
     const void* const* w = d->w; const float* const* p = d->p;
     const void *qw = w[0], *kvw = w[1], *pw = w[2], *f1w = w[3], *f2w = w[4], *ow = w[5 + 4 * depth], *pcw = w[6 + 4 * depth];
     const float *cnw = p[3], *qnw = p[5], *onw = p[7];
@@ -858,6 +911,7 @@ int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream
         // parameter / gradient tables of the blocks in stack order
         StackRun s = {B, n_q, D, d->heads, Hd, act, d->f32_gemm, d->grad_acc, w + 5, p + 11, nullptr, gblk, a.x1, a.blocks, t.blocks, depth,
                       d->ws_main, d->ws_main_elems, d->ws_side, d->ws_side_elems};
+        s.x3_w = c.x3_w; s.x3_n = c.x3_n; s.x3_tmp = c.x3_tmp; s.x3_tmp_bytes = c.x3_tmp_bytes;
         const float* o; const void* oa;
         if ((rc = run_blocks_bwd(s, 0, depth, dh, dh_act, false, false, nullptr, gb[15], nullptr, st, sd, &o, &oa))) return rc;
         dh = o; dh_act = oa;

@@ -193,6 +193,27 @@ int launch(const GemmArgs& g, int batch, hipStream_t st) {
     return mmae_check_launch("gemm_f32x3");
 }
 
+
+// Pre-split operands ("x3p"): out bf16 [rows][out_ld] with three segments of `cols` elements each, segment s at element offset
+// s * seg_stride of the row; segment lo_seg holds the low parts bf16(x - hi), the other two the high parts bf16(x).  With
+// A' = [hi | hi | lo] and B' = [hi | lo | hi] along the contraction, the three-term split product is ONE bf16 product over 3 K:
+// it runs on the ping-pong kernel (LDS-DMA cannot split on the fly) instead of this file's VGPR-staged 128 x 128 kernel.
+__global__ void __launch_bounds__(256) x3_split_kernel(const float* __restrict__ x, long long ldx, long long rows, int cols, uint16_t* __restrict__ out,
+                                                       long long out_ld, long long seg_stride, int lo_seg) {
+    const int cpr = cols >> 3;
+    const long long total = rows * cpr;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long r = idx / cpr;
+        const int c = (int)(idx - r * cpr) * 8;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + r * ldx + c), x1 = *reinterpret_cast<const f32x4*>(x + r * ldx + c + 4);
+        i32x4 hi, lo;
+        split8(x0, x1, hi, lo);
+        uint16_t* o = out + r * out_ld + c;
+#pragma unroll
+        for (int sgm = 0; sgm < 3; ++sgm) *reinterpret_cast<i32x4*>(o + sgm * seg_stride) = (sgm == lo_seg) ? lo : hi;
+    }
+}
+
 }  // namespace
 
 int mmae_gemm_f32x3_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st) {
@@ -212,3 +233,30 @@ int mmae_gemm_f32x3_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t
     if (aks && !bks) return launch<true, false>(g, d->batch, st);
     return launch<true, true>(g, d->batch, st);
 }
+
+extern "C" int mmae_x3_split(const float* x, int64_t ldx, int64_t rows, int cols, void* out, int64_t out_ld, int64_t seg_stride, int lo_seg, void* stream) {
+    MMAE_REQUIRE(x && out && rows > 0 && cols > 0, "x3_split: bad argument");
+    MMAE_REQUIRE(cols % 8 == 0 && ldx % 4 == 0 && out_ld % 8 == 0 && seg_stride % 8 == 0 && lo_seg >= 0 && lo_seg < 3 &&
+                 (uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0, "x3_split: widths multiples of 8, 16-byte aligned rows");
+    const long long total = rows * (cols / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(x3_split_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, (long long)rows, cols, (uint16_t*)out,
+                       (long long)out_ld, (long long)seg_stride, lo_seg);
+    return mmae_check_launch("x3_split");
+}
+
+// weights w[i] = [n_out[i]][k_in[i]] f32 -> dst[2 i]: bf16 [n_out][3 k_in] = [hi | lo | hi] (forward product),
+//                                           dst[2 i + 1]: bf16 [3 n_out][k_in] = rows [hi ; lo ; hi] (dX product)
+extern "C" int mmae_x3_prepare_weights(int n, const void* const* w, const int32_t* n_out, const int32_t* k_in, void* const* dst, void* stream) {
+    MMAE_REQUIRE(n >= 0 && (n == 0 || (w && n_out && k_in && dst)), "x3_prepare_weights: null argument");
+    for (int i = 0; i < n; ++i) {
+        MMAE_REQUIRE(w[i] && dst[2 * i] && dst[2 * i + 1], "x3_prepare_weights: null pointer");
+        int rc = mmae_x3_split((const float*)w[i], k_in[i], n_out[i], k_in[i], dst[2 * i], 3LL * k_in[i], k_in[i], 1, stream);
+        if (rc) return rc;
+        rc = mmae_x3_split((const float*)w[i], k_in[i], n_out[i], k_in[i], dst[2 * i + 1], k_in[i], (int64_t)n_out[i] * k_in[i], 1, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int64_t mmae_x3_tmp_bytes(int64_t rows, int cols) { return (rows * 3 * cols * 2 + 255) / 256 * 256; }

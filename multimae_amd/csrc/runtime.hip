@@ -125,7 +125,13 @@ int mmae_struct_size(int which) {
 }
 const char* mmae_last_error(void) { return g_err; }
 
-int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
+int mmae_gemm(const mmae_gemm_desc* d, void* stream) { return mmae_gemm_ex(d, stream, -1, 1.0); }
+
+}  // extern "C"
+
+// timing_cls >= 0 / flop_scale: how the launch is booked by mmae_gemm_timing_* (a pre-split x3 product is one bf16 launch over 3 K
+// that belongs to the f32 / split class with a third of its MFMA work as algorithmic FLOPs)
+int mmae_gemm_ex(const mmae_gemm_desc* d, void* stream, int timing_cls, double flop_scale) {
     MMAE_REQUIRE(d && d->A && d->B && d->C, "gemm: null operand");
     MMAE_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: empty problem");
     MMAE_REQUIRE(d->batch >= 1 && d->batch <= 65535 && d->batch_inner >= 1, "gemm: bad batch");
@@ -174,7 +180,8 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     struct TimingGuard {            // the bracket closes on every return path
         hipEvent_t a; hipStream_t st; double flop; int cls;
         ~TimingGuard() { mmae_timing_end(a, st, flop, cls); }
-    } t_guard{t_ev, st, 2.0 * d->M * d->N * d->K * d->batch, d->ab_dtype == MMAE_BF16 ? 0 : (d->ab_dtype == MMAE_MXFP8 ? 2 : 1)};
+    } t_guard{t_ev, st, 2.0 * d->M * d->N * d->K * d->batch * flop_scale,
+              timing_cls >= 0 ? timing_cls : (d->ab_dtype == MMAE_BF16 ? 0 : (d->ab_dtype == MMAE_MXFP8 ? 2 : 1))};
     // split-K: the dW-type products (small M x N, K = all rows of the batch) would otherwise occupy
     // a handful of the 256 CUs.  Each K slice writes a dense f32 partial slab into the caller's
     // workspace; a second launch sums the slabs into C in a fixed order (deterministic).
@@ -216,6 +223,8 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) {
     if (g.splitk <= 1) return 0;
     return mmae_splitk_reduce(g.ws, (float*)d->C, d->M, d->N, d->ldc, g.splitk, d->accumulate, st);
 }
+
+extern "C" {
 
 int mmae_gemm_timing_enable(int on) {
     std::lock_guard<std::mutex> lk(g_tmu);

@@ -577,6 +577,54 @@ def adapter_composite_ok(enc: Tensor, act: torch.dtype, heads: int, D: int, n_q:
     return act == torch.float32 and _F32_GEMM[0] == 'x3' and lds_bwd <= 160 * 1024
 
 
+class X3Weights:
+    """Pre-split bf16 copies of the f32 weights of an fp32 output adapter (mmae_x3_prepare_weights): [n][3k] = [hi | lo | hi] for the
+    forward product, [3n][k] = [hi ; lo ; hi] for dX, and the host table of {weight, copy, copy} triples mmae_adapter_desc.x3_w wants."""
+
+    def __init__(self, w_list: Sequence[Tensor]):
+        self.ws = list(w_list)
+        dev = self.ws[0].device
+        total, offs = 0, []
+        for w in self.ws:
+            nb = round_up(w.numel() * 3 * 2, 256)
+            offs += [total, total + nb]
+            total += 2 * nb
+        self.buf = torch.empty((total,), device=dev, dtype=torch.uint8)
+        base = self.buf.data_ptr()
+        self.dst = _ptr_arr([base + o for o in offs])
+        self.src = _ptr_arr([w.data_ptr() for w in self.ws])
+        self.n_out = (ctypes.c_int32 * len(self.ws))(*[w.shape[0] for w in self.ws])
+        self.k_in = (ctypes.c_int32 * len(self.ws))(*[w.numel() // w.shape[0] for w in self.ws])
+        self.triples = _ptr_arr([v for i, w in enumerate(self.ws) for v in (w.data_ptr(), base + offs[2 * i], base + offs[2 * i + 1])])
+        self.probe = tuple(w.data_ptr() for w in self.ws)
+
+    def matches(self, w_list: Sequence[Tensor]) -> bool:
+        return self.probe == tuple(w.data_ptr() for w in w_list)
+
+    def refresh(self) -> None:
+        check(_lib.load().mmae_x3_prepare_weights(len(self.ws), ctypes.cast(self.src, ctypes.c_void_p), self.n_out, self.k_in,
+                                                  ctypes.cast(self.dst, ctypes.c_void_p), _stream()), 'mmae_x3_prepare_weights')
+
+
+_X3_SETS = {}
+# Off by default: measured +1.2 ms per cfg3 step (36.2 against 35.0 ms, profiles/r02_x3_presplit_ab.txt).  The fp32 adapter's products
+# have K = 256: as ONE bf16 product over 3 K on the persistent 256 x 256 ping-pong kernel they are prologue / f32-epilogue bound and
+# no faster than on the 128 x 128 kernel that splits in registers (three workgroups per CU hide each other's epilogues), and the
+# split passes come on top.  MMAE_X3_PRESPLIT=1 turns it on for experiments.
+_X3_PRESPLIT = _os.environ.get('MMAE_X3_PRESPLIT', '0') == '1'
+
+
+def x3_weights(w_list: Sequence[Tensor]) -> X3Weights:
+    key = (id(w_list[0]), len(w_list))
+    m = _X3_SETS.get(key)
+    if m is None or not m.matches(w_list):
+        if len(_X3_SETS) > 16:
+            _X3_SETS.clear()
+        m = X3Weights(w_list)
+        _X3_SETS[key] = m
+    return m
+
+
 def adapter_fwd(enc: Tensor, enc_act: Optional[Tensor], ids_keep: Tensor, ids_restore: Tensor, cfg, w_list: Sequence[Tensor],
                 p_list: Sequence[Tensor], mask_token: Tensor, temb: Sequence[Optional[Tensor]], want_img: bool = True):
     """SpatialOutputAdapter.forward in one library call.  enc f32 [B, NC, Denc]; w_list / p_list in mmae_adapter_desc order.
@@ -600,6 +648,11 @@ def adapter_fwd(enc: Tensor, enc_act: Optional[Tensor], ids_keep: Tensor, ids_re
     d.enc = enc.data_ptr()
     d.enc_act = enc.data_ptr() if cfg.act == torch.float32 else _p(enc_act)
     d.ids_keep, d.ids_restore = ids_keep.data_ptr(), ids_restore.data_ptr()
+    x3 = None
+    if _X3_PRESPLIT and cfg.act == torch.float32 and _F32_GEMM[0] == 'x3' and all(w.dtype == torch.float32 and w.is_contiguous() and w.numel() % (8 * w.shape[0]) == 0 for w in w_list):
+        x3 = x3_weights(w_list)                 # forward / dX products of this fp32 adapter as ONE bf16 product over 3 K each
+        x3.refresh()
+        d.x3_w, d.x3_n = ctypes.cast(x3.triples, ctypes.c_void_p), len(w_list)
     slab = _slab(lib.mmae_adapter_act_bytes(ctypes.byref(d)), enc.device)
     d.act, d.act_bytes = slab.data_ptr(), slab.numel()
     img = torch.empty((B, cfg.C, cfg.nh * cfg.ph, cfg.nw * cfg.pw), device=enc.device, dtype=torch.float32) if want_img else None
@@ -613,7 +666,7 @@ def adapter_fwd(enc: Tensor, enc_act: Optional[Tensor], ids_keep: Tensor, ids_re
     off = lib.mmae_adapter_pat_offset(ctypes.byref(d))
     s.pat = slab[off:off + B * n_q * KP * 4].view(torch.float32).view(B * n_q, KP)
     s.desc, s.act, s.ld_pat = d, slab, KP
-    s.keep = (offs, w_arr, p_arr, te_arr, w_list, p_list, temb, mask_token, enc, enc_act, ids_keep, ids_restore, cfg.pos)
+    s.keep = (offs, w_arr, p_arr, te_arr, w_list, p_list, temb, mask_token, enc, enc_act, ids_keep, ids_restore, cfg.pos, x3)
     return img, s
 
 
