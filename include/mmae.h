@@ -146,6 +146,16 @@ int mmae_mx_scale_clear(void* scales, int rows, int cols, void* stream);
  * mmae_mx_quant applied to y -- for the Linear that follows (multimae_utils.py:230-231).  D % 32 == 0. */
 int mmae_layernorm_fwd_mx(const float* x, const float* gamma, const float* beta, void* y_bf16, float* mean, float* rstd, int64_t R, int D,
                           float eps, void* q, void* scales, void* stream);
+/* mmae_attn_fwd / mmae_attn_bwd (bf16) that also emit the MX-fp8 quantisation of their outputs -- bit-identical to mmae_mx_quant
+ * of them -- for the projection / qkv-dX product that follows: forward o must be dense [B * Nq][H * head_dim]; backward dq, dk, dv
+ * must be the column slices of one packed [B * N][3 * H * head_dim] tensor (self-attention), whose quantisation is written. */
+int mmae_attn_fwd_mx(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
+                     int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr,
+                     float scale, void* mx_q, void* mx_scale, void* stream);
+int mmae_attn_bwd_mx(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, void* dq, void* dk,
+                     void* dv, int B, int H, int Nq, int Nk, int hd, int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb,
+                     int64_t v_sr, int64_t o_sb, int64_t o_sr, int64_t dq_sb, int64_t dq_sr, int64_t dk_sb, int64_t dk_sr, int64_t dv_sb,
+                     int64_t dv_sr, float scale, void* mx_q, void* mx_scale, void* stream);
 /* scratch a composite call needs to quantise one [rows][cols] activation operand (bytes + scales, 256-byte aligned parts) */
 int64_t mmae_mx_tmp_bytes(int rows, int cols);
 /* Quantise n weights w[i] = [n_out[i]][k_in[i]] (f32 / bf16, contiguous) for both products that read them: dst[4 i] e4m3

@@ -32,6 +32,11 @@ struct AttnArgs {
     int B, H, Nq, Nk, nqp, nkp;
     long long q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, dq_sb, dq_sr, dk_sb, dk_sr, dv_sb, dv_sr;
     float scale;
+    // optional MX-fp8 mirror of the bf16 outputs (mmae_attn_*_mx): e4m3 bytes [mx_rows][mx_ld] + packed scales; the forward
+    // output's / dq, dk, dv's head columns start at mx_col[0..2]
+    unsigned char *mx_q, *mx_s;
+    long long mx_rows;
+    int mx_ld, mx_col[3];
 };
 
 // swizzled byte offset of 16-byte chunk c of row `row` in a row-major bf16 tile with HD columns
@@ -192,6 +197,23 @@ __device__ __forceinline__ void store_row32(uint16_t* p, const f32x16& v, float 
         if (ok) *reinterpret_cast<i32x4*>(p + (g + hi) * 8) = o;
     }
 }
+// the MX-fp8 copy of the same 32 values (one block: lanes l and l + 32 hold the two halves of the row), quantised from the
+// bf16-rounded values so that it equals mmae_mx_quant of the stored tensor.  Every lane must execute the shuffle.
+__device__ __forceinline__ void store_row32_mx(const AttnArgs& a, long long row, int col, const f32x16& v, float s, int hi, bool ok) {
+    float w[16];
+    float am = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { w[j] = bf16_bits_to_f32(f32_to_bf16_bits(v[j] * s)); am = fmaxf(am, fabsf(w[j])); }
+    am = fmaxf(am, __shfl_xor(am, 32, 64));
+    const int e = mx_shared_exp(am);
+    const float inv = mx_inv_scale(e);
+    if (!ok) return;
+    unsigned char* dst = a.mx_q + row * a.mx_ld + col;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<int*>(dst + 8 * g + 4 * hi) = mx_cvt4_e4m3(w[4 * g] * inv, w[4 * g + 1] * inv, w[4 * g + 2] * inv, w[4 * g + 3] * inv);
+    if (hi == 0) a.mx_s[mx_scale_addr(a.mx_rows, row, col >> 5)] = (unsigned char)e;
+}
 __device__ __forceinline__ void store_row32(float* p, const f32x16& v, float s, int hi, bool ok) {       // f32 rows: already 16-byte stores
     if (!ok) return;
 #pragma unroll
@@ -297,6 +319,10 @@ __global__ void __launch_bounds__(256, (NT == 4 && !X3) ? 3 : (NT <= 7 ? 2 : 1))
             const float inv = 1.0f / l;
 #pragma unroll
             for (int dt = 0; dt < HD / 32; ++dt) store_row32(ob + q * a.o_sr + dt * 32, o[dt], inv, hi, qok);
+            if (!X3 && a.mx_q) {
+#pragma unroll
+                for (int dt = 0; dt < HD / 32; ++dt) store_row32_mx(a, (long long)b * a.Nq + q, a.mx_col[0] + h * HD + dt * 32, o[dt], inv, hi, qok);
+            }
             if (qok && hi == 0) a.lse[((long long)b * a.H + h) * a.Nq + q] = m + __logf(l);
         }
     }
@@ -447,6 +473,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
             AT* dst = (AT*)a.dq + b * a.dq_sb + h * HD + q * a.dq_sr;
 #pragma unroll
             for (int dt = 0; dt < HD / 32; ++dt) store_row32(dst + dt * 32, dq[dt], 1.0f, hi, qok);
+            if (!X3 && a.mx_q) {
+#pragma unroll
+                for (int dt = 0; dt < HD / 32; ++dt) store_row32_mx(a, (long long)b * a.Nq + q, a.mx_col[0] + h * HD + dt * 32, dq[dt], 1.0f, hi, qok);
+            }
         }
     }
 
@@ -506,6 +536,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
                 store_row32(dkd + dt * 32, dk[dt], 1.0f, hi, kok);
                 store_row32(dvd + dt * 32, dv[dt], 1.0f, hi, kok);
             }
+            if (!X3 && a.mx_q) {
+#pragma unroll
+                for (int dt = 0; dt < HD / 32; ++dt) {
+                    store_row32_mx(a, (long long)b * a.Nk + key, a.mx_col[1] + h * HD + dt * 32, dk[dt], 1.0f, hi, kok);
+                    store_row32_mx(a, (long long)b * a.Nk + key, a.mx_col[2] + h * HD + dt * 32, dv[dt], 1.0f, hi, kok);
+                }
+            }
         }
     }
 }
@@ -523,7 +560,7 @@ extern "C" {
 
 static int attn_fwd_impl(bool x3, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
                          int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr,
-                         float scale, void* stream) {
+                         float scale, void* stream, void* mx_q = nullptr, void* mx_scale = nullptr) {
     MMAE_REQUIRE(q && k && v && o && lse, "attn_fwd: null pointer");
     const long long st[] = {q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr};
     const int rc = check_common(B, H, Nq, Nk, hd, st, 8);
@@ -534,6 +571,10 @@ static int attn_fwd_impl(bool x3, const void* q, const void* k, const void* v, v
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.nqp = (Nq + 31) / 32 * 32; a.nkp = (Nk + 31) / 32 * 32;
     a.q_sb = q_sb; a.q_sr = q_sr; a.k_sb = k_sb; a.k_sr = k_sr; a.v_sb = v_sb; a.v_sr = v_sr; a.o_sb = o_sb; a.o_sr = o_sr;
     a.scale = scale;
+    if (mx_q) {
+        MMAE_REQUIRE(!x3 && mx_scale && o_sr == (int64_t)H * hd && o_sb == (int64_t)Nq * o_sr, "attn_fwd_mx: bf16 output, dense [B * Nq][H * head_dim]");
+        a.mx_q = (unsigned char*)mx_q; a.mx_s = (unsigned char*)mx_scale; a.mx_rows = (long long)B * Nq; a.mx_ld = H * hd;
+    }
     const size_t lds = (size_t)2 * a.nkp * hd * 2 * (x3 ? 2 : 1);
     hipStream_t st_ = (hipStream_t)stream;
     dim3 grid(B * H), block(256);
@@ -559,7 +600,7 @@ static int attn_fwd_impl(bool x3, const void* q, const void* k, const void* v, v
 static int attn_bwd_impl(bool x3, const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, void* dq,
                          void* dk, void* dv, int B, int H, int Nq, int Nk, int hd, int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr,
                          int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr, int64_t dq_sb, int64_t dq_sr, int64_t dk_sb, int64_t dk_sr,
-                         int64_t dv_sb, int64_t dv_sr, float scale, void* stream) {
+                         int64_t dv_sb, int64_t dv_sr, float scale, void* stream, void* mx_q = nullptr, void* mx_scale = nullptr) {
     MMAE_REQUIRE(q && k && v && o && d_o && lse && dq && dk && dv, "attn_bwd: null pointer");
     MMAE_REQUIRE(((uintptr_t)dq % 16 == 0) && ((uintptr_t)dk % 16 == 0) && ((uintptr_t)dv % 16 == 0), "attn_bwd: unaligned output pointer");
     const long long st[] = {q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, dq_sb, dq_sr, dk_sb, dk_sr, dv_sb, dv_sr};
@@ -572,6 +613,14 @@ static int attn_bwd_impl(bool x3, const void* q, const void* k, const void* v, c
     a.q_sb = q_sb; a.q_sr = q_sr; a.k_sb = k_sb; a.k_sr = k_sr; a.v_sb = v_sb; a.v_sr = v_sr; a.o_sb = o_sb; a.o_sr = o_sr;
     a.dq_sb = dq_sb; a.dq_sr = dq_sr; a.dk_sb = dk_sb; a.dk_sr = dk_sr; a.dv_sb = dv_sb; a.dv_sr = dv_sr;
     a.scale = scale;
+    if (mx_q) {                                           // self-attention with dq | dk | dv packed in one [B * N][3 * H * head_dim] tensor
+        const int64_t Dm = (int64_t)H * hd;
+        MMAE_REQUIRE(!x3 && mx_scale && Nq == Nk && dq_sr == 3 * Dm && dk_sr == 3 * Dm && dv_sr == 3 * Dm && dq_sb == Nq * 3 * Dm && dk_sb == dq_sb && dv_sb == dq_sb &&
+                     (const uint16_t*)dk == (const uint16_t*)dq + Dm && (const uint16_t*)dv == (const uint16_t*)dq + 2 * Dm,
+                     "attn_bwd_mx: dq, dk, dv must be the column slices of one packed bf16 [B * N][3 D] tensor");
+        a.mx_q = (unsigned char*)mx_q; a.mx_s = (unsigned char*)mx_scale; a.mx_rows = (long long)B * Nq; a.mx_ld = (int)(3 * Dm);
+        a.mx_col[0] = 0; a.mx_col[1] = (int)Dm; a.mx_col[2] = (int)(2 * Dm);
+    }
     const size_t lds = (size_t)2 * (a.nqp + a.nkp) * hd * 2 * (x3 ? 2 : 1) + (size_t)2 * a.nqp * 4;
     if (lds > 160 * 1024) { mmae_set_error("attn_bwd: tiles exceed the 160 KB LDS (f32 split path: (Nq + Nk) * head_dim too large)"); return MMAE_ESUPPORT; }
     hipStream_t st_ = (hipStream_t)stream;
@@ -593,6 +642,12 @@ int mmae_attn_fwd(const void* q, const void* k, const void* v, void* o, float* l
                   float scale, void* stream) {
     return attn_fwd_impl(false, q, k, v, o, lse, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, scale, stream);
 }
+int mmae_attn_fwd_mx(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
+                     int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr,
+                     float scale, void* mx_q, void* mx_scale, void* stream) {
+    MMAE_REQUIRE(mx_q && mx_scale, "attn_fwd_mx: null MX destination");
+    return attn_fwd_impl(false, q, k, v, o, lse, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, scale, stream, mx_q, mx_scale);
+}
 int mmae_attn_fwd_f32x3(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
                         int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr,
                         float scale, void* stream) {
@@ -605,6 +660,14 @@ int mmae_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
                   int64_t dv_sr, float scale, void* stream) {
     return attn_bwd_impl(false, q, k, v, o, d_o, lse, dq, dk, dv, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, dq_sb,
                          dq_sr, dk_sb, dk_sr, dv_sb, dv_sr, scale, stream);
+}
+int mmae_attn_bwd_mx(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, void* dq, void* dk,
+                     void* dv, int B, int H, int Nq, int Nk, int hd, int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb,
+                     int64_t v_sr, int64_t o_sb, int64_t o_sr, int64_t dq_sb, int64_t dq_sr, int64_t dk_sb, int64_t dk_sr, int64_t dv_sb,
+                     int64_t dv_sr, float scale, void* mx_q, void* mx_scale, void* stream) {
+    MMAE_REQUIRE(mx_q && mx_scale, "attn_bwd_mx: null MX destination");
+    return attn_bwd_impl(false, q, k, v, o, d_o, lse, dq, dk, dv, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, dq_sb,
+                         dq_sr, dk_sb, dk_sr, dv_sb, dv_sr, scale, stream, mx_q, mx_scale);
 }
 int mmae_attn_bwd_f32x3(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, void* dq, void* dk,
                         void* dv, int B, int H, int Nq, int Nk, int hd, int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb,

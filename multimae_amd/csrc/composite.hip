@@ -280,11 +280,15 @@ int check_desc(const mmae_block_desc* d) {
     return 0;
 }
 
-int attn_strides_fwd(const mmae_block_desc* d, hipStream_t st) {
+// mx_q / mx_s: also leave the MX-fp8 copy of the attention output there (bf16 activations only)
+int attn_strides_fwd(const mmae_block_desc* d, hipStream_t st, void* mx_q = nullptr, void* mx_s = nullptr) {
     const int D = d->D, N = d->N, hd = D / d->heads;
     const size_t es = d->act_dtype == MMAE_BF16 ? 2 : 4;
     const char* qkv = (const char*)d->qkv;
     const float scale = 1.0f / sqrtf((float)hd);
+    if (mx_q)
+        return mmae_attn_fwd_mx(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, d->ao, d->lse, d->B, d->heads, N, N, hd, (int64_t)N * 3 * D, 3 * D,
+                                (int64_t)N * 3 * D, 3 * D, (int64_t)N * 3 * D, 3 * D, (int64_t)N * D, D, scale, mx_q, mx_s, st);
     auto fn = d->act_dtype == MMAE_BF16 ? mmae_attn_fwd : mmae_attn_fwd_f32x3;
     return fn(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, d->ao, d->lse, d->B, d->heads, N, N, hd, (int64_t)N * 3 * D, 3 * D,
               (int64_t)N * 3 * D, 3 * D, (int64_t)N * 3 * D, 3 * D, (int64_t)N * D, D, scale, st);
@@ -476,12 +480,15 @@ int mmae_block_fwd(const mmae_block_desc* d, void* stream) {
     };
     if ((rc = ln(d->x0, d->n1_w, d->n1_b, d->ln1, d->mean1, d->rstd1))) return rc;
     if ((rc = lin_fwd(c, d->ln1, d->qkv_w, d->qkv_b, d->qkv, act, R, 3 * D, D, nullptr, nullptr, MMAE_EPI_NONE, st, mx, pre))) return rc;
-    if ((rc = attn_strides_fwd(d, st))) return rc;
+    if (pre >= 0) {                                       // the attention kernel leaves the quantised copy of its output in half 0
+        void *aq, *as;
+        if ((rc = mx_slot(c, 0, R, D, &aq, &as)) || (rc = attn_strides_fwd(d, st, aq, as))) return rc;
+    } else if ((rc = attn_strides_fwd(d, st))) return rc;
     if (d->dp1) {
-        if ((rc = lin_fwd(c, d->ao, d->proj_w, d->proj_b, d->branch, MMAE_F32, R, D, D, nullptr, nullptr, MMAE_EPI_NONE, st, mx ? mx + 4 : nullptr))) return rc;
+        if ((rc = lin_fwd(c, d->ao, d->proj_w, d->proj_b, d->branch, MMAE_F32, R, D, D, nullptr, nullptr, MMAE_EPI_NONE, st, mx ? mx + 4 : nullptr, pre))) return rc;
         if ((rc = mmae_rowscale_add(d->x0, d->branch, d->dp1, d->x1, R, d->N, D, st))) return rc;
     } else {
-        if ((rc = lin_fwd(c, d->ao, d->proj_w, d->proj_b, d->x1, MMAE_F32, R, D, D, d->x0, nullptr, MMAE_EPI_NONE, st, mx ? mx + 4 : nullptr))) return rc;
+        if ((rc = lin_fwd(c, d->ao, d->proj_w, d->proj_b, d->x1, MMAE_F32, R, D, D, d->x0, nullptr, MMAE_EPI_NONE, st, mx ? mx + 4 : nullptr, pre))) return rc;
     }
     if ((rc = ln(d->x1, d->n2_w, d->n2_b, d->ln2, d->mean2, d->rstd2))) return rc;
     const int hq = pre < 0 ? -1 : 1;                     // quantised GELU output: half 1
@@ -553,11 +560,17 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
         char* dq = (char*)d->d_qkv;
         const int64_t sb3 = (int64_t)N * 3 * D, sb1 = (int64_t)N * D;
         auto fn = act == MMAE_BF16 ? mmae_attn_bwd : mmae_attn_bwd_f32x3;
-        if ((rc = fn(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, d->ao, d->d_ao, d->lse, dq, dq + (size_t)D * es, dq + (size_t)2 * D * es,
+        if (hq >= 0) {                                    // MX mode: the kernel leaves the quantised d_qkv in half 0 for the qkv dX product
+            void *gq, *gs;
+            if ((rc = mx_slot(c, 0, R, 3 * D, &gq, &gs))) return rc;
+            if ((rc = mmae_attn_bwd_mx(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, d->ao, d->d_ao, d->lse, dq, dq + (size_t)D * es,
+                                       dq + (size_t)2 * D * es, d->B, d->heads, N, N, hd, sb3, 3 * D, sb3, 3 * D, sb3, 3 * D, sb1, D, sb3, 3 * D, sb3, 3 * D,
+                                       sb3, 3 * D, 1.0f / sqrtf((float)hd), gq, gs, st))) return rc;
+        } else if ((rc = fn(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, d->ao, d->d_ao, d->lse, dq, dq + (size_t)D * es, dq + (size_t)2 * D * es,
                      d->B, d->heads, N, N, hd, sb3, 3 * D, sb3, 3 * D, sb3, 3 * D, sb1, D, sb3, 3 * D, sb3, 3 * D, sb3, 3 * D,
                      1.0f / sqrtf((float)hd), st))) return rc;
     }
-    if ((rc = lin_dx(c, d->d_qkv, 3 * D, d->qkv_w, d->d_ln1, act, R, 3 * D, D, nullptr, MMAE_EPI_NONE, nullptr, st, mx))) return rc;
+    if ((rc = lin_dx(c, d->d_qkv, 3 * D, d->qkv_w, d->d_ln1, act, R, 3 * D, D, nullptr, MMAE_EPI_NONE, nullptr, st, mx, hq >= 0 ? 0 : -1))) return rc;
     if ((rc = fork_to(st, sd))) return rc;                          // d_qkv
     if (!grp.add(d->d_qkv, 3 * D, d->ln1, D, d->g_qkv_w, d->g_qkv_b, 3 * D, D) &&
         (rc = lin_dw(c, d->d_qkv, 3 * D, d->ln1, d->g_qkv_w, d->g_qkv_b, R, 3 * D, D, sd))) return rc;

@@ -192,6 +192,59 @@ def test_fused_quantisation_equals_the_separate_pass():
         ops.gemm_mx(qa, qw, out, bias=bias, q_out=qo)
 
 
+@pytest.mark.parametrize('hd,N', [(64, 99), (64, 197), (32, 50)])
+def test_attention_mx_mirrors_equal_the_separate_pass(hd, N):
+    """mmae_attn_fwd_mx / mmae_attn_bwd_mx: same bf16 outputs as the plain kernels, and the MX copies of o and of the packed
+    d_qkv are exactly mmae_mx_quant of those outputs."""
+    B, H = 3, 4
+    D = H * hd
+    R = B * N
+    g = torch.Generator().manual_seed(N)
+    qkv = torch.randn(R, 3 * D, generator=g).bfloat16().to(DEV)
+    d_o = torch.randn(R, D, generator=g).bfloat16().to(DEV)
+    lib = _lib.load()
+    st = ops._stream()
+    es = 2
+    q, k, v = qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es
+    sb3, sb1 = N * 3 * D, N * D
+    scale = hd ** -0.5
+
+    def fwd(mx):
+        o = torch.empty((R, D), device=DEV, dtype=torch.bfloat16)
+        lse = torch.empty((B * H * N,), device=DEV, dtype=torch.float32)
+        if mx is None:
+            _lib.check(lib.mmae_attn_fwd(q, k, v, o.data_ptr(), lse.data_ptr(), B, H, N, N, hd, sb3, 3 * D, sb3, 3 * D, sb3, 3 * D, sb1, D, scale, st), 'attn_fwd')
+        else:
+            _lib.check(lib.mmae_attn_fwd_mx(q, k, v, o.data_ptr(), lse.data_ptr(), B, H, N, N, hd, sb3, 3 * D, sb3, 3 * D, sb3, 3 * D, sb1, D, scale,
+                                            mx.q.data_ptr(), mx.scales.data_ptr(), st), 'attn_fwd_mx')
+        return o, lse
+
+    o0, lse0 = fwd(None)
+    mo = ops.mx_empty(R, D, DEV)
+    o1, lse1 = fwd(mo)
+    assert torch.equal(o0, o1) and torch.equal(lse0, lse1)
+    sep = ops.mx_quant(o1)
+    assert torch.equal(mo.q, sep.q) and torch.equal(mo.scales, sep.scales)
+
+    def bwd(mx):
+        dqkv = torch.zeros((R, 3 * D), device=DEV, dtype=torch.bfloat16)
+        dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + D * es, dqkv.data_ptr() + 2 * D * es
+        args = (q, k, v, o0.data_ptr(), d_o.data_ptr(), lse0.data_ptr(), dq, dk, dv, B, H, N, N, hd, sb3, 3 * D, sb3, 3 * D, sb3, 3 * D, sb1, D,
+                sb3, 3 * D, sb3, 3 * D, sb3, 3 * D, scale)
+        if mx is None:
+            _lib.check(lib.mmae_attn_bwd(*args, st), 'attn_bwd')
+        else:
+            _lib.check(lib.mmae_attn_bwd_mx(*args, mx.q.data_ptr(), mx.scales.data_ptr(), st), 'attn_bwd_mx')
+        return dqkv
+
+    g0 = bwd(None)
+    mg = ops.mx_empty(R, 3 * D, DEV)
+    g1 = bwd(mg)
+    assert torch.equal(g0, g1)
+    sep = ops.mx_quant(g1)
+    assert torch.equal(mg.q, sep.q) and torch.equal(mg.scales, sep.scales)
+
+
 def test_mx_prepare_weights_batched_equals_per_tensor():
     """the per-step weight refresh (two batched launches per 32 weights) writes what mmae_mx_quant / mmae_mx_quant_t write"""
     import ctypes
