@@ -100,3 +100,51 @@ def test_standalone_modules_flow(stubbed):
     with torch.no_grad():
         outs = vit(torch.randn(1, 3, 32, 32), return_all_layers=True)
     assert len(outs) == 12 and outs[0].shape == (1, 5, 768)
+
+
+def test_mxfp8_mode_and_option_plumbing(stubbed):
+    """Host logic of the 'mxfp8' precision mode (weight table + refresh, the stack descriptor's mx_w, slab sizing calls) and of
+    the qkv_bias=False / learnable_pos_emb constructor options, against the type-checking stub of the C ABI."""
+    import multimae_amd as M
+    from multimae_amd import ops
+    from helpers import build_engine_model, make_inputs
+    from functools import partial
+    from torch import nn
+    doms, P, S, B, nvis = ['rgb', 'semseg'], 8, 32, 2, 9
+    model = build_engine_model(doms, P, S, enc=(256, 2, 4), posemb_size=32)
+    x = make_inputs(doms, B, S)
+    calls = []
+    lib = M._lib.load()
+    orig = lib.__getattr__
+
+    def spy(name):
+        fn = orig(name)
+
+        def wrapped(*a):
+            calls.append(name)
+            return fn(*a)
+        return wrapped
+    type(lib).__getattr__ = lambda self, name: spy(name)
+    try:
+        M.engine.set_direct_grads(True)
+        model.build_arena()
+        old = ops._X3_PRESPLIT
+        ops._X3_PRESPLIT = True
+        with M.engine.precision('mxfp8'):
+            assert M.engine.mx_encoder() and M.engine.precision_mode() == 'mxfp8' and M.engine.act_dtype() == torch.bfloat16
+            preds, masks = model(x, num_encoded_tokens=nvis, alphas=1.0, fp32_output_adapters=['semseg'])
+            sum(p.float().sum() for p in preds.values()).backward()
+        assert M.engine.precision_mode() == 'bf16'
+    finally:
+        ops._X3_PRESPLIT = old
+        M.engine.set_direct_grads(False)
+        type(lib).__getattr__ = orig
+    assert calls.count('mmae_mx_prepare_weights') == 1 and calls.count('mmae_stack_fwd') == 1 and calls.count('mmae_stack_bwd') == 1, calls
+    # constructor options that used to raise
+    from multimae_amd.multimae_utils import Block, run_blocks
+    blk = Block(64, 2, qkv_bias=False, norm_layer=partial(nn.LayerNorm, eps=1e-6))
+    assert 'attn.qkv.bias' not in blk.state_dict() and len(blk.state_dict()) == 11
+    run_blocks([blk], torch.randn(2, 5, 64, requires_grad=True)).sum().backward()
+    ad = M.PatchedInputAdapter(num_channels=3, stride_level=1, patch_size_full=8, dim_tokens=64, learnable_pos_emb=True, image_size=32)
+    ad(torch.randn(2, 3, 32, 32)).sum().backward()
+    assert ad.pos_emb.grad is not None and ad.pos_emb.grad.shape == ad.pos_emb.shape
