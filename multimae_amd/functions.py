@@ -553,7 +553,8 @@ class SpatialAdapterFn(torch.autograd.Function):
             enc_act = None
         ctx.comp = None
         KP = cfg.C * cfg.ph * cfg.pw
-        if ops.adapter_composite_ok(enc2, act, heads, D, n_q, NC, cfg.depth, T, KP):
+        xattn = bool(getattr(cfg, 'use_xattn', True))
+        if xattn and ops.adapter_composite_ok(enc2, act, heads, D, n_q, NC, cfg.depth, T, KP):
             # the whole adapter as ONE library call (same kernels, same order)
             w_list = [wc(qw), wc(kvw), wc(pw_), wc(f1w), wc(f2w)] + [wc(blocks[12 * l + i]) for l in range(cfg.depth) for i in (2, 4, 8, 10)] \
                 + [wc(ow), wc(pcw)]
@@ -576,6 +577,19 @@ class SpatialAdapterFn(torch.autograd.Function):
                 te[i].copy_(t.detach().reshape(D))
         queries, context = ops.decoder_build(ctx_tok, ids_keep, ids_restore, mask_token.detach().reshape(D), te, cfg.pos,
                                              cfg.task_offsets, cfg.q_task, B, n_keep, G, D, n_q)   # :183-234
+        if not xattn:                                # use_xattn=False (output_adapters.py:264-268): x = queries
+            h, bsaved = queries, []
+            for l in range(cfg.depth):
+                h, s = block_fwd(h, blocks[12 * l:12 * l + 12], wc, heads, eps, act, B, n_q, save)
+                bsaved.append(s)
+            h_act = ops.cast(h, act)
+            pat = _lin_fwd(h_act, ow, ob, wc, torch.float32)
+            img = ops.unpatchify(pat, B, cfg.C, cfg.nh, cfg.nw, cfg.ph, cfg.pw)
+            if save:
+                ctx.saved = (enc_act, context.shape, h_act, bsaved)
+            ctx.cfg, ctx.params, ctx.ids = cfg, params, (ids_keep, ids_restore)
+            ctx.dims = (B, NC, Denc, n_keep, n_q, T)
+            return img
         qn, qmean, qrstd = ops.layernorm_fwd(queries, qnw, qnb, eps, act)
         cn, cmean, crstd = ops.layernorm_fwd(context, cnw, cnb, eps, act)
         q = _lin_fwd(qn, qw, qb, wc, act)
@@ -633,8 +647,12 @@ class SpatialAdapterFn(torch.autograd.Function):
             if cfg.on_done is not None:
                 cfg.on_done()
             return (None, d_enc, None, None, *([None] * len(params) if acc else dsts))
-        (enc_act, queries, context, qn, qmean, qrstd, cn, cmean, crstd, q, kv, Pm, xo, x, on, omean, orstd, hpre, hact, h_act,
-         bsaved) = ctx.saved
+        xattn = bool(getattr(cfg, 'use_xattn', True))
+        if xattn:
+            (enc_act, queries, context, qn, qmean, qrstd, cn, cmean, crstd, q, kv, Pm, xo, x, on, omean, orstd, hpre, hact, h_act,
+             bsaved) = ctx.saved
+        else:
+            enc_act, ctx_shape, h_act, bsaved = ctx.saved
         if d_img is None:
             d_img = torch.zeros((B, cfg.C, cfg.nh * cfg.ph, cfg.nw * cfg.pw), device=params[0].device, dtype=torch.float32)
         mask_token = params[0]
@@ -653,13 +671,24 @@ class SpatialAdapterFn(torch.autograd.Function):
         bgrads: List[Optional[Tensor]] = [None] * (12 * cfg.depth)
         fc2b_done, g_cs = False, None
         for l in reversed(range(cfg.depth)):
-            cs_param = blocks[12 * (l - 1) + 11] if l > 0 else f2b
+            cs_param = blocks[12 * (l - 1) + 11] if l > 0 else (f2b if xattn else None)
             dh, dh_act, g_cs_next, g = block_bwd(dh, dh_act, fc2b_done, bsaved[l], blocks[12 * l:12 * l + 12], wc, sink, heads, act, B,
                                                  n_q, cs_param)
             bgrads[12 * l:12 * l + 12] = g
             if fc2b_done:
                 bgrads[12 * l + 11] = g_cs
-            fc2b_done, g_cs = cs_param.requires_grad, g_cs_next
+            fc2b_done, g_cs = (cs_param is not None and cs_param.requires_grad), g_cs_next
+        if not xattn:                                # the queries fed the blocks directly: no cross-attention / MLP parameters
+            d_ctx, part_b = ops.decoder_build_bwd(dh, torch.zeros(ctx_shape, device=dev, dtype=torch.float32), ids_keep, ids_restore,
+                                                  cfg.task_offsets, cfg.q_task, B, n_keep, G, D, n_q, raw=True)
+            g_build = sink.colsums(part_b, D, list(temb) + [mask_token])
+            d_ctx_act = ops.cast(d_ctx, act)
+            g_pcw, g_pcb = sink.linear(pcw, pcb, d_ctx_act, enc_act)
+            d_enc = ops.linear_dx(d_ctx_act, wc(pcw), torch.empty((B * NC, Denc), device=dev, dtype=torch.float32))
+            ctx.saved = None
+            if cfg.on_done is not None:
+                cfg.on_done()
+            return (None, d_enc.view(B, NC, Denc), None, None, g_build[T], *g_build[:T], *([None] * 16), *bgrads, g_ow, g_ob, g_pcw, g_pcb)
         # x1 = x + mlp(out_norm(x))
         Hd = f1w.shape[0]
         part_h = torch.empty(ops.dx_colsum_part_shape(B * n_q, Hd), device=dev, dtype=torch.float32)

@@ -49,9 +49,9 @@ class SpatialOutputAdapter(nn.Module):
         self.use_xattn = use_xattn
         self.num_heads = num_heads
         self.depth = depth
-        if not use_xattn:
-            raise NotImplementedError('use_xattn=False is not built in the HIP engine (pre-training default is True)')
         if learnable_pos_emb:
+            # (the reference allocates this table as (1, h, w, D) but resizes it with F.interpolate as if it were (1, D, h, w),
+            # output_adapters.py:108-111,172: not a behaviour worth mirroring)
             raise NotImplementedError('learnable decoder positional embeddings are not built in the HIP engine')
         if drop_path_rate != 0.0 or drop_rate != 0.0 or attn_drop_rate != 0.0:
             raise NotImplementedError('decoder dropout / drop-path > 0 is not built in the HIP engine')
@@ -74,13 +74,15 @@ class SpatialOutputAdapter(nn.Module):
         self.pos_emb = nn.Parameter(build_2d_sincos_posemb(h=h_posemb, w=w_posemb, embed_dim=self.dim_tokens),
                                     requires_grad=False)
 
-        self.decoder = CrossAttention(dim=self.dim_tokens, num_heads=num_heads, qkv_bias=qkv_bias,
-                                      attn_drop=attn_drop_rate, proj_drop=drop_rate)
-        self.context_norm = _as_hip_norm(norm_layer, self.dim_tokens)
-        self.query_norm = _as_hip_norm(norm_layer, self.dim_tokens)
-        self.out_norm = _as_hip_norm(norm_layer, self.dim_tokens)
-        mlp_hidden_dim = int(self.dim_tokens * mlp_ratio)
-        self.mlp = Mlp(in_features=self.dim_tokens, hidden_features=mlp_hidden_dim)
+        self._eps = _as_hip_norm(norm_layer, self.dim_tokens).eps
+        if self.use_xattn:           # output_adapters.py:114-123: without it the queries go straight into decoder_transformer
+            self.decoder = CrossAttention(dim=self.dim_tokens, num_heads=num_heads, qkv_bias=qkv_bias,
+                                          attn_drop=attn_drop_rate, proj_drop=drop_rate)
+            self.context_norm = _as_hip_norm(norm_layer, self.dim_tokens)
+            self.query_norm = _as_hip_norm(norm_layer, self.dim_tokens)
+            self.out_norm = _as_hip_norm(norm_layer, self.dim_tokens)
+            mlp_hidden_dim = int(self.dim_tokens * mlp_ratio)
+            self.mlp = Mlp(in_features=self.dim_tokens, hidden_features=mlp_hidden_dim)
 
         if depth > 0:
             dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
@@ -125,6 +127,12 @@ class SpatialOutputAdapter(nn.Module):
                 te.append(self.task_embeddings[t])
             else:
                 te.append(None)
+        if not self.use_xattn:
+            ps = [self.mask_token, *te] + [None] * 16
+            if self.depth > 0:
+                for blk in self.decoder_transformer:
+                    ps += block_params(blk)
+            return ps + [self.out_proj.weight, self.out_proj.bias, self.proj_context.weight, self.proj_context.bias]
         d = self.decoder
         ps = [self.mask_token, *te, d.q.weight, bias_or_zero(d.q, getattr(d, '_zero_q_bias', None)), d.kv.weight,
               bias_or_zero(d.kv, getattr(d, '_zero_kv_bias', None)), d.proj.weight, d.proj.bias,
@@ -158,7 +166,7 @@ class SpatialOutputAdapter(nn.Module):
             assert n == nh * nw, 'all tasks must share the decoder token grid (output_adapters.py:175)'
             offs.append(offs[-1] + n)
         G = input_info.get('num_global_tokens', 0)
-        cfg = _cfg(self, act=act_dtype, heads=self.num_heads, eps=self.query_norm.eps, task_offsets=offs,
+        cfg = _cfg(self, act=act_dtype, heads=self.num_heads, eps=self._eps, use_xattn=self.use_xattn, task_offsets=offs,
                    q_task=in_tasks.index(self.task), G=G, D=self.dim_tokens, pos=self._pos_tokens(nh, nw), depth=self.depth,
                    C=self.num_channels, nh=nh, nw=nw, ph=self.P_H, pw=self.P_W, on_done=on_done, f32_gemm=f32_gemm,
                    enc_act=encoder_tokens_act)

@@ -276,9 +276,10 @@ def encoder(x: Tensor, sd, cfg: OracleConfig, return_all_layers: bool = False, d
 # --------------------------------------------------------------------------- #
 def spatial_adapter(enc: Tensor, sd, cfg: OracleConfig, key: str, task: str,
                     tokens_per_task: Dict[str, int], ids_keep: Tensor, ids_restore: Tensor,
-                    image_hw: Tuple[int, int]) -> Tensor:
+                    image_hw: Tuple[int, int], use_xattn: bool = True) -> Tensor:
     """SpatialOutputAdapter.forward + get_queries_and_context,
-    output_adapters.py:183-282, for use_task_queries=True, use_xattn=True."""
+    output_adapters.py:183-282, for use_task_queries=True; use_xattn=False skips the cross-attention layer and its MLP
+    (output_adapters.py:264-268: x = queries)."""
     p = f'output_adapters.{key}.'
     dom = cfg.domains_by_name[task]
     ph, pw = cfg.patch_hw(dom)
@@ -314,10 +315,13 @@ def spatial_adapter(enc: Tensor, sd, cfg: OracleConfig, key: str, task: str,
         ctx2 = torch.cat([ctx2, ctx[:, -G:]], dim=1)                                 # :228-230
 
     eps = cfg.ln_eps
-    qn = layer_norm(queries, sd[p + 'query_norm.weight'], sd[p + 'query_norm.bias'], eps)
-    cn = layer_norm(ctx2, sd[p + 'context_norm.weight'], sd[p + 'context_norm.bias'], eps)
-    x = cross_attention(qn, cn, sd, p + 'decoder.', cfg.dec_heads)                   # :265 (no residual)
-    x = x + mlp(layer_norm(x, sd[p + 'out_norm.weight'], sd[p + 'out_norm.bias'], eps), sd, p + 'mlp.')  # :266
+    if use_xattn:
+        qn = layer_norm(queries, sd[p + 'query_norm.weight'], sd[p + 'query_norm.bias'], eps)
+        cn = layer_norm(ctx2, sd[p + 'context_norm.weight'], sd[p + 'context_norm.bias'], eps)
+        x = cross_attention(qn, cn, sd, p + 'decoder.', cfg.dec_heads)               # :265 (no residual)
+        x = x + mlp(layer_norm(x, sd[p + 'out_norm.weight'], sd[p + 'out_norm.bias'], eps), sd, p + 'mlp.')  # :266
+    else:
+        x = queries                                                                  # :268
     for i in range(cfg.dec_depth):
         x = block(x, sd, p + f'decoder_transformer.{i}.', cfg.dec_heads, eps)        # :271
     x = x @ sd[p + 'out_proj.weight'].t() + sd[p + 'out_proj.bias']                  # :274
