@@ -204,3 +204,30 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r['traffic'] is None or r['traffic'] > 0
     c = d['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['sample']
+
+
+def test_recorded_bench_lines_keep_the_contract():
+    """The committed bench lines (profiles/r02_bench_*.json, written by bench.py on the GPU box) carry every field the
+    measurement contract names: metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling /
+    vs_baseline / dtype / data / config.workload, a `roofline` object (bound, achieved, peak, unit, frac, traffic) whose frac is
+    achieved / peak, and -- at N = 1 on cfg3 -- a `cpu_baseline` object (value, unit, cores, kind, sample)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name, need_cpu in (('r02_bench_cfg3.json', True), ('r02_bench_cfg5_mxfp8.json', False)):
+        d = json.load(open(os.path.join(root, 'profiles', name)))
+        for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+                  'data', 'config', 'roofline'):
+            assert k in d, (name, k)
+        assert d['unit'] == 'images/s' and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['data'] == 'synthetic'
+        assert 'workload' in d['config'] and 'model' not in d['config']
+        assert abs(d['value'] - d['config']['global_batch'] / d['ms_per_step'] * 1e3) < 0.01 * d['value']
+        r = d['roofline']
+        for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+            assert k in r, (name, k)
+        assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+        assert r['peak'] == (5000.0 if 'mxfp8' in name else 2500.0)
+        if need_cpu:
+            c = d['cpu_baseline']
+            for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+                assert k in c, k
+            assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['value'] > 0
