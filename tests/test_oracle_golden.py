@@ -1,10 +1,12 @@
 """CPU: the oracle reproduces the reference-generated golden vectors (pins the oracle)."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 import multimae_oracle as orc
-from helpers import MINI, load_masks_base, load_mini, load_scalars, mini_oracle_cfg
+from helpers import GOLD, MINI, load_masks_base, load_mini, load_scalars, mini_oracle_cfg
 
 
 def test_oracle_masks_base_bit_exact():
@@ -303,3 +305,63 @@ def test_mx_block_quantisation_spec_vectors():
     ex = np.arange(3 * 12, dtype=np.uint8).reshape(3, 12)
     p = mx.pack_scales(ex).reshape(2, 3, 2, 4)
     assert p[0, 1, 1, 2] == ex[1, 2 * 2 + 1] and p[1, 2, 0, 1] == ex[2, 8 + 2] and p[1, 0, 1, 2] == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# constructor options added in round 2: the oracle's branches against goldens recorded from the REFERENCE's own classes
+# (tests/golden/make_golden_options.py)
+# ---------------------------------------------------------------------------------------------------------------------
+def _opt():
+    z = np.load(os.path.join(GOLD, 'options.npz'))
+    return lambda pre: {k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)}
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def test_oracle_output_adapter_without_cross_attention_vs_reference_golden():
+    g = _opt()
+    sd = {'output_adapters.rgb.' + k: v.clone() for k, v in g('noxattn/sd/').items()}
+    grads = g('noxattn/grad/')
+    for k in grads:
+        sd['output_adapters.rgb.' + k].requires_grad_(True)
+    t = g('noxattn/')
+    cfg = orc.standard_config(['rgb', 'depth'], patch_size=4, image_size=16, dim_tokens=96, depth=1, num_heads=2, dec_dim=64, dec_depth=1,
+                              dec_heads=2, extra_norm_pix=False)
+    enc = t['enc'].clone().requires_grad_(True)
+    p = orc.spatial_adapter(enc, sd, cfg, 'rgb', 'rgb', {'rgb': 16, 'depth': 16}, t['ids_keep'], t['ids_restore'], (16, 16), use_xattn=False)
+    p.backward(t['gout'])
+    assert _rel(p.detach(), t['pred']) < 1e-6 and _rel(enc.grad, t['d_enc']) < 1e-5
+    for k, v in grads.items():
+        assert _rel(sd['output_adapters.rgb.' + k].grad, v) < 1e-5, k
+
+
+def test_oracle_learnable_pos_emb_vs_reference_golden():
+    g = _opt()
+    for name, fn, pp in (('rgb', orc.image_tokens, (4, 4)), ('semseg', orc.semseg_tokens, (2, 2))):
+        t = g(f'lpos/{name}/')
+        sd = {name + '.' + k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in g(f'lpos/{name}/sd/').items()}
+        tok = fn(t['x'], sd, name + '.', *pp)
+        tok.backward(t['g'])
+        assert _rel(tok.detach(), t['tok']) < 1e-6 and _rel(sd[name + '.pos_emb'].grad, t['d_pos']) < 1e-5, name
+
+
+def test_oracle_blocks_without_qkv_bias_vs_reference_golden():
+    g = _opt()
+    sd = {k: v.clone().requires_grad_(True) for k, v in g('nobias/sd/').items()}
+    grads = g('nobias/grad/')
+    t = g('nobias/')
+    L = 1 + max(int(k.split('.')[0]) for k in sd)
+    D = t['x'].shape[-1]
+    full = dict(sd)
+    for l in range(L):
+        full[f'{l}.attn.qkv.bias'] = torch.zeros(3 * D)
+    x = t['x'].clone().requires_grad_(True)
+    y = x
+    for l in range(L):
+        y = orc.block(y, full, f'{l}.', 2, 1e-6)
+    y.backward(t['gy'])
+    assert _rel(y.detach(), t['y']) < 1e-6 and _rel(x.grad, t['dx']) < 1e-5
+    for k, v in grads.items():
+        assert _rel(sd[k].grad, v) < 1e-5, k
