@@ -456,9 +456,13 @@ class MxStackWeights:
         self.n_out = (ctypes.c_int32 * len(self.ws))(*[w.shape[0] for w in self.ws])
         self.k_in = (ctypes.c_int32 * len(self.ws))(*[w.shape[1] for w in self.ws])
         self.probe = tuple(w.data_ptr() for w in self.ws[:1] + self.ws[-1:])
+        self.shapes = tuple(tuple(w.shape) for w in self.ws)
 
     def matches(self, params: Sequence[Tensor]) -> bool:
-        return self.probe == (params[2].data_ptr(), params[-2].data_ptr()) and len(self.ws) * 3 == len(params)
+        if self.probe != (params[2].data_ptr(), params[-2].data_ptr()) or len(self.ws) * 3 != len(params):
+            return False
+        L = len(params) // 12
+        return self.shapes == tuple(tuple(params[12 * l + i].shape) for l in range(L) for i in (2, 4, 8, 10))
 
     def refresh(self) -> None:
         check(_lib.load().mmae_mx_prepare_weights(len(self.ws), ctypes.cast(self.src, ctypes.c_void_p), F32, self.n_out, self.k_in,
