@@ -636,6 +636,16 @@ int mmae_opt_step(const mmae_opt_desc* d, void* stream);
 int mmae_depth_standardize(const float* x, float* y, int B, int n, int lo, int hi, float eps, void* stream);
 
 /* hardware probes used by tests/ to pin instruction semantics the kernels rely on */
+/* SemSegInputAdapter(interpolate_class_emb=True) (input_adapters.py:192-198): the class-embedding image resized by 1 / patch with
+ * nn.Upsample(bilinear) -- per token the mean of the centre taps -- as out f32 [B][E][H/ph][W/pw] (then projected like a 1 x 1 patch
+ * image), and its gradient into class_emb (float atomics; pad_idx = nn.Embedding's padding_idx or -1).  mmae_rows_to_image is the
+ * data gradient of the patch embedding for an image-like input: the selected tokens' row gradients back into d_img (zeroed by
+ * the caller). */
+int mmae_semseg_avg_emb_fwd(const int64_t* x, const float* class_emb, float* out, int B, int H, int W, int E, int ph, int pw, int n_cls, void* stream);
+int mmae_semseg_avg_emb_bwd(const float* d_img, const int64_t* x, float* d_class_emb, int B, int H, int W, int E, int ph, int pw, int n_cls, int pad_idx,
+                            void* stream);
+int mmae_rows_to_image(const float* d_rows, int64_t ldr, int k_off, const int64_t* sel, float* d_img, int B, int n_sel, int64_t tok_off, int n_patches,
+                       int C, int H, int W, int ph, int pw, void* stream);
 /* Gradient of LEARNABLE positional embeddings (PatchedInputAdapter / SemSegInputAdapter with learnable_pos_emb=True,
  * input_adapters.py:75-78,183-186): d_pos[sel[b][j]][:] += d_tok[b][j][:] over the selected tokens (d_tok f32 [B][n_sel + G][D] as
  * mmae_tokens_assemble lays tokens out; sel as given to it; d_pos f32 [n_pos][D], all tasks' position tables stacked in task order,

@@ -431,6 +431,69 @@ __global__ void __launch_bounds__(256) patch_tile_kernel(const float* __restrict
 inline int patch_tile_cb(int ph, int W) { int cb = 8192 / (ph * W); return cb < 1 ? 0 : (cb > 16 ? 16 : cb); }
 
 // hardware probe: what does ds_read_b64_tr_b16 return for a given LDS image / lane addresses
+// SemSegInputAdapter(interpolate_class_emb=True), input_adapters.py:192-198: nn.Upsample(scale 1 / patch, bilinear) of the
+// class-embedding image = per token the mean of the centre taps (even patch: the 2 x 2 centre pixels, odd: the centre pixel;
+// src = (dst + 0.5) * patch - 0.5).  out f32 [B][E][nh][nw]; class ids outside [0, n_cls) embed as zeros.
+__device__ __forceinline__ void centre_taps(int i, int p, int& t0, int& t1) {
+    if (p & 1) { t0 = t1 = i * p + p / 2; } else { t0 = i * p + p / 2 - 1; t1 = t0 + 1; }
+}
+__global__ void __launch_bounds__(256) semseg_avg_emb_fwd_kernel(const long long* __restrict__ x, const float* __restrict__ emb, float* __restrict__ out,
+                                                                 int B, int H, int W, int E, int ph, int pw, int n_cls) {
+    const int nh = H / ph, nw = W / pw;
+    const long long total = (long long)B * E * nh * nw;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int j = (int)(idx % nw), i = (int)((idx / nw) % nh), e = (int)((idx / ((long long)nw * nh)) % E), b = (int)(idx / ((long long)nw * nh * E));
+        int r0, r1, c0, c1;
+        centre_taps(i, ph, r0, r1); centre_taps(j, pw, c0, c1);
+        const long long* xb = x + (long long)b * H * W;
+        float acc = 0.f;
+        const int rr[2] = {r0, r1}, cc[2] = {c0, c1};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const long long cls = xb[(long long)rr[a] * W + cc[c]];
+                if (cls >= 0 && cls < n_cls) acc += 0.25f * emb[cls * E + e];
+            }
+        out[idx] = acc;
+    }
+}
+// its gradient: d_emb[class of every tap][e] += 0.25 * d_img[b][e][i][j] (float atomics); pad_idx (nn.Embedding's padding_idx) gets none
+__global__ void __launch_bounds__(256) semseg_avg_emb_bwd_kernel(const float* __restrict__ d_img, const long long* __restrict__ x, float* __restrict__ d_emb,
+                                                                 int B, int H, int W, int E, int ph, int pw, int n_cls, int pad_idx) {
+    const int nh = H / ph, nw = W / pw;
+    const long long total = (long long)B * E * nh * nw;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int j = (int)(idx % nw), i = (int)((idx / nw) % nh), e = (int)((idx / ((long long)nw * nh)) % E), b = (int)(idx / ((long long)nw * nh * E));
+        int r0, r1, c0, c1;
+        centre_taps(i, ph, r0, r1); centre_taps(j, pw, c0, c1);
+        const long long* xb = x + (long long)b * H * W;
+        const float gq = 0.25f * d_img[idx];
+        const int rr[2] = {r0, r1}, cc[2] = {c0, c1};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const long long cls = xb[(long long)rr[a] * W + cc[c]];
+                if (cls >= 0 && cls < n_cls && cls != pad_idx) atomicAdd(d_emb + cls * E + e, gq);
+            }
+    }
+}
+// Gradient of an image-like input of the patch embedding: the selected tokens' row gradients d_rows (f32 [B * n_sel][ldr], this
+// task's K = C * ph * pw columns starting at k_off) back into d_img f32 [B][C][H][W] (zeroed by the caller; patches are disjoint).
+__global__ void __launch_bounds__(256) rows_to_image_kernel(const float* __restrict__ d_rows, long long ldr, int k_off, const long long* __restrict__ sel,
+                                                            float* __restrict__ d_img, int n_sel, long long tok_off, int n_patches, int C, int H, int W,
+                                                            int ph, int pw) {
+    const int row = blockIdx.x, b = row / n_sel;
+    const long long p = sel[row] - tok_off;
+    if (p < 0 || p >= n_patches) return;
+    const int nw = W / pw, pi = (int)(p / nw), pj = (int)(p % nw), K = C * ph * pw;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const int c = k / (ph * pw), di = (k / pw) % ph, dj = k % pw;
+        d_img[(((long long)b * C + c) * H + pi * ph + di) * W + pj * pw + dj] = d_rows[(long long)row * ldr + k_off + k];
+    }
+}
+
 // Gradient of learnable positional embeddings (input_adapters.py:75-78 with learnable_pos_emb=True): token (b, j) carries the
 // embedding of position sel[b][j] (task offsets included), so d_pos[sel[b][j]] += d_tok[b][j].  One wave per selected token,
 // float atomics (order-dependent in the last bit, like semseg_emb_bwd).
@@ -621,6 +684,30 @@ int mmae_patchify(const float* img, void* patches, int patches_dtype, int64_t ld
     if (patches_dtype == MMAE_BF16) hipLaunchKernelGGL((patchify_kernel<uint16_t>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, img, (uint16_t*)patches, (long long)ld, C, nh, nw, ph, pw, total);
     else hipLaunchKernelGGL((patchify_kernel<float>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, img, (float*)patches, (long long)ld, C, nh, nw, ph, pw, total);
     return mmae_check_launch("patchify");
+}
+
+int mmae_semseg_avg_emb_fwd(const int64_t* x, const float* class_emb, float* out, int B, int H, int W, int E, int ph, int pw, int n_cls, void* stream) {
+    MMAE_REQUIRE(x && class_emb && out && B > 0 && H > 0 && W > 0 && E > 0 && ph > 0 && pw > 0 && H % ph == 0 && W % pw == 0 && n_cls > 0, "semseg_avg_emb_fwd: bad argument");
+    const long long total = (long long)B * E * (H / ph) * (W / pw);
+    hipLaunchKernelGGL(semseg_avg_emb_fwd_kernel, dim3((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)x, class_emb, out, B, H, W, E, ph, pw, n_cls);
+    return mmae_check_launch("semseg_avg_emb_fwd");
+}
+int mmae_semseg_avg_emb_bwd(const float* d_img, const int64_t* x, float* d_class_emb, int B, int H, int W, int E, int ph, int pw, int n_cls, int pad_idx,
+                            void* stream) {
+    MMAE_REQUIRE(d_img && x && d_class_emb && B > 0 && H > 0 && W > 0 && E > 0 && ph > 0 && pw > 0 && H % ph == 0 && W % pw == 0 && n_cls > 0, "semseg_avg_emb_bwd: bad argument");
+    const long long total = (long long)B * E * (H / ph) * (W / pw);
+    hipLaunchKernelGGL(semseg_avg_emb_bwd_kernel, dim3((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), dim3(256), 0, (hipStream_t)stream,
+                       d_img, (const long long*)x, d_class_emb, B, H, W, E, ph, pw, n_cls, pad_idx);
+    return mmae_check_launch("semseg_avg_emb_bwd");
+}
+int mmae_rows_to_image(const float* d_rows, int64_t ldr, int k_off, const int64_t* sel, float* d_img, int B, int n_sel, int64_t tok_off, int n_patches,
+                       int C, int H, int W, int ph, int pw, void* stream) {
+    MMAE_REQUIRE(d_rows && sel && d_img && B > 0 && n_sel > 0 && n_patches > 0 && C > 0 && ph > 0 && pw > 0 && H % ph == 0 && W % pw == 0 &&
+                 (H / ph) * (W / pw) == n_patches, "rows_to_image: bad argument");
+    hipLaunchKernelGGL(rows_to_image_kernel, dim3((unsigned)(B * n_sel)), dim3(256), 0, (hipStream_t)stream, d_rows, (long long)ldr, k_off, (const long long*)sel,
+                       d_img, n_sel, (long long)tok_off, n_patches, C, H, W, ph, pw);
+    return mmae_check_launch("rows_to_image");
 }
 
 int mmae_pos_emb_bwd(const float* d_tok, const int64_t* sel, float* d_pos, int B, int n_sel, int G, int D, int n_pos, void* stream) {

@@ -400,6 +400,24 @@ class EncoderStackFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------
 # gather-first patch embedding (input adapters + token select + global tokens)
 # ------------------------------------------------------------------------------------------
+class AvgClassEmbFn(torch.autograd.Function):
+    """SemSegInputAdapter(interpolate_class_emb=True), input_adapters.py:192-198 + :223: class ids [B, H, W] -> the class-embedding
+    image resized by 1 / patch, f32 [B, E, nh, nw] (fed to the patch embedding as a 1 x 1-patch image)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, class_emb: Tensor, ph: int, pw: int, pad_idx: int):
+        x = x.contiguous()
+        ctx.x, ctx.emb, ctx.geom = x, class_emb, (ph, pw, pad_idx)
+        return ops.semseg_avg_emb_fwd(x, class_emb.detach().contiguous(), ph, pw)
+
+    @staticmethod
+    def backward(ctx, d_img: Tensor):
+        ph, pw, pad_idx = ctx.geom
+        sink = GradSink(engine.direct_grads())
+        buf = ops.semseg_avg_emb_bwd(d_img.contiguous(), ctx.x, ctx.emb.shape[0], ph, pw, pad_idx)
+        return None, sink.vec(ctx.emb, buf), None, None, None
+
+
 class EmbedFn(torch.autograd.Function):
     """forward(cfg, sel[B,n_sel] int64, global_tokens|None, *per task: data, proj.weight, proj.bias, class_emb|None, pos)
 
@@ -461,15 +479,21 @@ class EmbedFn(torch.autograd.Function):
                 gw = gw.view(w.shape)
             gb = g_small[i]
             ge = None
+            gdata = None
+            if t['kind'] == 0 and tens[5 * i].requires_grad:        # an image-like input that wants its gradient (e.g. AvgClassEmbFn's output)
+                d_rows = ops.linear_dx(d_proj, wc(w).view(D, t['K']), torch.empty((B * n_sel, t['K']), device=sel.device, dtype=torch.float32))
+                gdata = ops.rows_to_image(d_rows, 0, sel, B, n_sel, cfg.task_offsets[i], t['n_patches'], t['C'], t['H'], t['W'], t['ph'], t['pw'])
             if emb is not None and emb.requires_grad:
                 d_rows = ops.linear_dx(d_proj, wc(w).view(D, t['K']), torch.empty((B * n_sel, t['K']), device=sel.device, dtype=act))
                 ge_buf = torch.zeros(emb.shape, device=sel.device, dtype=torch.float32)
                 s = ctx.srcs[i]
                 ops.semseg_emb_bwd(d_rows, s['data'], sel, ge_buf, B=B, H=t['H'], W=t['W'], E=t['C'], ph=t['ph'], pw=t['pw'],
                                    n_sel=n_sel, k_off=0, tok_off=cfg.task_offsets[i], n_patches=t['n_patches'], n_cls=emb.shape[0])
+                if t.get('pad_idx') is not None:              # nn.Embedding(padding_idx=...): that row receives no gradient
+                    ge_buf[t['pad_idx']].zero_()
                 ge = sink.vec(emb, ge_buf)
             gp = d_pos[cfg.task_offsets[i]:cfg.task_offsets[i + 1]] if (d_pos is not None and tens[5 * i + 4].requires_grad) else None
-            out += [None, gw, gb, ge, gp]
+            out += [gdata, gw, gb, ge, gp]
         g_glob = g_small[T] if G > 0 else None
         if getattr(cfg, 'on_done', None) is not None:
             cfg.on_done()

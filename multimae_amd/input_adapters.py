@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import engine
-from .functions import EmbedFn, _Cfg
+from .functions import AvgClassEmbFn, EmbedFn, _Cfg
 from .multimae_utils import _cfg, build_2d_sincos_posemb, pair, trunc_normal_
 
 
@@ -133,10 +133,6 @@ class SemSegInputAdapter(nn.Module, _PosEmbMixin):
         self.emb_padding_idx = emb_padding_idx
         if self.emb_padding_idx is not None:
             self.num_classes += 1
-        if interpolate_class_emb:
-            raise NotImplementedError('interpolate_class_emb=True is not built (pre-training uses False, run_pretraining_multimae.py:67)')
-        if emb_padding_idx is not None:
-            raise NotImplementedError('emb_padding_idx is not built in the HIP engine')
         self.P_H = max(1, self.patch_size_full[0] // stride_level)
         self.P_W = max(1, self.patch_size_full[1] // stride_level)
         if self.dim_tokens is not None:
@@ -155,8 +151,13 @@ class SemSegInputAdapter(nn.Module, _PosEmbMixin):
         self.class_emb = nn.Embedding(num_embeddings=self.num_classes, embedding_dim=self.dim_class_emb,
                                       padding_idx=self.emb_padding_idx)
         trunc_normal_(self.class_emb.weight, std=0.02)
-        self.proj = nn.Conv2d(in_channels=self.dim_class_emb, out_channels=self.dim_tokens,
-                              kernel_size=(self.P_H, self.P_W), stride=(self.P_H, self.P_W))
+        if self.interpolate_class_emb:
+            # parameter containers only, as in the reference (input_adapters.py:192-198): proj.1.weight (D, E, 1, 1) / proj.1.bias
+            self.proj = nn.Sequential(nn.Upsample(scale_factor=(1 / self.P_H, 1 / self.P_W), mode='bilinear'),
+                                      nn.Conv2d(in_channels=self.dim_class_emb, out_channels=self.dim_tokens, kernel_size=1, stride=1))
+        else:
+            self.proj = nn.Conv2d(in_channels=self.dim_class_emb, out_channels=self.dim_tokens,
+                                  kernel_size=(self.P_H, self.P_W), stride=(self.P_H, self.P_W))
 
     @torch.jit.ignore
     def no_weight_decay(self):
@@ -172,8 +173,14 @@ class SemSegInputAdapter(nn.Module, _PosEmbMixin):
     def embed_args(self, x: torch.Tensor):
         nh, nw = self.check_input(x)
         H, W = x.shape[-2:]
+        pad = -1 if self.emb_padding_idx is None else int(self.emb_padding_idx)
+        if self.interpolate_class_emb:
+            # the resized class-embedding image enters the patch embedding as an E-channel image with 1 x 1 patches
+            img = AvgClassEmbFn.apply(x.long(), self.class_emb.weight, self.P_H, self.P_W, pad)
+            desc = dict(kind=0, C=self.dim_class_emb, H=nh, W=nw, ph=1, pw=1, K=self.dim_class_emb, n_patches=nh * nw, pos=self.pos_tokens(nh, nw))
+            return desc, (img, self.proj[1].weight, self.proj[1].bias, None, desc['pos'])
         desc = dict(kind=1, C=self.dim_class_emb, H=H, W=W, ph=self.P_H, pw=self.P_W, K=self.dim_class_emb * self.P_H * self.P_W,
-                    n_patches=nh * nw, pos=self.pos_tokens(nh, nw))
+                    n_patches=nh * nw, pos=self.pos_tokens(nh, nw), pad_idx=self.emb_padding_idx)
         return desc, (x.long(), self.proj.weight, self.proj.bias, self.class_emb.weight, desc['pos'])
 
     def forward(self, x):

@@ -970,6 +970,33 @@ def _ptr_array(ts: Sequence[Tensor]):
     return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
 
 
+def semseg_avg_emb_fwd(x: Tensor, class_emb: Tensor, ph: int, pw: int) -> Tensor:
+    """[B, H, W] class ids -> f32 [B, E, H/ph, W/pw]: the class-embedding image resized by 1 / patch (interpolate_class_emb)."""
+    _require_gpu(x, 'semseg input')
+    B, H, W = x.shape
+    n_cls, E = class_emb.shape
+    out = torch.empty((B, E, H // ph, W // pw), device=x.device, dtype=torch.float32)
+    check(_lib.load().mmae_semseg_avg_emb_fwd(x.data_ptr(), class_emb.data_ptr(), out.data_ptr(), B, H, W, E, ph, pw, n_cls, _stream()), 'semseg_avg_emb_fwd')
+    return out
+
+
+def semseg_avg_emb_bwd(d_img: Tensor, x: Tensor, n_cls: int, ph: int, pw: int, pad_idx: int = -1) -> Tensor:
+    B, H, W = x.shape
+    E = d_img.shape[1]
+    d_emb = torch.zeros((n_cls, E), device=x.device, dtype=torch.float32)
+    check(_lib.load().mmae_semseg_avg_emb_bwd(d_img.data_ptr(), x.data_ptr(), d_emb.data_ptr(), B, H, W, E, ph, pw, n_cls, pad_idx, _stream()), 'semseg_avg_emb_bwd')
+    return d_emb
+
+
+def rows_to_image(d_rows: Tensor, k_off: int, sel: Tensor, B: int, n_sel: int, tok_off: int, n_patches: int, C: int, H: int, W: int, ph: int,
+                  pw: int) -> Tensor:
+    """data gradient of the patch embedding for one image-like input: f32 [B, C, H, W] (zeros where no token was selected)."""
+    d_img = torch.zeros((B, C, H, W), device=d_rows.device, dtype=torch.float32)
+    check(_lib.load().mmae_rows_to_image(d_rows.data_ptr(), d_rows.stride(0), k_off, sel.data_ptr(), d_img.data_ptr(), B, n_sel, tok_off, n_patches,
+                                         C, H, W, ph, pw, _stream()), 'rows_to_image')
+    return d_img
+
+
 def pos_emb_bwd(d_tok: Tensor, sel: Tensor, n_pos: int, B: int, n_sel: int, G: int, D: int) -> Tensor:
     """d_pos f32 [n_pos, D]: the selected tokens' gradients summed per position (learnable positional embeddings)."""
     d_pos = torch.zeros((n_pos, D), device=d_tok.device, dtype=torch.float32)

@@ -127,16 +127,25 @@ def image_tokens(x: Tensor, sd: Dict[str, Tensor], prefix: str, ph: int, pw: int
     return tok + pos[None]
 
 
-def semseg_tokens(x: Tensor, sd: Dict[str, Tensor], prefix: str, ph: int, pw: int) -> Tensor:
+def semseg_tokens(x: Tensor, sd: Dict[str, Tensor], prefix: str, ph: int, pw: int, interpolate_class_emb: bool = False,
+                  padding_idx: Optional[int] = None) -> Tensor:
     """SemSegInputAdapter.forward, input_adapters.py:215-241: class-id -> embedding ->
-    per-patch linear (ph x pw conv) + bilinear-resized positional table."""
+    per-patch linear (ph x pw conv) + bilinear-resized positional table.
+    interpolate_class_emb (input_adapters.py:192-198): the embedding image is bilinearly resized by 1 / patch (nn.Upsample used as
+    a down-sampler: for even patch sizes the mean of the 2 x 2 centre pixels) and projected by a 1 x 1 conv (`proj.1.*`).
+    padding_idx (:186): that embedding row receives no gradient."""
     B, H, W = x.shape
     assert H % ph == 0 and W % pw == 0
-    emb = sd[prefix + 'class_emb.weight'][x]                 # (B,H,W,E)
+    emb = F.embedding(x, sd[prefix + 'class_emb.weight'], padding_idx=padding_idx)   # (B,H,W,E)
     emb = emb.permute(0, 3, 1, 2)                            # (B,E,H,W)
-    w = sd[prefix + 'proj.weight']
-    rows = patchify_rows(emb, ph, pw)
-    tok = rows @ w.reshape(w.shape[0], -1).t() + sd[prefix + 'proj.bias']
+    if interpolate_class_emb:
+        w = sd[prefix + 'proj.1.weight']
+        small = F.interpolate(emb, scale_factor=(1.0 / ph, 1.0 / pw), mode='bilinear')
+        tok = small.flatten(2).transpose(1, 2) @ w.reshape(w.shape[0], -1).t() + sd[prefix + 'proj.1.bias']
+    else:
+        w = sd[prefix + 'proj.weight']
+        rows = patchify_rows(emb, ph, pw)
+        tok = rows @ w.reshape(w.shape[0], -1).t() + sd[prefix + 'proj.bias']
     pos = resized_posemb_tokens(sd[prefix + 'pos_emb'], H // ph, W // pw, 'bilinear')
     return tok + pos[None]
 

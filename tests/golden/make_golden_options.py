@@ -99,6 +99,30 @@ def main():
         out[f'lpos/{name}/x'] = x.numpy(); out[f'lpos/{name}/g'] = gt.numpy(); out[f'lpos/{name}/tok'] = tok.detach().numpy()
         out[f'lpos/{name}/d_pos'] = mod.pos_emb.grad.numpy()
 
+    # ---- SemSegInputAdapter(interpolate_class_emb=True) and (emb_padding_idx=...)       input_adapters.py:186, 192-198
+    torch.manual_seed(9)
+    for tag, kw, P_ in (('interp4', dict(interpolate_class_emb=True), 4), ('interp2', dict(interpolate_class_emb=True), 2),
+                        ('pad', dict(emb_padding_idx=7), 4)):
+        mod = ria.SemSegInputAdapter(num_classes=11, stride_level=1, patch_size_full=P_, dim_tokens=D, image_size=16, dim_class_emb=16, **kw).train()
+        ncls = 12 if 'emb_padding_idx' in kw else 11
+        xs = torch.randint(0, ncls, (2, 16, 16), generator=g)
+        ntok = (16 // P_) ** 2
+        gs = torch.randn(2, ntok, D, generator=g)
+        tk = mod(xs); tk.backward(gs)
+        sdo = {'s.' + k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and k != 'pos_emb') for k, v in mod.state_dict().items()}
+        to = orc.semseg_tokens(xs, sdo, 's.', P_, P_, interpolate_class_emb=kw.get('interpolate_class_emb', False), padding_idx=kw.get('emb_padding_idx'))
+        to.backward(gs)
+        assert rel(to, tk) < 1e-6, (tag, rel(to, tk))
+        for k, p in mod.named_parameters():
+            if p.requires_grad:
+                assert rel(sdo['s.' + k].grad, p.grad) < 1e-5, (tag, k)
+                out[f'seg/{tag}/grad/{k}'] = p.grad.numpy()
+        if 'emb_padding_idx' in kw:
+            assert float(mod.class_emb.weight.grad[7].abs().max()) == 0.0 and (xs == 7).any()
+        for k, v in mod.state_dict().items():
+            out[f'seg/{tag}/sd/{k}'] = v.detach().numpy()
+        out[f'seg/{tag}/x'] = xs.numpy(); out[f'seg/{tag}/g'] = gs.numpy(); out[f'seg/{tag}/tok'] = tk.detach().numpy()
+
     # ---- blocks without qkv bias
     torch.manual_seed(3)
     L, D, heads = 1, 64, 2

@@ -365,3 +365,15 @@ def test_oracle_blocks_without_qkv_bias_vs_reference_golden():
     assert _rel(y.detach(), t['y']) < 1e-6 and _rel(x.grad, t['dx']) < 1e-5
     for k, v in grads.items():
         assert _rel(sd[k].grad, v) < 1e-5, k
+
+
+def test_oracle_semseg_interpolate_and_padding_idx_vs_reference_golden():
+    g = _opt()
+    for tag, P_, kw in (('interp4', 4, dict(interpolate_class_emb=True)), ('interp2', 2, dict(interpolate_class_emb=True)), ('pad', 4, dict(padding_idx=7))):
+        t = g(f'seg/{tag}/')
+        sd = {'s.' + k: v.clone().requires_grad_(v.dtype.is_floating_point and k != 'pos_emb') for k, v in g(f'seg/{tag}/sd/').items()}
+        tok = orc.semseg_tokens(t['x'], sd, 's.', P_, P_, **kw)
+        tok.backward(t['g'])
+        assert _rel(tok.detach(), t['tok']) < 1e-6, tag
+        for k, v in g(f'seg/{tag}/grad/').items():
+            assert _rel(sd['s.' + k].grad, v) < 1e-5, (tag, k)
