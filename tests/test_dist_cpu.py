@@ -188,3 +188,14 @@ def test_model_backward_drives_reducer_world4_gloo():
         assert ok, f'rank {rank}: {order}'
         assert order == sorted(order) and mid >= nb - 1, (order, mid, nb)      # everything but the tail launched inside backward
     assert all(r[2] == res[0][2] for r in res)
+
+
+def test_model_backward_drives_reducer_world8_gloo():
+    """The node size the driver's scaling run uses (8 ranks): identical bucket order on every rank, all buckets but the tail
+    launched inside backward, summed gradients equal to the closed form (the optimiser applies 1 / 8)."""
+    res = _run_model_workers(8)
+    assert len(res) == 8
+    for rank, ok, order, mid, nb in res:
+        assert ok, f'rank {rank}: {order}'
+        assert order == sorted(order) and mid >= nb - 1, (order, mid, nb)
+    assert all(r[2] == res[0][2] for r in res)
