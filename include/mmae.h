@@ -90,7 +90,9 @@ typedef struct mmae_gemm_desc {
     float alpha;
     int32_t tile;                /* bf16 kernel variant.  0 = let the library choose (mmae_gemm_plan; env MMAE_GEMM_TILE overrides);
                                     1/2 = 128x128 / 256x128 2-stage LDS-DMA, 3/4 = same tiles, VGPR-staged, 5..8 = LDS-DMA ring
-                                    with counted vmcnt (BK = 32), 9/10 = 8-wave ping-pong on 256x256 / 320x256 tiles */
+                                    with counted vmcnt (BK = 32), 9/10 = 8-wave ping-pong on 256x256 / 320x256 tiles,
+                                    11 = "duo": two independent 4-wave workgroups per CU on 128x256 tiles (12 = the same wave
+                                    schedule on one 8-wave workgroup, 256x256); shapes / epilogues they do not carry run on 9 */
     int32_t split_k;             /* <= 1: off; n: n K-slices, each writing a dense f32 [M][N] partial into ws,
                                     then summed into C in a fixed order (plain unbatched f32 C only).  The library
                                     never allocates: ask mmae_gemm_auto_splitk() and pass a workspace. */
@@ -121,6 +123,9 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream);
 int mmae_gemm_plan(const mmae_gemm_desc* d, int* tile, int* split_k);
 /* suggested number of K slices for a dW-shaped (both operands k-strided) [M,N,K] product (1 = do not split) */
 int mmae_gemm_auto_splitk(int M, int N, int K, int ab_dtype);
+/* resident workgroups per CU the HIP runtime reports for the duo kernel of tile code 11 / 12 with its dynamic LDS size
+ * (11 must report 2: the kernel's design is two independent workgroups per CU); < 0 on error */
+int mmae_gemm_duo_occupancy(int tile);
 
 /* ------------------------------------------------------------------------- *
  * MX-fp8 operands (BASELINE.json configs[4], "fp8 MFMA path"; OCP Microscaling v1.0: e4m3 elements, one power-of-two E8M0

@@ -218,7 +218,7 @@ def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], out: Tensor, *, res
 
 
 def linear_dx(dy: Tensor, w: Tensor, out: Tensor, *, aux: Optional[Tensor] = None, epi: int = EPI_NONE,
-              colsum_out: Optional[Tensor] = None, colsum_part: Optional[Tensor] = None) -> Tensor:
+              colsum_out: Optional[Tensor] = None, colsum_part: Optional[Tensor] = None, tile: int = 0) -> Tensor:
     """out[M,K] = dy[M,N] @ w[N,K]   (w read through the transposing LDS path).
     dGELU epilogue only -- the column sums of `out` (= the bias gradient of the Linear whose pre-activation gradient `out`
     is) collected in the GEMM epilogue instead of a separate pass over out:
@@ -229,7 +229,7 @@ def linear_dx(dy: Tensor, w: Tensor, out: Tensor, *, aux: Optional[Tensor] = Non
     part = colsum_part
     if colsum_out is not None and part is None:
         part = torch.empty(dx_colsum_part_shape(M, K), device=dy.device, dtype=torch.float32)
-    gemm(dy, w, out, M, K, N, lda=dy.stride(0), ldb=K, ldc=K, b_trans=True, aux=aux, ldaux=K, epi=epi, colsum_part=part)
+    gemm(dy, w, out, M, K, N, lda=dy.stride(0), ldb=K, ldc=K, b_trans=True, aux=aux, ldaux=K, epi=epi, colsum_part=part, tile=tile)
     if colsum_out is not None:
         colsum(part, colsum_out, False)
     return out
