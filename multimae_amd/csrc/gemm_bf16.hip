@@ -252,7 +252,7 @@ int dispatch_layout(const GemmArgs& g, int batch, bool aks, bool bks, hipStream_
 
 int mmae_gemm_bf16_pipe_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hipStream_t st);
 int mmae_gemm_bf16_pp_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hipStream_t st);
-int mmae_gemm_bf16_duo_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hipStream_t st);
+int mmae_gemm_bf16_ext_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hipStream_t st);
 
 int mmae_gemm_bf16_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hipStream_t st) {
     MMAE_REQUIRE(d->lda % 8 == 0 && d->ldb % 8 == 0, "gemm bf16: lda/ldb must be multiples of 8");
@@ -264,13 +264,18 @@ int mmae_gemm_bf16_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hi
     if (d->a_trans) MMAE_REQUIRE(d->M % 8 == 0 || d->lda >= ((d->M + 7) / 8) * 8, "gemm bf16: transposed A row too short");
     if (d->b_trans) MMAE_REQUIRE(d->N % 8 == 0 || d->ldb >= ((d->N + 7) / 8) * 8, "gemm bf16: transposed B row too short");
     // tile codes (chosen by runtime.hip's gemm_plan): 1 = 128x128 LDS-DMA, 2 = 256x128 LDS-DMA, 3 = 128x128 VGPR-staged, 4 = 256x128 VGPR-staged
+    if (code > 14) {                       // experiment / dissection builds of the newer structures (-DMMAE_EXPERIMENTS)
+        const int rc = mmae_gemm_bf16_ext_impl(d, g, code, st);
+        if (rc != MMAE_ESUPPORT) return rc;
+        code = 9;
+    }
     switch (code) {
         case 5: case 6: case 7: case 8: return mmae_gemm_bf16_pipe_impl(d, g, code, st);     // LDS-DMA ring, BK = 32
         case 9: case 10: return mmae_gemm_bf16_pp_impl(d, g, code, st);                     // 8-wave ping-pong, 256/320 x 256
-        case 11: case 12: case 21: case 22: case 31: case 32: case 41: case 42: case 51: case 52: {                                                              // duo: 2 x (4 waves, 128 x 256) per CU
-            const int rc = mmae_gemm_bf16_duo_impl(d, g, code, st);
+        case 11: case 12: case 13: case 14: {                                              // newer structures, dispatched in gemm_bf16_pp64.hip
+            const int rc = mmae_gemm_bf16_ext_impl(d, g, code, st);
             if (rc != MMAE_ESUPPORT) return rc;
-            return mmae_gemm_bf16_pp_impl(d, g, 9, st);
+            return mmae_gemm_bf16_pp_impl(d, g, code == 14 ? 10 : 9, st);
         }
         case 2: return dispatch_layout<4, 2, true>(g, d->batch, d->a_trans != 0, d->b_trans != 0, st);
         case 3: return dispatch_layout<2, 2, false>(g, d->batch, d->a_trans != 0, d->b_trans != 0, st);

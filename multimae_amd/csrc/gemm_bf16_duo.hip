@@ -4,13 +4,36 @@
 // Replaces nn.Linear forward / backward-input under autocast: multimae/multimae_utils.py:138-155 (Mlp), 158-182 (Attention
 // qkv / proj), 217-232 (Block) of the reference.
 #include <mutex>
+#ifdef MMAE_EXPERIMENTS
+// phase trace (experiments build): workgroup b, tile t, event e (0 loop start, 1 loop end, 2 epilogue end) -> 100 MHz time stamp
+__device__ unsigned g_duo_trace[2048 * 8 * 3];
+#define DUO_TRACE(tile_no, what) do { if (threadIdx.x == 0 && (tile_no) < 8 && blockIdx.x < 2048 && blockIdx.y == 0 && blockIdx.z == 0) \
+    g_duo_trace[(blockIdx.x * 8 + (tile_no)) * 3 + (what)] = (unsigned)__builtin_amdgcn_s_memrealtime(); } while (0)
+#endif
 #include "gemm_duo_body.h"
 
 namespace {
 
+#ifdef MMAE_EXPERIMENTS
+// residency census (experiments build): per workgroup {HW_ID, XCC_ID, start, end} with the 100 MHz real-time counter
+__device__ unsigned g_duo_census[4 * 2048];
+#endif
+
 template <int NW, bool AKS, bool BKS, int FL, int VAR = 0>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm_bf16_duo_kernel(const GemmArgs g) {
+#ifdef MMAE_EXPERIMENTS
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     duo_body<NW, AKS, BKS, FL, true, VAR>(g, blockIdx.x, gridDim.x);
+#ifdef MMAE_EXPERIMENTS
+    if (threadIdx.x == 0 && blockIdx.x < 2048 && blockIdx.y == 0 && blockIdx.z == 0) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        unsigned* c = g_duo_census + 4 * blockIdx.x;
+        c[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        c[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        c[2] = (unsigned)t0; c[3] = (unsigned)t1;
+    }
+#endif
 }
 
 int duo_cu_count() {
@@ -23,7 +46,7 @@ int duo_cu_count() {
 template <int NW, bool AKS, bool BKS, int FL, int VAR = 0>
 int duo_launch(const GemmArgs& g, int batch, hipStream_t st) {
     constexpr int BM = (NW / 4) * 128, BN = 256, NST = NW == 4 ? 3 : 4;
-    constexpr size_t LDS = (size_t)NST * (BM + BN) * 64 + 8192;
+    constexpr size_t LDS = (size_t)NST * (BM + BN) * 64;
     const int tiles_m = (g.M + BM - 1) / BM;
     GemmArgs a = g;
     a.tiles_n = (g.N + BN - 1) / BN;
@@ -89,14 +112,27 @@ extern "C" int mmae_gemm_duo_occupancy(int tile) {
     int n = -1;
     hipError_t e;
     if (tile == 12) {
-        constexpr size_t LDS = (size_t)4 * (256 + 256) * 64 + 8192;
+        constexpr size_t LDS = (size_t)4 * (256 + 256) * 64;
         (void)hipFuncSetAttribute((const void*)gemm_bf16_duo_kernel<8, false, false, FL_BF16_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_bf16_duo_kernel<8, false, false, FL_BF16_BIAS>, 512, LDS);
     } else {
-        constexpr size_t LDS = (size_t)3 * (128 + 256) * 64 + 8192;
+        constexpr size_t LDS = (size_t)3 * (128 + 256) * 64;
         (void)hipFuncSetAttribute((const void*)gemm_bf16_duo_kernel<4, false, false, FL_BF16_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_bf16_duo_kernel<4, false, false, FL_BF16_BIAS>, 256, LDS);
     }
     if (e != hipSuccess) { mmae_set_error(hipGetErrorString(e)); return -1; }
     return n;
 }
+
+#ifdef MMAE_EXPERIMENTS
+extern "C" int mmae_debug_duo_census(unsigned* out_host, int n_words) {
+    if (n_words > 4 * 2048) n_words = 4 * 2048;
+    (void)hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_duo_census), (size_t)n_words * 4) == hipSuccess ? 0 : -1;
+}
+extern "C" int mmae_debug_duo_trace(unsigned* out_host, int n_words) {
+    if (n_words > 2048 * 8 * 3) n_words = 2048 * 8 * 3;
+    (void)hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_duo_trace), (size_t)n_words * 4) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -24,6 +24,9 @@
 // is re-targeted after B_u, which every wave passes with its reads of tile u drained.
 #pragma once
 #include "gemm_pp_body.h"
+#ifndef DUO_TRACE
+#define DUO_TRACE(tile_no, what)
+#endif
 
 namespace {
 
@@ -47,10 +50,11 @@ __device__ __forceinline__ void duo_body(const GemmArgs& g, const int v0, const 
     constexpr int PA = A_BYTES / 1024, PB = B_BYTES / 1024;
     constexpr int LA = PA / NW, LB = PB / NW, NP = LA + LB;     // DMA pieces per wave and K tile
     constexpr int NST = NW == 4 ? 3 : 4;
-    constexpr int PRE = 2;                                       // K tiles of the NEXT output tile prefetched under the epilogue
+    constexpr int PRE = NW == 4 ? 1 : 2;                         // K tiles of the NEXT output tile prefetched under the epilogue (NW = 4: one, so that the
+                                                                 // staging fits in 72 KiB -- two 80-KiB workgroups were NOT co-resident although the occupancy query said so)
     constexpr int STG = PRE * STAGE;                             // epilogue staging: NW x 8 KiB above the first PRE slots
     static_assert(PA % NW == 0 && PB % NW == 0, "whole pieces per wave");
-    static_assert(STG + NW * 8192 <= NST * STAGE + 8192, "staging must fit behind the prefetch slots");
+    static_assert(STG + NW * 8192 <= NST * STAGE, "staging must fit behind the prefetch slots");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -303,12 +307,20 @@ __device__ __forceinline__ void duo_body(const GemmArgs& g, const int v0, const 
         }
     };
 
+    // Two workgroups that share a CU must run OUT OF PHASE for one's epilogue to sit under the other's K loop: started
+    // together on identical work they stay in lock step (both in the loop at half speed, then both in the epilogue).  The
+    // second half of the grid (the workgroups dispatched onto already occupied CUs) starts g.dephase x ~4 us late.
+    if (NW == 4 && g.dephase && blockIdx.x >= (gridDim.x >> 1)) {
+        for (int i = 0; i < g.dephase; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     // prologue of the first tile: K tiles 0 .. NST-1
 #pragma unroll
     for (int s = 0; s < NST; ++s) dma_tile(s, s);
 
     char* stage = smem + STG + wave * 8192;
-    for (int v = v0; v < g.tiles_total; v += vstep) {
+    int tile_no = 0;
+    for (int v = v0; v < g.tiles_total; v += vstep, ++tile_no) {
+        DUO_TRACE(tile_no, 0);
         asm volatile("" : "+v"(lane));
         derive();
 #pragma unroll
@@ -357,6 +369,7 @@ __device__ __forceinline__ void duo_body(const GemmArgs& g, const int v0, const 
         }
         duo_wait_vm<0>();                                    // the zero-fill tail pieces must not land on live data
         __syncthreads();                                     // every wave is out of the ring
+        DUO_TRACE(tile_no, 1);
 
         const int mw = m0 + wm * 128, nw = n0 + wn * 64;
         const bool has_next = v + vstep < g.tiles_total;
@@ -382,6 +395,7 @@ __device__ __forceinline__ void duo_body(const GemmArgs& g, const int v0, const 
 #pragma unroll
             for (int s = PRE; s < NST; ++s) dma_tile(s, s);
         }
+        DUO_TRACE(tile_no, 2);
     }
 }
 

@@ -200,10 +200,17 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
     auto frag_kc = [&](const char* base, int row0, int kk) -> bf16x8 {
         return *reinterpret_cast<const bf16x8*>(base + kc_off(row0 + fr, kk * 2 + fk));
     };
+    // Transposing fragment read of a k-strided operand image.  Issued as INLINE ASM: for the builtin (a DS read with an LDS memory
+    // operand) hipcc's wait-count pass assumes it may alias the LDS-DMA writes in flight and puts s_waitcnt vmcnt(0) in front of
+    // every group of transposing reads -- the whole prefetch ring drained once per 16-wide K slice in every dX and dW product
+    // (found in the round-3 ISA audit; the plain ds_read_b128 fragment loads do not get that wait).  The compiler neither counts
+    // nor waits for an asm load: mfma_phase() opens with s_waitcnt lgkmcnt(0) + sched_barrier (cdna_hip_programming.md 5.7).
+    // The two 64-bit halves (k rows k_lo .. k_lo+3 and +4: same swizzle term, 4 x 512 B further) share one address register.
     auto frag_ks = [&](const char* base, int col0, int kk) -> bf16x8 {            // both operands' images are 256 columns wide
         const int col = col0 + t_i0 + (tp & 3) * 4, k_lo = kk * 16 + t_kh + (tp >> 2);
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(base + ks_off<256>(k_lo, col >> 3) + (col & 7) * 2));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(base + ks_off<256>(k_lo + 4, col >> 3) + (col & 7) * 2));
+        const unsigned addr = (unsigned)(size_t)(LDS_AS const char*)(base + ks_off<256>(k_lo, col >> 3) + (col & 7) * 2);
+        s16x4 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048" : "=&v"(lo), "=&v"(hi) : "v"(addr));
         return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
 
@@ -224,6 +231,10 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
     // (Issuing all, or one, of the phase's DMA pieces between the MFMAs instead -- an LDS-DMA issue stalls its wave 60-180
     // cycles -- measured 0-10 % slower than keeping them in the memory half-phase.)
     auto mfma_phase = [&]() {
+        if (AKS || BKS) {                                    // the asm fragment reads of this phase's operands (see frag_ks)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
