@@ -74,7 +74,7 @@ def pmc_traffic(dom):
     roofline.traffic_source), or None if no PMC pass is committed."""
     if dom != torch.bfloat16:
         return None, None
-    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         f = os.path.join(ROOT, 'profiles', name)
         try:
             return json.load(open(f)).get('gemm_bf16_traffic_per_launch'), f'recorded: profiles/{name} (rocprofv3 --pmc passes of this command; not measured in this run)'
@@ -261,7 +261,9 @@ def main():
     ap.add_argument('--adapter-streams', type=int, default=1, help='1: output adapters on separate HIP streams')
     ap.add_argument('--wgrad-stream', type=int, default=1, help='1: weight-gradient GEMMs on a side stream')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for --gpus > 1 ('nccl' = RCCL; 'gloo' for functional tests)")
-    ap.add_argument('--force-dist', type=int, default=0, help='1: run the data-parallel path (process group, bucketed all-reduce overlapped with backward, chunked encoder backward) even at world size 1 -- exercises RCCL and the reducer\'s stream logic on a single GPU')
+    ap.add_argument('--force-dist', type=int, default=0, help='1: run the data-parallel path (process group, bucketed all-reduce overlapped with backward, chunked encoder backward) even at world size 1 -- the one-rank all-reduces ARE issued (RCCL copy path), so the launch-stream / event ordering of the reducer runs on a single GPU')
+    ap.add_argument('--bucket-mb', type=float, default=64.0, help='gradient all-reduce bucket size (MiB of fp32 gradients)')
+    ap.add_argument('--bf16-buckets', type=int, default=0, help='1: gradient buckets travel as bf16 (half the xGMI bytes, bf16-rounded sum; multimae_amd/dist.py)')
     ap.add_argument('--share-device', type=int, default=0, help='1: every rank uses cuda:0 (functional test of the multi-process path on one GPU; use with --backend gloo)')
     ap.add_argument('--graph', type=int, default=-1, help='1: capture the step once as a hipGraph and replay it (multimae_amd.graph.StepGraph; 1 GPU only). Default 0: on ROCm 7.2 the replay of this ~1 100-node, 10-stream graph measured 46.2 ms/step against 44.1 ms eager')
     args = ap.parse_args()
@@ -299,7 +301,7 @@ def main():
     reducer = None
     if use_dist:
         broadcast_parameters(arena)
-        reducer = GradAllReducer.for_arena(arena)
+        reducer = GradAllReducer.for_arena(arena, bucket_mb=args.bucket_mb, bf16_buckets=bool(args.bf16_buckets), force_collective=bool(args.force_dist))
     M.engine.set_precision(args.precision)
     M.engine.set_direct_grads(True)
     M.engine.set_adapter_streams(bool(args.adapter_streams))
@@ -326,7 +328,7 @@ def main():
 
     def step():
         g = opt.param_groups[0]
-        g['lr'], g['weight_decay'] = lr_tab[min(it[0], n_tab - 1)] * g['lr_scale'], wd_tab[min(it[0], n_tab - 1)]
+        g['lr'], g['weight_decay'] = lr_tab[min(it[0], n_tab - 1)], wd_tab[min(it[0], n_tab - 1)]     # FusedAdamW.step applies g['lr_scale'] itself
         it[0] += 1
         opt.zero_grad()
         preds, masks = model(x, num_encoded_tokens=n_vis, alphas=1.0, sample_tasks_uniformly=False, fp32_output_adapters=fp32_adapters)
@@ -362,6 +364,9 @@ def main():
     sync()
     log('warmup done; timing')
     opt.host_wait_s = 0.0
+    if reducer is not None:
+        reducer.timing = True
+        reducer.exposed_wait_ms()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
@@ -378,6 +383,16 @@ def main():
         dt = float(t)
     ms_per_step = dt / args.steps * 1e3
     img_s = B * world * args.steps / dt
+    dp_diag = None
+    if reducer is not None:
+        # self-diagnosis of the data-parallel run: how much of the gradient exchange was NOT hidden by backward
+        reducer.timing = False
+        seen = torch.ones(1, device=device)
+        dist.all_reduce(seen)
+        dp_diag = {'exposed_allreduce_ms_per_step': round(reducer.exposed_wait_ms() / args.steps, 3), 'bucket_mb': args.bucket_mb,
+                   'buckets': len(reducer.buckets), 'bucket_dtype': 'bf16' if args.bf16_buckets else 'f32',
+                   'allreduce_mb_per_step': round(sum(e - s for s, e, _ in reducer.buckets) * (2 if args.bf16_buckets else 4) / 2 ** 20, 1),
+                   'rccl_ranks_seen': int(seen.item()), 'backend': args.backend, 'encoder_bwd_chunk_layers': int(getattr(model, '_bwd_chunk_layers', 0))}
     final_loss = float(last['loss'].detach())
     counters = opt.counters()
     log(f'timed region done: {ms_per_step:.2f} ms/step, {img_s:.1f} img/s, loss {final_loss:.4f} (host enqueue work {host_ms:.2f} ms/step + {host_wait_ms:.2f} ms waiting in the 2-step run-ahead bound)')
@@ -420,7 +435,7 @@ def main():
         dom = torch.float32 if args.precision == 'fp32' else torch.bfloat16
         peak = PEAK_BF16_TFLOPS if dom == torch.bfloat16 else 157.3
         ach = tot_fl[dom] / (tot_ms[dom] * 1e-3) / 1e12 if tot_ms[dom] > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(dom)
+        traffic, traffic_src = pmc_traffic(dom) if args.config == 'cfg3' else (None, 'no PMC pass of this configuration is committed (the recorded one is cfg3)')
         roof = {'bound': 'mfma', 'kernel': 'gemm_bf16_pp_kernel (+ its grouped weight-gradient form gemm_bf16_pp_dwgroup_kernel) / gemm_bf16_kernel: all bf16 MFMA GEMM calls of one production step, each bracketed by HIP events on its launch stream inside the library, single-stream' if dom == torch.bfloat16 else 'gemm_f32_kernel',
                 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_source': traffic_src,
                 'launches_per_step': cnt[dom], 'gemm_ms_per_step': round(tot_ms[dom], 3),
@@ -454,12 +469,14 @@ def main():
                                    + (('ViT-L (MX-fp8 encoder products), ' if args.precision == 'mxfp8' else 'ViT-L (bf16 run of the fp8 config), ') if args.config == 'cfg5' else 'ViT-B, ')
                                    + ('RGB-only' if args.config == 'cfg2' else 'RGB+depth+semseg')
                                    + f', 224^2, Dirichlet alpha=1.0, {n_vis} visible tokens, {len(doms) + 1} cross-attention decoders (dim 256, depth 2), '
-                                   + ('fp32 semseg adapter, ' if 'semseg' in doms else '') + 'AdamW; fwd+losses+bwd+optimizer',
+                                   + ('semseg adapter with fp32 activations and x3 split-bf16 GEMMs (a_hi.b_hi + a_hi.b_lo + a_lo.b_hi, fp32 accumulate), ' if 'semseg' in doms else '') + 'AdamW; fwd+losses+bwd+optimizer',
                        'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}'},
             'final_loss': round(final_loss, 5), 'launch': 'hipGraph replay of the captured step' if use_graph else 'eager, one library call per encoder stack / output adapter / loss / optimiser step',
             'host_enqueue_ms_per_step': round(host_ms, 3), 'host_throttle_wait_ms_per_step': round(host_wait_ms, 3), 'optimizer_counters': counters,
             'roofline': roof, 'cpu_baseline': cpu,
         }
+        if dp_diag is not None:
+            out['data_parallel'] = dp_diag
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -518,6 +518,9 @@ int mmae_tokens_assemble_bwd(const float* d_tok, void* d_proj, int proj_dtype, c
  *                                        + task_emb[q_task] + pos[j]
  *   context  f32 [B][n_keep+G][D]: c[b][r] = ctx[b][r] + task_emb[task(ids_keep[b][r])]
  *                                        + pos[ids_keep[b][r] - off(task)];  global rows copied.
+ *   q_task = -1: pure mask-token queries (output_adapters.py:213-220 -- the adapter's task is not among the encoder
+ *  inputs, or use_task_queries=False): q[b][j] = mask_token + pos[j]; the caller adds the adapter's own task embedding
+ *  (if it has one) to the mask_token vector it passes.  n_q = N_H * N_W then.
  *   task_emb f32 [T][D]; pos f32 [n_patch][D] (same table for every task: all tasks share
  *  the decoder's N_H x N_W grid, output_adapters.py:172-175); task_offsets int32 [T+1] (host).
  * ------------------------------------------------------------------------- */
@@ -527,7 +530,7 @@ int mmae_decoder_build(const float* ctx, const int64_t* ids_keep, const int64_t*
                        int n_q, float* queries, float* context, void* stream);
 /* backward: d_ctx (f32, overwritten) from d_queries/d_context; parameter gradients are
  * accumulated through partials: part f32 [nblk][T+1][D] (rows 0..T-1 task_emb, row T
- * mask_token), nblk = mmae_decoder_build_bwd_nblk(B). */
+ * mask_token; with q_task = -1 row T is the sum of ALL query-row gradients), nblk = mmae_decoder_build_bwd_nblk(B). */
 int mmae_decoder_build_bwd_nblk(int B);
 int mmae_decoder_build_bwd(const float* d_queries, const float* d_context, const int64_t* ids_keep,
                            const int64_t* ids_restore, const int32_t* task_offsets_host, int T, int q_task,

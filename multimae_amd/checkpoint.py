@@ -95,8 +95,11 @@ def interpolate_pos_embed_multimae(model, checkpoint_model: Dict[str, Tensor]) -
 
 # ------------------------------------------------------------------------------------------ optimiser state
 def _trainable(opt):
+    """Trainable tensors in ``named_parameters()`` order -- the order ``torch.optim.AdamW`` numbers its state by when the
+    reference builds it from ``[p for n, p in model.named_parameters() if p.requires_grad]`` (utils/optim_factory.py:138-149).
+    The arena itself is laid out in backward-readiness order (engine.ParamArena(groups=...)); offsets do the translation."""
     a = opt.arena
-    return [(n, a.offsets[n], a.sizes[n], a._params[n].shape) for n in a.names if a.trainable[n]]
+    return [(n, a.offsets[n], a.sizes[n], a._params[n].shape) for n in a.param_order if a.trainable[n]]
 
 
 def optimizer_state_to_torch(opt) -> dict:

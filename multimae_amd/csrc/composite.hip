@@ -767,7 +767,7 @@ AdapterTmp carve_adapter_tmp(Carver& cv, const mmae_adapter_desc* d) {
 int check_adapter(const mmae_adapter_desc* d) {
     MMAE_REQUIRE(d, "adapter: null descriptor");
     MMAE_REQUIRE(d->B > 0 && d->NC > 0 && d->Denc > 0 && d->D > 0 && d->heads > 0 && d->Hd > 0 && d->D % d->heads == 0 && d->depth >= 0 &&
-                 d->depth <= 8 && d->T >= 1 && d->T <= 7 && d->q_task >= 0 && d->q_task < d->T && d->G >= 0 && d->n_q > 0 && d->NC > d->G,
+                 d->depth <= 8 && d->T >= 1 && d->T <= 7 && d->q_task >= -1 && d->q_task < d->T && d->G >= 0 && d->n_q > 0 && d->NC > d->G,
                  "adapter: bad geometry");
     MMAE_REQUIRE(d->C > 0 && d->nh > 0 && d->nw > 0 && d->ph > 0 && d->pw > 0 && d->nh * d->nw == d->n_q, "adapter: bad patch geometry");
     MMAE_REQUIRE(d->act_dtype == MMAE_BF16 || (d->act_dtype == MMAE_F32 && d->f32_gemm == MMAE_F32X3),

@@ -411,7 +411,8 @@ __global__ void opt_finalize_kernel(float* __restrict__ state, int* __restrict__
                                     float b1, float b2, float clip, float skip_at, float prescale, const float* __restrict__ loss) {
     const float norm = sqrtf(state[0]) * prescale;
     const bool loss_bad = loss && !isfinite(loss[0]);
-    const bool skip = !isfinite(norm) || (skip_at > 0.f && norm >= skip_at) || loss_bad;
+    // clip and skip are exclusive, clip first: utils/native_scaler.py:24-32 is `if clip_grad ... elif skip_grad`
+    const bool skip = !isfinite(norm) || (clip <= 0.f && skip_at > 0.f && norm >= skip_at) || loss_bad;
     float scale = prescale;
     if (clip > 0.f) { const float cc = clip / (norm + 1e-6f); scale *= cc < 1.f ? cc : 1.f; }
     int t = istate[1];

@@ -206,13 +206,16 @@ __global__ void __launch_bounds__(256) decoder_build_kernel(const float* __restr
     const int NC = n_keep + G;
     if (rr < n_q) {
         const int j = rr;
-        const long long rank = ids_restore[(long long)b * Ntot + tt.off[q_task] + j];
+        // q_task < 0: pure mask-token queries (output_adapters.py:213-220: the task is not among the encoder inputs, or
+        // use_task_queries=False): mask_token + pos[j]; the optional task embedding of the adapter's own task is folded into
+        // the mask_token vector the caller passes (it is added to every query row, exactly like the mask token)
+        const long long rank = q_task < 0 ? (long long)n_keep : ids_restore[(long long)b * Ntot + tt.off[q_task] + j];
         const float* base = (rank < n_keep) ? ctx + ((long long)b * NC + rank) * D : mask_token;
-        const float* te = task_emb + (long long)q_task * D;
+        const float* te = q_task < 0 ? nullptr : task_emb + (long long)q_task * D;
         const float* pe = pos + (long long)j * D;
         float* o = queries + ((long long)b * n_q + j) * D;
         for (int c = threadIdx.x * 4; c < D; c += 1024) {
-            const f32x4 a = ld4(base + c), t4 = ld4(te + c), p4 = ld4(pe + c);
+            const f32x4 a = ld4(base + c), t4 = te ? ld4(te + c) : f32x4{0.f, 0.f, 0.f, 0.f}, p4 = ld4(pe + c);
             f32x4 v;
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = a[k] + (t4[k] + p4[k]);
@@ -281,7 +284,7 @@ __global__ void __launch_bounds__(256) decoder_build_bwd_kernel(const float* __r
                 } else {                                  // query row: task embedding of the query task + mask token of the masked ones
                     const int j = rr - NC;
                     const f32x4 q = ld4(d_queries + ((long long)b * n_q + j) * D + c);
-                    const bool vis = ids_restore[(long long)b * Ntot + tt.off[q_task] + j] < n_keep;
+                    const bool vis = q_task >= 0 && ids_restore[(long long)b * Ntot + tt.off[q_task] + j] < n_keep;     // q_task < 0: every query row is mask_token + pos
 #pragma unroll
                     for (int i = 0; i < MAX_TASKS; ++i) if (i == q_task) {
 #pragma unroll
@@ -620,8 +623,8 @@ int mmae_decoder_build(const float* ctx, const int64_t* ids_keep, const int64_t*
     MMAE_REQUIRE(ctx && ids_keep && ids_restore && mask_token && task_emb && pos && queries && context, "decoder_build: null pointer");
     MMAE_REQUIRE(D % 4 == 0 && D <= 1024 && B > 0, "decoder_build: bad sizes");
     TaskTable tt;
-    MMAE_REQUIRE(fill_tt(tt, task_offsets_host, T) == 0 && q_task >= 0 && q_task < T, "decoder_build: bad task table");
-    MMAE_REQUIRE(tt.off[q_task + 1] - tt.off[q_task] == n_q, "decoder_build: n_q != tokens of the query task");
+    MMAE_REQUIRE(fill_tt(tt, task_offsets_host, T) == 0 && q_task >= -1 && q_task < T, "decoder_build: bad task table");
+    MMAE_REQUIRE(n_q > 0 && (q_task < 0 || tt.off[q_task + 1] - tt.off[q_task] == n_q), "decoder_build: n_q != tokens of the query task");
     hipLaunchKernelGGL(decoder_build_kernel, dim3((unsigned)((long long)B * (n_q + n_keep + G))), dim3(256), 0, (hipStream_t)stream, ctx,
                        (const long long*)ids_keep, (const long long*)ids_restore, mask_token, task_emb, pos, tt, q_task, n_keep, G, D,
                        n_q, tt.off[T], queries, context);
@@ -637,7 +640,7 @@ int mmae_decoder_build_bwd(const float* d_queries, const float* d_context, const
     MMAE_REQUIRE(d_queries && d_context && ids_keep && ids_restore && d_ctx && part, "decoder_build_bwd: null pointer");
     MMAE_REQUIRE(D % 4 == 0 && D <= 1024 && B > 0, "decoder_build_bwd: bad sizes");
     TaskTable tt;
-    MMAE_REQUIRE(fill_tt(tt, task_offsets_host, T) == 0 && q_task >= 0 && q_task < T, "decoder_build_bwd: bad task table");
+    MMAE_REQUIRE(fill_tt(tt, task_offsets_host, T) == 0 && q_task >= -1 && q_task < T, "decoder_build_bwd: bad task table");
     hipLaunchKernelGGL(decoder_build_bwd_kernel, dim3(B < 1024 ? B : 1024, dbb_split(B)), dim3(256), 0, (hipStream_t)stream, d_queries,
                        d_context, (const long long*)ids_keep, (const long long*)ids_restore, tt, q_task, B, n_keep, G, D, n_q,
                        tt.off[T], d_ctx, part);

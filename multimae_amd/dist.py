@@ -55,8 +55,20 @@ class GradAllReducer:
     """Bucketed, overlap-capable all-reduce(sum) of a flat gradient buffer; average = sum * grad_prescale in the optimiser."""
 
     def __init__(self, grad: torch.Tensor, sizes: List[Tuple[str, int, int]], bucket_mb: float = 64.0,
-                 group: Optional[dist.ProcessGroup] = None, cut_before: Iterable[str] = (), average_in_place: bool = False):
+                 group: Optional[dist.ProcessGroup] = None, cut_before: Iterable[str] = (), average_in_place: bool = False,
+                 bf16_buckets: bool = False, force_collective: bool = False):
         self.grad = grad
+        self.bucket_mb = bucket_mb
+        # bf16_buckets: every bucket travels as bf16 (cast -> all-reduce -> widen back into the fp32 arena): half the bytes on
+        # the xGMI links (196 instead of 392 MB for ViT-B) for a bf16-rounded SUM -- the trade torch DDP's bf16_compress_hook
+        # makes; off by default (the fp32 sum is what the reference's DDP produces)
+        self.bf16_buckets = bf16_buckets
+        # force_collective: issue the all-reduces even at world size 1 (bench.py --force-dist: RCCL + the launch-stream / event
+        # ordering run on a single GPU; a one-rank all-reduce is a copy)
+        self.force_collective = force_collective
+        self.timing = False                             # bench.py: event-time the exposed wait in finish()
+        self._wait_events: List[tuple] = []
+        self._bf16_tmp: Dict[int, torch.Tensor] = {}
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets = plan_buckets(sizes, int(bucket_mb * 1024 * 1024 / 4), cut_before)
@@ -113,10 +125,20 @@ class GradAllReducer:
         if self._launched[i]:
             return
         self._launched[i] = True
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return
         s, e, _ = self.buckets[i]
         view = self.grad[s:e]
+
+        def exchange():
+            if not self.bf16_buckets:
+                return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            tmp = self._bf16_tmp.get(i)
+            if tmp is None:
+                tmp = self._bf16_tmp[i] = torch.empty(e - s, device=self.grad.device, dtype=torch.bfloat16)
+            tmp.copy_(view)
+            return dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
         if self.grad.is_cuda:
             if self._launch_stream is None:
                 self._launch_stream = torch.cuda.Stream(device=self.grad.device)
@@ -125,9 +147,9 @@ class GradAllReducer:
             for ev in self._events[i]:
                 ls.wait_event(ev)
             with torch.cuda.stream(ls):
-                h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                h = exchange()
         else:
-            h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            h = exchange()
         self._handles.append((h, i))
 
     # -- readiness ----------------------------------------------------------------------------------------------------
@@ -156,18 +178,39 @@ class GradAllReducer:
     def finish(self) -> None:
         """Launch whatever is left (parameters that never reported) and make the current stream wait for all buckets."""
         pending = [i for i in range(len(self.buckets)) if not self._launched[i]]
-        if pending and self.grad.is_cuda and self.world > 1:
+        active = self.world > 1 or self.force_collective
+        if pending and self.grad.is_cuda and active:
             # gradients that were not reported may have been written on any stream: order behind all of them (autograd has
             # joined the streams it ran backward nodes on with the caller's stream; the side streams are joined here)
             self._join_all(pending)
         for i in pending:
             self._launch(i)
+        ev0 = None
+        if self.timing and self.grad.is_cuda and self._handles:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
         for h, i in self._handles:
-            h.wait()
+            h.wait()                                     # the calling stream waits for the collective (no host block on NCCL / RCCL)
+            s, e, _ = self.buckets[i]
+            if self.bf16_buckets:
+                self.grad[s:e].copy_(self._bf16_tmp[i])  # widen the bf16 sum back into the fp32 arena
             if self.average_in_place and self.world > 1:
-                s, e, _ = self.buckets[i]
                 self.grad[s:e].mul_(1.0 / self.world)
+        if ev0 is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            self._wait_events.append((ev0, ev1))
         self.reset()
+
+    def exposed_wait_ms(self) -> float:
+        """Sum of the event-timed waits finish() put on the calling stream since the last call (timing = True): the part of the
+        gradient exchange that did NOT overlap backward.  Synchronises; call after the timed region."""
+        tot = 0.0
+        for a, b in self._wait_events:
+            b.synchronize()
+            tot += a.elapsed_time(b)
+        self._wait_events = []
+        return tot
 
     def _join_all(self, buckets: Sequence[int]) -> None:
         from . import engine

@@ -249,6 +249,9 @@ class ParamArena:
         params = [(n, p) for n, p in module.named_parameters()]
         if not params:
             raise ValueError('module has no parameters')
+        # registration order (named_parameters()): what torch.optim state dicts index by -- the arena layout below is the
+        # backward-readiness order and must never leak into a checkpoint (checkpoint.py iterates param_order)
+        self.param_order: List[str] = [n for n, _ in params]
         self._tail: List[str] = []
         if groups:
             taken, ordered_all = set(), []

@@ -352,7 +352,9 @@ class EncoderStackFn(torch.autograd.Function):
             dsts, acc = _grad_targets(sink, params)
             use_side = sink.side is not None and acc
             chunks, on_chunk = None, None
-            if cfg.on_layer_done is not None:
+            # readiness reports only when the gradients really are final in the arena at that point: with fresh tensors handed to
+            # autograd (acc False) AccumulateGrad writes them later, and a bucket reduced now would miss them
+            if cfg.on_layer_done is not None and acc:
                 c = max(1, int(getattr(cfg, 'bwd_chunk', 1) or 1))
                 chunks = [(max(0, hi - c), hi) for hi in range(L, 0, -c)]
 
@@ -392,8 +394,8 @@ class EncoderStackFn(torch.autograd.Function):
                 grads[12 * l + 11] = g_cs
             fc2b_done, g_cs = cs_param is not None and cs_param.requires_grad, g_cs_next
             ctx.saved[l] = None
-            if cfg.on_layer_done is not None:
-                cfg.on_layer_done(l)
+            if cfg.on_layer_done is not None and all(x is None for x in grads[12 * l:12 * l + 12]):
+                cfg.on_layer_done(l)                         # every gradient of the layer went straight into the arena
         return (None, dx.view(B, N, D), *grads)
 
 
@@ -495,7 +497,12 @@ class EmbedFn(torch.autograd.Function):
             gp = d_pos[cfg.task_offsets[i]:cfg.task_offsets[i + 1]] if (d_pos is not None and tens[5 * i + 4].requires_grad) else None
             out += [gdata, gw, gb, ge, gp]
         g_glob = g_small[T] if G > 0 else None
-        if getattr(cfg, 'on_done', None) is not None:
+        # The embedding parameters are reported ready only if nothing is still on its way through autograd: a learnable pos_emb's
+        # gradient (gp) reaches pos_emb.grad through F.interpolate's backward + AccumulateGrad, interpolate_class_emb's class
+        # table through AvgClassEmbFn.backward (gdata), and without direct gradients everything does.  Otherwise the reducer's
+        # finish() takes the tail bucket after backward has ended (the early report raced with those later nodes).
+        late = g_glob is not None or any(x is not None for x in out)
+        if getattr(cfg, 'on_done', None) is not None and not late:
             cfg.on_done()
         return (None, None, g_glob, *out)
 
@@ -562,7 +569,7 @@ class SpatialAdapterFn(torch.autograd.Function):
         T = len(cfg.task_offsets) - 1
         B, NC, Denc = enc.shape
         n_keep = NC - G
-        n_q = cfg.task_offsets[cfg.q_task + 1] - cfg.task_offsets[cfg.q_task]
+        n_q = cfg.nh * cfg.nw if cfg.q_task < 0 else cfg.task_offsets[cfg.q_task + 1] - cfg.task_offsets[cfg.q_task]
         mask_token = params[0]
         temb = params[1:1 + T]
         (qw, qb, kvw, kvb, pw_, pb, cnw, cnb, qnw, qnb, onw, onb, f1w, f1b, f2w, f2b) = params[1 + T:17 + T]
@@ -668,7 +675,7 @@ class SpatialAdapterFn(torch.autograd.Function):
             if use_side:
                 engine.mark_side_dirty(sink.side)
                 engine.keep_until_join(keep)
-            if cfg.on_done is not None:
+            if cfg.on_done is not None and acc:
                 cfg.on_done()
             return (None, d_enc, None, None, *([None] * len(params) if acc else dsts))
         xattn = bool(getattr(cfg, 'use_xattn', True))
@@ -710,7 +717,7 @@ class SpatialAdapterFn(torch.autograd.Function):
             g_pcw, g_pcb = sink.linear(pcw, pcb, d_ctx_act, enc_act)
             d_enc = ops.linear_dx(d_ctx_act, wc(pcw), torch.empty((B * NC, Denc), device=dev, dtype=torch.float32))
             ctx.saved = None
-            if cfg.on_done is not None:
+            if cfg.on_done is not None and all(x is None for x in (g_build[T], *g_build[:T], *bgrads, g_ow, g_ob, g_pcw, g_pcb)):
                 cfg.on_done()
             return (None, d_enc.view(B, NC, Denc), None, None, g_build[T], *g_build[:T], *([None] * 16), *bgrads, g_ow, g_ob, g_pcw, g_pcb)
         # x1 = x + mlp(out_norm(x))
@@ -755,7 +762,7 @@ class SpatialAdapterFn(torch.autograd.Function):
         grads = [g_mask, *g_temb, g_qw, g_qb, g_kvw, g_kvb, g_pw, g_pb, g_cnw, g_cnb,
                  g_qnw, g_qnb, g_onw, g_onb, g_f1w, g_f1b, g_f2w, g_f2b,
                  *bgrads, g_ow, g_ob, g_pcw, g_pcb]
-        if cfg.on_done is not None:
+        if cfg.on_done is not None and all(x is None for x in grads):
             cfg.on_done()
         return (None, d_enc.view(B, NC, Denc), None, None, *grads)
 

@@ -636,7 +636,7 @@ def adapter_fwd(enc: Tensor, enc_act: Optional[Tensor], ids_keep: Tensor, ids_re
     lib = _lib.load()
     B, NC, Denc = enc.shape
     T = len(cfg.task_offsets) - 1
-    n_q = cfg.task_offsets[cfg.q_task + 1] - cfg.task_offsets[cfg.q_task]
+    n_q = cfg.nh * cfg.nw if cfg.q_task < 0 else cfg.task_offsets[cfg.q_task + 1] - cfg.task_offsets[cfg.q_task]
     d = AdapterDesc()
     d.B, d.NC, d.Denc, d.D, d.heads, d.Hd, d.depth, d.T, d.q_task, d.G, d.n_q = (B, NC, Denc, cfg.D, cfg.heads, w_list[3].shape[0], cfg.depth, T,
                                                                                   cfg.q_task, cfg.G, n_q)

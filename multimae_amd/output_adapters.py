@@ -157,9 +157,10 @@ class SpatialOutputAdapter(nn.Module):
         nh = H // (self.stride_level * self.P_H)
         nw = W // (self.stride_level * self.P_W)
         in_tasks = list(input_info['tasks'].keys())
-        if not (self.use_task_queries and self.task in input_info['tasks']):
-            raise NotImplementedError('decoding a task that is not among the encoder inputs (pure mask-token queries) is not built; '
-                                      'pre-training always decodes input tasks')
+        # queries (output_adapters.py:208-220): the task's own rows of the unshuffled context, or -- when the task is not an
+        # encoder input (e.g. --in_domains rgb --out_domains rgb-depth-semseg) or use_task_queries=False -- mask_token + pos
+        # (+ the task's embedding if the adapter has one) on every grid position
+        task_queries = bool(self.use_task_queries and self.task in input_info['tasks'])
         offs = [0]
         for t in in_tasks:
             n = input_info['tasks'][t]['num_tokens']
@@ -167,10 +168,15 @@ class SpatialOutputAdapter(nn.Module):
             offs.append(offs[-1] + n)
         G = input_info.get('num_global_tokens', 0)
         cfg = _cfg(self, act=act_dtype, heads=self.num_heads, eps=self._eps, use_xattn=self.use_xattn, task_offsets=offs,
-                   q_task=in_tasks.index(self.task), G=G, D=self.dim_tokens, pos=self._pos_tokens(nh, nw), depth=self.depth,
+                   q_task=in_tasks.index(self.task) if task_queries else -1, G=G, D=self.dim_tokens, pos=self._pos_tokens(nh, nw), depth=self.depth,
                    C=self.num_channels, nh=nh, nw=nw, ph=self.P_H, pw=self.P_W, on_done=on_done, f32_gemm=f32_gemm,
                    enc_act=encoder_tokens_act)
-        img, token = SpatialAdapterFn.apply(cfg, encoder_tokens, ids_keep.contiguous(), ids_restore.contiguous(), *self._params(in_tasks))
+        params = self._params(in_tasks)
+        if not task_queries and self.task_embeddings is not None and self.task in self.task_embeddings:
+            # the query rows are mask_token + task_embeddings[task] + pos: one vector added to every row, passed in the mask-token
+            # slot (the kernels use that slot for nothing else in this mode); autograd splits its gradient between the two
+            params[0] = self.mask_token + self.task_embeddings[self.task]
+        img, token = SpatialAdapterFn.apply(cfg, encoder_tokens, ids_keep.contiguous(), ids_restore.contiguous(), *params)
         if cfg.handle is not None:
             img._mmae_pat = cfg.handle       # a masked loss applied to exactly this tensor works on the patch rows (criterion.py)
         return img

@@ -285,10 +285,11 @@ def encoder(x: Tensor, sd, cfg: OracleConfig, return_all_layers: bool = False, d
 # --------------------------------------------------------------------------- #
 def spatial_adapter(enc: Tensor, sd, cfg: OracleConfig, key: str, task: str,
                     tokens_per_task: Dict[str, int], ids_keep: Tensor, ids_restore: Tensor,
-                    image_hw: Tuple[int, int], use_xattn: bool = True) -> Tensor:
-    """SpatialOutputAdapter.forward + get_queries_and_context,
-    output_adapters.py:183-282, for use_task_queries=True; use_xattn=False skips the cross-attention layer and its MLP
-    (output_adapters.py:264-268: x = queries)."""
+                    image_hw: Tuple[int, int], use_xattn: bool = True, use_task_queries: bool = True) -> Tensor:
+    """SpatialOutputAdapter.forward + get_queries_and_context, output_adapters.py:183-282.  Queries: the task's own rows of
+    the unshuffled context (use_task_queries and the task is an encoder input, :209-212) or mask_token + pos-emb
+    (+ the task's embedding, if the adapter has one) on every grid position (:213-220).  use_xattn=False skips the
+    cross-attention layer and its MLP (:264-268: x = queries)."""
     p = f'output_adapters.{key}.'
     dom = cfg.domains_by_name[task]
     ph, pw = cfg.patch_hw(dom)
@@ -306,19 +307,25 @@ def spatial_adapter(enc: Tensor, sd, cfg: OracleConfig, key: str, task: str,
     full = torch.gather(full, 1, ids_restore[:, :, None].expand(-1, -1, D))         # :201-202
     # context embeddings: task embedding + bilinear pos-emb, per input task (:160-181)
     embs = []
+    pe = resized_posemb_tokens(sd[p + 'pos_emb'], nh, nw, 'bilinear')
     for t, n in tokens_per_task.items():
-        te = sd[p + f'task_embeddings.{t}'].reshape(1, 1, D)
-        pe = resized_posemb_tokens(sd[p + 'pos_emb'], nh, nw, 'bilinear')
         assert pe.shape[0] == n
-        embs.append((te + pe[None]).expand(B, n, D))
+        if p + f'task_embeddings.{t}' in sd:                                         # :166-169 (zeros for a task without an embedding)
+            embs.append((sd[p + f'task_embeddings.{t}'].reshape(1, 1, D) + pe[None]).expand(B, n, D))
+        else:
+            embs.append(pe[None].expand(B, n, D))
     full = full + torch.cat(embs, dim=1)                                             # :207
-    start = 0
-    for t, n in tokens_per_task.items():
-        if t == task:
-            break
-        start += n
-    assert task in tokens_per_task, 'oracle covers the use_task_queries path only'
-    queries = full[:, start:start + tokens_per_task[task]]                           # :210-213
+    if use_task_queries and task in tokens_per_task:
+        start = 0
+        for t, n in tokens_per_task.items():
+            if t == task:
+                break
+            start += n
+        queries = full[:, start:start + tokens_per_task[task]]                       # :209-212
+    else:
+        queries = sd[p + 'mask_token'].reshape(1, 1, D) + pe[None].expand(B, nh * nw, D)     # :214-217
+        if p + f'task_embeddings.{task}' in sd:
+            queries = queries + sd[p + f'task_embeddings.{task}'].reshape(1, 1, D)           # :218-220
     ctx2 = torch.gather(full, 1, ids_keep[:, :, None].expand(-1, -1, D))            # :224-225
     if G > 0:
         ctx2 = torch.cat([ctx2, ctx[:, -G:]], dim=1)                                 # :228-230

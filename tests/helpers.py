@@ -42,7 +42,7 @@ def mini_oracle_cfg():
 
 
 def build_engine_model(doms, P, S, *, enc=None, dec_dim=256, dec_depth=2, dec_heads=8, class_emb=64, posemb_size=None,
-                       factory='pretrain_multimae_base'):
+                       factory='pretrain_multimae_base', learnable_pos=False):
     """Engine model built with the same call sequence as tests/golden/make_golden.py::build_ref."""
     import multimae_amd as M
     from functools import partial
@@ -52,9 +52,10 @@ def build_engine_model(doms, P, S, *, enc=None, dec_dim=256, dec_depth=2, dec_he
     for d in doms:
         if d == 'semseg':
             ins[d] = M.SemSegInputAdapter(num_classes=133, dim_class_emb=class_emb, interpolate_class_emb=False, stride_level=4,
-                                          patch_size_full=P, image_size=Sg)
+                                          patch_size_full=P, image_size=Sg, learnable_pos_emb=learnable_pos)
         else:
-            ins[d] = M.PatchedInputAdapter(num_channels=3 if d == 'rgb' else 1, stride_level=1, patch_size_full=P, image_size=Sg)
+            ins[d] = M.PatchedInputAdapter(num_channels=3 if d == 'rgb' else 1, stride_level=1, patch_size_full=P, image_size=Sg,
+                                           learnable_pos_emb=learnable_pos)
     outs = {}
     for key, task in [(d, d) for d in doms] + ([('norm_rgb', 'rgb')] if 'rgb' in doms else []):
         ch = {'rgb': 3, 'depth': 1, 'semseg': 133}[task]
@@ -67,10 +68,10 @@ def build_engine_model(doms, P, S, *, enc=None, dec_dim=256, dec_depth=2, dec_he
                       qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6)).train()
 
 
-def build_mini_engine():
+def build_mini_engine(learnable_pos=False):
     m = MINI
     return build_engine_model(m['doms'], m['P'], m['S'], enc=(m['dim'], m['depth'], m['heads']), dec_dim=m['dec_dim'],
-                              dec_depth=m['dec_depth'], dec_heads=m['dec_heads'], class_emb=m['class_emb'])
+                              dec_depth=m['dec_depth'], dec_heads=m['dec_heads'], class_emb=m['class_emb'], learnable_pos=learnable_pos)
 
 
 def make_inputs(doms, B, S):

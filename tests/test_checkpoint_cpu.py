@@ -91,3 +91,44 @@ def test_optimizer_state_interchanges_with_torch_adamw(tmp_path):
     assert ck.load_checkpoint(p9, model, fresh) == 10
     assert torch.equal(model[0].weight, w9) and _same_moments(fresh, opt) and fresh.step_count == 3
     assert ck.latest_checkpoint(str(tmp_path / 'nothing_here')) is None
+
+
+def test_optimizer_state_order_is_registration_order_with_readiness_arena():
+    """build_arena() lays the arena out in backward-readiness order (output adapters, encoder.L-1 .. 0, then
+    the embeddings); a checkpoint must still number the optimiser state the way torch.optim.AdamW over
+    ``[p for n, p in model.named_parameters() if p.requires_grad]`` does (utils/optim_factory.py:138-149) -- same-shaped tensors
+    (encoder.0 <-> encoder.1) would otherwise swap moments silently."""
+    from multimae_amd import engine
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.global_tokens = torch.nn.Parameter(torch.zeros(1, 1, 4))
+            self.encoder = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Linear(4, 4), torch.nn.Linear(4, 4))
+            self.output_adapters = torch.nn.ModuleDict({'rgb': torch.nn.Linear(4, 2), 'depth': torch.nn.Linear(4, 2)})
+
+    torch.manual_seed(0)
+    model = Toy()
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    groups = [f'output_adapters.{d}.' for d in reversed(list(model.output_adapters))] + [f'encoder.{l}.' for l in reversed(range(3))]
+    arena = engine.ParamArena(model, groups=groups)
+    assert arena.names != names and arena.param_order == names          # the layout really is permuted; the registration order is kept
+    # a real AdamW over model.parameters() takes one step; its state must map onto the arena by NAME
+    ref = torch.optim.AdamW([p for n, p in model.named_parameters() if p.requires_grad], lr=1e-2, betas=(0.9, 0.95), weight_decay=0.05)
+    for p in model.parameters():
+        p.grad = torch.randn_like(p)
+    ref.step()
+    opt = types.SimpleNamespace(arena=arena, m=torch.zeros(arena.n_trainable), v=torch.zeros(arena.n_trainable), step_count=0,
+                                param_groups=[dict(lr=1e-2, weight_decay=0.05, lr_scale=1.0, betas=(0.9, 0.95), eps=1e-8)])
+    ck.optimizer_state_from_torch(opt, ref.state_dict())
+    byname = dict(model.named_parameters())
+    for n in names:
+        o, s = arena.offsets[n], arena.sizes[n]
+        assert torch.equal(opt.m[o:o + s].view(byname[n].shape), ref.state[byname[n]]['exp_avg']), n
+        assert torch.equal(opt.v[o:o + s].view(byname[n].shape), ref.state[byname[n]]['exp_avg_sq']), n
+    # ... and back: the exported dict loads into a fresh AdamW with every tensor's moments in its own slot
+    out = ck.optimizer_state_to_torch(opt)
+    ref2 = torch.optim.AdamW([p for n, p in model.named_parameters() if p.requires_grad], lr=1e-2, betas=(0.9, 0.95), weight_decay=0.05)
+    ref2.load_state_dict(out)
+    for n in names:
+        assert torch.equal(ref2.state[byname[n]]['exp_avg'], ref.state[byname[n]]['exp_avg']), n

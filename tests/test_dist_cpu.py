@@ -55,7 +55,14 @@ def _worker_body(rank, world, port, q):
     other = torch.empty_like(mine)
     torch.manual_seed(1 - rank)
     other = torch.randn(off)
-    q.put((rank, torch.allclose(grad, mine + other, atol=1e-6), launched_mid))
+    ok = torch.allclose(grad, mine + other, atol=1e-6)
+    # the same exchange with bf16 buckets: the fp32 arena receives the bf16-rounded sum of the bf16-rounded addends
+    g2 = mine.clone()
+    red2 = GradAllReducer(g2, sizes, bucket_mb=700 * 4 / (1024 * 1024), bf16_buckets=True)
+    red2.finish()
+    exact = mine + other
+    ok = ok and bool(((g2 - exact).abs() <= 2.0 ** -7 * (mine.abs() + other.abs()) + 1e-6).all()) and not torch.equal(g2, exact)
+    q.put((rank, ok, launched_mid))
     dist.destroy_process_group()
 
 
@@ -74,7 +81,7 @@ def test_grad_allreduce_world2_gloo():
         assert any(launched_mid) and not all(launched_mid), 'buckets must launch incrementally as layers finish'
 
 
-def _model_worker(rank, world, port, q, direct=True, average=False):
+def _model_worker(rank, world, port, q, direct=True, average=False, learnable_pos=False, bf16_buckets=False):
     try:
         import sys
         here = os.path.dirname(os.path.abspath(__file__))
@@ -87,14 +94,14 @@ def _model_worker(rank, world, port, q, direct=True, average=False):
         from multimae_amd.dist import attach, broadcast_parameters
         from helpers import MINI, build_mini_engine, load_mini
         torch.manual_seed(100 + rank)                 # ranks build different initial weights (run_pretraining_multimae.py:300)
-        model = build_mini_engine()
+        model = build_mini_engine(learnable_pos=learnable_pos)
         arena = model.build_arena()
         before = arena.param.clone()
         broadcast_parameters(arena)                   # DDP-constructor semantics: rank 0's values everywhere
         gathered = [torch.empty_like(arena.param) for _ in range(world)]
         dist.all_gather(gathered, arena.param)
         same_params = all(torch.equal(g, gathered[0]) for g in gathered)
-        red = GradAllReducer.for_arena(arena, bucket_mb=0.25, average_in_place=average)
+        red = GradAllReducer.for_arena(arena, bucket_mb=0.25, average_in_place=average, bf16_buckets=bf16_buckets)
         attach(model, red)
         # arena = gradient-readiness order: last output adapter first, encoder from the top down, embedding parameters last
         names = [n for n in arena.names if arena.trainable[n]]
@@ -199,3 +206,24 @@ def test_model_backward_drives_reducer_world8_gloo():
         assert ok, f'rank {rank}: {order}'
         assert order == sorted(order) and mid >= nb - 1, (order, mid, nb)
     assert all(r[2] == res[0][2] for r in res)
+
+
+def test_tail_bucket_waits_for_autograd_delivered_embedding_gradients_world2_gloo():
+    """with learnable_pos_emb=True the position tables' gradients reach .grad through F.interpolate's
+    backward + AccumulateGrad AFTER EmbedFn.backward has returned; reporting 'input_adapters' ready from inside that node let
+    the tail bucket's all-reduce race with (or miss) them.  The embedding bucket must now stay un-launched until finish()."""
+    res = _run_model_workers(2, learnable_pos=True)
+    for rank, ok, order, mid, nb in res:
+        assert ok, f'rank {rank}: {order}'
+        assert mid == nb - 1, (mid, nb)                      # everything but the embedding (tail) bucket launched inside backward
+        assert order == sorted(order) and order[-1] == nb - 1
+    assert res[0][2] == res[1][2]
+
+
+def test_bf16_gradient_buckets_world2_gloo():
+    """bf16_buckets=True: every bucket travels as bf16 and is widened back into the fp32 arena.  The stand-in
+    gradients (rank + 1) are exact in bf16, so the sum must match the fp32-bucket result bit for bit."""
+    res = _run_model_workers(2, bf16_buckets=True)
+    for rank, ok, order, mid, nb in res:
+        assert ok, f'rank {rank}: {order}'
+    assert res[0][2] == res[1][2]

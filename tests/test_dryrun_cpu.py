@@ -62,6 +62,11 @@ def test_full_step_control_flow(stubbed, mode, direct, composite):
             assert p.grad is not None and p.grad.shape == p.shape, n
         else:
             assert p.grad is None, n
+    if not direct:
+        # gradients handed to autograd are written by AccumulateGrad AFTER the node returns: no unit may be reported ready
+        # from inside backward; the reducer's finish() takes everything
+        assert ready == []
+        return
     assert ready[:2] == ['output_adapters.norm_rgb', 'output_adapters.semseg'] or set(ready) >= {'encoder.0', 'encoder.1'}
     assert ready[-3:] == ['encoder.0', 'global_tokens', 'input_adapters']           # readiness order = arena order
 

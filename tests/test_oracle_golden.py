@@ -377,3 +377,24 @@ def test_oracle_semseg_interpolate_and_padding_idx_vs_reference_golden():
         assert _rel(tok.detach(), t['tok']) < 1e-6, tag
         for k, v in g(f'seg/{tag}/grad/').items():
             assert _rel(sd['s.' + k].grad, v) < 1e-5, (tag, k)
+
+
+@pytest.mark.parametrize('tag,task,in_tasks,utq', [('notin', 'depth', ['rgb'], True), ('noq', 'rgb', ['rgb', 'depth'], False)])
+def test_oracle_mask_token_queries_vs_reference_golden(tag, task, in_tasks, utq):
+    """get_queries_and_context's else-branch (output_adapters.py:213-220): the task is not an encoder input ('notin') or
+    use_task_queries=False ('noq'); recorded from the reference's class by tests/golden/make_golden_queries.py."""
+    z = np.load(os.path.join(GOLD, 'mask_queries.npz'))
+    g = lambda pre: {k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)}
+    sd = {f'output_adapters.{task}.' + k: v.clone() for k, v in g(f'{tag}/sd/').items()}
+    grads = g(f'{tag}/grad/')
+    for k in grads:
+        sd[f'output_adapters.{task}.' + k].requires_grad_(True)
+    t = g(f'{tag}/')
+    cfg = orc.standard_config(['rgb', 'depth'], patch_size=4, image_size=16, dim_tokens=96, depth=1, num_heads=2, dec_dim=64, dec_depth=1,
+                              dec_heads=2, extra_norm_pix=False)
+    enc = t['enc'].clone().requires_grad_(True)
+    p = orc.spatial_adapter(enc, sd, cfg, task, task, {d: 16 for d in in_tasks}, t['ids_keep'], t['ids_restore'], (16, 16), use_task_queries=utq)
+    p.backward(t['gout'])
+    assert _rel(p.detach(), t['pred']) < 1e-6 and _rel(enc.grad, t['d_enc']) < 1e-5
+    for k, v in grads.items():
+        assert _rel(sd[f'output_adapters.{task}.' + k].grad, v) < 1e-5, k
