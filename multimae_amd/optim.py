@@ -21,8 +21,15 @@ from torch import nn
 from . import engine, ops
 
 
-class FusedAdamW:
-    """state (device, mmae_opt_desc): ``_state`` f32[8] = [sum of squares, gradient norm, applied gradient scale, lr, weight
+class FusedAdamW(torch.optim.Optimizer):
+    """A ``torch.optim.Optimizer`` (one param group holding every trainable tensor in ``named_parameters()`` order, exactly the
+    group the reference's dict branch builds, utils/optim_factory.py:138-149), so the reference's loop services drive it
+    unchanged: ``for g in optimizer.param_groups: g['lr'] = table[it] * g['lr_scale']`` (run_pretraining_multimae.py:474-480),
+    ``GradScaler.unscale_(optimizer)`` / ``GradScaler.step(optimizer)`` / ``clip_grad_norm_`` as utils/native_scaler.py:20-40
+    calls them -- ``step()`` then runs the one fused library call over the arena.  The parameters' ``.grad`` must be the arena
+    views (``zero_grad()`` re-binds them; AccumulateGrad / DDP write into them in place).
+
+    state (device, mmae_opt_desc): ``_state`` f32[8] = [sum of squares, gradient norm, applied gradient scale, lr, weight
     decay, 1 - beta1^t, sqrt(1 - beta2^t), -]; ``_istate`` i32[4] = [skip flag of the last step, t = updates applied, steps
     with a non-finite loss, skipped steps].  The step counter lives on the device: a skipped iteration (non-finite gradient
     norm or loss, skip_grad) does not advance Adam's t -- the reference never calls optimizer.step() for it
@@ -33,9 +40,10 @@ class FusedAdamW:
         self.arena = engine.arena_of(model) or engine.ParamArena(model)
         a = self.arena
         n = a.n_trainable
+        params = [a._params[nm] for nm in a.param_order if a.trainable[nm]]
+        super().__init__([dict(params=params, lr_scale=1.0)], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.m = torch.zeros(n, device=a.device, dtype=torch.float32)
         self.v = torch.zeros(n, device=a.device, dtype=torch.float32)
-        self.param_groups = [dict(lr=lr, weight_decay=weight_decay, lr_scale=1.0, betas=betas, eps=eps)]
         self.clip_grad, self.skip_grad = clip_grad, skip_grad
         self.grad_prescale = 1.0          # 1 / world_size when the gradient arena holds rank SUMS (dist.GradAllReducer sets it)
         self._state = torch.zeros(8, device=a.device, dtype=torch.float32)
@@ -62,12 +70,13 @@ class FusedAdamW:
         return dict(steps=c[1], nonfinite_loss=c[2], skipped=c[3])
 
     def zero_grad(self, set_to_none: bool = False) -> None:
+        """One memset of the gradient arena; ``p.grad`` stays (or becomes again) the arena view, whatever ``set_to_none`` says."""
         engine.join_wgrad_streams()
         self.arena.zero_grad()
         self.arena.rebind_grads()
 
     @torch.no_grad()
-    def step(self, loss: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def step(self, loss: Optional[torch.Tensor] = None, closure=None) -> torch.Tensor:
         """One AdamW update in ONE library call (mmae_opt_step); returns the (device) gradient 2-norm, as the reference's
         loss_scaler does.  lr / weight_decay are read from ``param_groups[0]`` (the reference's per-iteration cosine tables,
         run_pretraining_multimae.py:474-480, plug in unchanged).  ``loss``: optional device scalar; a non-finite value skips
@@ -105,9 +114,16 @@ class FusedAdamW:
         return self.grad_norm
 
     def state_dict(self):
-        return dict(m=self.m, v=self.v, step=self.step_count, param_groups=self.param_groups)
+        """Flat native form (checkpoint.optimizer_state_to_torch gives the torch.optim.AdamW layout of reference checkpoints)."""
+        return dict(m=self.m, v=self.v, step=self.step_count,
+                    param_groups=[{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])
 
     def load_state_dict(self, sd):
+        if 'm' not in sd:                                # a torch.optim.AdamW state dict (reference checkpoint)
+            from .checkpoint import optimizer_state_from_torch
+            optimizer_state_from_torch(self, sd)
+            return
         self.m.copy_(sd['m']); self.v.copy_(sd['v'])
         self.step_count = sd['step']
-        self.param_groups = sd['param_groups']
+        for g, new in zip(self.param_groups, sd['param_groups']):
+            g.update({k: v for k, v in new.items() if k != 'params'})
