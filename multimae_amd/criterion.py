@@ -19,7 +19,10 @@ from .functions import MaskedCEFn, MaskedCEPatFn, MaskedPixelLossFn, MaskedPixel
 
 def _pat_handle(x: torch.Tensor, patch: int, ce: bool = False):
     """The adapter's patch rows behind prediction x (functions.PatHandle), if x is exactly what an output adapter returned
-    (``preds[task].float()`` of an f32 tensor is the same object) and the loss's patch grid is the adapter's."""
+    (``preds[task].float()`` of an f32 tensor is the same object) and the loss's patch grid is the adapter's.  Anything else --
+    a modified prediction, or the CLONES torch DDP's output sink returns with find_unused_parameters=True -- takes the
+    image-domain loss (same value, gradient rows through the f32 image instead of the adapter's activation dtype;
+    tests/test_reference_loop_gpu.py pins the two against each other under DDP)."""
     h = getattr(x, '_mmae_pat', None)
     if h is None or not h.matches(x, patch):
         return None

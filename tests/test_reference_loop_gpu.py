@@ -11,7 +11,12 @@ exist in this torch): ``GradScaler.scale(loss).backward()``, ``unscale_``, gradi
      for the pre-training dict branch (one group of all trainable tensors, lr_scale 1), GradScaler-driven step;
   B  the same NativeScaler sequence driving ``multimae_amd.optim.FusedAdamW`` (a torch.optim.Optimizer whose step() is the one
      fused library call), no DDP;
-  C  the engine-native loop: direct gradients into the arena, ``FusedAdamW.step(loss)``.
+  C  the engine-native loop: direct gradients into the arena, ``FusedAdamW.step(loss)``;
+  D  driver A without the DDP wrapper, E  driver D with the patch-domain losses switched off, A2  driver A again.
+
+Findings the assertions pin: B == C and A == E == A2 bit for bit (DDP at world 1 and the power-of-two loss scale are exactly
+transparent; the only thing that separates the DDP run from the native one is that DDP's output sink clones the predictions,
+so the criterion evaluates the image-domain form of the same losses); D tracks B (torch AdamW vs the fused step).
 """
 import os
 import socket
@@ -62,8 +67,10 @@ def _run(driver, sd0, x, lr_tab, wd_tab, steps):
     model.build_arena()
     M.engine.set_direct_grads(driver == 'C')
     net = model
-    if driver == 'A':
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[torch.cuda.current_device()], find_unused_parameters=True)
+    M.engine.set_patch_domain_loss(driver != 'E')
+    if driver in ('A', 'A2', 'D', 'E'):
+        if driver in ('A', 'A2'):
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[torch.cuda.current_device()], find_unused_parameters=True)
         optimizer = torch.optim.AdamW([{'params': [p for n, p in model.named_parameters() if p.requires_grad], 'lr_scale': 1.0}],
                                       lr=lr_tab[0], betas=(0.9, 0.95), weight_decay=0.05)          # optim_factory.py:138-155, 166
     else:
@@ -87,11 +94,14 @@ def _run(driver, sd0, x, lr_tab, wd_tab, steps):
             norms.append(float(optimizer.step(loss)))
         else:
             norms.append(float(_native_scaler_call(scaler, loss, optimizer, list(model.parameters()))))
+        if it == 0:
+            g0 = {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
         torch.cuda.synchronize()                                   # :540
     out = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
     scale = float(scaler.get_scale())
     M.engine.set_direct_grads(False)
-    return losses_seen, norms, out, scale
+    M.engine.set_patch_domain_loss(True)
+    return losses_seen, norms, out, scale, g0
 
 
 def test_reference_loop_body_runs_on_the_engine_under_ddp_autocast_gradscaler():
@@ -107,23 +117,49 @@ def test_reference_loop_body_runs_on_the_engine_under_ddp_autocast_gradscaler():
         x = {k: v.to(DEV) for k, v in make_inputs(MINI['doms'], 6, MINI['S']).items()}
         steps = 3
         lr_tab, wd_tab = [1e-3, 2e-3, 1.5e-3], [0.05, 0.05, 0.04]
-        res = {d: _run(d, sd0, x, lr_tab, wd_tab, steps) for d in ('A', 'B', 'C')}
+        res = {d: _run(d, sd0, x, lr_tab, wd_tab, steps) for d in ('A', 'B', 'C', 'D', 'A2', 'E')}
     finally:
         dist.destroy_process_group()
-    la, na, wa, sa = res['A']
+    la, na, wa, sa, ga = res['A']
     assert sa == 65536.0                         # the GradScaler really scaled the loss (no inf found: the scale is untouched)
+
+    def update_err(w, wref):
+        """(global, worst 2-D tensor): |w - wref| relative to the size of the reference UPDATE.  Vectors are judged only through the
+        global figure: a third of every attention bias (the key part) has an exactly-zero true gradient -- softmax is invariant to
+        it -- so Adam normalises rounding noise there and its update is implementation-defined in EVERY framework."""
+        num = den = 0.0
+        worst = (0.0, '')
+        for k in wref:
+            if not wref[k].dtype.is_floating_point or wref[k].numel() <= 1:
+                continue
+            d2, u2 = float((w[k] - wref[k]).double().pow(2).sum()), float((wref[k] - sd0[k]).double().pow(2).sum())
+            num, den = num + d2, den + u2
+            if wref[k].dim() >= 2 and u2 > 0:
+                worst = max(worst, ((d2 / u2) ** 0.5, k))
+        return (num / den) ** 0.5, worst
+
+    # B == C bit for bit: the NativeScaler sequence driving FusedAdamW is the engine-native step (the 2^16 loss scale is exact)
+    assert res['B'][0] == res['C'][0] and res['B'][1] == res['C'][1]
+    assert update_err(res['B'][2], res['C'][2])[0] == 0.0
+    # A == E bit for bit: DDP (world 1, RCCL) is transparent; what separates A from B is the LOSS path -- _DDPSink hands the loop
+    # clones of the predictions, so the criterion takes the image-domain form instead of the adapters' patch rows
+    assert res['A'][0] == res['E'][0] and update_err(res['E'][2], wa)[0] == 0.0
+    assert res['A'][0] == res['A2'][0] and update_err(res['A2'][2], wa)[0] == 0.0          # and it is deterministic
+    # D vs B: torch.optim.AdamW against the fused step.  Step 0 sees bit-identical gradients (equal norms) and the updates agree to
+    # fp32 round-off (loss of step 1: 5e-7 apart); from there the two runs are two bf16 trajectories -- a 1e-7 weight difference
+    # flips bf16 roundings of the weight shadow, Adam normalises the resulting gradient noise -- measured 1.6 % of the update
+    # after three steps (worst matrix 5.4 %)
+    assert res['D'][1][0] == res['B'][1][0]
+    assert abs(res['D'][0][1] - res['B'][0][1]) < 5e-6 * abs(res['B'][0][1]), (res['D'][0], res['B'][0])
+    d_glob, d_worst = update_err(res['D'][2], res['B'][2])
+    assert d_glob < 4e-2 and d_worst[0] < 0.15, (d_glob, d_worst)
+    # A vs B / C: image-domain against patch-domain loss gradients (bf16 rounding at the head of the backward chain), three Adam steps on
     for d in ('B', 'C'):
-        l, n, w, _ = res[d]
+        l, n, w, _, _ = res[d]
         for i in range(steps):
-            # same kernels, same masks: the only differences are the power-of-two loss scale (exact), torch's AdamW against the
-            # fused one and AccumulateGrad / DDP's bucket copy against direct arena writes
-            assert abs(l[i] - la[i]) < 2e-3 * max(1.0, abs(la[i])), (d, i, l[i], la[i])
+            assert abs(l[i] - la[i]) < 1e-3 * abs(la[i]), (d, i, l[i], la[i])
             assert abs(n[i] - na[i]) < 2e-3 * na[i], (d, i, n[i], na[i])
-        worst = 0.0
-        for k in wa:
-            if wa[k].dtype.is_floating_point and wa[k].numel() > 1:
-                e = float((w[k] - wa[k]).norm() / (wa[k].norm() + 1e-12))
-                worst = max(worst, e)
-        assert worst < 2e-3, (d, worst)
+        glob, worst = update_err(w, wa)
+        assert glob < 6e-2 and worst[0] < 0.2, (d, glob, worst)
     # and the weights did move
     assert float((wa['encoder.0.attn.qkv.weight'] - sd0['encoder.0.attn.qkv.weight']).abs().max()) > 1e-4
