@@ -241,6 +241,31 @@ def cpu_baseline(cfg: str, sample_B: int, steps: int, threads: int = 0):
                       + f', {cores} threads (best of the 8/16/32/64 sweep)'}
 
 
+def result_line(args, B, world, ms_per_step, img_s, final_loss, counters, roof, cpu, dp_diag, host_ms, host_wait_ms, use_graph, n_vis, doms):
+    """The ONE JSON line of the measurement contract (metric / value / unit / n_gpus / steps / warmup / ms_per_step /
+    higher_is_better / scaling / vs_baseline / dtype / data / config.workload + roofline + cpu_baseline [+ data_parallel])."""
+    out = {
+        'metric': {'cfg3': 'pre-train images/sec (whole node), ViT-B RGB+D+S 224^2 98-vis-tok',
+                   'cfg2': 'pre-train images/sec (whole node), ViT-B RGB-only 224^2 98-vis-tok',
+                   'cfg5': 'pre-train images/sec (whole node), ViT-L RGB+D+S 224^2 196-vis-tok'}[args.config],
+        'value': round(img_s, 1), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': {'bf16': 'bf16', 'fp32': 'f32', 'mxfp8': 'mxfp8 (e4m3 + E8M0/32) encoder forward and dX products, bf16 everywhere else'}[args.precision], 'data': 'synthetic',
+        'config': {'workload': f'BASELINE.json configs[{ {"cfg3": 2, "cfg2": 1, "cfg5": 4}[args.config] }]: '
+                               + (('ViT-L (MX-fp8 encoder products), ' if args.precision == 'mxfp8' else 'ViT-L (bf16 run of the fp8 config), ') if args.config == 'cfg5' else 'ViT-B, ')
+                               + ('RGB-only' if args.config == 'cfg2' else 'RGB+depth+semseg')
+                               + f', 224^2, Dirichlet alpha=1.0, {n_vis} visible tokens, {len(doms) + 1} cross-attention decoders (dim 256, depth 2), '
+                               + ('semseg adapter with fp32 activations and x3 split-bf16 GEMMs (a_hi.b_hi + a_hi.b_lo + a_lo.b_hi, fp32 accumulate), ' if 'semseg' in doms else '') + 'AdamW; fwd+losses+bwd+optimizer',
+                   'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}'},
+        'final_loss': round(final_loss, 5), 'launch': 'hipGraph replay of the captured step' if use_graph else 'eager, one library call per encoder stack / output adapter / loss / optimiser step',
+        'host_enqueue_ms_per_step': round(host_ms, 3), 'host_throttle_wait_ms_per_step': round(host_wait_ms, 3), 'optimizer_counters': counters,
+        'roofline': roof, 'cpu_baseline': cpu,
+    }
+    if dp_diag is not None:
+        out['data_parallel'] = dp_diag
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -458,25 +483,7 @@ def main():
         cpu = cpu_baseline(args.config, args.cpu_sample_batch, args.cpu_steps, args.cpu_threads)
 
     if rank == 0:
-        out = {
-            'metric': {'cfg3': 'pre-train images/sec (whole node), ViT-B RGB+D+S 224^2 98-vis-tok',
-                       'cfg2': 'pre-train images/sec (whole node), ViT-B RGB-only 224^2 98-vis-tok',
-                       'cfg5': 'pre-train images/sec (whole node), ViT-L RGB+D+S 224^2 196-vis-tok'}[args.config],
-            'value': round(img_s, 1), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'bf16': 'bf16', 'fp32': 'f32', 'mxfp8': 'mxfp8 (e4m3 + E8M0/32) encoder forward and dX products, bf16 everywhere else'}[args.precision], 'data': 'synthetic',
-            'config': {'workload': f'BASELINE.json configs[{ {"cfg3": 2, "cfg2": 1, "cfg5": 4}[args.config] }]: '
-                                   + (('ViT-L (MX-fp8 encoder products), ' if args.precision == 'mxfp8' else 'ViT-L (bf16 run of the fp8 config), ') if args.config == 'cfg5' else 'ViT-B, ')
-                                   + ('RGB-only' if args.config == 'cfg2' else 'RGB+depth+semseg')
-                                   + f', 224^2, Dirichlet alpha=1.0, {n_vis} visible tokens, {len(doms) + 1} cross-attention decoders (dim 256, depth 2), '
-                                   + ('semseg adapter with fp32 activations and x3 split-bf16 GEMMs (a_hi.b_hi + a_hi.b_lo + a_lo.b_hi, fp32 accumulate), ' if 'semseg' in doms else '') + 'AdamW; fwd+losses+bwd+optimizer',
-                       'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}'},
-            'final_loss': round(final_loss, 5), 'launch': 'hipGraph replay of the captured step' if use_graph else 'eager, one library call per encoder stack / output adapter / loss / optimiser step',
-            'host_enqueue_ms_per_step': round(host_ms, 3), 'host_throttle_wait_ms_per_step': round(host_wait_ms, 3), 'optimizer_counters': counters,
-            'roofline': roof, 'cpu_baseline': cpu,
-        }
-        if dp_diag is not None:
-            out['data_parallel'] = dp_diag
+        out = result_line(args, B, world, ms_per_step, img_s, final_loss, counters, roof, cpu, dp_diag, host_ms, host_wait_ms, use_graph, n_vis, doms)
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -16,6 +16,20 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 void mmae_set_error(const char* msg);
 int mmae_check_launch(const char* what);
+int mmae_cu_count();                                          // runtime.hip: compute units of the CURRENT device (cached per device)
+
+// A/B switches of the experiments (environment variables) exist only in builds with -DMMAE_EXPERIMENTS (make EXTRA=-DMMAE_EXPERIMENTS);
+// the production library reads no environment: every switch is its default.
+#include <stdlib.h>
+static inline int mmae_env_int(const char* name, int dflt) {
+#ifdef MMAE_EXPERIMENTS
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
 int mmae_gemm_ex(const mmae_gemm_desc* d, void* stream, int timing_cls, double flop_scale);   // runtime.hip
 
 #define MMAE_REQUIRE(cond, msg) do { if (!(cond)) { mmae_set_error(msg); return MMAE_EINVAL; } } while (0)

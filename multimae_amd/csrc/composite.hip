@@ -35,7 +35,7 @@ Ctx ctx_of(const mmae_block_desc* d) {
 // Pre-split x3 product (mmae.h, mmae_x3_split): if this f32 call carries a pre-split copy of weight w and the contraction is a
 // multiple of 32, split the activation operand [M][kc] (row stride ldx) into the scratch and return the weight triple.
 const void* const* x3_operand(const Ctx& c, const void* x, int64_t ldx, const void* w, int M, int kc, const void** a3, hipStream_t st, int* rc) {
-    static const bool on = !(getenv("MMAE_X3_PRESPLIT") && atoi(getenv("MMAE_X3_PRESPLIT")) == 0);    // the host side only passes x3_w when asked to (ops.py)
+    static const bool on = (mmae_env_int("MMAE_X3_PRESPLIT", 1) != 0);    // the host side only passes x3_w when asked to (ops.py)
     *rc = 0;
     if (!on || c.act_dtype != MMAE_F32 || c.f32_gemm != MMAE_F32X3 || !c.x3_w || !c.x3_tmp || (kc % 32) || (ldx % 4)) return nullptr;
     const void* const* t3 = nullptr;
@@ -216,7 +216,7 @@ int lin_dw(const Ctx& c, const void* dy, int64_t ldy, const void* x, float* dw, 
 // weight gradients of one block collected into ONE grouped launch (mmae_gemm_dw_group); bf16 only.  MMAE_DW_GROUP=0 restores
 // one split-K launch (+ reduce) per product.
 bool dw_group_enabled() {
-    static const bool on = !(getenv("MMAE_DW_GROUP") && atoi(getenv("MMAE_DW_GROUP")) == 0);
+    static const bool on = (mmae_env_int("MMAE_DW_GROUP", 1) != 0);
     return on;
 }
 struct DwGroup {
@@ -470,7 +470,7 @@ int mmae_block_fwd(const mmae_block_desc* d, void* stream) {
     const void* const* mx = (d->mx_w && act == MMAE_BF16) ? d->mx_w : nullptr;
     // MX mode: the LayerNorms leave the quantised copy of their output in half 0 of the scratch; fc1's epilogue leaves the
     // quantised GELU output in half 1 (the separate passes cost 7 % of the step, profiles/r02_mxfp8_*)
-    static const bool mx_fuse = !(getenv("MMAE_MX_FUSE") && atoi(getenv("MMAE_MX_FUSE")) == 0);
+    static const bool mx_fuse = (mmae_env_int("MMAE_MX_FUSE", 1) != 0);
     const int pre = (mx && mx_fuse) ? 0 : -1;
     auto ln = [&](const float* x, const float* w, const float* b, void* y, float* mu, float* rs) -> int {
         if (pre < 0) return mmae_layernorm_fwd(x, w, b, y, act, mu, rs, R, D, d->eps, st);
@@ -526,7 +526,7 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
     const void* const* mx = (d->mx_w && act == MMAE_BF16) ? d->mx_w : nullptr;
     DwGroup grp(c, R);                                               // the block's four weight gradients: one launch at the end
     if (d->dp1 || d->dp2) grp.on = false;                           // stochastic depth re-uses dxs_act between the two branches
-    static const bool mx_fuse = !(getenv("MMAE_MX_FUSE") && atoi(getenv("MMAE_MX_FUSE")) == 0);
+    static const bool mx_fuse = (mmae_env_int("MMAE_MX_FUSE", 1) != 0);
     const int hq = (mx && mx_fuse) ? 1 : -1;                 // fc2's dX epilogue leaves the quantised d_hpre in half 1 for fc1's dX
     if ((rc = lin_dx(c, dm_act, D, d->fc2_w, d->d_hpre, act, R, D, Hd, d->hpre, MMAE_EPI_DGELU, part_h, st, mx ? mx + 12 : nullptr, -1, hq))) return rc;
     if ((rc = fork_to(st, sd))) return rc;                          // dx_act, d_hpre ready for the weight-gradient stream

@@ -10,6 +10,7 @@
 //    gfx950 transposing LDS read ds_read_b64_tr_b16.
 //  * the MFMA is issued as D[n][m] so that a lane owns 4 consecutive n of one row m.
 #include <stdlib.h>
+#include <mutex>
 #include "gemm_common.h"
 
 #define LDS_AS __attribute__((address_space(3)))
@@ -231,11 +232,10 @@ int launch(const GemmArgs& g, int batch, hipStream_t st) {
     a.tiles_n = (g.N + BN - 1) / BN;
     dim3 grid(tiles_m * a.tiles_n, batch, a.splitk), block(WM * WN * 64);
     const size_t lds = 2 * (BM + BN) * 128;
-    static bool attr_done = false;   // benign race: idempotent
-    if (!attr_done) {
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] {
         hipFuncSetAttribute((const void*)gemm_bf16_kernel<WM, WN, AKS, BKS, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    });
     hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, AKS, BKS, DMA>), grid, block, lds, st, a);
     return mmae_check_launch("gemm_bf16");
 }

@@ -36,12 +36,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm_bf16_duo_kernel
 #endif
 }
 
-int duo_cu_count() {
-    int dev = 0, n = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 0 ? n : 256;
-}
+int duo_cu_count() { return mmae_cu_count(); }
 
 template <int NW, bool AKS, bool BKS, int FL, int VAR = 0>
 int duo_launch(const GemmArgs& g, int batch, hipStream_t st) {

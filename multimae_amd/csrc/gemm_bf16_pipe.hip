@@ -7,6 +7,7 @@
 // kernel waits a full HBM/L2 round trip (~1 us) per 64-wide K tile -- with K = 768 that is 12 exposed
 // round trips per output tile (measured 21 % MFMA utilisation); here the round trips overlap.
 #include "gemm_common.h"
+#include <mutex>
 
 #define LDS_AS __attribute__((address_space(3)))
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -179,11 +180,10 @@ int launch(const GemmArgs& g, int batch, hipStream_t st) {
     a.kt_per_split = g.kt_per_split * 2;
     dim3 grid(tiles_m * a.tiles_n, batch, a.splitk), block(WM * WN * 64);
     const size_t lds = (size_t)NSTAGE * (BM + BN) * 64;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_pipe_kernel<WM, WN, AKS, BKS, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    });
     hipLaunchKernelGGL((gemm_bf16_pipe_kernel<WM, WN, AKS, BKS, NSTAGE>), grid, block, lds, st, a);
     return mmae_check_launch("gemm_bf16_pipe");
 }

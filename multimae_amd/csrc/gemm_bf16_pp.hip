@@ -2,6 +2,7 @@
 // weight-gradient kernel.  The kernel body lives in gemm_pp_body.h; gemm_bf16_pp_fl.hip holds the instantiations with the
 // epilogue flavour fixed at compile time.
 #include "gemm_pp_body.h"
+#include <mutex>
 
 namespace {
 
@@ -65,7 +66,7 @@ int mmae_gemm_bf16_pp_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code,
     const bool aks = d->a_trans != 0, bks = d->b_trans != 0;
     // epilogue flavour known before the launch: use the instantiation that contains only that epilogue (fewer live registers:
     // no spills in the 320-row kernels, whose per-tile scratch reloads cost a full vmcnt(0) drain of the prefetched K tiles)
-    static const int env_fl = getenv("MMAE_PP_FL") ? atoi(getenv("MMAE_PP_FL")) : 1;
+    static const int env_fl = mmae_env_int("MMAE_PP_FL", 1);
     if (env_fl && !aks) {
         const int fl = gemm_flavour(g, d->batch);
         if (fl) {
@@ -121,10 +122,10 @@ __global__ void __launch_bounds__(256) dw_group_reduce_kernel(const DwReduceArgs
 }
 
 int dw_group_splits(const mmae_dw_group_desc* d, long long* tiles_out) {
-    static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    const int n_cu = mmae_cu_count();
     long long tiles = 0;
     for (int i = 0; i < d->n; ++i) tiles += (long long)((d->p[i].n_out + 255) / 256) * ((d->p[i].k_in + 255) / 256);
-    static const int env_split = getenv("MMAE_DW_SPLIT") ? atoi(getenv("MMAE_DW_SPLIT")) : 0;     // experiments: slices when the group has > 64 tiles
+    static const int env_split = mmae_env_int("MMAE_DW_SPLIT", 0);     // experiments: slices when the group has > 64 tiles
     int s = d->split_k > 0 ? d->split_k : ((env_split > 0 && tiles > 64) ? env_split : (int)(n_cu / (tiles > 0 ? tiles : 1)));
     // (Filling whole rounds of the chip -- ViT-L's 192 tiles as 4 slices = 768 workgroups instead of 192 on 256 CUs -- measured
     // +1.8 % on the bf16 cfg5 step and -1.3 % on the mxfp8 one: the launch shares the chip with the dX chain of the main stream,
@@ -185,20 +186,19 @@ extern "C" int mmae_gemm_dw_group(const mmae_dw_group_desc* d, void* stream) {
     }
     ra.total4 = b4;
     ga.tiles_total = tb;
-    static const int env_xcd = getenv("MMAE_DW_XCD") ? atoi(getenv("MMAE_DW_XCD")) : 1;
+    static const int env_xcd = mmae_env_int("MMAE_DW_XCD", 1);
     ga.xcd = env_xcd;
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)4 * (256 + 256) * 64 + 1024;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_dwgroup_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_dwgroup_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    });
 #ifdef MMAE_NO_KF
     static const int env_kf = 0;
 #else
-    static const int env_kf = getenv("MMAE_PP_KF") ? atoi(getenv("MMAE_PP_KF")) : 1;
+    static const int env_kf = mmae_env_int("MMAE_PP_KF", 1);
 #endif
     double flop = 0.0;
     for (int i = 0; i < d->n; ++i) flop += 2.0 * d->rows * d->p[i].n_out * d->p[i].k_in;

@@ -20,10 +20,7 @@ int launch64(const GemmArgs& g, int batch, hipStream_t st) {
     GemmArgs a = g;
     a.tiles_n = (g.N + BN - 1) / BN;
     a.tiles_total = tiles_m * a.tiles_n;                 // kt_per_split already counts 64-wide K tiles (runtime.hip)
-    int dev = 0, n_cu = 256;
-    (void)hipGetDevice(&dev);
-    static const int cus = [&] { int n = 256; (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-    n_cu = cus;
+    const int n_cu = mmae_cu_count();
     const int gx = a.tiles_total > n_cu ? n_cu : a.tiles_total;      // one resident workgroup per CU walks the tile list
     static std::once_flag once;
     std::call_once(once, [] {

@@ -10,6 +10,7 @@
 // 8-element chunk), split in registers, and written to separate hi / lo LDS tiles (same swizzled layouts,
 // same ds_read_b128 / ds_read_b64_tr_b16 fragment fetch as the bf16 kernels).
 #include "gemm_common.h"
+#include <mutex>
 
 #define LDS_AS __attribute__((address_space(3)))
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -184,11 +185,10 @@ int launch(const GemmArgs& g, int batch, hipStream_t st) {
     a.kt_per_split = g.kt_per_split * 2;           // runtime.hip counts 64-wide K tiles for 16-bit operands
     dim3 grid(((g.M + 127) / 128) * a.tiles_n, batch, a.splitk), block(256);
     const size_t lds = 2 * 4 * 128 * 64;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute((const void*)gemm_f32x3_kernel<AKS, BKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    });
     hipLaunchKernelGGL((gemm_f32x3_kernel<AKS, BKS>), grid, block, lds, st, a);
     return mmae_check_launch("gemm_f32x3");
 }

@@ -23,6 +23,7 @@
 // which every wave reaches after b_4t+4, when the last reader (group 1, MEM(2t+1)) has drained its lgkmcnt.
 #pragma once
 #include <stdlib.h>
+#include <mutex>
 #include "gemm_common.h"
 
 #define LDS_AS __attribute__((address_space(3)))
@@ -399,16 +400,15 @@ int launch(const GemmArgs& g, int batch, hipStream_t st) {
     a.tiles_n = (g.N + BN - 1) / BN;
     a.kt_per_split = g.kt_per_split * 2;                 // runtime.hip counts 64-wide K tiles; this kernel steps by 32
     a.tiles_total = tiles_m * a.tiles_n;
-    static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-    static const int env_persist = getenv("MMAE_PP_PERSIST") ? atoi(getenv("MMAE_PP_PERSIST")) : 1;
+    const int n_cu = mmae_cu_count();
+    static const int env_persist = mmae_env_int("MMAE_PP_PERSIST", 1);
     const int gx = (env_persist && a.tiles_total > n_cu) ? n_cu : a.tiles_total;      // one resident workgroup per CU walks the tile list
     dim3 grid(gx, batch, a.splitk), block(512);
     const size_t lds = (size_t)4 * (BM + BN) * 64 + 1024;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<TM, AKS, BKS, FL, KF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    });
     hipLaunchKernelGGL((gemm_bf16_pp_kernel<TM, AKS, BKS, FL, KF>), grid, block, lds, st, a);
     return mmae_check_launch("gemm_bf16_pp");
 }

@@ -17,6 +17,7 @@
 // of 64 BYTES per row as before -- now 64 elements: the LDS images, DMA pieces and their counted waits are byte-identical; a
 // wave's two half-phases per K tile split its (TM x 2) scaled MFMAs (64 cycles each) by output rows instead of by K slice.
 #include <stdlib.h>
+#include <mutex>
 #include <type_traits>
 #include "gemm_common.h"
 
@@ -455,14 +456,13 @@ int launch_mx(const GemmArgs& g, hipStream_t st) {
     a.tiles_n = (g.N + BN - 1) / BN;
     a.tiles_total = ((g.M + BM - 1) / BM) * a.tiles_n;
     a.splitk = 1;
-    static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    const int n_cu = mmae_cu_count();
     const int gx = a.tiles_total > n_cu ? n_cu : a.tiles_total;
     const size_t lds = (size_t)4 * (BM + BN) * 64 + 1024;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute((const void*)gemm_mxfp8_kernel<TM, FL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    });
     hipLaunchKernelGGL((gemm_mxfp8_kernel<TM, FL>), dim3(gx), dim3(512), lds, st, a);
     return mmae_check_launch("gemm_mxfp8");
 }
@@ -505,7 +505,7 @@ int mmae_gemm_mxfp8_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t
     const long long nt = (d->N + 255) / 256;
     const long long t4 = ((d->M + 255) / 256) * nt, t5 = ((d->M + 319) / 320) * nt;
     const long long c4 = ((t4 + 255) / 256) * 256, c5 = ((t5 + 255) / 256) * 320;
-    static const int env_tm = getenv("MMAE_MX_TM") ? atoi(getenv("MMAE_MX_TM")) : 0;
+    static const int env_tm = mmae_env_int("MMAE_MX_TM", 0);
     (void)c4; (void)c5;                                   // 320-row tiles spill ~35 registers in this body and measured 14 % slower: opt-in only
     const bool five = env_tm == 5;
     return five ? launch_mx_fl<5>(g, fl, st) : launch_mx_fl<4>(g, fl, st);

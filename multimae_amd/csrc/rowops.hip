@@ -545,8 +545,8 @@ int mmae_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float
     // workgroups per CU: a 1 024-workgroup grid at D = 768 ran as 1.33 rounds of the chip (768 resident).  Launch what is
     // resident at once -- every workgroup walks rows block-stride, so fewer workgroups just take more rows each.  (Measured: -0.1 ms
     // per cfg3 step, i.e. close to nothing -- the kernel is HBM-bound either way; MMAE_LN_BWD_RESIDENT=0 restores the full grid.)
-    static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-    static const int env_res = getenv("MMAE_LN_BWD_RESIDENT") ? atoi(getenv("MMAE_LN_BWD_RESIDENT")) : 1;
+    const int n_cu = mmae_cu_count();
+    static const int env_res = mmae_env_int("MMAE_LN_BWD_RESIDENT", 1);
     const int part_rows = mmae_layernorm_bwd_nblk(R);
     const int per_cu = nv == 1 ? 5 : (nv == 2 ? 4 : (nv == 3 ? 3 : 2));
     const int resident = env_res ? n_cu * per_cu : part_rows;

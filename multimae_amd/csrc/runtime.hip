@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include "gemm_common.h"
 
 static thread_local char g_err[256] = "";
@@ -10,6 +11,19 @@ static thread_local char g_err[256] = "";
 void mmae_set_error(const char* msg) {
     strncpy(g_err, msg, sizeof(g_err) - 1);
     g_err[sizeof(g_err) - 1] = 0;
+}
+
+int mmae_cu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    n = 256;
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n <= 0) n = 256;
+    cached[dev].store(n, std::memory_order_relaxed);
+    return n;
 }
 
 int mmae_check_launch(const char* what) {
@@ -64,7 +78,7 @@ bool split_eligible(const mmae_gemm_desc* d) {
 // Kernel variant + split-K choice for one product (256 CUs; the ping-pong kernel holds one workgroup per CU, the
 // 128 x 128 kernels about three).
 void gemm_plan(const mmae_gemm_desc* d, int* tile_out, int* split_out) {
-    static const int env_tile = getenv("MMAE_GEMM_TILE") ? atoi(getenv("MMAE_GEMM_TILE")) : 0;
+    static const int env_tile = mmae_env_int("MMAE_GEMM_TILE", 0);
     const int bk = d->ab_dtype == MMAE_F32 ? 16 : 64;
     const int nkt = (d->K + bk - 1) / bk;
     const bool can_split = split_eligible(d) && nkt >= 32;
@@ -74,11 +88,11 @@ void gemm_plan(const mmae_gemm_desc* d, int* tile_out, int* split_out) {
         tile = 3;
         if (d->ab_dtype == MMAE_BF16 && d->batch == 1) {
             const long long t4 = ((d->M + 255) / 256) * nt256, t5 = ((d->M + 319) / 320) * nt256;
-            static const int env_min_k = getenv("MMAE_PP_MIN_K") ? atoi(getenv("MMAE_PP_MIN_K")) : 128;
+            static const int env_min_k = mmae_env_int("MMAE_PP_MIN_K", 128);
             if (d->M >= 2048 && d->N >= 192 && d->K >= env_min_k) {
                 // whole rounds of 256 workgroups x rows per tile: 320-row tiles when they waste less of the last round
                 const long long c4 = ((t4 + 255) / 256) * 256, c5 = ((t5 + 255) / 256) * 320;
-                static const int env_t10cs = getenv("MMAE_GEMM_T10_CS") ? atoi(getenv("MMAE_GEMM_T10_CS")) : 1;     // 0: 256-row tiles for the column-sum epilogue (A/B)
+                static const int env_t10cs = mmae_env_int("MMAE_GEMM_T10_CS", 1);     // 0: 256-row tiles for the column-sum epilogue (A/B)
                 tile = (c5 <= c4 && !d->a_trans && (env_t10cs || !d->colsum_part)) ? 10 : 9;
             } else if (t4 >= 4 && can_split && d->K >= 4096) {
                 tile = 9;                                   // dW-shaped: few tiles, split along K below
@@ -88,7 +102,7 @@ void gemm_plan(const mmae_gemm_desc* d, int* tile_out, int* split_out) {
     int s = 1;
     // workgroups a split product should reach (ping-pong kernel: one per CU).  Below 256 the dW launches leave CUs to the dX
     // chain they run beside, write fewer partial slabs and run longer K loops; tunable for experiments.
-    static const int env_wgs = getenv("MMAE_SPLITK_WGS") ? atoi(getenv("MMAE_SPLITK_WGS")) : 256;
+    static const int env_wgs = mmae_env_int("MMAE_SPLITK_WGS", 256);
     if (can_split) {
         if (tile == 9 || tile == 10) {
             const long long t = ((d->M + (tile == 9 ? 255 : 319)) / (tile == 9 ? 256 : 320)) * nt256;
@@ -153,13 +167,13 @@ int mmae_gemm_ex(const mmae_gemm_desc* d, void* stream, int timing_cls, double f
     g.epi = d->epi; g.accumulate = d->accumulate; g.alpha = d->alpha;
     g.tiles_n = 0;
     g.colpart = d->colsum_part;
-    static const int env_swz = getenv("MMAE_GEMM_XCD") ? atoi(getenv("MMAE_GEMM_XCD")) : 1;
+    static const int env_swz = mmae_env_int("MMAE_GEMM_XCD", 1);
     g.xcd_swizzle = env_swz;
-    static const int env_wide = getenv("MMAE_EPI_WIDE") ? atoi(getenv("MMAE_EPI_WIDE")) : 1;
+    static const int env_wide = mmae_env_int("MMAE_EPI_WIDE", 1);
     g.wide_st = env_wide;
-    static const int env_dbg = getenv("MMAE_EPI_DBG") ? atoi(getenv("MMAE_EPI_DBG")) : 0;
+    static const int env_dbg = mmae_env_int("MMAE_EPI_DBG", 0);
     g.dbg = env_dbg;
-    static const int env_dephase = getenv("MMAE_PP_DEPHASE") ? atoi(getenv("MMAE_PP_DEPHASE")) : 0;
+    static const int env_dephase = mmae_env_int("MMAE_PP_DEPHASE", 0);
     g.dephase = env_dephase;
     g.scA = d->a_scale; g.scB = d->b_scale;
     g.qout = (unsigned char*)d->q_out; g.qsc = (unsigned char*)d->q_scale; g.ldq = d->ldq;
