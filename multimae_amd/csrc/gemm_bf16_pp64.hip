@@ -9,7 +9,7 @@ namespace {
 
 template <int TM, bool AKS, bool BKS, int FL, int VAR = 0>
 __global__ void __launch_bounds__(512) gemm_bf16_pp64_kernel(const GemmArgs g) {
-    pp64_body<TM, AKS, BKS, FL, VAR % 10, (VAR < 10)>(g, blockIdx.x, gridDim.x);      // VAR >= 10: without the L2 prefetch
+    pp64_body<TM, AKS, BKS, FL, VAR % 10, (VAR >= 10)>(g, blockIdx.x, gridDim.x);      // VAR >= 10: with the L2 prefetch (measured slower)
 }
 
 template <int TM, bool AKS, bool BKS, int FL, int VAR = 0>
@@ -62,7 +62,7 @@ int mmae_gemm_bf16_pp64_impl(const mmae_gemm_desc* d, const GemmArgs& g, int cod
         case 13: return dispatch64<4>(d, g, fl, st);
         case 14: return dispatch64<5>(d, g, fl, st);
 #ifdef MMAE_EXPERIMENTS
-        case 64: return dispatch64<5, 10>(d, g, fl, st);      // production schedule without the L2 prefetch
+        case 64: return dispatch64<5, 10>(d, g, fl, st);      // production schedule + L2 prefetch three K tiles ahead
         case 74: return dispatch64<5, 15>(d, g, fl, st);
         case 84: return dispatch64<5, 16>(d, g, fl, st);
         case 24: return dispatch64<5, 1>(d, g, fl, st);       // dissection builds: code = 14 + 10 x VAR

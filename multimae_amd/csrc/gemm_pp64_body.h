@@ -33,7 +33,7 @@ __device__ __forceinline__ int kc64_off(int row, int c) { return row * 128 + ((c
 
 // VAR: 0 = production; dissection builds (wrong results): 1 = no DMA in the K loop, 2 = no fragment reads, 3 = neither, 4 = neither and no barriers,
 // 5 = the loop never waits for its DMA pieces, 6 = every K tile re-fetches K tile 0 (L2-hot lines)
-template <int TM, bool AKS, bool BKS, int FL, int VAR = 0, bool PF = true>
+template <int TM, bool AKS, bool BKS, int FL, int VAR = 0, bool PF = false>
 __device__ __forceinline__ void pp64_body(const GemmArgs& g, const int v0, const int vstep) {
     constexpr int WMR = TM * 32;
     constexpr int BM = 2 * WMR, BN = 256;
@@ -73,10 +73,10 @@ __device__ __forceinline__ void pp64_body(const GemmArgs& g, const int v0, const
     // i * rowstep + K offset (soffset) instead of a running per-piece offset register.  Rows past the operand's edge: M, N are
     // multiples of 8 (checked by the launcher), so a k-contiguous piece (8 rows) is inside or outside as a whole -- bit i of vmask.
     unsigned base = OOB, vmask = 0;
-    // L2 prefetch (PF): one lane per 128-byte line of a K tile, issued three K tiles ahead as plain sc1 loads into a dead
-    // register.  The two-slot ring gives a DMA piece half a K-tile period (~1 us) to land, an HBM miss of the activation
-    // operand takes longer -- and the workgroups that share a row panel run in lock step, so all of them waited for it once per
-    // K tile (profiles/r03_pp64_dissection.txt: the pieces cost 20-28 % of the loop with nothing else in their way).
+    // L2 prefetch (PF, experiment -- measured 4 % SLOWER, profiles/r03_pp64_dissection.txt): one lane per 128-byte line of a K
+    // tile, issued three K tiles ahead as plain sc1 loads into a dead register, on the idea that the two-slot ring's half K-tile
+    // period of cover is too short for an HBM miss of the activation operand.  The prefetch loads travel through the same per-CU
+    // L1 miss machinery as the DMA pieces, so they take from the resource they were meant to relieve.
     unsigned pfa = OOB, pfb = OOB;                       // byte offset of this lane's line in K tile 0
     const unsigned my_ld2 = (unsigned)((wm ? g.lda : g.ldb) * 2);
     const bool my_ks = wm ? AKS : BKS;
