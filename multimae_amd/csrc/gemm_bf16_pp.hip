@@ -22,7 +22,7 @@ struct DwGroupArgs {
     DwProblem p[8];
 };
 
-template <bool KF>
+template <bool KF, bool WIDE = false>
 __global__ void __launch_bounds__(512) gemm_bf16_pp_dwgroup_kernel(const DwGroupArgs ga) {
     // XCD-aware order (workgroup b runs on XCD b % 8): every XCD takes a contiguous range of the concatenated tile lists, so the
     // tiles resident on one XCD share dY / X column panels in its L2 instead of every XCD streaming every panel
@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_dwgroup_kernel(const DwGroup
     g.colpart = nullptr;
     g.wide_st = 0;
     g.dbg = 0; g.dephase = 0;
-    pp_body<4, true, true, 0, KF, KF>(g, local, 1 << 30);
+    pp_body<4, true, true, 0, KF, KF, WIDE>(g, local, 1 << 30);
 }
 
 }  // namespace
@@ -193,6 +193,7 @@ extern "C" int mmae_gemm_dw_group(const mmae_dw_group_desc* d, void* stream) {
     static std::once_flag attr_once;
     std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_dwgroup_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_dwgroup_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_dwgroup_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
 #ifdef MMAE_NO_KF
@@ -203,7 +204,9 @@ extern "C" int mmae_gemm_dw_group(const mmae_dw_group_desc* d, void* stream) {
     double flop = 0.0;
     for (int i = 0; i < d->n; ++i) flop += 2.0 * d->rows * d->p[i].n_out * d->p[i].k_in;
     hipEvent_t t_ev = mmae_timing_begin(st);
-    if (env_kf && (d->rows & 31) == 0) hipLaunchKernelGGL(gemm_bf16_pp_dwgroup_kernel<true>, dim3(tb, 1, s), dim3(512), lds, st, ga);
+    static const int env_wide = mmae_env_int("MMAE_DW_WIDE", 0);      // one phase pair per K tile: measured neutral (421 vs 411-436 us per block), off
+    if (env_kf && env_wide && (d->rows & 31) == 0) hipLaunchKernelGGL((gemm_bf16_pp_dwgroup_kernel<true, true>), dim3(tb, 1, s), dim3(512), lds, st, ga);
+    else if (env_kf && (d->rows & 31) == 0) hipLaunchKernelGGL(gemm_bf16_pp_dwgroup_kernel<true>, dim3(tb, 1, s), dim3(512), lds, st, ga);
     else hipLaunchKernelGGL(gemm_bf16_pp_dwgroup_kernel<false>, dim3(tb, 1, s), dim3(512), lds, st, ga);
     int rc = mmae_check_launch("gemm_bf16_pp_dwgroup");
     if (rc) { mmae_timing_end(t_ev, st, flop, 0); return rc; }

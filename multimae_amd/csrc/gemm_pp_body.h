@@ -49,6 +49,13 @@ template <> __device__ __forceinline__ void wait_vm<5>() { asm volatile("s_waitc
 template <> __device__ __forceinline__ void wait_vm<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vm<7>() { asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
 
+template <int N> __device__ __forceinline__ void duo_like_wait() {
+    static_assert(N >= 3 && N <= 5, "add the immediate");
+    if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+}
+
 template <typename T>
 __device__ __forceinline__ T* sgpr_ptr(T* p) {            // wave-uniform pointer -> SGPR pair
     const unsigned long long v = (unsigned long long)p;
@@ -73,7 +80,11 @@ __device__ __forceinline__ void wg_barrier() {
 // UNR: the K loop unrolled over the NST ring slots (slot-dependent LDS addresses and M0 values become immediates: 29 fewer
 // instructions per K tile in the memory half-phases); off where the extra address registers would spill (generic flavours,
 // 320-row k-strided B).
-template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false, bool UNR = false>
+// WIDE: one memory half-phase and one MFMA half-phase per 32-wide K TILE instead of per 16-wide slice (2 x TM x 2 MFMAs per phase,
+// both slices' fragments in registers): half the workgroup barriers per K tile.  Schedule: G0: MEM(u) b_2u MFMA(u) b_2u+1, G1: b_2u
+// MEM(u) b_2u+1 MFMA(u); MEM(u) reads tile u and issues the pieces of tile u+2 (its slot held tile u-2, whose last reads were
+// drained before b_2u-1); every wave waits for its pieces of tile u+2 -- those of tile u+3 may still fly -- before b_2u+3.
+template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false, bool UNR = false, bool WIDE = false>
 __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const int vstep) {
     constexpr int WMR = TM * 32;                         // output rows per wave
     constexpr int BM = 2 * WMR, BN = 256, NW = 8;
@@ -216,6 +227,7 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
     };
 
     bf16x8 af[TM], bf[2];
+    bf16x8 af2[WIDE ? TM : 1], bf2[2];                      // WIDE: the second 16-wide slice of the K tile
     // optional column sums of the k-strided A operand (bias gradient of a dW product): the wn = 0 waves of the n-tile-0
     // workgroups add up the A fragments they hold anyway (v_dot2c with a vector of ones, in the shadow of the MFMAs)
     bool do_acs = false;
@@ -253,14 +265,67 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
         }
     };
 
+    auto mem_phase_w = [&](int u, int slot) {
+        const char* sa = smem + slot * STAGE;
+        const char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bf[t] = BKS ? frag_ks(sb, wn * 64 + t * 32, 0) : frag_kc(sb, wn * 64 + t * 32, 0);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) af[t] = AKS ? frag_ks(sa, wm * WMR + t * 32, 0) : frag_kc(sa, wm * WMR + t * 32, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bf2[t] = BKS ? frag_ks(sb, wn * 64 + t * 32, 1) : frag_kc(sb, wn * 64 + t * 32, 1);
+#pragma unroll
+        for (int t = 0; t < (WIDE ? TM : 1); ++t) af2[t] = AKS ? frag_ks(sa, wm * WMR + t * 32, 1) : frag_kc(sa, wm * WMR + t * 32, 1);
+        dma_first(u + 2, (slot + 2) & (NST - 1));
+        dma_second(u + 2, (slot + 2) & (NST - 1));
+    };
+    auto mfma_phase_w = [&]() {
+        if (AKS || BKS) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+                acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < (WIDE ? TM : 1); ++tm)
+                acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf2[tn], af2[tm], acc[tn][tm], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (AKS && do_acs) {
+#pragma unroll
+            for (int tm = 0; tm < (WIDE ? TM : 1); ++tm) {
+                const i32x4 w = __builtin_bit_cast(i32x4, af[tm]), w2 = __builtin_bit_cast(i32x4, af2[tm]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acs[tm]) : "v"(w[j]), "v"(0x3f803f80));
+                    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acs[tm]) : "v"(w2[j]), "v"(0x3f803f80));
+                }
+            }
+        }
+    };
+    // pieces of ONE K tile may still be in flight at the point the tile before it must have landed
+    auto wait_tile_w = [&]() {
+        constexpr int NPW = LA + LB;
+        if (LA == 3 && !has3) duo_like_wait<NPW - 1>(); else duo_like_wait<NPW>();
+    };
+
     if (g.dephase && (blockIdx.x & 1)) {                 // experiment: half of the CUs run out of phase with the other half
         for (int i = 0; i < g.dephase; ++i) __builtin_amdgcn_s_sleep(127);
     }
     // prologue of the first tile: K tiles 0, 1 and the first half of K tile 2
     dma_first(0, 0); dma_second(0, 0);
     dma_first(1, 1); dma_second(1, 1);
-    dma_first(2, 2);
-    wait_tile();                                        // K tile 0 has landed (this wave's share)
+    if (WIDE) {
+        wait_tile_w();                                  // K tile 0 has landed, tile 1 may still fly
+    } else {
+        dma_first(2, 2);
+        wait_tile();                                    // K tile 0 has landed (this wave's share)
+    }
     wg_barrier();
 
     // epilogue staging lives in ring slots 2-3 so that slots 0-1 can already receive the NEXT output tile's first two K
@@ -280,7 +345,37 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
 #pragma unroll
         for (int t = 0; t < TM; ++t) acs[t] = 0.f;
 
-        if (UNR) {
+        if (WIDE) {
+            if (wm == 0) {
+                for (int u0 = 0; u0 < T; u0 += NST) {
+#pragma unroll
+                    for (int j = 0; j < NST; ++j) {
+                        const int u = u0 + j;
+                        if (u < T) {
+                            mem_phase_w(u, j);
+                            wg_barrier();
+                            mfma_phase_w();
+                            wait_tile_w();                  // K tile u + 1 (tile u + 2 may still fly)
+                            wg_barrier();
+                        }
+                    }
+                }
+            } else {
+                for (int u0 = 0; u0 < T; u0 += NST) {
+#pragma unroll
+                    for (int j = 0; j < NST; ++j) {
+                        const int u = u0 + j;
+                        if (u < T) {
+                            wg_barrier();
+                            mem_phase_w(u, j);
+                            wait_tile_w();
+                            wg_barrier();
+                            mfma_phase_w();
+                        }
+                    }
+                }
+            }
+        } else if (UNR) {
             // the K loop unrolled over the NST ring slots: slot = u mod NST is a constant in every copy of the body
             if (wm == 0) {
                 for (int u0 = 0; u0 < T; u0 += NST) {
@@ -381,7 +476,7 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
             // slots 2-3 back to the DMA ring
             wait_vm<0>();
             __syncthreads();
-            dma_first(2, 2);
+            if (!WIDE) dma_first(2, 2);
         }
     }
 }

@@ -163,3 +163,71 @@ def test_reference_loop_body_runs_on_the_engine_under_ddp_autocast_gradscaler():
         assert glob < 6e-2 and worst[0] < 0.2, (d, glob, worst)
     # and the weights did move
     assert float((wa['encoder.0.attn.qkv.weight'] - sd0['encoder.0.attn.qkv.weight']).abs().max()) > 1e-4
+
+
+def _rccl_rank(rank, world, port, q):
+    """one data-parallel rank of a REAL two-GPU RCCL step (spawned by the test below)"""
+    try:
+        import sys
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path[:0] = [here, os.path.join(os.path.dirname(here), 'oracle')]
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                          HSA_ENABLE_IPC_MODE_LEGACY='0')
+        import torch.distributed as dist
+        import multimae_amd as M
+        from multimae_amd.dist import GradAllReducer, attach, broadcast_parameters
+        from multimae_amd.optim import FusedAdamW
+        torch.cuda.set_device(rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+        dev = torch.device('cuda', rank)
+        torch.manual_seed(100 + rank)
+        model = build_mini_engine().to(dev)
+        arena = model.build_arena()
+        broadcast_parameters(arena)
+        red = GradAllReducer.for_arena(arena, bucket_mb=0.25)
+        opt = FusedAdamW(model, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
+        attach(model, red, opt)
+        M.engine.set_direct_grads(True)
+        torch.manual_seed(7 + rank)                       # every rank its own shard of the global batch
+        x = {k: v.to(dev) for k, v in make_inputs(MINI['doms'], 4, MINI['S']).items()}
+        losses = []
+        for it in range(2):
+            torch.manual_seed(50 + 10 * it + rank)
+            opt.zero_grad()
+            with M.engine.precision('bf16'):
+                preds, masks = model(x, num_encoded_tokens=MINI['nvis'], alphas=1.0, fp32_output_adapters=['semseg'])
+                loss = sum(_losses(M, preds, masks, x).values())
+                loss.backward()
+            red.finish()
+            opt.step(loss)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        gathered = [torch.empty_like(arena.param) for _ in range(world)]
+        dist.all_gather(gathered, arena.param)
+        same = all(torch.equal(g, gathered[0]) for g in gathered)
+        q.put((rank, same, losses, red.grad_prescale))
+        dist.destroy_process_group()
+    except Exception:          # noqa: BLE001
+        import traceback
+        q.put((rank, False, traceback.format_exc(), 0.0))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs (the driver scaling node); the 1-GPU box skips it')
+def test_two_rank_rccl_step_keeps_the_replicas_identical():
+    """a real 2-rank RCCL data-parallel step -- broadcast_parameters, readiness-ordered bucketed all-reduce from
+    the launch stream overlapped with backward, 1 / world folded into mmae_opt_step -- on different data per rank: after two
+    optimiser steps the parameter arenas of both ranks must be BIT-identical (run_pretraining_multimae.py:300,372-387)."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_rccl_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    for rank, same, losses, pre in res:
+        assert same, f'rank {rank}: {losses}'
+        assert pre == 0.5
+    assert res[0][2] != res[1][2]                        # the ranks really saw different data
