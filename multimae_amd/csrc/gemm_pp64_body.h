@@ -140,9 +140,11 @@ __device__ __forceinline__ void pp64_body(const GemmArgs& g, const int v0, const
         return *reinterpret_cast<const bf16x8*>(base + kc64_off(row0 + fr, s * 2 + fk));
     };
     auto frag_ks = [&](const char* base, int col0, int s) -> bf16x8 {            // both operands' k-strided images are 256 columns wide
+        // inline asm, not the builtin: see frag_ks in gemm_pp_body.h (hipcc drains vmcnt before every builtin transposing read)
         const int col = col0 + t_i0 + (tp & 3) * 4, k_lo = s * 16 + t_kh + (tp >> 2);
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(base + ks_off<256>(k_lo, col >> 3) + (col & 7) * 2));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(base + ks_off<256>(k_lo + 4, col >> 3) + (col & 7) * 2));
+        const unsigned addr = (unsigned)(size_t)(LDS_AS const char*)(base + ks_off<256>(k_lo, col >> 3) + (col & 7) * 2);
+        s16x4 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048" : "=&v"(lo), "=&v"(hi) : "v"(addr));
         return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
 
@@ -185,6 +187,10 @@ __device__ __forceinline__ void pp64_body(const GemmArgs& g, const int v0, const
         }
     };
     auto mfma_phase = [&]() {
+        if (AKS || BKS) {                                    // the asm fragment reads of this phase's operands
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)

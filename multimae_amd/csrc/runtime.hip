@@ -94,6 +94,13 @@ void gemm_plan(const mmae_gemm_desc* d, int* tile_out, int* split_out) {
                 const long long c4 = ((t4 + 255) / 256) * 256, c5 = ((t5 + 255) / 256) * 320;
                 static const int env_t10cs = mmae_env_int("MMAE_GEMM_T10_CS", 1);     // 0: 256-row tiles for the column-sum epilogue (A/B)
                 tile = (c5 <= c4 && !d->a_trans && (env_t10cs || !d->colsum_part)) ? 10 : 9;
+                // 64-wide K tiles (whole-cache-line DMA pieces, gemm_pp64_body.h): in isolation the products with a plain bf16
+                // epilogue run 3-6 % faster on them (qkv forward, dX of fc1 / qkv / proj, profiles/r03_pp64_ab.txt), inside the
+                // training step the same switch measured +0.2 ms (33.52 vs 33.32 ms, encoder step 18.24 vs 18.10): off.
+                static const int env_pp64 = mmae_env_int("MMAE_PP64", 0);
+                if (env_pp64 && tile == 10 && d->c_dtype == MMAE_BF16 && d->epi == MMAE_EPI_NONE && !d->resid && !d->accumulate &&
+                    d->alpha == 1.0f && (d->K % 64) == 0 && (d->M % 8) == 0 && (d->N % 8) == 0 && d->split_k <= 1)
+                    tile = 14;
             } else if (t4 >= 4 && can_split && d->K >= 4096) {
                 tile = 9;                                   // dW-shaped: few tiles, split along K below
             }

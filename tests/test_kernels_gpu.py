@@ -646,3 +646,50 @@ def test_masked_cross_entropy_label_smoothing(eps, domain):
         got = ops.unpatchify(h.d_pat[:, :C * P * P].contiguous(), B, C, 4, 4, P, P)
     assert abs(float(out) - float(ref)) < 5e-6
     assert rel_err(got, lr.grad) < 1e-5
+
+
+@pytest.mark.parametrize('tile', [11, 12, 13, 14])
+@pytest.mark.parametrize('shape', [(2504, 520, 256), (1000, 768, 768), (4104, 1032, 128)])
+def test_round3_gemm_structures_vs_fp32_reference(tile, shape):
+    """The GEMM structures added in round 3 -- 11 / 12: "duo" (two independent 4-wave workgroups per CU, 128 x 256 tiles, and its
+    8-wave form), 13 / 14: the ping-pong kernel on 64-wide K tiles (whole-cache-line LDS-DMA pieces; 14 is what the planner picks
+    for plain bf16 epilogues) -- with every epilogue flavour they carry, on ragged shapes (M, N not multiples of the tile; rows
+    past the edge masked by the out-of-range DMA offset), against an fp32 torch reference of the same bf16 operands."""
+    from multimae_amd import ops
+    from multimae_amd._lib import EPI_DGELU, EPI_GELU
+    M, N, K = shape
+    torch.manual_seed(M + tile)
+    x, w = bf(torch.randn(M, K) * 0.5).float(), bf(torch.randn(N, K) * 0.2).float()
+    bias, resid = torch.randn(N), torch.randn(M, N)
+    xd, wd = x.to(DEV, torch.bfloat16), w.to(DEV, torch.bfloat16)
+    lin = x @ w.t() + bias
+    # forward flavours: bias -> bf16, bias + GELU -> 2 x bf16, bias + residual -> f32, bias -> f32
+    c16 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    ops.linear_fwd(xd, wd, bias.to(DEV), c16, tile=tile)
+    assert rel_err(c16.float(), lin) < 4e-3
+    aux, act = torch.empty_like(c16), torch.empty_like(c16)
+    ops.linear_fwd(xd, wd, bias.to(DEV), act, aux=aux, epi=EPI_GELU, tile=tile)
+    assert rel_err(aux.float(), lin) < 4e-3 and rel_err(act.float(), orc.gelu_erf(lin)) < 4e-3
+    out = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(xd, wd, bias.to(DEV), out, resid=resid.to(DEV), tile=tile)
+    assert rel_err(out, lin + resid) < 1e-5
+    ops.linear_fwd(xd, wd, bias.to(DEV), out, tile=tile)
+    assert rel_err(out, lin) < 1e-5
+    # dX flavours (W read through the transposing LDS path): plain bf16, dGELU, dGELU + column sums, f32
+    dy = bf(torch.randn(M, N) * 0.3).float()
+    dyd = dy.to(DEV, torch.bfloat16)
+    dx_ref = dy @ w
+    dxo = torch.empty(M, K, device=DEV, dtype=torch.bfloat16)
+    ops.linear_dx(dyd, wd, dxo, tile=tile)
+    assert rel_err(dxo.float(), dx_ref) < 4e-3
+    pre = bf(torch.randn(M, K)).float()
+    p = pre.clone().requires_grad_(True)
+    orc.gelu_erf(p).backward(dx_ref)
+    ops.linear_dx(dyd, wd, dxo, aux=pre.to(DEV, torch.bfloat16), epi=EPI_DGELU, tile=tile)
+    assert rel_err(dxo.float(), p.grad) < 4e-3
+    cs = torch.empty(K, device=DEV)
+    ops.linear_dx(dyd, wd, dxo, aux=pre.to(DEV, torch.bfloat16), epi=EPI_DGELU, colsum_out=cs, tile=tile)
+    assert rel_err(dxo.float(), p.grad) < 4e-3 and rel_err(cs, p.grad.sum(0)) < 1e-4
+    dx32 = torch.empty(M, K, device=DEV)
+    ops.gemm(dyd, wd, dx32, M, K, N, lda=N, ldb=K, ldc=K, b_trans=True, tile=tile)
+    assert rel_err(dx32, dx_ref) < 1e-5
