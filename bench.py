@@ -291,9 +291,35 @@ def main():
     ap.add_argument('--bf16-buckets', type=int, default=0, help='1: gradient buckets travel as bf16 (half the xGMI bytes, bf16-rounded sum; multimae_amd/dist.py)')
     ap.add_argument('--share-device', type=int, default=0, help='1: every rank uses cuda:0 (functional test of the multi-process path on one GPU; use with --backend gloo)')
     ap.add_argument('--graph', type=int, default=-1, help='1: capture the step once as a hipGraph and replay it (multimae_amd.graph.StepGraph; 1 GPU only). Default 0: on ROCm 7.2 the replay of this ~1 100-node, 10-stream graph measured 46.2 ms/step against 44.1 ms eager')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary line (cfg5 = BASELINE configs[4] geometry, ViT-L, MX-fp8 encoder products, B = 128, a few steps) that the default single-GPU cfg3 run appends as `secondary`')
     args = ap.parse_args()
     if args.precision is None:
         args.precision = 'mxfp8' if args.config == 'cfg5' else 'bf16'
+    out = run_once(args)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if out is not None and world == 1 and not args.force_dist and args.config == 'cfg3' and not args.no_secondary and not args.batch:
+        # the fp8 configuration of BASELINE.json (configs[4]) measured by the same command, so that the driver's run records it:
+        # a short run (the primary line above is the metric; this one is reported beside it, never as `value`)
+        import copy
+        import gc
+        a2 = copy.copy(args)
+        a2.config, a2.precision, a2.steps, a2.warmup, a2.no_cpu_baseline = 'cfg5', 'mxfp8', 5, 2, True
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            o2 = run_once(a2)
+            out['secondary'] = {k: o2[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config', 'final_loss', 'roofline')}
+        except Exception as e:      # noqa: BLE001 -- the secondary line must never cost the primary one
+            out['secondary'] = {'error': repr(e)[:300]}
+    if out is not None:
+        print(json.dumps(out))
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def run_once(args):
+    """One measured configuration; returns the result line (rank 0) or None."""
 
     import torch.distributed as dist
     import multimae_amd as M
@@ -482,11 +508,11 @@ def main():
         M.engine.set_direct_grads(False)
         cpu = cpu_baseline(args.config, args.cpu_sample_batch, args.cpu_steps, args.cpu_threads)
 
+    M.engine.set_direct_grads(False)
+    M.engine.set_precision('bf16')
     if rank == 0:
-        out = result_line(args, B, world, ms_per_step, img_s, final_loss, counters, roof, cpu, dp_diag, host_ms, host_wait_ms, use_graph, n_vis, doms)
-        print(json.dumps(out))
-    if use_dist:
-        dist.destroy_process_group()
+        return result_line(args, B, world, ms_per_step, img_s, final_loss, counters, roof, cpu, dp_diag, host_ms, host_wait_ms, use_graph, n_vis, doms)
+    return None
 
 
 if __name__ == '__main__':
