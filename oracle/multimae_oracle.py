@@ -61,9 +61,10 @@ class OracleConfig:
     dec_heads: int = 8
     ln_eps: float = 1e-6
     domains_by_name: Dict[str, DomainSpec] = field(default_factory=dict)
+    out_only_domains: List[DomainSpec] = field(default_factory=list)      # decoded but not fed to the encoder (--in_domains rgb --out_domains rgb-depth)
 
     def __post_init__(self):
-        self.domains_by_name = {d.name: d for d in self.in_domains}
+        self.domains_by_name = {d.name: d for d in list(self.in_domains) + list(self.out_only_domains)}
 
     def patch_hw(self, d: DomainSpec) -> Tuple[int, int]:
         p = max(1, self.patch_size // d.stride_level)     # input_adapters.py:61-62
