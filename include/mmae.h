@@ -510,6 +510,26 @@ int mmae_tokens_assemble_bwd(const float* d_tok, void* d_proj, int proj_dtype, c
                              const int64_t* sel, float* part, int B, int n_sel, int G, int D, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Fused patch embedding + positional embedding (csrc/embed.hip) -- the forward of
+ * PatchedInputAdapter / SemSegInputAdapter (input_adapters.py:97-119, 215-241: Conv2d with
+ * kernel = stride = patch, + pos_emb) and of the token selection of MultiMAE.forward
+ * (multimae.py:340-347) in ONE kernel, bf16 MFMA with f32 accumulation:
+ *   tok[b][r][:] = W_t . patch(b, sel[b][r]) + bias_t + pos_t[p];  tok[b][n_sel+g][:] = global_tok[g][:]
+ * = mmae_patch_rows + one mmae_gemm per task + mmae_tokens_assemble without their HBM
+ * intermediates.  w_bf16_host: T device pointers to bf16 [D][C*ph*pw] (Conv2d weight, flattened);
+ * bias_host / pos_host as for mmae_tokens_assemble.  rows_bf16 (optional, may be NULL): the
+ * zero-padded bf16 patch rows [B*n_sel][Ktot] of mmae_patch_rows, written on the side for the
+ * weight-gradient products of the backward pass.
+ * mmae_patch_embed_supported: 1 if the fused kernel takes the geometry (D % 32 == 0, D <= 1024,
+ * n_sel <= 1024, C*ph*pw % 16 == 0, k_off % 8 == 0; semseg: ph*pw <= 64 and a class table of
+ * at most 64 KiB in bf16); otherwise use the three calls above.
+ * ------------------------------------------------------------------------- */
+int mmae_patch_embed_supported(const mmae_patch_src* srcs_host, int T, int n_sel, int D);
+int mmae_patch_embed_fwd(const mmae_patch_src* srcs_host, const void* const* w_bf16_host, const float* const* bias_host,
+                         const float* const* pos_host, const int32_t* task_offsets_host, int T, const int64_t* sel,
+                         const float* global_tok, float* tok, void* rows_bf16, int B, int n_sel, int G, int D, int Ktot, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Decoder query / context builder.  Replaces SpatialOutputAdapter.
  * get_queries_and_context + generate_context_embeddings, output_adapters.py:160-234
  * (use_task_queries path), without materialising the (B, Ntot, D) tensor.

@@ -445,14 +445,21 @@ class EmbedFn(torch.autograd.Function):
             srcs.append(dict(data=d.contiguous(), emb=e, kind=t['kind'], C=t['C'], H=t['H'], W=t['W'], ph=t['ph'], pw=t['pw'],
                              k_off=t['k_off']))
         sel = sel.contiguous()
-        rows = ops.patch_rows(srcs, cfg.task_offsets, sel, B, n_sel, Ktot, act)
-        proj = torch.empty((B * n_sel, D), device=sel.device, dtype=torch.float32)
-        for i, (t, w) in enumerate(zip(cfg.tasks, ws)):
-            ops.gemm(rows, wc(w).view(D, t['K']), proj, B * n_sel, D, t['K'], lda=Ktot, ldb=t['K'], ldc=D, a_off=t['k_off'],
-                     accumulate=(i > 0))
         gt = global_tokens.detach().reshape(G, D) if G > 0 else None
-        tok = ops.tokens_assemble(proj, [b.detach() for b in bs], [p.detach() for p in poss], cfg.task_offsets, sel, gt,
-                                  B, n_sel, G, D)
+        if act == torch.bfloat16 and D <= 768 and ops.patch_embed_supported(srcs, n_sel, D):   # (ViT-L width, 196 kept tokens: measured slower than the three passes)
+            # ONE kernel (csrc/embed.hip): gather of the kept patches, bf16 MFMA against the task's projection, + bias + pos-emb, token
+            # rows out; the zero-padded bf16 patch rows the weight-gradient products contract over are written on the side
+            tok, rows = ops.patch_embed_fwd(srcs, [wc(w).view(D, t['K']) for t, w in zip(cfg.tasks, ws)], [b.detach() for b in bs],
+                                            [p.detach() for p in poss], cfg.task_offsets, sel, gt, B, n_sel, G, D, Ktot,
+                                            want_rows=any(ctx.needs_input_grad))
+        else:
+            rows = ops.patch_rows(srcs, cfg.task_offsets, sel, B, n_sel, Ktot, act)
+            proj = torch.empty((B * n_sel, D), device=sel.device, dtype=torch.float32)
+            for i, (t, w) in enumerate(zip(cfg.tasks, ws)):
+                ops.gemm(rows, wc(w).view(D, t['K']), proj, B * n_sel, D, t['K'], lda=Ktot, ldb=t['K'], ldc=D, a_off=t['k_off'],
+                         accumulate=(i > 0))
+            tok = ops.tokens_assemble(proj, [b.detach() for b in bs], [p.detach() for p in poss], cfg.task_offsets, sel, gt,
+                                      B, n_sel, G, D)
         ctx.cfg, ctx.sel, ctx.rows = cfg, sel, rows
         ctx.tens, ctx.gt = tens, global_tokens
         ctx.srcs = srcs

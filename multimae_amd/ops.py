@@ -959,6 +959,46 @@ def patch_rows(srcs: Sequence[dict], task_offsets: Sequence[int], sel: Tensor, B
     return rows
 
 
+def _patch_src_array(srcs: Sequence[dict]):
+    arr = (PatchSrc * len(srcs))()
+    for i, s in enumerate(srcs):
+        _require_gpu(s['data'], 'input image')
+        arr[i].data = s['data'].data_ptr()
+        arr[i].emb = _p(s.get('emb'))
+        arr[i].kind, arr[i].C, arr[i].H, arr[i].W = s['kind'], s['C'], s['H'], s['W']
+        arr[i].ph, arr[i].pw, arr[i].k_off = s['ph'], s['pw'], s['k_off']
+        arr[i].n_cls = s['emb'].shape[0] if s.get('emb') is not None else 0
+    return arr
+
+
+_FUSED_EMBED = [_os.environ.get('MMAE_FUSED_EMBED', '1') != '0']
+
+
+def patch_embed_supported(srcs: Sequence[dict], n_sel: int, D: int) -> bool:
+    """True if mmae_patch_embed_fwd (ONE kernel: gather + bf16 MFMA + bias + pos-emb, csrc/embed.hip) takes this geometry."""
+    if not _FUSED_EMBED[0]:
+        return False
+    arr = _patch_src_array(srcs)
+    return bool(_lib.load().mmae_patch_embed_supported(ctypes.cast(arr, ctypes.c_void_p), len(srcs), n_sel, D))
+
+
+def patch_embed_fwd(srcs: Sequence[dict], weights_bf16: Sequence[Tensor], biases: Sequence[Tensor], poss: Sequence[Tensor],
+                    task_offsets: Sequence[int], sel: Tensor, global_tok: Optional[Tensor], B: int, n_sel: int, G: int, D: int, Ktot: int,
+                    want_rows: bool = True):
+    """Fused patch embedding: returns (tok f32 [B, n_sel+G, D], rows bf16 [B*n_sel, Ktot] or None)."""
+    arr = _patch_src_array(srcs)
+    for w, s in zip(weights_bf16, srcs):
+        if w.dtype != torch.bfloat16 or not w.is_contiguous() or w.numel() != D * s['C'] * s['ph'] * s['pw']:
+            raise ValueError('patch_embed_fwd: weights must be contiguous bf16 [D, C*ph*pw]')
+    tok = torch.empty((B, n_sel + G, D), device=sel.device, dtype=torch.float32)
+    rows = torch.empty((B * n_sel, Ktot), device=sel.device, dtype=torch.bfloat16) if want_rows else None
+    check(_lib.load().mmae_patch_embed_fwd(ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(_ptr_array(weights_bf16), ctypes.c_void_p),
+                                           ctypes.cast(_ptr_array(biases), ctypes.c_void_p), ctypes.cast(_ptr_array(poss), ctypes.c_void_p),
+                                           ctypes.cast(_i32_array(task_offsets), ctypes.c_void_p), len(srcs), sel.data_ptr(), _p(global_tok),
+                                           tok.data_ptr(), _p(rows), B, n_sel, G, D, Ktot, _stream()), 'patch_embed_fwd')
+    return tok, rows
+
+
 def semseg_emb_bwd(d_rows: Tensor, cls: Tensor, sel: Tensor, d_emb: Tensor, *, B, H, W, E, ph, pw, n_sel, k_off, tok_off,
                    n_patches, n_cls) -> None:
     check(_lib.load().mmae_semseg_emb_bwd(d_rows.data_ptr(), dcode(d_rows.dtype), d_rows.stride(0), cls.data_ptr(), sel.data_ptr(),

@@ -376,6 +376,97 @@ def test_patch_embed_assemble_vs_oracle():
         assert rel_err(tok, g['enc_in']) < 1e-2
 
 
+def _embed_case(name):
+    """(tasks, D, n_sel, G, B) of a fused-embedding test geometry; each task: kind, C (channels / class-embedding width), H, W, patch, n_cls."""
+    return {
+        # the bench geometry: RGB + depth 224^2 patch 16, semseg class ids 56^2 patch 4 with 64-wide class embeddings, ViT-B width
+        'cfg3': ([(0, 3, 224, 224, 16, 0), (0, 1, 224, 224, 16, 0), (1, 64, 56, 56, 4, 133)], 768, 98, 1, 5),
+        # ViT-L width (the four-column-block kernel), 196 kept tokens: up to four 64-row groups per task
+        'vitl': ([(0, 3, 224, 224, 16, 0), (0, 1, 224, 224, 16, 0), (1, 64, 56, 56, 4, 133)], 1024, 196, 1, 3),
+        # a width that is no multiple of 256 (waves without a column block), K = 192 (no multiple of the 128-element chunk), two global tokens
+        'tiny': ([(0, 3, 64, 64, 8, 0), (1, 16, 32, 32, 4, 7)], 192, 49, 2, 4),
+        # image patches whose rows are not 8-pixel multiples (element-wise gather), one task that keeps nothing at all
+        'p4': ([(0, 4, 32, 32, 4, 0), (0, 4, 48, 48, 12, 0), (0, 4, 16, 16, 4, 0)], 256, 40, 0, 3),
+    }[name]
+
+
+@pytest.mark.parametrize('case', ['cfg3', 'vitl', 'tiny', 'p4'])
+def test_fused_patch_embedding_vs_fp32_formula_and_the_three_pass_path(case):
+    """mmae_patch_embed_fwd (ONE kernel: gather of the kept patches, bf16 MFMA, + bias + pos-emb; input_adapters.py:97-119, 215-241 and
+    multimae.py:340-347) against (a) the formula in f64 on the bf16-rounded operands -- the only rounding the kernel adds is the f32
+    accumulation, tolerance 2e-6 of the row scale -- and (b) patch_rows -> per-task GEMM -> tokens_assemble; the side rows are bit-exact."""
+    from multimae_amd import ops
+    tasks, D, n_sel, G, B = _embed_case(case)
+    gen = torch.Generator().manual_seed(11)
+    srcs, ws, bs, poss, offs, k_off = [], [], [], [], [0], 0
+    for kind, C, H, W, P, n_cls in tasks:
+        n_p = (H // P) * (W // P)
+        if kind == 0:
+            data, emb = torch.randn(B, C, H, W, generator=gen), None
+        else:
+            data, emb = torch.randint(-1, n_cls + 1, (B, H, W), generator=gen), torch.randn(n_cls, C, generator=gen)   # -1 and n_cls: ids that embed as zeros
+        K = C * P * P
+        srcs.append(dict(data=data, emb=emb, kind=kind, C=C, H=H, W=W, ph=P, pw=P, k_off=k_off))
+        ws.append(torch.randn(D, K, generator=gen) * K ** -0.5)
+        bs.append(torch.randn(D, generator=gen))
+        poss.append(torch.randn(n_p, D, generator=gen))
+        offs.append(offs[-1] + n_p)
+        k_off += K
+    Ktot = k_off
+    ntot = offs[-1]
+    sel = torch.stack([torch.randperm(ntot, generator=gen)[:n_sel] for _ in range(B)])
+    if case == 'p4':
+        sel = torch.stack([torch.randperm(offs[2], generator=gen)[:n_sel] for _ in range(B)])      # nothing from the third task
+    if case == 'vitl':
+        sel[0] = torch.randperm(offs[1], generator=gen)[:n_sel]                                    # sample 0: all 196 tokens from RGB
+    glob = torch.randn(G, D, generator=gen) if G else None
+
+    # (a) f64 formula on bf16-rounded operands
+    ref = torch.zeros(B, n_sel + G, D, dtype=torch.float64)
+    rows_ref = torch.zeros(B * n_sel, Ktot)
+    for b in range(B):
+        for r in range(n_sel):
+            idx = int(sel[b, r])
+            t = max(i for i in range(len(tasks)) if idx >= offs[i])
+            kind, C, H, W, P, n_cls = tasks[t]
+            p = idx - offs[t]
+            py, px = divmod(p, W // P)
+            if kind == 0:
+                patch = srcs[t]['data'][b, :, py * P:(py + 1) * P, px * P:(px + 1) * P]
+            else:
+                ids = srcs[t]['data'][b, py * P:(py + 1) * P, px * P:(px + 1) * P]
+                ok = (ids >= 0) & (ids < n_cls)
+                patch = (srcs[t]['emb'][ids.clamp(0, n_cls - 1)] * ok[..., None]).permute(2, 0, 1)
+            v = bf(patch.reshape(-1))
+            rows_ref[b * n_sel + r, srcs[t]['k_off']:srcs[t]['k_off'] + v.numel()] = v
+            ref[b, r] = bf(ws[t]).double() @ v.double() + bs[t].double() + poss[t][p].double()
+        if G:
+            ref[b, n_sel:] = glob.double()
+
+    dsrcs = [dict(s, data=s['data'].to(DEV), emb=None if s['emb'] is None else s['emb'].to(DEV)) for s in srcs]
+    assert ops.patch_embed_supported(dsrcs, n_sel, D)
+    w16 = [w.to(DEV).to(torch.bfloat16).contiguous() for w in ws]
+    dbs, dps = [x.to(DEV) for x in bs], [x.to(DEV) for x in poss]
+    dsel, dglob = sel.to(DEV), None if glob is None else glob.to(DEV)
+    tok, rows = ops.patch_embed_fwd(dsrcs, w16, dbs, dps, offs, dsel, dglob, B, n_sel, G, D, Ktot)
+    assert torch.equal(rows.float().cpu(), rows_ref)
+    scale = ref[:, :n_sel].abs().max()
+    assert float((tok.double().cpu() - ref).abs().max() / scale) < 2e-6
+    if G:
+        assert torch.equal(tok[:, n_sel:].cpu(), glob.expand(B, G, D))
+    tok2, none = ops.patch_embed_fwd(dsrcs, w16, dbs, dps, offs, dsel, dglob, B, n_sel, G, D, Ktot, want_rows=False)
+    assert none is None and torch.equal(tok2, tok)                                               # deterministic, with or without the side rows
+
+    # (b) the three-pass path on the same operands
+    rows3 = ops.patch_rows(dsrcs, offs, dsel, B, n_sel, Ktot, torch.bfloat16)
+    assert torch.equal(rows3, rows)
+    proj = torch.empty((B * n_sel, D), device=DEV, dtype=torch.float32)
+    for i, (s, w) in enumerate(zip(srcs, w16)):
+        ops.gemm(rows3, w, proj, B * n_sel, D, w.shape[1], lda=Ktot, ldb=w.shape[1], ldc=D, a_off=s['k_off'], accumulate=(i > 0))
+    tok3 = ops.tokens_assemble(proj, dbs, dps, offs, dsel, dglob, B, n_sel, G, D)
+    assert float((tok3 - tok).abs().max() / scale) < 2e-6
+
+
 @pytest.mark.parametrize('geom', [(3, 5, 4, 6, 2, 4), (2, 3, 3, 5, 16, 16), (2, 133, 2, 3, 4, 4), (3, 2, 4, 6, 3, 2)])
 def test_patchify_roundtrip_and_layout(geom):
     """'b (nh nw) (c ph pw) <-> b c (nh ph) (nw pw)' (output_adapters.py:277-280): the vectorised pw % 4 == 0 kernels and the
