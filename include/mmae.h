@@ -145,6 +145,15 @@ int mmae_gemm_duo_occupancy(int tile);
 int64_t mmae_mx_scale_bytes(int rows, int cols);
 int mmae_mx_quant(const void* x, int x_dtype, int64_t ldx, int rows, int cols, void* q, int64_t ldq, void* scales, void* stream);
 int mmae_mx_quant_t(const void* w, int w_dtype, int64_t ldw, int n, int k, void* q, int64_t ldq, void* scales, void* stream);
+/* activation [M][C] (bf16, row stride ldx) -> q [C][ldq] e4m3 with the blocks along M (+ scales for C rows, ldq cols; rows M .. ldq - 1
+ * are zeros): an operand of the weight-gradient product dW[n][k] = sum_m dy[m][n] x[m][k], whose contraction runs over the rows.
+ * C % 64 == 0, ldq % 256 == 0, ldq >= M.  With both operands quantised this way mmae_gemm (MMAE_MXFP8, split_k > 1 + workspace:
+ * slices of whole 256-row scale groups write dense f32 slabs that are summed in a fixed order) computes dW on the scaled MFMA. */
+int mmae_mx_quant_rows_t(const void* x, int x_dtype, int64_t ldx, int M, int C, void* q, int64_t ldq, void* scales, void* stream);
+/* Process-wide policy for the encoder stack's weight gradients in MX-fp8 mode (mmae_stack_bwd with mx_w set): 1 = the four dW
+ * products of a block run on the scaled MFMA from row-blocked quantised copies of dy and x (scratch carved from ws_side),
+ * 0 = they stay bf16 (grouped launch).  Default 1.  Returns the previous value; on < 0 only queries. */
+int mmae_mx_wgrad(int on);
 /* zero a packed scale array (only needed by producers that write the blocks of a width that is not a multiple of 256) */
 int mmae_mx_scale_clear(void* scales, int rows, int cols, void* stream);
 /* nn.LayerNorm forward (mmae_layernorm_fwd, bf16 y) that also emits the MX-fp8 quantisation of y -- bit-identical to

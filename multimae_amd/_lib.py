@@ -170,6 +170,8 @@ def load() -> ctypes.CDLL:
     for which, cls in enumerate((GemmDesc, BlockDesc, StackDesc, AdapterDesc, OptDesc, PatchSrc, DwGroupDesc)):
         if lib.mmae_struct_size(which) != ctypes.sizeof(cls):
             raise RuntimeError(f'{cls.__name__}: ctypes mirror ({ctypes.sizeof(cls)} B) != library struct ({lib.mmae_struct_size(which)} B)')
+    if os.environ.get('MMAE_MX_WGRAD') is not None:      # A/B: bf16 (0) or MX-fp8 (1) weight gradients in MX-fp8 mode (ops.mx_wgrad)
+        lib.mmae_mx_wgrad(int(os.environ['MMAE_MX_WGRAD'] != '0'))
     _lib = lib
     return lib
 

@@ -8,6 +8,7 @@
 // step is ~40 library calls.
 #include <math.h>
 #include <stdlib.h>
+#include <atomic>
 #include <mutex>
 #include "gemm_common.h"
 
@@ -241,6 +242,46 @@ struct DwGroup {
         return rc;
     }
 };
+
+// MX-fp8 weight gradient of one Linear (BASELINE.json configs[4]): dw[n][k] (+)= sum_m dy[m][n] x[m][k] on the scaled MFMA.  Both operands
+// are re-quantised with their 32-element blocks along m (mmae_mx_quant_rows_t: e4m3 [n][Mp] and [k][Mp], Mp = m rounded up to 256, zero
+// rows past m), the product is the k-contiguous MX GEMM with the contraction split into slices of whole scale groups.  Scratch = the
+// tail of ws_side behind the f32 slabs.  Returns MMAE_ESUPPORT-free: false when the shape is outside the path (caller falls back to bf16).
+std::atomic<int> g_mx_wgrad{1};
+bool mx_lin_dw(const Ctx& c, const void* dy, int64_t ldy, const void* x, int64_t ldx, float* dw, int M, int n_out, int k_in, hipStream_t st, int* rc) {
+    *rc = 0;
+    if (!g_mx_wgrad.load(std::memory_order_relaxed) || c.act_dtype != MMAE_BF16 || !dw || (n_out % 64) || (k_in % 64) || (ldy % 8) || (ldx % 8) || M <= 256) return false;
+    const int64_t Mp = ((int64_t)M + 255) / 256 * 256;
+    const int groups = (int)(Mp / 256);
+    const int64_t tiles = (int64_t)((n_out + 255) / 256) * ((k_in + 255) / 256);
+    int split = (int)(256 / tiles);                                       // one workgroup per CU
+    if (split > groups / 2) split = groups / 2;                           // two scale groups (8 K tiles) per slice ...
+    if (split < 2) split = 2;                                             // ... or one each for 257 .. 1024 rows: the slabs + reduce carry the accumulate
+    if (split > groups) return false;
+    const int64_t slab = (int64_t)split * n_out * k_in;                    // f32 elements
+    const int64_t qa = (int64_t)n_out * Mp, qb = (int64_t)k_in * Mp;
+    const int64_t sa = mmae_mx_scale_bytes(n_out, (int)Mp), sb = mmae_mx_scale_bytes(k_in, (int)Mp);
+    const int64_t need = slab * 4 + ((qa + 255) / 256 + (qb + 255) / 256 + (sa + 255) / 256 + (sb + 255) / 256) * 256;
+    if (need > c.ws_side_elems * 4) return false;
+    char* base = (char*)c.ws_side + slab * 4;
+    unsigned char* a_q = (unsigned char*)base; base += (qa + 255) / 256 * 256;
+    unsigned char* b_q = (unsigned char*)base; base += (qb + 255) / 256 * 256;
+    unsigned char* a_s = (unsigned char*)base; base += (sa + 255) / 256 * 256;
+    unsigned char* b_s = (unsigned char*)base;
+    if ((*rc = mmae_mx_quant_rows_t(dy, MMAE_BF16, ldy, M, n_out, a_q, Mp, a_s, st))) return true;
+    if ((*rc = mmae_mx_quant_rows_t(x, MMAE_BF16, ldx, M, k_in, b_q, Mp, b_s, st))) return true;
+    mmae_gemm_desc g = {};
+    g.A = a_q; g.B = b_q; g.C = dw;
+    g.a_scale = a_s; g.b_scale = b_s;
+    g.ab_dtype = MMAE_MXFP8; g.c_dtype = MMAE_F32;
+    g.M = n_out; g.N = k_in; g.K = (int)Mp;
+    g.lda = Mp; g.ldb = Mp; g.ldc = k_in;
+    g.batch = g.batch_inner = 1;
+    g.accumulate = c.grad_acc; g.alpha = 1.0f;
+    g.split_k = split; g.ws = c.ws_side; g.ws_elems = slab;
+    *rc = mmae_gemm(&g, st);
+    return true;
+}
 
 // column sums of part [rows][nseg * seg_w] scattered into up to 8 gradient destinations (NULL = dropped)
 int scatter(const Ctx& c, const float* part, int rows, int seg_w, float* const* dsts, int nseg, hipStream_t st) {
@@ -500,6 +541,12 @@ int mmae_block_fwd(const mmae_block_desc* d, void* stream) {
     return lin_fwd(c, d->hact, d->fc2_w, d->fc2_b, d->x2, MMAE_F32, R, D, Hd, d->x1, nullptr, MMAE_EPI_NONE, st, mx ? mx + 12 : nullptr, hq);
 }
 
+int mmae_mx_wgrad(int on) {
+    const int prev = g_mx_wgrad.load(std::memory_order_relaxed);
+    if (on >= 0) g_mx_wgrad.store(on ? 1 : 0, std::memory_order_relaxed);
+    return prev;
+}
+
 int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
     int rc = check_desc(d);
     if (rc) return rc;
@@ -526,15 +573,24 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
     const void* const* mx = (d->mx_w && act == MMAE_BF16) ? d->mx_w : nullptr;
     DwGroup grp(c, R);                                               // the block's four weight gradients: one launch at the end
     if (d->dp1 || d->dp2) grp.on = false;                           // stochastic depth re-uses dxs_act between the two branches
+    // one weight gradient (+ bias gradient): MX-fp8 product in MX mode where the shape allows, else the grouped bf16 launch, else its own
+    auto wgrad = [&](const void* dy, int64_t ldy, const void* x, int64_t ldx, float* dw, float* db, int n_out, int k_in) -> int {
+        int r = 0;
+        if (mx && mx_lin_dw(c, dy, ldy, x, ldx, dw, R, n_out, k_in, sd, &r)) {
+            if (r || !db) return r;
+            if (mmae_colsum_ws_elems(R, n_out) > c.ws_side_elems) { mmae_set_error("composite: ws_side too small"); return MMAE_EINVAL; }
+            return mmae_colsum(dy, c.act_dtype, R, n_out, ldy, db, c.grad_acc, c.ws_side, sd);
+        }
+        if (grp.add(dy, ldy, x, ldx, dw, db, n_out, k_in)) return 0;
+        return lin_dw(c, dy, ldy, x, dw, db, R, n_out, k_in, sd);
+    };
     static const bool mx_fuse = (mmae_env_int("MMAE_MX_FUSE", 1) != 0);
     const int hq = (mx && mx_fuse) ? 1 : -1;                 // fc2's dX epilogue leaves the quantised d_hpre in half 1 for fc1's dX
     if ((rc = lin_dx(c, dm_act, D, d->fc2_w, d->d_hpre, act, R, D, Hd, d->hpre, MMAE_EPI_DGELU, part_h, st, mx ? mx + 12 : nullptr, -1, hq))) return rc;
     if ((rc = fork_to(st, sd))) return rc;                          // dx_act, d_hpre ready for the weight-gradient stream
-    if (!grp.add(dm_act, D, d->hact, Hd, d->g_fc2_w, d->fc2_b_done ? nullptr : d->g_fc2_b, D, Hd) &&
-        (rc = lin_dw(c, dm_act, D, d->hact, d->g_fc2_w, d->fc2_b_done ? nullptr : d->g_fc2_b, R, D, Hd, sd))) return rc;
+    if ((rc = wgrad(dm_act, D, d->hact, Hd, d->g_fc2_w, d->fc2_b_done ? nullptr : d->g_fc2_b, D, Hd))) return rc;
     if ((rc = lin_dx(c, d->d_hpre, Hd, d->fc1_w, d->d_ln2, act, R, Hd, D, nullptr, MMAE_EPI_NONE, nullptr, st, mx ? mx + 8 : nullptr, hq))) return rc;
-    if (!grp.add(d->d_hpre, Hd, d->ln2, D, d->g_fc1_w, nullptr, Hd, D) &&
-        (rc = lin_dw(c, d->d_hpre, Hd, d->ln2, d->g_fc1_w, nullptr, R, Hd, D, sd))) return rc;
+    if ((rc = wgrad(d->d_hpre, Hd, d->ln2, D, d->g_fc1_w, nullptr, Hd, D))) return rc;
     if (part_h) {
         float* dst[1] = {d->g_fc1_b};
         if ((rc = scatter(c, part_h, hrows, Hd, dst, 1, sd))) return rc;
@@ -552,8 +608,7 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
     if ((rc = fork_to(st, sd))) return rc;                          // part2, dx1_act
     // proj's bias gradient: colsum(dx1) from the LayerNorm partials, or colsum of the rescaled copy under stochastic depth
     if ((rc = scatter3(c, d->part2, nblk, D, d->g_n2_w, d->g_n2_b, d->dp1 ? nullptr : d->g_proj_b, sd))) return rc;
-    if (!grp.add(da_act, D, d->ao, D, d->g_proj_w, d->dp1 ? d->g_proj_b : nullptr, D, D) &&
-        (rc = lin_dw(c, da_act, D, d->ao, d->g_proj_w, d->dp1 ? d->g_proj_b : nullptr, R, D, D, sd))) return rc;
+    if ((rc = wgrad(da_act, D, d->ao, D, d->g_proj_w, d->dp1 ? d->g_proj_b : nullptr, D, D))) return rc;
     {
         const size_t es = act == MMAE_BF16 ? 2 : 4;
         const char* qkv = (const char*)d->qkv;
@@ -572,8 +627,7 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
     }
     if ((rc = lin_dx(c, d->d_qkv, 3 * D, d->qkv_w, d->d_ln1, act, R, 3 * D, D, nullptr, MMAE_EPI_NONE, nullptr, st, mx, hq >= 0 ? 0 : -1))) return rc;
     if ((rc = fork_to(st, sd))) return rc;                          // d_qkv
-    if (!grp.add(d->d_qkv, 3 * D, d->ln1, D, d->g_qkv_w, d->g_qkv_b, 3 * D, D) &&
-        (rc = lin_dw(c, d->d_qkv, 3 * D, d->ln1, d->g_qkv_w, d->g_qkv_b, R, 3 * D, D, sd))) return rc;
+    if ((rc = wgrad(d->d_qkv, 3 * D, d->ln1, D, d->g_qkv_w, d->g_qkv_b, 3 * D, D))) return rc;
     if ((rc = grp.flush(c, sd))) return rc;
     void* dx0_act = act == MMAE_F32 ? nullptr : d->dx0_act;
     if ((rc = mmae_layernorm_bwd(d->d_ln1, act, d->x0, d->n1_w, d->mean1, d->rstd1, d->dx1, d->dx0, dx0_act, act, d->part1, R, D, st))) return rc;

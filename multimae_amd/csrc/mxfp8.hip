@@ -96,6 +96,38 @@ __global__ void __launch_bounds__(256) mx_quant_t_kernel(const T* __restrict__ w
     }
 }
 
+// activation [M][C] (bf16) -> e4m3 [C][Mp], blocks of 32 along M (the contraction of the weight-gradient products dW = dY^T X), rows
+// past M are zeros.  One workgroup per 128 x 64 tile: whole 128-byte lines in (8 lanes per row), a transposing pass through LDS
+// (the column of a piece is rotated by 16 per 32-row block so the four blocks a wave reads sit in different banks), whole
+// 128-byte lines out (four lanes write the four 32-byte blocks of one output row).
+__global__ void __launch_bounds__(256) mx_quant_rows_t_kernel(const uint16_t* __restrict__ x, long long ldx, int M, int C, unsigned char* __restrict__ q,
+                                                              long long ldq, unsigned char* __restrict__ sc) {
+    __shared__ __attribute__((aligned(16))) uint16_t tile[128][72];
+    const int m0 = blockIdx.x * 128, c0 = blockIdx.y * 64, tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = p * 32 + (tid >> 3), cc = (tid & 7) * 8;
+        i32x4 v = {0, 0, 0, 0};
+        if (m0 + r < M) v = *reinterpret_cast<const i32x4*>(x + (long long)(m0 + r) * ldx + c0 + cc);
+        *reinterpret_cast<i32x4*>(&tile[r][(cc + 16 * p) & 63]) = v;
+    }
+    __syncthreads();
+    const int c = tid >> 2, blk = tid & 3;
+    float v[32];
+    float am = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { v[i] = bf16_bits_to_f32(tile[blk * 32 + i][(c + 16 * blk) & 63]); am = fmaxf(am, fabsf(v[i])); }
+    const int e = mx_shared_exp(am);
+    const float inv = mx_inv_scale(e);
+    int o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = cvt4_e4m3(v[4 * i] * inv, v[4 * i + 1] * inv, v[4 * i + 2] * inv, v[4 * i + 3] * inv);
+    i32x4* dst = reinterpret_cast<i32x4*>(q + (long long)(c0 + c) * ldq + m0 + blk * 32);
+    dst[0] = i32x4{o[0], o[1], o[2], o[3]};
+    dst[1] = i32x4{o[4], o[5], o[6], o[7]};
+    sc[mx_scale_addr(C, c0 + c, (m0 >> 5) + blk)] = (unsigned char)e;
+}
+
 // up to 32 weights per launch (blockIdx.y = weight): the per-step refresh of a ViT-L encoder is 6 launches instead of 192
 struct MxWeightTab { const void* w[32]; unsigned char* q[32]; unsigned char* s[32]; int n[32]; int k[32]; };
 
@@ -228,15 +260,26 @@ __global__ void __launch_bounds__(512) gemm_mxfp8_kernel(const GemmArgs g) {
     char* Cz = (char*)g.C;
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Az, 0, 0x80000000, 0x00020000);
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bz, 0, 0x80000000, 0x00020000);
-    const int T = g.K >> 6;                              // K tiles of 64 elements; the host guarantees K % 256 == 0
-    const int groups = T >> 2;
+    // K tiles of 64 elements; the host guarantees K % 256 == 0.  Split-K (the weight-gradient products: few output tiles, the whole
+    // batch as contraction): virtual tile v = (slice, output tile); a slice covers kt_per_split K tiles (a multiple of 4, i.e. whole
+    // scale groups) and writes its own dense f32 slab of the workspace, summed afterwards in a fixed order (mmae_splitk_reduce).
+    const int T_all = g.K >> 6;
+    const int groups = T_all >> 2;
+    const int Tper = g.splitk > 1 ? g.kt_per_split : T_all;
+    int T = T_all, gb = 0;                               // this virtual tile's K tiles and first scale group
+    long long c_off = 0;                                 // ... and the byte offset of its slab
     const auto rsSA = __builtin_amdgcn_make_buffer_rsrc((void*)sgpr_ptr((const unsigned*)g.scA), 0, (int)((long long)groups * g.M * 8), 0x00020000);
     const auto rsSB = __builtin_amdgcn_make_buffer_rsrc((void*)sgpr_ptr((const unsigned*)g.scB), 0, (int)((long long)groups * g.N * 8), 0x00020000);
 
     unsigned a_cur[LA], b_cur[LB];
     unsigned sa_off[TM], sb_off[2];                      // byte offset of this lane's scale dword in group 0
     int m0 = 0, n0 = 0;
-    auto set_tile = [&](int v, int& tm0, int& tn0) {
+    auto set_tile = [&](int vv, int& tm0, int& tn0) {
+        const int sk = __builtin_amdgcn_readfirstlane(vv / g.tiles_total), v = vv - sk * g.tiles_total;
+        const unsigned k0 = (unsigned)(sk * Tper) * 64u;
+        T = T_all - sk * Tper < Tper ? T_all - sk * Tper : Tper;
+        gb = (sk * Tper) >> 2;
+        c_off = (long long)sk * g.M * g.N * 4;
         const int tile = g.xcd_swizzle ? xcd_tile(v, g.tiles_total) : v;
         const int tile_m = __builtin_amdgcn_readfirstlane(tile / g.tiles_n);
         tm0 = tile_m * BM; tn0 = (tile - tile_m * g.tiles_n) * BN;
@@ -245,14 +288,14 @@ __global__ void __launch_bounds__(512) gemm_mxfp8_kernel(const GemmArgs g) {
             const int seg = i * NW + wave;
             const int b_abs = 4 * seg + (lane >> 4), j = (lane & 15) ^ (b_abs & 15);
             const int row = 4 * b_abs + (j >> 2), c = j & 3;
-            a_cur[i] = (seg < PA && tm0 + row < g.M) ? (unsigned)(((long long)(tm0 + row)) * g.lda + c * 16) : OOB;
+            a_cur[i] = (seg < PA && tm0 + row < g.M) ? (unsigned)(((long long)(tm0 + row)) * g.lda + c * 16) + k0 : OOB;
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             const int seg = i * NW + wave;
             const int b_abs = 4 * seg + (lane >> 4), j = (lane & 15) ^ (b_abs & 15);
             const int row = 4 * b_abs + (j >> 2), c = j & 3;
-            b_cur[i] = (tn0 + row < g.N) ? (unsigned)(((long long)(tn0 + row)) * g.ldb + c * 16) : OOB;
+            b_cur[i] = (tn0 + row < g.N) ? (unsigned)(((long long)(tn0 + row)) * g.ldb + c * 16) + k0 : OOB;
         }
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
@@ -305,6 +348,7 @@ __global__ void __launch_bounds__(512) gemm_mxfp8_kernel(const GemmArgs g) {
     i32x8 af[H0], bf[2];
     int sa[TM], sb[2], sa_n[TM], sb_n[2];
     auto load_scales = [&](int grp, int (&da)[TM], int (&db)[2]) {
+        grp += gb;
         grp = grp < groups ? grp : groups - 1;                           // past the last group: any valid dwords (never used)
         const int go_a = grp * g.M * 8, go_b = grp * g.N * 8;            // wave-uniform group offset (soffset)
 #pragma unroll
@@ -357,9 +401,11 @@ __global__ void __launch_bounds__(512) gemm_mxfp8_kernel(const GemmArgs g) {
 
     char* stage = smem + 2 * STAGE + wave * 8192;
     static_assert(2 * STAGE >= 8 * 8192, "staging must fit in ring slots 2-3");
-    for (int v = blockIdx.x; v < g.tiles_total; v += gridDim.x) {
+    const int n_virtual = g.tiles_total * (g.splitk > 1 ? g.splitk : 1);
+    for (int v = blockIdx.x; v < n_virtual; v += gridDim.x) {
         asm volatile("" : "+v"(lane));
         derive();
+        char* Cv = Cz + c_off;                           // (set_tile below moves c_off on to the next virtual tile)
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -421,7 +467,7 @@ __global__ void __launch_bounds__(512) gemm_mxfp8_kernel(const GemmArgs g) {
         __syncthreads();
 
         const int mw = m0 + wm * WMR, nw = n0 + wn * 64;
-        const bool has_next = v + (int)gridDim.x < g.tiles_total;
+        const bool has_next = v + (int)gridDim.x < n_virtual;
         if (has_next) {
             asm volatile("" : "+v"(lane));
             set_tile(v + gridDim.x, m0, n0);
@@ -431,15 +477,15 @@ __global__ void __launch_bounds__(512) gemm_mxfp8_kernel(const GemmArgs g) {
         }
         {
             f32x16 sub[2][2] = {{acc[0][0], acc[0][1]}, {acc[1][0], acc[1][1]}};
-            gemm_store_tile64_fl<FL>(g, Cz, stage, lane, sub, mw, nw);
+            gemm_store_tile64_fl<FL>(g, Cv, stage, lane, sub, mw, nw);
         }
         {
             f32x16 sub[2][2] = {{acc[0][2], acc[0][3]}, {acc[1][2], acc[1][3]}};
-            gemm_store_tile64_fl<FL>(g, Cz, stage, lane, sub, mw + 64, nw);
+            gemm_store_tile64_fl<FL>(g, Cv, stage, lane, sub, mw + 64, nw);
         }
         if (TM & 1) {
             f32x16 sub[2][2] = {{acc[0][TM - 1], acc[0][TM - 1]}, {acc[1][TM - 1], acc[1][TM - 1]}};
-            gemm_store_tile64_fl<FL>(g, Cz, stage, lane, sub, mw + (TM - 1) * 32, nw, 1);
+            gemm_store_tile64_fl<FL>(g, Cv, stage, lane, sub, mw + (TM - 1) * 32, nw, 1);
         }
         if (has_next) {
             wait_vm<0>();
@@ -455,9 +501,10 @@ int launch_mx(const GemmArgs& g, hipStream_t st) {
     GemmArgs a = g;
     a.tiles_n = (g.N + BN - 1) / BN;
     a.tiles_total = ((g.M + BM - 1) / BM) * a.tiles_n;
-    a.splitk = 1;
+    if (a.splitk > 1) { a.C = a.ws; a.ldc = a.N; a.accumulate = 0; }      // slices write dense f32 slabs [splitk][M][N]
     const int n_cu = mmae_cu_count();
-    const int gx = a.tiles_total > n_cu ? n_cu : a.tiles_total;
+    const long long nv = (long long)a.tiles_total * (a.splitk > 1 ? a.splitk : 1);
+    const int gx = nv > n_cu ? n_cu : (int)nv;
     const size_t lds = (size_t)4 * (BM + BN) * 64 + 1024;
     static std::once_flag attr_once;
     std::call_once(attr_once, [&] {
@@ -491,12 +538,14 @@ int launch_mx_fl(const GemmArgs& g, int fl, hipStream_t st) {
 int mmae_gemm_mxfp8_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st) {
     MMAE_REQUIRE(d->a_scale && d->b_scale, "gemm(mxfp8): operands need their scale arrays");
     MMAE_REQUIRE(!d->a_trans && !d->b_trans, "gemm(mxfp8): both operands must be k-contiguous (quantise the transposed copy)");
-    MMAE_REQUIRE(d->batch == 1 && d->split_k <= 1, "gemm(mxfp8): unbatched, unsplit products only");
+    MMAE_REQUIRE(d->batch == 1, "gemm(mxfp8): unbatched products only");
+    MMAE_REQUIRE(g.splitk <= 1 || (g.kt_per_split % 4 == 0 && g.ws && !d->q_out && (long long)g.splitk * d->M * d->N * 4 < 0x7fffffffLL * 4LL),
+                 "gemm(mxfp8): split_k slices must be whole scale groups and need the workspace");
     MMAE_REQUIRE(d->K % 256 == 0, "gemm(mxfp8): K must be a multiple of 256 (four 64-element K tiles per scale dword)");
     MMAE_REQUIRE(d->lda % 16 == 0 && d->ldb % 16 == 0 && (uintptr_t)d->A % 16 == 0 && (uintptr_t)d->B % 16 == 0, "gemm(mxfp8): operand rows must be 16-byte aligned");
     MMAE_REQUIRE((long long)d->M * d->lda < 0x7fffffffLL && (long long)d->N * d->ldb < 0x7fffffffLL, "gemm(mxfp8): operand larger than a 2 GiB buffer window");
     MMAE_REQUIRE((long long)(d->K / 256) * d->M * 8 < 0x7fffffffLL && (long long)(d->K / 256) * d->N * 8 < 0x7fffffffLL, "gemm(mxfp8): scale array too large");
-    int fl = gemm_flavour(g, d->batch);
+    int fl = g.splitk > 1 ? (int)FL_F32 : gemm_flavour(g, d->batch);      // split-K slices: plain dense f32 slabs
     if (d->q_out) {                                       // fused quantisation of the output for the next MX product
         MMAE_REQUIRE(d->q_scale && d->N % 32 == 0 && d->ldq % 8 == 0 && (uintptr_t)d->q_out % 8 == 0, "gemm(mxfp8): q_out needs q_scale, N % 32 == 0 and 8-byte aligned rows");
         fl = fl == FL_BF16_BIAS_GELU ? FL_BF16_BIAS_GELU_Q : fl == FL_BF16_DGELU_CS ? FL_BF16_DGELU_CS_Q : fl == FL_BF16_DGELU ? FL_BF16_DGELU_Q : -1;
@@ -549,6 +598,16 @@ int mmae_mx_quant_t(const void* w, int w_dtype, int64_t ldw, int n, int k, void*
     else
         hipLaunchKernelGGL(mx_quant_t_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)w, (long long)ldw, n, k, (unsigned char*)q, (long long)ldq, (unsigned char*)scales);
     return mmae_check_launch("mx_quant_t");
+}
+
+int mmae_mx_quant_rows_t(const void* x, int x_dtype, int64_t ldx, int M, int C, void* q, int64_t ldq, void* scales, void* stream) {
+    MMAE_REQUIRE(x && q && scales && M > 0 && C > 0, "mx_quant_rows_t: bad argument");
+    MMAE_REQUIRE(x_dtype == MMAE_BF16, "mx_quant_rows_t: bf16 activations only");
+    MMAE_REQUIRE(C % 64 == 0 && ldx % 8 == 0 && (uintptr_t)x % 16 == 0 && ldq % 256 == 0 && ldq >= M && (uintptr_t)q % 16 == 0,
+                 "mx_quant_rows_t: C % 64, 16-byte aligned rows, ldq a multiple of 256 >= M");
+    hipLaunchKernelGGL(mx_quant_rows_t_kernel, dim3((unsigned)(ldq / 128), (unsigned)(C / 64)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+                       (long long)ldx, M, C, (unsigned char*)q, (long long)ldq, (unsigned char*)scales);
+    return mmae_check_launch("mx_quant_rows_t");
 }
 
 int mmae_mx_scale_clear(void* scales, int rows, int cols, void* stream) {

@@ -230,9 +230,14 @@ int mmae_gemm_ex(const mmae_gemm_desc* d, void* stream, int timing_cls, double f
         g.acs = (float*)d->ws + slab;
     }
     if (d->ab_dtype == MMAE_MXFP8) {
-        MMAE_REQUIRE(splitk == 1 && !d->a_colsum, "gemm(mxfp8): no split_k / a_colsum");
-        g.splitk = 1;
-        return mmae_gemm_mxfp8_impl(d, g, st);
+        MMAE_REQUIRE(!d->a_colsum, "gemm(mxfp8): no a_colsum");
+        if (splitk > 1) {                                   // slices of whole scale groups (four K tiles)
+            g.kt_per_split = (g.kt_per_split + 3) / 4 * 4;
+            g.splitk = (nkt + g.kt_per_split - 1) / g.kt_per_split;
+        }
+        const int rc = mmae_gemm_mxfp8_impl(d, g, st);
+        if (rc || g.splitk <= 1) return rc;
+        return mmae_splitk_reduce(g.ws, (float*)d->C, d->M, d->N, d->ldc, g.splitk, d->accumulate, st);
     }
     int rc = (d->ab_dtype == MMAE_BF16) ? mmae_gemm_bf16_impl(d, g, code, st)
            : (d->ab_dtype == MMAE_F32X3 ? mmae_gemm_f32x3_impl(d, g, st) : mmae_gemm_f32_impl(d, g, st));

@@ -181,9 +181,28 @@ def mx_quant_t(w: Tensor, out: Optional[MxTensor] = None) -> MxTensor:
     return out
 
 
+def mx_quant_rows_t(x: Tensor) -> MxTensor:
+    """x [M, C] bf16 -> MX-fp8 of x^T: bytes [C, Mp] (Mp = M rounded up to 256, zero rows past M), blocks along M -- an operand of a
+    weight-gradient product, whose contraction runs over the rows (mmae_mx_quant_rows_t)."""
+    _require_gpu(x, 'mx_quant_rows_t input')
+    M, C = x.shape
+    Mp = round_up(M, 256)
+    out = MxTensor(torch.empty((C, Mp), device=x.device, dtype=torch.uint8),
+                   torch.empty((mx_scale_bytes(C, Mp),), device=x.device, dtype=torch.uint8), C, Mp)
+    check(_lib.load().mmae_mx_quant_rows_t(x.data_ptr(), dcode(x.dtype), x.stride(0), M, C, out.q.data_ptr(), Mp, out.scales.data_ptr(),
+                                           _stream()), 'mmae_mx_quant_rows_t')
+    return out
+
+
+def mx_wgrad(on: Optional[bool] = None) -> bool:
+    """Policy of the encoder stack's weight gradients in MX-fp8 mode: True = on the scaled MFMA from row-blocked quantised copies of dy
+    and x, False = bf16 (grouped launch).  Sets it when `on` is given; returns the previous value."""
+    return bool(_lib.load().mmae_mx_wgrad(-1 if on is None else int(bool(on))))
+
+
 def gemm_mx(a: MxTensor, b: MxTensor, C: Tensor, *, bias: Optional[Tensor] = None, resid: Optional[Tensor] = None,
             aux: Optional[Tensor] = None, epi: int = EPI_NONE, colsum_part: Optional[Tensor] = None,
-            q_out: Optional[MxTensor] = None) -> Tensor:
+            q_out: Optional[MxTensor] = None, split_k: int = 1, accumulate: bool = False) -> Tensor:
     """C[M, N] = a[M, K] . b[N, K]^T on the block-scaled MFMA, with the fused epilogues of mmae_gemm.
     q_out (GELU / dGELU epilogues, bf16 C): also receives the MX-fp8 quantisation of C."""
     assert a.cols == b.cols, (a.cols, b.cols)
@@ -199,7 +218,11 @@ def gemm_mx(a: MxTensor, b: MxTensor, C: Tensor, *, bias: Optional[Tensor] = Non
     d.resid, d.ldr = _p(resid), N
     d.aux, d.ldaux = _p(aux), N
     d.aux_dtype = dcode(aux.dtype) if aux is not None else F32
-    d.epi, d.alpha, d.split_k = epi, 1.0, 1
+    d.epi, d.alpha, d.split_k = epi, 1.0, split_k
+    d.accumulate = int(accumulate)
+    if split_k > 1:                                       # slices of whole 256-element scale groups write f32 slabs, summed in a fixed order
+        ws = stream_workspace(_stream(), C.device, max(_WS_ELEMS[0], split_k * M * N))
+        d.ws, d.ws_elems = ws.data_ptr(), ws.numel()
     d.colsum_part = _p(colsum_part)
     if q_out is not None:
         assert q_out.rows == M and q_out.cols == N

@@ -78,6 +78,57 @@ def test_mx_quant_t_bit_exact_vs_oracle():
     assert np.array_equal(q.scales.cpu().numpy(), mx.pack_scales(e_ref))
 
 
+@pytest.mark.parametrize('shape', [(300, 64), (1000, 192), (12672, 1024)])
+def test_mx_quant_rows_t_bit_exact_vs_oracle(shape):
+    """activation [M, C] -> e4m3 [C, Mp] with the blocks along M (the operands of the weight-gradient products): bit-exact against the
+    MX emulation applied to the zero-padded transpose, and against mmae_mx_quant of that transpose."""
+    M, C = shape
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(shape, generator=g) * torch.exp2(torch.randint(-20, 12, (M // 4 + 1, C), generator=g).float()).repeat_interleave(4, 0)[:M]
+    x[:32, 0] = 0.0                                        # an empty block
+    x[32, 1] = 500.0; x[33:64, 1] = 0.25                   # amax mantissa > 1.75
+    x = x.bfloat16()
+    q = ops.mx_quant_rows_t(x.to(DEV))
+    Mp = (M + 255) // 256 * 256
+    xt = torch.zeros(C, Mp, dtype=torch.bfloat16)
+    xt[:, :M] = x.T
+    assert q.q.shape == (C, Mp)
+    if M <= 1000:
+        q_ref, e_ref = mx.mx_quantize(xt.float().numpy())
+        assert np.array_equal(q.q.cpu().numpy(), q_ref)
+        assert np.array_equal(q.scales.cpu().numpy(), mx.pack_scales(e_ref))
+    q2 = ops.mx_quant(xt.to(DEV).contiguous())
+    assert torch.equal(q.q, q2.q) and torch.equal(q.scales, q2.scales)
+
+
+@pytest.mark.parametrize('N,K,M,split', [(256, 256, 2048, 4), (1024, 768, 12672, 5), (320, 512, 1500, 3)])
+def test_mx_weight_gradient_product_split_k_vs_emulation(N, K, M, split):
+    """dW[n][k] = sum_m dy[m][n] x[m][k] on the scaled MFMA: both operands quantised along m, contraction split into slices of whole scale
+    groups, slabs summed in a fixed order.  Against the MX emulation of the same product (f64 accumulate) to f32-accumulation accuracy;
+    accumulate=True adds onto an existing gradient; the unsplit product of the same operands agrees to summation-order accuracy."""
+    g = torch.Generator().manual_seed(N + M)
+    dy = (torch.randn(M, N, generator=g) * 0.02).bfloat16()
+    x = torch.randn(M, K, generator=g).bfloat16()
+    a, b = ops.mx_quant_rows_t(dy.to(DEV)), ops.mx_quant_rows_t(x.to(DEV))
+    Mp = a.cols
+    dyt, xt = torch.zeros(N, Mp), torch.zeros(K, Mp)
+    dyt[:, :M], xt[:, :M] = dy.float().T, x.float().T
+    ref = _mx_ref(dyt, xt) if M <= 2048 else None
+    out = torch.full((N, K), 7.0, device=DEV)
+    ops.gemm_mx(a, b, out, split_k=split)
+    one = torch.empty((N, K), device=DEV)
+    ops.gemm_mx(a, b, one)
+    scale = float(one.abs().max())
+    assert float((out - one).abs().max()) < 2e-5 * scale
+    if ref is not None:
+        assert float((out.cpu() - ref).abs().max()) < 2e-5 * scale
+    acc = torch.full((N, K), 0.5, device=DEV)
+    ops.gemm_mx(a, b, acc, split_k=split, accumulate=True)
+    assert float((acc - 0.5 - out).abs().max()) < 2e-6 * scale
+    exact = dy.double().T @ x.double()
+    assert float((out.double().cpu() - exact).norm() / exact.norm()) < 6e-2        # fp8 class: ~2^-4 per element, averaged over the contraction
+
+
 def _mx_ref(a, b):
     return torch.from_numpy(mx.mx_matmul(a.float().numpy(), b.float().numpy()))
 
