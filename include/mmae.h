@@ -62,6 +62,11 @@ const char* mmae_last_error(void);
  *          C = accumulate ? C + v : v.
  *   epi = MMAE_EPI_GELU : aux[m,n] = v (pre-activation, act dtype); v = gelu_erf(v)
  *   epi = MMAE_EPI_DGELU: v *= gelu_erf'(aux[m,n])
+ *   epi = MMAE_EPI_GELU_G: aux[m,n] = gelu_erf'(v) (the DERIVATIVE at the pre-activation, act dtype); v = gelu_erf(v)
+ *   epi = MMAE_EPI_MUL  : v *= aux[m,n]
+ *         -- the same pair with the derivative evaluated once, in the forward epilogue that has the erf terms in registers
+ *            anyway, so that the backward epilogue is a multiply (Mlp.forward / its backward, multimae_utils.py:137-149;
+ *            the composite encoder / decoder calls use this pair for bf16 activations).  Same kernels and restrictions.
  * bf16 operands need lda/ldb % 8 == 0 and 16-byte aligned bases; a k-contiguous
  * operand may have any K as long as the bytes up to the next multiple of 8 along
  * k are readable and finite*0-safe (the engine zero-pads).
@@ -69,6 +74,8 @@ const char* mmae_last_error(void);
 #define MMAE_EPI_NONE  0
 #define MMAE_EPI_GELU  1
 #define MMAE_EPI_DGELU 2
+#define MMAE_EPI_GELU_G 3
+#define MMAE_EPI_MUL   4
 
 typedef struct mmae_gemm_desc {
     const void* A; const void* B; void* C;
@@ -154,6 +161,11 @@ int mmae_mx_quant_rows_t(const void* x, int x_dtype, int64_t ldx, int M, int C, 
  * products of a block run on the scaled MFMA from row-blocked quantised copies of dy and x (scratch carved from ws_side),
  * 0 = they stay bf16 (grouped launch).  Default 1.  Returns the previous value; on < 0 only queries. */
 int mmae_mx_wgrad(int on);
+/* Process-wide policy of the composite encoder / decoder calls with bf16 activations: 1 (default) = the MLP's fc1 epilogue stores
+ * GELU'(pre-activation) (MMAE_EPI_GELU_G) and fc2's dX epilogue multiplies by it (MMAE_EPI_MUL); 0 = it stores the pre-activation and
+ * the backward epilogue re-evaluates the derivative (MMAE_EPI_GELU / MMAE_EPI_DGELU), as autograd does.  Must not change between a
+ * forward call and its backward.  Returns the previous value; on < 0 only queries. */
+int mmae_gelu_grad_aux(int on);
 /* zero a packed scale array (only needed by producers that write the blocks of a width that is not a multiple of 256) */
 int mmae_mx_scale_clear(void* scales, int rows, int cols, void* stream);
 /* nn.LayerNorm forward (mmae_layernorm_fwd, bf16 y) that also emits the MX-fp8 quantisation of y -- bit-identical to

@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get('MMAE_LIB') or os.path.join(_PKG, 'libmmae_hip.so')   
 
 F32, BF16, F32X3 = 0, 1, 2
 MXFP8 = 4
-EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
+EPI_NONE, EPI_GELU, EPI_DGELU, EPI_GELU_G, EPI_MUL = 0, 1, 2, 3, 4
 
 
 class GemmDesc(ctypes.Structure):
@@ -172,6 +172,8 @@ def load() -> ctypes.CDLL:
             raise RuntimeError(f'{cls.__name__}: ctypes mirror ({ctypes.sizeof(cls)} B) != library struct ({lib.mmae_struct_size(which)} B)')
     if os.environ.get('MMAE_MX_WGRAD') is not None:      # A/B: bf16 (0) or MX-fp8 (1) weight gradients in MX-fp8 mode (ops.mx_wgrad)
         lib.mmae_mx_wgrad(int(os.environ['MMAE_MX_WGRAD'] != '0'))
+    if os.environ.get('MMAE_GELU_GRAD_AUX') is not None:  # A/B: the MLP pair with the derivative stored by the forward (1) or re-evaluated (0)
+        lib.mmae_gelu_grad_aux(int(os.environ['MMAE_GELU_GRAD_AUX'] != '0'))
     _lib = lib
     return lib
 

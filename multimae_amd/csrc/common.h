@@ -86,6 +86,7 @@ __device__ __forceinline__ void gelu_cdf_exp(float x, float& cdf, float& e) {
     cdf = x < 0.f ? h : 1.0f - h;
 }
 __device__ __forceinline__ float gelu_erf(float x) { float c, e; gelu_cdf_exp(x, c, e); return x * c; }
+__device__ __forceinline__ void gelu_both(float x, float& y, float& dy) { float c, e; gelu_cdf_exp(x, c, e); y = x * c; dy = c + x * e * 0.39894228040143268f; }
 __device__ __forceinline__ float gelu_erf_grad(float x) { float c, e; gelu_cdf_exp(x, c, e); return c + x * e * 0.39894228040143268f; }
 
 // ---- MX-fp8 quantisation helpers (mxfp8.hip, the ..._Q GEMM epilogue flavours, the LayerNorm kernels) ----------------

@@ -181,6 +181,13 @@ int lin_dx(const Ctx& c, const void* dy, int64_t ldy, const void* w, void* out, 
     return x3p ? mmae_gemm_ex(&g, st, 1, 1.0 / 3.0) : mmae_gemm(&g, st);
 }
 
+// The MLP's activation pair.  bf16 activations: fc1's epilogue stores GELU'(pre-activation) in the `hpre` buffer (it has the erf terms
+// in registers anyway) and fc2-dX's epilogue multiplies by it -- no transcendental work in the backward epilogue, the largest product
+// of a block.  f32 activations (the exact parity mode) keep the pre-activation and re-evaluate, as autograd does.
+std::atomic<int> g_gelu_grad_aux{1};                                 // mmae_gelu_grad_aux(): must not change between a forward and its backward
+inline int epi_gelu(int act) { return (act == MMAE_BF16 && g_gelu_grad_aux.load(std::memory_order_relaxed)) ? MMAE_EPI_GELU_G : MMAE_EPI_GELU; }
+inline int epi_dgelu(int act) { return (act == MMAE_BF16 && g_gelu_grad_aux.load(std::memory_order_relaxed)) ? MMAE_EPI_MUL : MMAE_EPI_DGELU; }
+
 // dw[N,K] (+)= dy[M,N]^T x[M,K]; db[N] (+)= column sums of dy (inside the GEMM where the kernel can) -- ops.linear_dw
 int lin_dw(const Ctx& c, const void* dy, int64_t ldy, const void* x, float* dw, float* db, int M, int N, int K, hipStream_t st) {
     if (!dw && !db) return 0;
@@ -533,12 +540,18 @@ int mmae_block_fwd(const mmae_block_desc* d, void* stream) {
     }
     if ((rc = ln(d->x1, d->n2_w, d->n2_b, d->ln2, d->mean2, d->rstd2))) return rc;
     const int hq = pre < 0 ? -1 : 1;                     // quantised GELU output: half 1
-    if ((rc = lin_fwd(c, d->ln2, d->fc1_w, d->fc1_b, d->hact, act, R, Hd, D, nullptr, d->hpre, MMAE_EPI_GELU, st, mx ? mx + 8 : nullptr, pre, hq))) return rc;
+    if ((rc = lin_fwd(c, d->ln2, d->fc1_w, d->fc1_b, d->hact, act, R, Hd, D, nullptr, d->hpre, epi_gelu(act), st, mx ? mx + 8 : nullptr, pre, hq))) return rc;
     if (d->dp2) {
         if ((rc = lin_fwd(c, d->hact, d->fc2_w, d->fc2_b, d->branch, MMAE_F32, R, D, Hd, nullptr, nullptr, MMAE_EPI_NONE, st, mx ? mx + 12 : nullptr, hq))) return rc;
         return mmae_rowscale_add(d->x1, d->branch, d->dp2, d->x2, R, d->N, D, st);
     }
     return lin_fwd(c, d->hact, d->fc2_w, d->fc2_b, d->x2, MMAE_F32, R, D, Hd, d->x1, nullptr, MMAE_EPI_NONE, st, mx ? mx + 12 : nullptr, hq);
+}
+
+int mmae_gelu_grad_aux(int on) {
+    const int prev = g_gelu_grad_aux.load(std::memory_order_relaxed);
+    if (on >= 0) g_gelu_grad_aux.store(on ? 1 : 0, std::memory_order_relaxed);
+    return prev;
 }
 
 int mmae_mx_wgrad(int on) {
@@ -586,7 +599,7 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
     };
     static const bool mx_fuse = (mmae_env_int("MMAE_MX_FUSE", 1) != 0);
     const int hq = (mx && mx_fuse) ? 1 : -1;                 // fc2's dX epilogue leaves the quantised d_hpre in half 1 for fc1's dX
-    if ((rc = lin_dx(c, dm_act, D, d->fc2_w, d->d_hpre, act, R, D, Hd, d->hpre, MMAE_EPI_DGELU, part_h, st, mx ? mx + 12 : nullptr, -1, hq))) return rc;
+    if ((rc = lin_dx(c, dm_act, D, d->fc2_w, d->d_hpre, act, R, D, Hd, d->hpre, epi_dgelu(act), part_h, st, mx ? mx + 12 : nullptr, -1, hq))) return rc;
     if ((rc = fork_to(st, sd))) return rc;                          // dx_act, d_hpre ready for the weight-gradient stream
     if ((rc = wgrad(dm_act, D, d->hact, Hd, d->g_fc2_w, d->fc2_b_done ? nullptr : d->g_fc2_b, D, Hd))) return rc;
     if ((rc = lin_dx(c, d->d_hpre, Hd, d->fc1_w, d->d_ln2, act, R, Hd, D, nullptr, MMAE_EPI_NONE, nullptr, st, mx ? mx + 8 : nullptr, hq))) return rc;
@@ -906,7 +919,7 @@ int mmae_adapter_fwd(const mmae_adapter_desc* d, void* stream) {
     }
     if ((rc = lin_fwd(c, a.xo, pw, pb, a.x, MMAE_F32, Rq, D, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;                      // :265
     if ((rc = mmae_layernorm_fwd(a.x, onw, onb, a.on, act, a.omean, a.orstd, Rq, D, d->eps, st))) return rc;
-    if ((rc = lin_fwd(c, a.on, f1w, f1b, a.hact, act, Rq, Hd, D, nullptr, a.hpre, MMAE_EPI_GELU, st))) return rc;
+    if ((rc = lin_fwd(c, a.on, f1w, f1b, a.hact, act, Rq, Hd, D, nullptr, a.hpre, epi_gelu(act), st))) return rc;
     if ((rc = lin_fwd(c, a.hact, f2w, f2b, a.x1, MMAE_F32, Rq, D, Hd, a.x, nullptr, MMAE_EPI_NONE, st))) return rc;                    // :266
     const float* h = a.x1;
     for (int l = 0; l < depth; ++l) {                                                                                                // :271
@@ -985,7 +998,7 @@ int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream
         fc2_done = gb[15] != nullptr;
     }
     // ---- x1 = x + mlp(out_norm(x))
-    if ((rc = lin_dx(c, dh_act, D, f2w, t.d_hpre, act, Rq, D, Hd, a.hpre, MMAE_EPI_DGELU, gb[13] ? t.part_h : nullptr, st))) return rc;
+    if ((rc = lin_dx(c, dh_act, D, f2w, t.d_hpre, act, Rq, D, Hd, a.hpre, epi_dgelu(act), gb[13] ? t.part_h : nullptr, st))) return rc;
     if ((rc = fork_to(st, sd))) return rc;
     if (!grp_q.add(dh_act, D, a.hact, Hd, gb[14], fc2_done ? nullptr : gb[15], D, Hd) &&
         (rc = lin_dw(c, dh_act, D, a.hact, gb[14], fc2_done ? nullptr : gb[15], Rq, D, Hd, sd))) return rc;

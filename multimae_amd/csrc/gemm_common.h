@@ -20,6 +20,7 @@ struct GemmArgs {
     float* acs;                   // optional [splitk][M] partial column sums of the k-strided A operand (ping-pong kernel)
     float* colpart;               // optional [ceil(M/32)][N] column sums of the epilogue output per 32-row block (dGELU flavour)
     int wide_st;                  // bf16 epilogues with 8-column (16-byte) lanes (store_tile64_bf16x8); env MMAE_EPI_WIDE=0 turns it off
+    int aux_grad;                 // MMAE_EPI_GELU_G / MMAE_EPI_MUL: aux keeps GELU'(pre-activation) instead of the pre-activation (mmae.h)
     int dephase;                  // experiment (env MMAE_PP_DEPHASE = n): odd workgroups of the ping-pong kernel start n x ~4 us late
     const void* scA; const void* scB;   // MX-fp8 products: packed E8M0 scales of the two operands (mxfp8.hip)
     unsigned char* qout; unsigned char* qsc; long long ldq;   // ..._Q flavours: also emit the MX-fp8 quantisation of the bf16 output C ([M][ldq] bytes + packed scales)
@@ -59,15 +60,16 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, char* Cz, int 
     }
     if (g.epi == MMAE_EPI_GELU) {
         const long long ao = (long long)m * g.ldaux + n;
+        float s4[4];                                     // what aux keeps: the pre-activation, or (aux_grad) GELU' of it
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { float y, dy; gelu_both(v[j], y, dy); s4[j] = g.aux_grad ? dy : v[j]; v[j] = y; }
         if (g.aux_f32) {
             float* a = (float*)g.aux + ao;
-            if (full) { f32x4 t = {v[0], v[1], v[2], v[3]}; st4(a, t); } else for (int j = 0; j < cnt; ++j) a[j] = v[j];
+            if (full) { f32x4 t = {s4[0], s4[1], s4[2], s4[3]}; st4(a, t); } else for (int j = 0; j < cnt; ++j) a[j] = s4[j];
         } else {
             uint16_t* a = (uint16_t*)g.aux + ao;
-            if (full) { f32x4 t = {v[0], v[1], v[2], v[3]}; st4(a, t); } else for (int j = 0; j < cnt; ++j) a[j] = f32_to_bf16_bits(v[j]);
+            if (full) { f32x4 t = {s4[0], s4[1], s4[2], s4[3]}; st4(a, t); } else for (int j = 0; j < cnt; ++j) a[j] = f32_to_bf16_bits(s4[j]);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
     } else if (g.epi == MMAE_EPI_DGELU) {
         const long long ao = (long long)m * g.ldaux + n;
         float p[4] = {0.f, 0.f, 0.f, 0.f};
@@ -78,8 +80,13 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, char* Cz, int 
             const uint16_t* a = (const uint16_t*)g.aux + ao;
             if (full) { f32x4 t = ld4(a); p[0] = t[0]; p[1] = t[1]; p[2] = t[2]; p[3] = t[3]; } else for (int j = 0; j < cnt; ++j) p[j] = bf16_bits_to_f32(a[j]);
         }
+        if (g.aux_grad) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(p[j]);
+            for (int j = 0; j < 4; ++j) v[j] *= p[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(p[j]);
+        }
     }
     if (g.resid) {
         const float* r = g.resid + (long long)m * g.ldr + n;
@@ -212,15 +219,21 @@ __device__ __forceinline__ void store_tile64_fast(const GemmArgs& g, char* Cbase
                     for (int j = 0; j < 4; ++j) v[j] += b4[j];
                 }
                 if (EPI == MMAE_EPI_GELU) {
-                    if (AUX_F32) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rsAux, voff(tm, it, g.ldaux, 4), 0, 0);
-                    else __builtin_amdgcn_raw_buffer_store_b64(pack4_bf16(v), rsAux, voff(tm, it, g.ldaux, 2), 0, 0);
+                    f32x4 sv;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+                    for (int j = 0; j < 4; ++j) { float y, dy; gelu_both(v[j], y, dy); sv[j] = g.aux_grad ? dy : v[j]; v[j] = y; }
+                    if (AUX_F32) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, sv), rsAux, voff(tm, it, g.ldaux, 4), 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b64(pack4_bf16(sv), rsAux, voff(tm, it, g.ldaux, 2), 0, 0);
                 } else if (EPI == MMAE_EPI_DGELU) {
                     i32x2 lo2; lo2[0] = pre_aux[(tm * 8 + it) % PD][0]; lo2[1] = pre_aux[(tm * 8 + it) % PD][1];
                     const f32x4 p = AUX_F32 ? __builtin_bit_cast(f32x4, pre_aux[(tm * 8 + it) % PD]) : unpack4_bf16(lo2);
+                    if (g.aux_grad) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(p[j]);
+                        for (int j = 0; j < 4; ++j) v[j] *= p[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(p[j]);
+                    }
                 }
                 if (RESID) {
                     const f32x4 t = __builtin_bit_cast(f32x4, pre_res[(tm * 8 + it) % PD]);
@@ -305,17 +318,27 @@ __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cba
                     for (int j = 0; j < 4; ++j) { v0[j] += b0[j]; v1[j] += b1[j]; }
                 }
                 if (EPI == MMAE_EPI_GELU) {
-                    if (DBG != 2 && DBG != 3) __builtin_amdgcn_raw_buffer_store_b128(pack8_bf16(v0, v1), rsAux, voff(gi, g.ldaux), 0, 0);
+                    f32x4 s0 = v0, s1 = v1;                  // what aux keeps: the pre-activation, or (aux_grad) GELU' of it
                     if (DBG != 1) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { v0[j] = gelu_erf(v0[j]); v1[j] = gelu_erf(v1[j]); }
+                        for (int j = 0; j < 4; ++j) {
+                            float y, dy;
+                            gelu_both(v0[j], y, dy); s0[j] = g.aux_grad ? dy : v0[j]; v0[j] = y;
+                            gelu_both(v1[j], y, dy); s1[j] = g.aux_grad ? dy : v1[j]; v1[j] = y;
+                        }
                     }
+                    if (DBG != 2 && DBG != 3) __builtin_amdgcn_raw_buffer_store_b128(pack8_bf16(s0, s1), rsAux, voff(gi, g.ldaux), 0, 0);
                 } else if (EPI == MMAE_EPI_DGELU) {
                     const i32x4 pa = pre_aux[gi % PD];
                     i32x2 lo2, hi2; lo2[0] = pa[0]; lo2[1] = pa[1]; hi2[0] = pa[2]; hi2[1] = pa[3];
                     const f32x4 p0 = unpack4_bf16(lo2), p1 = unpack4_bf16(hi2);
+                    if (g.aux_grad) {                        // the forward stored GELU' itself: no transcendental work here
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { v0[j] *= gelu_erf_grad(p0[j]); v1[j] *= gelu_erf_grad(p1[j]); }
+                        for (int j = 0; j < 4; ++j) { v0[j] *= p0[j]; v1[j] *= p1[j]; }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { v0[j] *= gelu_erf_grad(p0[j]); v1[j] *= gelu_erf_grad(p1[j]); }
+                    }
                     if (gi + PD < nsteps) pre_aux[gi % PD] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, voff(gi + PD, g.ldaux), 0, 0);
                 }
                 if (COLSUM) {

@@ -171,7 +171,11 @@ int mmae_gemm_ex(const mmae_gemm_desc* d, void* stream, int timing_cls, double f
     g.bias = d->bias; g.resid = d->resid; g.ldr = d->ldr;
     g.aux = d->aux; g.ldaux = d->ldaux;
     g.c_f32 = d->c_dtype == MMAE_F32; g.aux_f32 = d->aux_dtype == MMAE_F32;
-    g.epi = d->epi; g.accumulate = d->accumulate; g.alpha = d->alpha;
+    MMAE_REQUIRE(d->epi >= MMAE_EPI_NONE && d->epi <= MMAE_EPI_MUL, "gemm: bad epi");
+    // GELU_G / MUL are GELU / DGELU with aux holding the derivative: same kernels and flavours, one flag
+    g.aux_grad = (d->epi == MMAE_EPI_GELU_G || d->epi == MMAE_EPI_MUL) ? 1 : 0;
+    g.epi = d->epi == MMAE_EPI_GELU_G ? MMAE_EPI_GELU : (d->epi == MMAE_EPI_MUL ? MMAE_EPI_DGELU : d->epi);
+    g.accumulate = d->accumulate; g.alpha = d->alpha;
     g.tiles_n = 0;
     g.colpart = d->colsum_part;
     static const int env_swz = mmae_env_int("MMAE_GEMM_XCD", 1);
@@ -185,7 +189,7 @@ int mmae_gemm_ex(const mmae_gemm_desc* d, void* stream, int timing_cls, double f
     g.scA = d->a_scale; g.scB = d->b_scale;
     g.qout = (unsigned char*)d->q_out; g.qsc = (unsigned char*)d->q_scale; g.ldq = d->ldq;
     MMAE_REQUIRE(!d->q_out || d->ab_dtype == MMAE_MXFP8, "gemm: q_out is an MX-fp8 product option");
-    MMAE_REQUIRE(!d->colsum_part || (d->epi == MMAE_EPI_DGELU && !d->bias && !d->resid && !d->accumulate && d->batch == 1 && d->split_k <= 1 &&
+    MMAE_REQUIRE(!d->colsum_part || ((d->epi == MMAE_EPI_DGELU || d->epi == MMAE_EPI_MUL) && !d->bias && !d->resid && !d->accumulate && d->batch == 1 && d->split_k <= 1 &&
                                      d->alpha == 1.0f && d->N % 4 == 0) ,
                  "gemm: colsum_part is only supported with the plain dGELU epilogue");
     // vector (4-element) epilogue accesses need every touched row start 4-element aligned

@@ -175,6 +175,23 @@ def test_gemm_epilogues(dtype):
     orc.gelu_erf(p).backward(dy @ w)
     assert rel_err(dxo.float(), p.grad) < t2
     assert rel_err(cs, p.grad.sum(0)) < 1e-4            # bias gradient accumulated in the epilogue
+    # the same pair with the derivative taken in the forward epilogue (EPI_GELU_G: aux = gelu'(pre)) and a plain multiply backward (EPI_MUL)
+    from multimae_amd._lib import EPI_GELU_G, EPI_MUL
+    aux_g = torch.empty(M, N, device=DEV, dtype=dtype)
+    act_g = torch.empty(M, N, device=DEV, dtype=dtype)
+    ops.linear_fwd(xd, wd, bias.to(DEV), act_g, aux=aux_g, epi=EPI_GELU_G)
+    assert torch.equal(act_g, act)
+    lp = lin.clone().requires_grad_(True)
+    orc.gelu_erf(lp).sum().backward()
+    assert rel_err(aux_g.float(), lp.grad) < t2
+    dxm = torch.empty(M, K, device=DEV, dtype=dtype)
+    csm = torch.empty(K, device=DEV)
+    gpre = torch.randn(M, K)
+    if dtype == torch.bfloat16:
+        gpre = bf(gpre).float()
+    ops.linear_dx(dy.to(DEV, dtype), wd, dxm, aux=gpre.to(DEV, dtype), epi=EPI_MUL, colsum_out=csm)
+    assert rel_err(dxm.float(), (dy @ w) * gpre) < t2
+    assert rel_err(csm, ((dy @ w) * gpre).sum(0)) < 1e-4
     # dW with accumulate
     dw = torch.ones(N, K, device=DEV)
     ops.linear_dw(dy.to(DEV, dtype), xd, dw, accumulate=True)
@@ -706,6 +723,37 @@ def test_pingpong_dgelu_colsum_epilogue(tile, M):
     assert part.shape[0] == (M + 31) // 32 and not torch.isnan(part).any()
     ref_blocks = torch.stack([p.grad[i:i + 32].sum(0) for i in range(0, M, 32)])
     assert rel_err(part.cpu(), ref_blocks) < 1e-4
+
+
+@pytest.mark.parametrize('tile,M', [(9, 2100), (10, 2600)])
+def test_pingpong_gelu_derivative_pair(tile, M):
+    """The MLP pair of the composite calls on the ping-pong flavours: fc1 forward with EPI_GELU_G (C = gelu(pre), aux = gelu'(pre) -- the
+    derivative taken where the erf terms are in registers) and fc2's dX with EPI_MUL + column sums (out = (dy @ W) * aux): against
+    the fp32 formulas, and the forward output bit-identical to the EPI_GELU flavour's."""
+    from multimae_amd import ops
+    from multimae_amd._lib import EPI_GELU, EPI_GELU_G, EPI_MUL
+    g = torch.Generator().manual_seed(5)
+    K, Nn = 264, 520
+    x, w, b = bf(torch.randn(M, K, generator=g) * 0.5), bf(torch.randn(Nn, K, generator=g) * 0.2), torch.randn(Nn, generator=g) * 0.1
+    h0, a0 = (torch.empty(M, Nn, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+    h1, a1 = (torch.empty(M, Nn, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+    ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), h0, aux=a0, epi=EPI_GELU, tile=tile)
+    ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), h1, aux=a1, epi=EPI_GELU_G, tile=tile)
+    assert torch.equal(h0, h1)
+    pre = (x.float() @ w.float().t() + b).clone().requires_grad_(True)
+    orc.gelu_erf(pre).sum().backward()
+    assert rel_err(a1.float(), pre.grad) < 4e-3 and rel_err(a0.float(), pre.detach()) < 4e-3
+    dy = bf(torch.randn(M, K, generator=g) * 0.3)           # gradient of the fc2 output; W2 [K, Nn]
+    w2 = bf(torch.randn(K, Nn, generator=g) * 0.2)
+    out = torch.empty(M, Nn, device=DEV, dtype=torch.bfloat16)
+    part = torch.full(ops.dx_colsum_part_shape(M, Nn), float('nan'), device=DEV)
+    ops.gemm(dy.to(DEV), w2.to(DEV), out, M, Nn, K, lda=K, ldb=Nn, ldc=Nn, b_trans=True, aux=a1, ldaux=Nn, epi=EPI_MUL, tile=tile,
+             colsum_part=part)
+    want = (dy.float() @ w2.float()) * a1.float().cpu()
+    assert rel_err(out.float(), want) < 4e-3
+    ref_blocks = torch.stack([want[i:i + 32].sum(0) for i in range(0, M, 32)])
+    e_part = rel_err(part.cpu(), ref_blocks)
+    assert not torch.isnan(part).any() and e_part < 1e-4, (e_part, int(torch.isnan(part).sum()), tuple(part.shape), tuple(ref_blocks.shape))
 
 
 @pytest.mark.parametrize('domain', ['image', 'patch'])

@@ -138,19 +138,22 @@ def test_reference_loop_body_runs_on_the_engine_under_ddp_autocast_gradscaler():
                 worst = max(worst, ((d2 / u2) ** 0.5, k))
         return (num / den) ** 0.5, worst
 
-    # B == C bit for bit: the NativeScaler sequence driving FusedAdamW is the engine-native step (the 2^16 loss scale is exact)
-    assert res['B'][0] == res['C'][0] and res['B'][1] == res['C'][1]
+    # B == C bit for bit: the NativeScaler sequence driving FusedAdamW is the engine-native step (the 2^16 loss scale is exact): same
+    # losses, same weights.  The logged gradient norms come from two different reductions of identical gradients (native_scaler.py's
+    # norm of per-tensor torch norms against the fused step's single pass over the arena): equal to f32 summation order
+    assert res['B'][0] == res['C'][0]
+    assert all(abs(a - b) <= 2e-6 * abs(b) for a, b in zip(res['B'][1], res['C'][1])), (res['B'][1], res['C'][1])
     assert update_err(res['B'][2], res['C'][2])[0] == 0.0
     # A == E bit for bit: DDP (world 1, RCCL) is transparent; what separates A from B is the LOSS path -- _DDPSink hands the loop
     # clones of the predictions, so the criterion takes the image-domain form instead of the adapters' patch rows
     assert res['A'][0] == res['E'][0] and update_err(res['E'][2], wa)[0] == 0.0
     assert res['A'][0] == res['A2'][0] and update_err(res['A2'][2], wa)[0] == 0.0          # and it is deterministic
     # D vs B: torch.optim.AdamW against the fused step.  Step 0 sees bit-identical gradients (equal norms) and the updates agree to
-    # fp32 round-off (loss of step 1: 5e-7 apart); from there the two runs are two bf16 trajectories -- a 1e-7 weight difference
-    # flips bf16 roundings of the weight shadow, Adam normalises the resulting gradient noise -- measured 1.6 % of the update
-    # after three steps (worst matrix 5.4 %)
+    # fp32 round-off; a 1e-7 weight difference already flips a few bf16 roundings of the weight shadow, so the loss of step 1 is
+    # 5e-7 ... 8e-6 apart (which weights flip depends on the last bits of the gradients), and from there the two runs are two bf16
+    # trajectories -- Adam normalises the resulting gradient noise -- measured 1.6 % of the update after three steps (worst matrix 5.4 %)
     assert res['D'][1][0] == res['B'][1][0]
-    assert abs(res['D'][0][1] - res['B'][0][1]) < 5e-6 * abs(res['B'][0][1]), (res['D'][0], res['B'][0])
+    assert abs(res['D'][0][1] - res['B'][0][1]) < 5e-5 * abs(res['B'][0][1]), (res['D'][0], res['B'][0])
     d_glob, d_worst = update_err(res['D'][2], res['B'][2])
     assert d_glob < 4e-2 and d_worst[0] < 0.15, (d_glob, d_worst)
     # A vs B / C: image-domain against patch-domain loss gradients (bf16 rounding at the head of the backward chain), three Adam steps on
