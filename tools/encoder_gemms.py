@@ -7,8 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 R, D, H = 25344, 768, 3072
 REP = 5
 # name, flops
-CASES = [('fwd qkv  bias', 2.0 * R * D * 3 * D), ('fwd proj bias+resid f32', 2.0 * R * D * D), ('fwd fc1  bias+gelu+aux', 2.0 * R * D * H),
-         ('fwd fc2  bias+resid f32', 2.0 * R * D * H), ('dx  fc2  dgelu+colsum', 2.0 * R * D * H), ('dx  fc1', 2.0 * R * D * H),
+CASES = [('fwd qkv  bias', 2.0 * R * D * 3 * D), ('fwd proj bias+resid f32', 2.0 * R * D * D), ('fwd fc1  bias+gelu, aux=gelu\'', 2.0 * R * D * H),
+         ('fwd fc2  bias+resid f32', 2.0 * R * D * H), ('dx  fc2  x aux + colsum', 2.0 * R * D * H), ('dx  fc1', 2.0 * R * D * H),
          ('dx  proj', 2.0 * R * D * D), ('dx  qkv', 2.0 * R * D * 3 * D), ('dw  fc2', 2.0 * R * D * H), ('dw  fc1', 2.0 * R * D * H),
          ('dw  proj', 2.0 * R * D * D), ('dw  qkv', 2.0 * R * D * 3 * D)]
 if len(sys.argv) > 2 and sys.argv[1] == '--parse':
@@ -34,7 +34,7 @@ if len(sys.argv) > 2 and sys.argv[1] == '--parse':
     sys.exit(0)
 import torch
 from multimae_amd import ops
-from multimae_amd._lib import EPI_DGELU, EPI_GELU
+from multimae_amd._lib import EPI_GELU_G, EPI_MUL      # the pair the composite calls use with bf16 activations
 dev = 'cuda'
 bf = torch.bfloat16
 g = lambda *s: torch.randn(*s, device=dev)
@@ -52,9 +52,9 @@ gw = {k: torch.zeros_like(v, dtype=torch.float32) for k, v in dict(qkv=wqkv, pro
 marker = torch.zeros(1, device=dev, dtype=torch.int32)
 fns = [lambda: ops.linear_fwd(x_act, wqkv, bqkv, qkv),
        lambda: ops.linear_fwd(ao, wproj, bproj, x1, resid=x_res),
-       lambda: ops.linear_fwd(x_act, wfc1, bfc1, hout, aux=hpre, epi=EPI_GELU),
+       lambda: ops.linear_fwd(x_act, wfc1, bfc1, hout, aux=hpre, epi=EPI_GELU_G),
        lambda: ops.linear_fwd(hact, wfc2, bfc2, x1, resid=x_res),
-       lambda: ops.linear_dx(d_x, wfc2, dout_h, aux=hpre, epi=EPI_DGELU, colsum_out=cs),
+       lambda: ops.linear_dx(d_x, wfc2, dout_h, aux=hpre, epi=EPI_MUL, colsum_out=cs),
        lambda: ops.linear_dx(d_h, wfc1, dout_d),
        lambda: ops.linear_dx(d_x, wproj, dout_d),
        lambda: ops.linear_dx(d_qkv, wqkv, dout_d),
