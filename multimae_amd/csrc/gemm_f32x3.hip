@@ -52,7 +52,20 @@ __global__ void __launch_bounds__(256) gemm_f32x3_kernel(const GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile = g.xcd_swizzle ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
+    // Split-K products (the weight gradients: a handful of output tiles, the batch as contraction): workgroups reach the XCDs round-robin in
+    // flattened (x, z) order, so with the plain mapping an XCD kept the same two output tiles through all slices and every XCD streamed
+    // all of the narrower operand -- 482 MB fetched per launch against 256 MB of operands.  Remapped: an XCD takes whole K slices, all
+    // output tiles of a slice back to back, so both operand slabs of a slice are fetched by one L2 only: 243 MB per launch, 3 % faster
+    // (the re-reads had been MALL hits; profiles/r03_x3_splitk_remap.txt).
+    // (slices beyond the last multiple of 8 keep the plain order.)
+    int tile, zsplit = blockIdx.z;
+    if (gridDim.z >= 8 && gridDim.y == 1) {
+        const int T = gridDim.x, S8 = (int)(gridDim.z & ~7u), L = blockIdx.x + T * blockIdx.z;
+        if (L < T * S8) { zsplit = (L & 7) + 8 * (L / (8 * T)); tile = (L >> 3) % T; }
+        else { const int Lr = L - T * S8; zsplit = S8 + Lr / T; tile = Lr % T; }
+    } else {
+        tile = g.xcd_swizzle ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
+    }
     const int m0 = (tile / g.tiles_n) * BM, n0 = (tile % g.tiles_n) * BN;
     const int z = blockIdx.y, zo = z / g.nb_inner, zi = z % g.nb_inner;
     const float* Az = (const float*)g.A + zo * g.sAo + zi * g.sAi;
@@ -145,7 +158,7 @@ __global__ void __launch_bounds__(256) gemm_f32x3_kernel(const GemmArgs g) {
     };
 
     const int nkt_all = (g.K + BK - 1) / BK;
-    const int kt_begin = blockIdx.z * g.kt_per_split;
+    const int kt_begin = zsplit * g.kt_per_split;
     const int nkt = (kt_begin + g.kt_per_split < nkt_all) ? kt_begin + g.kt_per_split : nkt_all;
     gload(kt_begin);
     lstore(0);
@@ -175,7 +188,9 @@ __global__ void __launch_bounds__(256) gemm_f32x3_kernel(const GemmArgs g) {
         if (kt + 1 < nkt) lstore((kt + 1 - kt_begin) & 1);
         __syncthreads();
     }
-    gemm_store_tile64(g, Cz, smem + wave * 8192, lane, acc, m0 + wm * 64, n0 + wn * 64);   // (loop ended on a barrier)
+    GemmArgs gs = g;                                       // the shared epilogue addresses the slab of slice blockIdx.z: point it at slice zsplit's
+    if (g.splitk > 1) gs.ws = g.ws + ((long long)zsplit - (long long)blockIdx.z) * g.M * g.N;
+    gemm_store_tile64(gs, Cz, smem + wave * 8192, lane, acc, m0 + wm * 64, n0 + wn * 64);   // (loop ended on a barrier)
 }
 
 template <bool AKS, bool BKS>

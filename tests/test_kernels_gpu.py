@@ -136,6 +136,24 @@ def test_gemm_splitk_workspace(dtype):
     assert rel_err(dw2, ref) < 2e-6 and torch.equal(dw2, dw3)
 
 
+@pytest.mark.parametrize('Mr,N,K', [(12544, 1024, 256), (5000, 256, 136), (50176, 256, 256), (3000, 384, 264)])
+def test_gemm_f32x3_split_k_weight_gradient_shapes(Mr, N, K):
+    """The fp32 output adapter's weight gradients (split-bf16 x3 products, contraction = all rows, split along it): the kernel hands whole
+    K slices to an XCD (slice / tile remap of the flattened workgroup id, plain order for the slices past the last multiple of 8) --
+    every (slice, tile) pair must be computed exactly once: against fp64, accumulate-into-C, and bit-reproducible."""
+    from multimae_amd import ops
+    g = torch.Generator().manual_seed(Mr + N)
+    dy, x = torch.randn(Mr, N, generator=g) * 0.1, torch.randn(Mr, K, generator=g)
+    ref = dy.double().t() @ x.double()
+    with ops.f32_gemm_mode('x3'):
+        dw = torch.full((N, K), 2.0, device=DEV)
+        ops.linear_dw(dy.to(DEV), x.to(DEV), dw, accumulate=True)
+        dw2, dw3 = torch.empty((N, K), device=DEV), torch.empty((N, K), device=DEV)
+        ops.linear_dw(dy.to(DEV), x.to(DEV), dw2, accumulate=False)
+        ops.linear_dw(dy.to(DEV), x.to(DEV), dw3, accumulate=False)
+    assert rel_err(dw2, ref) < 2e-5 and rel_err(dw, 2.0 + ref) < 2e-5 and torch.equal(dw2, dw3)
+
+
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
 def test_gemm_epilogues(dtype):
     from multimae_amd import ops
