@@ -250,7 +250,7 @@ def result_line(args, B, world, ms_per_step, img_s, final_loss, counters, roof, 
                    'cfg5': 'pre-train images/sec (whole node), ViT-L RGB+D+S 224^2 196-vis-tok'}[args.config],
         'value': round(img_s, 1), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': {'bf16': 'bf16', 'fp32': 'f32', 'mxfp8': 'mxfp8 (e4m3 + E8M0/32) encoder forward and dX products, bf16 everywhere else'}[args.precision], 'data': 'synthetic',
+        'dtype': {'bf16': 'bf16', 'fp32': 'f32', 'mxfp8': 'mxfp8 (e4m3 + E8M0/32) encoder forward, dX and weight-gradient products, bf16 everywhere else'}[args.precision], 'data': 'synthetic',
         'config': {'workload': f'BASELINE.json configs[{ {"cfg3": 2, "cfg2": 1, "cfg5": 4}[args.config] }]: '
                                + (('ViT-L (MX-fp8 encoder products), ' if args.precision == 'mxfp8' else 'ViT-L (bf16 run of the fp8 config), ') if args.config == 'cfg5' else 'ViT-B, ')
                                + ('RGB-only' if args.config == 'cfg2' else 'RGB+depth+semseg')
@@ -275,7 +275,7 @@ def main():
     ap.add_argument('--config', default='cfg3', choices=['cfg3', 'cfg2', 'cfg5'],
                     help='cfg3 = BASELINE.json configs[2] (the metric), cfg2 = configs[1] (RGB-only), cfg5 = configs[4] geometry (ViT-L, 196 visible tokens; bf16 -- the MX-fp8 path is not built)')
     ap.add_argument('--precision', default=None, choices=['bf16', 'fp32', 'mxfp8'],
-                    help="'mxfp8': encoder forward / dX products on OCP MX-fp8 operands (block-scaled MFMA), everything else as bf16.  "
+                    help="'mxfp8': encoder forward / dX / weight-gradient products on OCP MX-fp8 operands (block-scaled MFMA), everything else as bf16.  "
                          "Default: bf16; mxfp8 for --config cfg5 (BASELINE.json configs[4] names the fp8 MFMA path)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-batch', type=int, default=16)

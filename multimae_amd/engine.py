@@ -40,9 +40,9 @@ def act_dtype() -> torch.dtype:
 def set_precision(mode: str) -> None:
     """'bf16' (default): bf16 MFMA operands, fp32 accumulate/residual/softmax/LN/loss.
     'fp32': every operand f32 on the exact-f32 MFMA path (parity mode, 1/16 the rate).
-    'mxfp8': as 'bf16', but the forward and dX products of the encoder blocks run on the block-scaled MFMA with OCP MX-fp8
-    operands (e4m3 elements, one power-of-two scale per 32 contraction elements; BASELINE.json configs[4]); weight gradients,
-    attention, the adapters and everything else stay as in 'bf16'.  Needs dim_tokens and the MLP width to be multiples of 256
+    'mxfp8': as 'bf16', but the forward, dX and (ops.mx_wgrad, default on) weight-gradient products of the encoder blocks run on
+    the block-scaled MFMA with OCP MX-fp8 operands (e4m3 elements, one power-of-two scale per 32 contraction elements;
+    BASELINE.json configs[4]); attention, the adapters and everything else stay as in 'bf16'.  Needs dim_tokens and the MLP width to be multiples of 256
     (ViT-B / ViT-L); other encoders silently keep their bf16 products."""
     if mode not in ('bf16', 'fp32', 'mxfp8'):
         raise ValueError(mode)

@@ -514,7 +514,8 @@ def stack_fwd(x: Tensor, params: Sequence[Tensor], wc, heads: int, eps: float, a
               dp: Optional[Sequence[Optional[Tensor]]] = None, mx: bool = False):
     """L = len(params) // 12 pre-LN blocks on x f32 [B*N, D] in one library call.
     Returns ([output of every block as f32 [B*N, D] views of the slab], StackState).
-    mx: forward / dX products on MX-fp8 operands (weights re-quantised here from their f32 masters, once per call)."""
+    mx: forward / dX products on MX-fp8 operands (weights re-quantised here from their f32 masters, once per call); the backward
+    call also runs the weight gradients on them (mx_wgrad)."""
     lib = _lib.load()
     R, D = x.shape
     L = len(params) // 12
