@@ -10,6 +10,7 @@ AdamW(betas .9/.95, wd .05 on every tensor).  Synthetic inputs resident in HBM, 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 5
+    python bench.py --gpus 8 --steps 20 --warmup 5        # no launcher in the environment: re-executes itself under the line above
 
 Prints ONE JSON line (rank 0) with the driver's contract plus "roofline" and "cpu_baseline".
 """
@@ -266,6 +267,23 @@ def result_line(args, B, world, ms_per_step, img_s, final_loss, counters, roof, 
     return out
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher in the environment (no WORLD_SIZE): re-execute this command as N ranks under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 at a free port).  Rank 0 of the children prints the one
+    JSON line on the inherited stdout; returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC (RCCL across processes on this driver)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f'--gpus {n} without a launcher: ' + ' '.join(cmd))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -273,7 +291,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default 256; 128 for cfg5)')
     ap.add_argument('--config', default='cfg3', choices=['cfg3', 'cfg2', 'cfg5'],
-                    help='cfg3 = BASELINE.json configs[2] (the metric), cfg2 = configs[1] (RGB-only), cfg5 = configs[4] geometry (ViT-L, 196 visible tokens; bf16 -- the MX-fp8 path is not built)')
+                    help='cfg3 = BASELINE.json configs[2] (the metric), cfg2 = configs[1] (RGB-only), cfg5 = configs[4] geometry (ViT-L, 196 visible tokens, B = 128; MX-fp8 encoder products by default, --precision bf16 for the bf16 run of the same geometry)')
     ap.add_argument('--precision', default=None, choices=['bf16', 'fp32', 'mxfp8'],
                     help="'mxfp8': encoder forward / dX / weight-gradient products on OCP MX-fp8 operands (block-scaled MFMA), everything else as bf16.  "
                          "Default: bf16; mxfp8 for --config cfg5 (BASELINE.json configs[4] names the fp8 MFMA path)")
@@ -292,7 +310,11 @@ def main():
     ap.add_argument('--share-device', type=int, default=0, help='1: every rank uses cuda:0 (functional test of the multi-process path on one GPU; use with --backend gloo)')
     ap.add_argument('--graph', type=int, default=-1, help='1: capture the step once as a hipGraph and replay it (multimae_amd.graph.StepGraph; 1 GPU only). Default 0: on ROCm 7.2 the replay of this ~1 100-node, 10-stream graph measured 46.2 ms/step against 44.1 ms eager')
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary line (cfg5 = BASELINE configs[4] geometry, ViT-L, MX-fp8 encoder products, B = 128, a few steps) that the default single-GPU cfg3 run appends as `secondary`')
+    ap.add_argument('--gemm-cu-reserve', type=int, default=-1, help='compute units the persistent GEMM grids leave free (for RCCL\'s channel kernels while gradient buckets are in flight); -1: 16 when gradient buckets are exchanged (N > 1 or --force-dist), else 0')
+    ap.add_argument('--dry-run', type=int, default=0, help='1: CPU tensors and a type-checking stub of the C ABI (tests/dryrun_harness.py): exercises the LAUNCH path of this script (self-launch, process group, reducer, the JSON line) without a GPU -- the numbers are meaningless and the line says so')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args.gpus))
     if args.precision is None:
         args.precision = 'mxfp8' if args.config == 'cfg5' else 'bf16'
     out = run_once(args)
@@ -332,18 +354,30 @@ def run_once(args):
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if args.share_device:
         local = 0
+    dry = bool(args.dry_run)
+    if dry:
+        # launch-path test on CPU (tests/test_bench_launch_cpu.py): the C ABI is the type-checking stub of tests/dryrun_harness.py
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        import dryrun_harness
+        dryrun_harness.install()
+        args.adapter_streams = args.wgrad_stream = 0
+        args.no_kernel_timing = args.no_cpu_baseline = args.no_secondary = True
+        args.backend = 'gloo'
     use_dist = world > 1 or bool(args.force_dist)
     if args.force_dist and 'MASTER_ADDR' not in os.environ:
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
     if args.gpus > 1 or use_dist:
-        assert world == args.gpus, f'launch with torch.distributed.run --nproc-per-node {args.gpus}'
-        torch.cuda.set_device(local)
+        if world != args.gpus and not args.force_dist:
+            raise SystemExit(f'bench.py --gpus {args.gpus} inside a launcher environment with WORLD_SIZE={world}: the two must agree')
+        if not dry:
+            torch.cuda.set_device(local)
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
         else:
             dist.init_process_group(args.backend)
-    device = torch.device('cuda', local)
-    torch.cuda.set_device(device)
+    device = torch.device('cpu') if dry else torch.device('cuda', local)
+    if not dry:
+        torch.cuda.set_device(device)
 
     torch.manual_seed(0 + rank)                                   # run_pretraining_multimae.py:300
     model, doms = build_model(args.config)
@@ -357,7 +391,11 @@ def run_once(args):
     M.engine.set_direct_grads(True)
     M.engine.set_adapter_streams(bool(args.adapter_streams))
     M.engine.set_wgrad_stream(bool(args.wgrad_stream))
-    B = args.batch or (128 if args.config == 'cfg5' else 256)
+    B = args.batch or (2 if dry else (128 if args.config == 'cfg5' else 256))
+    # compute units the persistent GEMM grids leave to RCCL's channel kernels while gradient buckets are in flight
+    cu_reserve = args.gemm_cu_reserve if args.gemm_cu_reserve >= 0 else (16 if use_dist else 0)
+    if reducer is not None:
+        reducer.gemm_cu_reserve = cu_reserve
     n_vis = 196 if args.config == 'cfg5' else 98
     lr = 1e-4 * B * world / 256                                   # blr * global_bs / 256 (:372-373)
     opt = FusedAdamW(model, lr=lr, betas=(0.9, 0.95), weight_decay=0.05)
@@ -379,7 +417,7 @@ def run_once(args):
 
     def step():
         g = opt.param_groups[0]
-        g['lr'], g['weight_decay'] = lr_tab[min(it[0], n_tab - 1)], wd_tab[min(it[0], n_tab - 1)]     # FusedAdamW.step applies g['lr_scale'] itself
+        g['lr'], g['weight_decay'] = lr_tab[min(it[0], n_tab - 1)] * g['lr_scale'], wd_tab[min(it[0], n_tab - 1)]     # as the reference loop (:474-480)
         it[0] += 1
         opt.zero_grad()
         preds, masks = model(x, num_encoded_tokens=n_vis, alphas=1.0, sample_tasks_uniformly=False, fp32_output_adapters=fp32_adapters)
@@ -395,7 +433,8 @@ def run_once(args):
     def sync():
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
     use_graph = False if args.graph < 0 else bool(args.graph)
     if use_graph and world > 1:
@@ -443,8 +482,11 @@ def run_once(args):
         dp_diag = {'exposed_allreduce_ms_per_step': round(reducer.exposed_wait_ms() / args.steps, 3), 'bucket_mb': args.bucket_mb,
                    'buckets': len(reducer.buckets), 'bucket_dtype': 'bf16' if args.bf16_buckets else 'f32',
                    'allreduce_mb_per_step': round(sum(e - s for s, e, _ in reducer.buckets) * (2 if args.bf16_buckets else 4) / 2 ** 20, 1),
-                   'rccl_ranks_seen': int(seen.item()), 'backend': args.backend, 'encoder_bwd_chunk_layers': int(getattr(model, '_bwd_chunk_layers', 0))}
+                   'rccl_ranks_seen': int(seen.item()), 'backend': args.backend, 'encoder_bwd_chunk_layers': int(getattr(model, '_bwd_chunk_layers', 0)),
+                   'gemm_cu_reserved': cu_reserve}
     final_loss = float(last['loss'].detach())
+    if dry and final_loss != final_loss:
+        final_loss = 0.0
     counters = opt.counters()
     log(f'timed region done: {ms_per_step:.2f} ms/step, {img_s:.1f} img/s, loss {final_loss:.4f} (host enqueue work {host_ms:.2f} ms/step + {host_wait_ms:.2f} ms waiting in the 2-step run-ahead bound)')
 
@@ -511,7 +553,10 @@ def run_once(args):
     M.engine.set_direct_grads(False)
     M.engine.set_precision('bf16')
     if rank == 0:
-        return result_line(args, B, world, ms_per_step, img_s, final_loss, counters, roof, cpu, dp_diag, host_ms, host_wait_ms, use_graph, n_vis, doms)
+        out = result_line(args, B, world, ms_per_step, img_s, final_loss, counters, roof, cpu, dp_diag, host_ms, host_wait_ms, use_graph, n_vis, doms)
+        if dry:
+            out['data'] = 'DRY RUN on CPU against a stub of the C ABI (launch-path test): every number in this line is meaningless'
+        return out
     return None
 
 

@@ -98,8 +98,8 @@ typedef struct mmae_gemm_desc {
     int32_t tile;                /* bf16 kernel variant.  0 = let the library choose (mmae_gemm_plan; env MMAE_GEMM_TILE overrides);
                                     1/2 = 128x128 / 256x128 2-stage LDS-DMA, 3/4 = same tiles, VGPR-staged, 5..8 = LDS-DMA ring
                                     with counted vmcnt (BK = 32), 9/10 = 8-wave ping-pong on 256x256 / 320x256 tiles,
-                                    11 = "duo": two independent 4-wave workgroups per CU on 128x256 tiles (12 = the same wave
-                                    schedule on one 8-wave workgroup, 256x256); shapes / epilogues they do not carry run on 9 */
+                                    11 .. 14 = the round-3 experiment structures ("duo": two 4-wave workgroups per CU; 64-wide K tiles):
+                                    compiled only into experiment builds (-DMMAE_EXPERIMENTS); the production library runs them on 9 / 10 */
     int32_t split_k;             /* <= 1: off; n: n K-slices, each writing a dense f32 [M][N] partial into ws,
                                     then summed into C in a fixed order (plain unbatched f32 C only).  The library
                                     never allocates: ask mmae_gemm_auto_splitk() and pass a workspace. */
@@ -130,9 +130,18 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream);
 int mmae_gemm_plan(const mmae_gemm_desc* d, int* tile, int* split_k);
 /* suggested number of K slices for a dW-shaped (both operands k-strided) [M,N,K] product (1 = do not split) */
 int mmae_gemm_auto_splitk(int M, int N, int K, int ab_dtype);
-/* resident workgroups per CU the HIP runtime reports for the duo kernel of tile code 11 / 12 with its dynamic LDS size
- * (11 must report 2: the kernel's design is two independent workgroups per CU); < 0 on error */
+/* Compute units the library's persistent GEMM grids (bf16 ping-pong, MX-fp8, grouped weight gradients) leave free: launches
+ * enqueued after the call are at most n_cu - k workgroups wide (never fewer than 16).  Those kernels hold one workgroup with the
+ * whole register file and 147 KiB of LDS per CU, so nothing else can co-reside with them; a data-parallel caller reserves a few CUs
+ * for RCCL's channel kernels while gradient buckets are in flight (multimae_amd/dist.py) instead of letting a full-width
+ * statically strided persistent grid run its last k workgroups as a second round.  A host-side launch policy (not stream
+ * ordered, process wide).  k < 0 only reads.  Returns the previous value. */
+int mmae_gemm_cu_reserve(int k);
+#ifdef MMAE_EXPERIMENTS
+/* experiment builds only: resident workgroups per CU the HIP runtime reports for the duo kernel of tile code 11 / 12 with its
+ * dynamic LDS size (11 must report 2: the kernel's design is two independent workgroups per CU); < 0 on error */
 int mmae_gemm_duo_occupancy(int tile);
+#endif
 
 /* ------------------------------------------------------------------------- *
  * MX-fp8 operands (BASELINE.json configs[4], "fp8 MFMA path"; OCP Microscaling v1.0: e4m3 elements, one power-of-two E8M0
@@ -258,6 +267,21 @@ int mmae_colsum(const void* dy, int dtype, int64_t M, int N, int64_t ld, float* 
  * (autograd's three AccumulateGrad nodes of multimae_utils.py:222-232). */
 int mmae_colsum_scatter(const void* dy, int dtype, int64_t M, int N, int64_t ld, int seg_w, const void* dsts_host,
                         int nseg, int accumulate, float* ws, void* stream);
+
+/* Up to MMAE_COLSUM_MAX_JOBS such reductions in ONE launch (round 4: the parameter-gradient column sums of a transformer block
+ * -- LayerNorm partial blocks, the dGELU epilogue's partials, f32 bias gradients -- were 6 launches of 5-6 us, 176 per cfg3 step).
+ * A job is a mmae_colsum_scatter call: src act dtype [rows][ld], `cols` columns, column c delivered to dst[c / seg_w][c % seg_w].
+ * Phase 1 (row slices -> ws) and phase 2 (the slices of a 256-column group summed in a fixed order by whichever workgroup
+ * finishes that group last: a self-resetting ticket per group in a per-stream slot of a device-global table) run in the same
+ * kernel; results are bit-identical to the two-launch form for any arrival order.  ws: mmae_colsum_batch_ws_elems() floats.
+ * All jobs share `accumulate`. */
+#define MMAE_COLSUM_MAX_JOBS 8
+typedef struct mmae_colsum_job {
+    const void* src; int32_t dtype; int32_t cols; int64_t rows; int64_t ld;
+    int32_t seg_w; int32_t nseg; float* dst[8];
+} mmae_colsum_job;
+int64_t mmae_colsum_batch_ws_elems(const mmae_colsum_job* jobs, int n);
+int mmae_colsum_batch(const mmae_colsum_job* jobs, int n, int accumulate, float* ws, int64_t ws_elems, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Row softmax over materialised attention scores (unfused attention path and the
@@ -541,9 +565,12 @@ int mmae_tokens_assemble_bwd(const float* d_tok, void* d_proj, int proj_dtype, c
  * bias_host / pos_host as for mmae_tokens_assemble.  rows_bf16 (optional, may be NULL): the
  * zero-padded bf16 patch rows [B*n_sel][Ktot] of mmae_patch_rows, written on the side for the
  * weight-gradient products of the backward pass.
- * mmae_patch_embed_supported: 1 if the fused kernel takes the geometry (D % 32 == 0, D <= 1024,
- * n_sel <= 1024, C*ph*pw % 16 == 0, k_off % 8 == 0; semseg: ph*pw <= 64 and a class table of
- * at most 64 KiB in bf16); otherwise use the three calls above.
+ * mmae_patch_embed_supported: 1 if the fused kernel takes the geometry -- exactly what csrc/embed.hip: check_geometry tests:
+ * 32 <= D <= 1024 and D % 32 == 0; 1 <= n_sel <= 1024; for every task H % ph == 0, W % pw == 0, k_off % 8 == 0 and
+ * C*ph*pw a multiple of the kernel's staging unit (64 elements for D <= 768, 32 above); semseg: ph*pw <= 64 and at most
+ * 32 767 classes; and the workgroup's LDS image (token ids + the double-buffered gather chunk + the per-wave weight images +
+ * the semseg class tables in bf16) within the CU's 160 KiB.  Otherwise use the three calls above.  (The framework's dispatch,
+ * multimae_amd/functions.py: EmbedFn, additionally keeps ViT-L width on the three passes, where they measured faster.)
  * ------------------------------------------------------------------------- */
 int mmae_patch_embed_supported(const mmae_patch_src* srcs_host, int T, int n_sel, int D);
 int mmae_patch_embed_fwd(const mmae_patch_src* srcs_host, const void* const* w_bf16_host, const float* const* bias_host,

@@ -96,6 +96,11 @@ class DwGroupDesc(ctypes.Structure):
     _fields_ = [('n', _I), ('rows', _I), ('ab_dtype', _I), ('accumulate', _I), ('split_k', _I), ('p', DwProblem * 8), ('ws', _P), ('ws_elems', _L)]
 
 
+class ColsumJob(ctypes.Structure):
+    """mirror of mmae_colsum_job"""
+    _fields_ = [('src', _P), ('dtype', _I), ('cols', _I), ('rows', _L), ('ld', _L), ('seg_w', _I), ('nseg', _I), ('dst', _P * 8)]
+
+
 class OptDesc(ctypes.Structure):
     """mirror of mmae_opt_desc"""
     _fields_ = [('p', _P), ('g', _P), ('m', _P), ('v', _P), ('n', _L), ('shadow', _P), ('shadow_dtype', _I),
@@ -122,6 +127,8 @@ _RET = {'int': ctypes.c_int, 'int64_t': ctypes.c_int64, 'const char*': ctypes.c_
 
 def _parse_header(path: str) -> Dict[str, Tuple[object, List[object]]]:
     src = open(path).read()
+    if not os.environ.get('MMAE_EXPERIMENTS'):           # prototypes that exist in experiment builds of the library only
+        src = re.sub(r'#ifdef\s+MMAE_EXPERIMENTS.*?#endif', ' ', src, flags=re.S)
     src = re.sub(r'/\*.*?\*/', ' ', src, flags=re.S)
     src = re.sub(r'//[^\n]*', ' ', src)
     src = re.sub(r'typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;', ' ', src, flags=re.S)
@@ -167,7 +174,7 @@ def load() -> ctypes.CDLL:
         fn.argtypes = argtypes
     if lib.mmae_abi_version() != 3:
         raise RuntimeError('libmmae_hip.so ABI version mismatch')
-    for which, cls in enumerate((GemmDesc, BlockDesc, StackDesc, AdapterDesc, OptDesc, PatchSrc, DwGroupDesc)):
+    for which, cls in enumerate((GemmDesc, BlockDesc, StackDesc, AdapterDesc, OptDesc, PatchSrc, DwGroupDesc, ColsumJob)):
         if lib.mmae_struct_size(which) != ctypes.sizeof(cls):
             raise RuntimeError(f'{cls.__name__}: ctypes mirror ({ctypes.sizeof(cls)} B) != library struct ({lib.mmae_struct_size(which)} B)')
     if os.environ.get('MMAE_MX_WGRAD') is not None:      # A/B: bf16 (0) or MX-fp8 (1) weight gradients in MX-fp8 mode (ops.mx_wgrad)

@@ -351,11 +351,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
     float* lse_s = (float*)(Vs + a.nkp * HD * 2 + (X3 ? lo : 0));
     float* delta_s = lse_s + a.nqp;
     const AT* qg = (const AT*)a.q + b * a.q_sb + h * HD;
-    const AT* og = (const AT*)a.o + b * a.o_sb + h * HD;
     const AT* dog = (const AT*)a.d_o + b * a.o_sb + h * HD;
     const AT* kg = (const AT*)a.k + b * a.k_sb + h * HD;
     const AT* vg = (const AT*)a.v + b * a.v_sb + h * HD;
-    bf16x8 of0[HD / 16];                                 // bf16 path: O fragments of query block `wave`, fetched with the tiles
     if constexpr (X3) {
         {
             TileLoaderF32<HD, NTH> lq, ld;
@@ -378,14 +376,6 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
         ld.issue(dog, a.o_sr, a.Nq, a.nqp, tid);
         lk.issue(kg, a.k_sr, a.Nk, a.nkp, tid);
         lv.issue(vg, a.v_sr, a.Nk, a.nkp, tid);
-        // the O rows of this wave's first query block (for delta) ride in the same burst: loaded after the LDS commit they
-        // were a second, serial HBM round trip in front of the first MFMA
-        {
-            const auto rsO0 = __builtin_amdgcn_make_buffer_rsrc((void*)og, 0, 0x80000000, 0x00020000);
-            const int q0 = wave * 32 + (lane & 31);
-#pragma unroll
-            for (int ks = 0; ks < HD / 16; ++ks) of0[ks] = load_frag_global(rsO0, q0 < a.Nq, q0, a.o_sr, ks, hi);
-        }
         for (int q = tid; q < a.nqp; q += NTH) lse_s[q] = q < a.Nq ? a.lse[((long long)b * a.H + h) * a.Nq + q] : 0.f;
         lq.commit(Qs, a.nqp, tid);
         ld.commit(dOs, a.nqp, tid);
@@ -393,32 +383,45 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
         lv.commit(Vs, a.nkp, tid);
     }
     const int nt = a.nkp >> 5, nqb = a.nqp >> 5;
-    const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void*)og, 0, 0x80000000, 0x00020000);
-    const auto rsdO = __builtin_amdgcn_make_buffer_rsrc((void*)dog, 0, 0x80000000, 0x00020000);
-    // delta[q] = sum_d dO[q][d] * O[q][d]
-    if constexpr (!X3) __syncthreads();                  // bf16 path reads dO from its LDS tile
+    __syncthreads();
+    // delta[q] = sum_j P[q][j] dP[q][j], from the SAME fp32 P and dP the two passes form dS = P (dP - delta) with -- exactly what
+    // autograd's softmax backward computes.  (Rounds 1-3 used the flash-attention shortcut delta = rowsum(dO . O) with the STORED
+    // bf16 O.  O = sum_j P_j V_j carries the keys' common component V_mean; its 2^-9 rounding error, dotted with dO, is a common-mode
+    // error of every dS_j of the row that the dQ / dK products multiply by the keys' / queries' common component K_mean -- while
+    // the true signal only sees V_j - V_mean and K_j - K_mean.  On the 24-layer ViT-L step of cfg5, where |mean| / |spread| is ~4
+    // for both, that was 22 % on dQ of the decoders' cross-attention and 4.8 % on decoder.q.weight, against 0.7 % / 0.4 % with
+    // this delta: tools/xattn_delta_probe.py)  One extra S / dP sweep per query block, spread over all waves;
+    // O is no longer read.
     for (int qblk = wave; qblk < nqb; qblk += NW) {
         const int q = qblk * 32 + (lane & 31);
-        const bool qok = q < a.Nq;
-        float d = 0.f;
+        bf16x8 qf[HD / 16], dof[HD / 16], ql[HD / 16], dol[HD / 16];
 #pragma unroll
         for (int ks = 0; ks < HD / 16; ++ks) {
-            if constexpr (X3) {
+            qf[ks] = frag_rows<HD>(Qs, qblk * 32, ks, lane); dof[ks] = frag_rows<HD>(dOs, qblk * 32, ks, lane);
+            ql[ks] = X3 ? frag_rows<HD>(Qs + lo, qblk * 32, ks, lane) : qf[ks];
+            dol[ks] = X3 ? frag_rows<HD>(dOs + lo, qblk * 32, ks, lane) : dof[ks];
+        }
+        const float lse_q = lse_s[q];
+        float d0 = 0.f, d1 = 0.f;
+        for (int t = 0; t < nt; ++t) {
+            f32x16 st, dpt;
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const unsigned off = qok ? (unsigned)((q * a.o_sr + ks * 16 + hi * 8 + half * 4) * 4) : OOB;
-                    const f32x4 of = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsO, off, 0, 0));
-                    const f32x4 df = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsdO, off, 0, 0));
+            for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) d += of[j] * df[j];
-                }
-            } else {
-                const bf16x8 of = (qblk == wave) ? of0[ks] : load_frag_global(rsO, qok, q, a.o_sr, ks, hi);
-                const bf16x8 df = frag_rows<HD>(dOs, qblk * 32, ks, lane);      // rows >= Nq are zero-padded
+            for (int ks = 0; ks < HD / 16; ++ks) {
+                const bf16x8 kh = frag_rows<HD>(Ks, t * 32, ks, lane), vh = frag_rows<HD>(Vs, t * 32, ks, lane);
+                const bf16x8 kl = X3 ? frag_rows<HD>(Ks + lo, t * 32, ks, lane) : kh, vl = X3 ? frag_rows<HD>(Vs + lo, t * 32, ks, lane) : vh;
+                st = mma<X3>(kh, kl, qf[ks], ql[ks], st);
+                dpt = mma<X3>(vh, vl, dof[ks], dol[ks], dpt);
+            }
+            // (zero-padded keys: dP is exactly 0 there, whatever exp(-lse) their P is)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) d += (float)of[j] * (float)df[j];
+            for (int r = 0; r < 16; r += 2) {
+                d0 += __expf(st[r] * a.scale - lse_q) * dpt[r];
+                d1 += __expf(st[r + 1] * a.scale - lse_q) * dpt[r + 1];
             }
         }
+        float d = d0 + d1;
         d += __shfl_xor(d, 32, 64);
         if (hi == 0) delta_s[q] = d;
     }

@@ -17,6 +17,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 void mmae_set_error(const char* msg);
 int mmae_check_launch(const char* what);
 int mmae_cu_count();                                          // runtime.hip: compute units of the CURRENT device (cached per device)
+int mmae_cu_avail();                                          // ... minus the ones mmae_gemm_cu_reserve() keeps free: width of a persistent GEMM grid
 
 // A/B switches of the experiments (environment variables) exist only in builds with -DMMAE_EXPERIMENTS (make EXTRA=-DMMAE_EXPERIMENTS);
 // the production library reads no environment: every switch is its default.
@@ -88,6 +89,45 @@ __device__ __forceinline__ void gelu_cdf_exp(float x, float& cdf, float& e) {
 __device__ __forceinline__ float gelu_erf(float x) { float c, e; gelu_cdf_exp(x, c, e); return x * c; }
 __device__ __forceinline__ void gelu_both(float x, float& y, float& dy) { float c, e; gelu_cdf_exp(x, c, e); y = x * c; dy = c + x * e * 0.39894228040143268f; }
 __device__ __forceinline__ float gelu_erf_grad(float x) { float c, e; gelu_cdf_exp(x, c, e); return c + x * e * 0.39894228040143268f; }
+
+// ---- the same pair for bf16 OUTPUTS: no transcendental, packed fp32 math ---------------------------------------------------------
+// Phi(x) - 1/2 and GELU'(x) - 1/2 are odd: x Q(x^2) and x R(x^2) with degree-8 minimax polynomials in s = x^2 on |x| <= 4, x clamped
+// to that range first (Phi(4) = 1 - 3.2e-5: beyond it gelu(x) = x Phi(+-4), GELU' = GELU'(+-4) = 1 + 5e-4 | -5e-4).  Evaluated in
+// fp32 Horner form (measured against fp64, tools/gelu_poly_fit.py): |Phi error| 6.6e-6, |GELU' error| 8.4e-5, gelu relative
+// error 1.3e-4 for x > -2 and an absolute error <= 2.7e-5 everywhere -- all below the bf16 rounding (2^-9 = 2e-3) the result gets
+// anyway.  Two elements per instruction (v_pk_fma_f32 / v_pk_mul_f32): 8 + 8 packed FMAs per pair against one v_exp, one v_rcp and
+// ~17 scalar FMA-class operations per ELEMENT of the exact form, which kept the bias + GELU epilogue of fc1 VALU-bound behind its
+// two store streams (profiles/r02_epilogue_dissection.txt: 17-30 us of 166).  The exact form above stays for every f32 output
+// (the parity mode, the fp32 output adapters).
+__device__ __forceinline__ void gelu_both_fast2(f32x2 x, f32x2& y, f32x2& dy) {
+    f32x2 t;
+    t[0] = __builtin_amdgcn_fmed3f(x[0], -4.0f, 4.0f);
+    t[1] = __builtin_amdgcn_fmed3f(x[1], -4.0f, 4.0f);
+    const f32x2 s = t * t;
+    f32x2 q = {8.063375031e-11f, 8.063375031e-11f}, r = {9.796052989e-10f, 9.796052989e-10f};
+#define MMAE_PK_STEP(acc, c) acc = __builtin_elementwise_fma(acc, s, (f32x2){c, c})
+    MMAE_PK_STEP(q, -7.003438364e-09f); MMAE_PK_STEP(r, -8.218800834e-08f);
+    MMAE_PK_STEP(q, 2.716148569e-07f);  MMAE_PK_STEP(r, 3.028347546e-06f);
+    MMAE_PK_STEP(q, -6.294988571e-06f); MMAE_PK_STEP(r, -6.495757385e-05f);
+    MMAE_PK_STEP(q, 9.890799001e-05f);  MMAE_PK_STEP(r, 9.073266031e-04f);
+    MMAE_PK_STEP(q, -1.133921717e-03f); MMAE_PK_STEP(r, -8.716320413e-03f);
+    MMAE_PK_STEP(q, 9.877475989e-03f);  MMAE_PK_STEP(r, 5.845610030e-02f);
+    MMAE_PK_STEP(q, -6.641059427e-02f); MMAE_PK_STEP(r, -2.648265329e-01f);
+    MMAE_PK_STEP(q, 3.989227094e-01f);  MMAE_PK_STEP(r, 7.976095497e-01f);
+#undef MMAE_PK_STEP
+    const f32x2 half = {0.5f, 0.5f};
+    const f32x2 cdf = __builtin_elementwise_fma(t, q, half);
+    y = x * cdf;
+    dy = __builtin_elementwise_fma(t, r, half);
+}
+__device__ __forceinline__ void gelu_both_fast4(f32x4 x, f32x4& y, f32x4& dy) {
+    f32x2 ya, da, yb, db;
+    gelu_both_fast2((f32x2){x[0], x[1]}, ya, da);
+    gelu_both_fast2((f32x2){x[2], x[3]}, yb, db);
+    y = (f32x4){ya[0], ya[1], yb[0], yb[1]};
+    dy = (f32x4){da[0], da[1], db[0], db[1]};
+}
+__device__ __forceinline__ f32x4 gelu_grad_fast4(f32x4 x) { f32x4 y, dy; gelu_both_fast4(x, y, dy); return dy; }
 
 // ---- MX-fp8 quantisation helpers (mxfp8.hip, the ..._Q GEMM epilogue flavours, the LayerNorm kernels) ----------------
 // shared exponent of a block as a biased E8M0 byte, clamped at 0: floor(log2(amax)) - emax(e4m3 = 8) as OCP MX v1.0 section 6.3 has

@@ -188,8 +188,45 @@ std::atomic<int> g_gelu_grad_aux{1};                                 // mmae_gel
 inline int epi_gelu(int act) { return (act == MMAE_BF16 && g_gelu_grad_aux.load(std::memory_order_relaxed)) ? MMAE_EPI_GELU_G : MMAE_EPI_GELU; }
 inline int epi_dgelu(int act) { return (act == MMAE_BF16 && g_gelu_grad_aux.load(std::memory_order_relaxed)) ? MMAE_EPI_MUL : MMAE_EPI_DGELU; }
 
+// Parameter-gradient column sums collected into ONE launch (mmae_colsum_batch): the LayerNorm partial blocks, the dGELU epilogue's
+// partials and the bias gradients that no GEMM carries.  add() queues; flush() launches on the weight-gradient stream once every
+// source is final there.  A full batch flushes itself, so add() must only be called when the sources queued SO FAR are ordered
+// before `st` -- the callers add right behind a fork_to(compute, side).
+struct ColBatch {
+    mmae_colsum_job j[MMAE_COLSUM_MAX_JOBS];
+    int n = 0;
+    int add(const Ctx& c, const void* src, int dtype, int64_t rows, int cols, int64_t ld, int seg_w, float* const* dsts, int nseg, hipStream_t st) {
+        bool any = false;
+        for (int i = 0; i < nseg; ++i) any = any || dsts[i];
+        if (!any) return 0;
+        if (n == MMAE_COLSUM_MAX_JOBS) { const int rc = flush(c, st); if (rc) return rc; }
+        mmae_colsum_job& q = j[n++];
+        q = mmae_colsum_job{};
+        q.src = src; q.dtype = dtype; q.rows = rows; q.cols = cols; q.ld = ld; q.seg_w = seg_w; q.nseg = nseg;
+        for (int i = 0; i < nseg; ++i) q.dst[i] = dsts[i];
+        return 0;
+    }
+    int add3(const Ctx& c, const float* part, int rows, int seg_w, float* d0, float* d1, float* d2, hipStream_t st) {
+        float* dsts[3] = {d0, d1, d2};
+        return add(c, part, MMAE_F32, rows, 3 * seg_w, 3 * seg_w, seg_w, dsts, 3, st);
+    }
+    int add1(const Ctx& c, const void* src, int dtype, int64_t rows, int cols, int64_t ld, float* dst, hipStream_t st) {
+        float* dsts[1] = {dst};
+        return add(c, src, dtype, rows, cols, ld, cols, dsts, 1, st);
+    }
+    int flush(const Ctx& c, hipStream_t st) {
+        if (n == 0) return 0;
+        const int64_t need = mmae_colsum_batch_ws_elems(j, n);
+        if (need > c.ws_side_elems) { mmae_set_error("composite: ws_side too small for the batched column sums"); return MMAE_EINVAL; }
+        const int rc = mmae_colsum_batch(j, n, c.grad_acc, c.ws_side, c.ws_side_elems, st);
+        n = 0;
+        return rc;
+    }
+};
+
 // dw[N,K] (+)= dy[M,N]^T x[M,K]; db[N] (+)= column sums of dy (inside the GEMM where the kernel can) -- ops.linear_dw
-int lin_dw(const Ctx& c, const void* dy, int64_t ldy, const void* x, float* dw, float* db, int M, int N, int K, hipStream_t st) {
+// cb: where a bias gradient that no GEMM kernel carries is queued (one batched column-sum launch later) instead of its own launches
+int lin_dw(const Ctx& c, const void* dy, int64_t ldy, const void* x, float* dw, float* db, int M, int N, int K, hipStream_t st, ColBatch* cb = nullptr) {
     if (!dw && !db) return 0;
     const int acc = c.grad_acc;
     if (dw) {
@@ -215,6 +252,7 @@ int lin_dw(const Ctx& c, const void* dy, int64_t ldy, const void* x, float* dw, 
         if (rc) return rc;
     }
     if (db) {
+        if (cb) return cb->add1(c, dy, c.act_dtype, M, N, ldy, db, st);
         if (mmae_colsum_ws_elems(M, N) > c.ws_side_elems) { mmae_set_error("composite: ws_side too small"); return MMAE_EINVAL; }
         return mmae_colsum(dy, c.act_dtype, M, N, ldy, db, acc, c.ws_side, st);
     }
@@ -288,19 +326,6 @@ bool mx_lin_dw(const Ctx& c, const void* dy, int64_t ldy, const void* x, int64_t
     g.split_k = split; g.ws = c.ws_side; g.ws_elems = slab;
     *rc = mmae_gemm(&g, st);
     return true;
-}
-
-// column sums of part [rows][nseg * seg_w] scattered into up to 8 gradient destinations (NULL = dropped)
-int scatter(const Ctx& c, const float* part, int rows, int seg_w, float* const* dsts, int nseg, hipStream_t st) {
-    bool any = false;
-    for (int i = 0; i < nseg; ++i) any = any || dsts[i];
-    if (!any) return 0;
-    if (mmae_colsum_ws_elems(rows, nseg * seg_w) > c.ws_side_elems) { mmae_set_error("composite: ws_side too small"); return MMAE_EINVAL; }
-    return mmae_colsum_scatter(part, MMAE_F32, rows, nseg * seg_w, nseg * seg_w, seg_w, dsts, nseg, c.grad_acc, c.ws_side, st);
-}
-int scatter3(const Ctx& c, const float* part, int rows, int seg_w, float* d0, float* d1, float* d2, hipStream_t st) {
-    float* dsts[3] = {d0, d1, d2};
-    return scatter(c, part, rows, seg_w, dsts, 3, st);
 }
 
 int cast_to_act(int act, const float* src, void* dst, int64_t n, hipStream_t st) {       // f32 -> act dtype (bf16 only: f32 callers alias)
@@ -505,6 +530,10 @@ int run_blocks_bwd(const StackRun& s, int lo, int hi, const float* dx_top, const
 
 }  // namespace
 
+int mmae_decoder_build_rows(const float* ctx, const int64_t* ids_keep, const int64_t* ids_restore, const float* mask_token,
+                            const float* const* task_emb_rows, const float* pos, const int32_t* task_offsets_host, int T, int q_task, int B,
+                            int n_keep, int G, int D, int n_q, float* queries, float* context, void* stream);      // tokens.hip
+
 extern "C" {
 
 int mmae_block_fwd(const mmae_block_desc* d, void* stream) {
@@ -586,6 +615,11 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
     const void* const* mx = (d->mx_w && act == MMAE_BF16) ? d->mx_w : nullptr;
     DwGroup grp(c, R);                                               // the block's four weight gradients: one launch at the end
     if (d->dp1 || d->dp2) grp.on = false;                           // stochastic depth re-uses dxs_act between the two branches
+    // the block's parameter-gradient column sums (two LayerNorm partial blocks, the dGELU partials, bias gradients no GEMM
+    // carries): ONE launch at the end of the block instead of two each (round 4; 72 of a cfg3 step's 176 column-sum launches
+    // were the encoder's).  Not for sources that are rewritten inside the block (the rescaled copies of stochastic depth).
+    ColBatch cbat;
+    ColBatch* const cb_defer = (d->dp1 || d->dp2) ? nullptr : &cbat;
     // one weight gradient (+ bias gradient): MX-fp8 product in MX mode where the shape allows, else the grouped bf16 launch, else its own
     auto wgrad = [&](const void* dy, int64_t ldy, const void* x, int64_t ldx, float* dw, float* db, int n_out, int k_in) -> int {
         int r = 0;
@@ -595,7 +629,7 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
             return mmae_colsum(dy, c.act_dtype, R, n_out, ldy, db, c.grad_acc, c.ws_side, sd);
         }
         if (grp.add(dy, ldy, x, ldx, dw, db, n_out, k_in)) return 0;
-        return lin_dw(c, dy, ldy, x, dw, db, R, n_out, k_in, sd);
+        return lin_dw(c, dy, ldy, x, dw, db, R, n_out, k_in, sd, cb_defer);
     };
     static const bool mx_fuse = (mmae_env_int("MMAE_MX_FUSE", 1) != 0);
     const int hq = (mx && mx_fuse) ? 1 : -1;                 // fc2's dX epilogue leaves the quantised d_hpre in half 1 for fc1's dX
@@ -604,10 +638,7 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
     if ((rc = wgrad(dm_act, D, d->hact, Hd, d->g_fc2_w, d->fc2_b_done ? nullptr : d->g_fc2_b, D, Hd))) return rc;
     if ((rc = lin_dx(c, d->d_hpre, Hd, d->fc1_w, d->d_ln2, act, R, Hd, D, nullptr, MMAE_EPI_NONE, nullptr, st, mx ? mx + 8 : nullptr, hq))) return rc;
     if ((rc = wgrad(d->d_hpre, Hd, d->ln2, D, d->g_fc1_w, nullptr, Hd, D))) return rc;
-    if (part_h) {
-        float* dst[1] = {d->g_fc1_b};
-        if ((rc = scatter(c, part_h, hrows, Hd, dst, 1, sd))) return rc;
-    }
+    if (part_h && (rc = cbat.add1(c, part_h, MMAE_F32, hrows, Hd, Hd, d->g_fc1_b, sd))) return rc;
     void* dx1_act = act == MMAE_F32 ? nullptr : d->dx1_act;
     if ((rc = mmae_layernorm_bwd(d->d_ln2, act, d->x1, d->n2_w, d->mean2, d->rstd2, d->dx, d->dx1, dx1_act, act, d->part2, R, D, st))) return rc;
     // ---- attention: x1 = x0 + dp1 * attn(norm1(x0))
@@ -620,7 +651,7 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
     if ((rc = lin_dx(c, da_act, D, d->proj_w, d->d_ao, act, R, D, D, nullptr, MMAE_EPI_NONE, nullptr, st, mx ? mx + 4 : nullptr))) return rc;
     if ((rc = fork_to(st, sd))) return rc;                          // part2, dx1_act
     // proj's bias gradient: colsum(dx1) from the LayerNorm partials, or colsum of the rescaled copy under stochastic depth
-    if ((rc = scatter3(c, d->part2, nblk, D, d->g_n2_w, d->g_n2_b, d->dp1 ? nullptr : d->g_proj_b, sd))) return rc;
+    if ((rc = cbat.add3(c, d->part2, nblk, D, d->g_n2_w, d->g_n2_b, d->dp1 ? nullptr : d->g_proj_b, sd))) return rc;
     if ((rc = wgrad(da_act, D, d->ao, D, d->g_proj_w, d->dp1 ? d->g_proj_b : nullptr, D, D))) return rc;
     {
         const size_t es = act == MMAE_BF16 ? 2 : 4;
@@ -645,7 +676,8 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
     void* dx0_act = act == MMAE_F32 ? nullptr : d->dx0_act;
     if ((rc = mmae_layernorm_bwd(d->d_ln1, act, d->x0, d->n1_w, d->mean1, d->rstd1, d->dx1, d->dx0, dx0_act, act, d->part1, R, D, st))) return rc;
     if ((rc = fork_to(st, sd))) return rc;                          // part1
-    return scatter3(c, d->part1, nblk, D, d->g_n1_w, d->g_n1_b, d->g_cs, sd);
+    if ((rc = cbat.add3(c, d->part1, nblk, D, d->g_n1_w, d->g_n1_b, d->g_cs, sd))) return rc;
+    return cbat.flush(c, sd);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -900,13 +932,9 @@ int mmae_adapter_fwd(const mmae_adapter_desc* d, void* stream) {
         enc_act = a.enc_act;
     }
     if ((rc = lin_fwd(c, enc_act, pcw, pcb, a.ctx_tok, MMAE_F32, Rc, D, d->Denc, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;      // :258
-    for (int t = 0; t < T; ++t) {
-        hipError_t e = d->task_emb[t] ? hipMemcpyAsync(a.te + (size_t)t * D, d->task_emb[t], (size_t)D * 4, hipMemcpyDeviceToDevice, st)
-                                      : hipMemsetAsync(a.te + (size_t)t * D, 0, (size_t)D * 4, st);
-        if (e != hipSuccess) { mmae_set_error("adapter_fwd: task embedding copy failed"); return MMAE_ELAUNCH; }
-    }
-    if ((rc = mmae_decoder_build(a.ctx_tok, d->ids_keep, d->ids_restore, d->mask_token, a.te, d->pos, d->task_offsets_host, T, d->q_task, B,
-                                 NC - d->G, d->G, D, n_q, a.queries, a.context, st))) return rc;                                       // :183-234
+    // the task-embedding rows are read where the parameters live (no staging copies)
+    if ((rc = mmae_decoder_build_rows(a.ctx_tok, d->ids_keep, d->ids_restore, d->mask_token, (const float* const*)d->task_emb, d->pos, d->task_offsets_host, T,
+                                      d->q_task, B, NC - d->G, d->G, D, n_q, a.queries, a.context, st))) return rc;                    // :183-234
     if ((rc = mmae_layernorm_fwd(a.queries, qnw, qnb, a.qn, act, a.qmean, a.qrstd, Rq, D, d->eps, st))) return rc;
     if ((rc = mmae_layernorm_fwd(a.context, cnw, cnb, a.cn, act, a.cmean, a.crstd, Rc, D, d->eps, st))) return rc;
     if ((rc = lin_fwd(c, a.qn, qw, qb, a.q, act, Rq, D, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;
@@ -979,8 +1007,9 @@ int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream
     // the adapter's own weight gradients: two grouped launches at the end (products over the B * n_q query rows / over the
     // B * NC context rows); whatever a group cannot take (f32 activations, odd widths) is issued on its own right away
     DwGroup grp_q(c, Rq), grp_c(c, Rc);
+    ColBatch cbat;                                                   // the adapter's own parameter-gradient column sums: one launch at the end
     if ((rc = fork_to(st, sd))) return rc;
-    if (!grp_q.add(d_pat, ldp, h_act, D, gtail[0], gtail[1], KP, D) && (rc = lin_dw(c, d_pat, ldp, h_act, gtail[0], gtail[1], Rq, KP, D, sd))) return rc;
+    if (!grp_q.add(d_pat, ldp, h_act, D, gtail[0], gtail[1], KP, D) && (rc = lin_dw(c, d_pat, ldp, h_act, gtail[0], gtail[1], Rq, KP, D, sd, &cbat))) return rc;
     if ((rc = lin_dx(c, d_pat, ldp, ow, t.dh_act, act, Rq, KP, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
     const float* dh = (const float*)t.dh_act;
     if (bf) { if ((rc = mmae_cast_bf16_to_f32(t.dh_act, t.dh, (int64_t)Rq * D, st))) return rc; dh = t.dh; }
@@ -1001,16 +1030,16 @@ int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream
     if ((rc = lin_dx(c, dh_act, D, f2w, t.d_hpre, act, Rq, D, Hd, a.hpre, epi_dgelu(act), gb[13] ? t.part_h : nullptr, st))) return rc;
     if ((rc = fork_to(st, sd))) return rc;
     if (!grp_q.add(dh_act, D, a.hact, Hd, gb[14], fc2_done ? nullptr : gb[15], D, Hd) &&
-        (rc = lin_dw(c, dh_act, D, a.hact, gb[14], fc2_done ? nullptr : gb[15], Rq, D, Hd, sd))) return rc;
+        (rc = lin_dw(c, dh_act, D, a.hact, gb[14], fc2_done ? nullptr : gb[15], Rq, D, Hd, sd, &cbat))) return rc;
     if ((rc = lin_dx(c, t.d_hpre, Hd, f1w, t.d_on, act, Rq, Hd, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
     if (!grp_q.add(t.d_hpre, Hd, a.on, D, gb[12], nullptr, Hd, D) && (rc = lin_dw(c, t.d_hpre, Hd, a.on, gb[12], nullptr, Rq, Hd, D, sd))) return rc;
-    if (gb[13]) { float* dst[1] = {gb[13]}; if ((rc = scatter(c, t.part_h, (Rq + 31) / 32, Hd, dst, 1, sd))) return rc; }
+    if (gb[13] && (rc = cbat.add1(c, t.part_h, MMAE_F32, (Rq + 31) / 32, Hd, Hd, gb[13], sd))) return rc;
     if ((rc = mmae_layernorm_bwd(t.d_on, act, a.x, onw, a.omean, a.orstd, dh, t.dx, bf ? t.dx_act : nullptr, act, t.part_o, Rq, D, st))) return rc;
     const void* dx_act = bf ? (const void*)t.dx_act : (const void*)t.dx;
     // ---- x = proj(attn(q, k, v))
     if ((rc = lin_dx(c, dx_act, D, pw, t.d_xo, act, Rq, D, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
     if ((rc = fork_to(st, sd))) return rc;
-    if ((rc = scatter3(c, t.part_o, mmae_layernorm_bwd_nblk(Rq), D, gb[10], gb[11], gb[5], sd))) return rc;      // outn_w, outn_b, proj_b
+    if ((rc = cbat.add3(c, t.part_o, mmae_layernorm_bwd_nblk(Rq), D, gb[10], gb[11], gb[5], sd))) return rc;      // outn_w, outn_b, proj_b
     if (!grp_q.add(dx_act, D, a.xo, D, gb[4], nullptr, D, D) && (rc = lin_dw(c, dx_act, D, a.xo, gb[4], nullptr, Rq, D, D, sd))) return rc;
     {
         auto fn = bf ? mmae_attn_bwd : mmae_attn_bwd_f32x3;
@@ -1022,8 +1051,8 @@ int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream
     if ((rc = lin_dx(c, t.d_q, D, qw, t.d_qn, act, Rq, D, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
     if ((rc = lin_dx(c, t.d_kv, 2 * D, kvw, t.d_cn, act, Rc, 2 * D, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
     if ((rc = fork_to(st, sd))) return rc;
-    if (!grp_q.add(t.d_q, D, a.qn, D, gb[0], gb[1], D, D) && (rc = lin_dw(c, t.d_q, D, a.qn, gb[0], gb[1], Rq, D, D, sd))) return rc;
-    if (!grp_c.add(t.d_kv, 2 * D, a.cn, D, gb[2], gb[3], 2 * D, D) && (rc = lin_dw(c, t.d_kv, 2 * D, a.cn, gb[2], gb[3], Rc, 2 * D, D, sd))) return rc;
+    if (!grp_q.add(t.d_q, D, a.qn, D, gb[0], gb[1], D, D) && (rc = lin_dw(c, t.d_q, D, a.qn, gb[0], gb[1], Rq, D, D, sd, &cbat))) return rc;
+    if (!grp_c.add(t.d_kv, 2 * D, a.cn, D, gb[2], gb[3], 2 * D, D) && (rc = lin_dw(c, t.d_kv, 2 * D, a.cn, gb[2], gb[3], Rc, 2 * D, D, sd, &cbat))) return rc;
     if ((rc = mmae_layernorm_bwd(t.d_qn, act, a.queries, qnw, a.qmean, a.qrstd, nullptr, t.d_queries, nullptr, MMAE_F32, t.part_q, Rq, D, st))) return rc;
     if ((rc = mmae_layernorm_bwd(t.d_cn, act, a.context, cnw, a.cmean, a.crstd, nullptr, t.d_context, nullptr, MMAE_F32, t.part_c, Rc, D, st))) return rc;
     if ((rc = mmae_decoder_build_bwd(t.d_queries, t.d_context, d->ids_keep, d->ids_restore, d->task_offsets_host, T, d->q_task, B, NC - d->G, d->G, D,
@@ -1031,18 +1060,19 @@ int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream
     const void* d_ctx_act = t.d_ctx;
     if (bf) { if ((rc = mmae_cast_f32_to_bf16(t.d_ctx, t.d_ctx_act, (int64_t)Rc * D, st))) return rc; d_ctx_act = t.d_ctx_act; }
     if ((rc = fork_to(st, sd))) return rc;
-    if ((rc = scatter3(c, t.part_q, mmae_layernorm_bwd_nblk(Rq), D, gb[8], gb[9], nullptr, sd))) return rc;      // qn_w, qn_b
-    if ((rc = scatter3(c, t.part_c, mmae_layernorm_bwd_nblk(Rc), D, gb[6], gb[7], nullptr, sd))) return rc;      // ctxn_w, ctxn_b
+    if ((rc = cbat.add3(c, t.part_q, mmae_layernorm_bwd_nblk(Rq), D, gb[8], gb[9], nullptr, sd))) return rc;      // qn_w, qn_b
+    if ((rc = cbat.add3(c, t.part_c, mmae_layernorm_bwd_nblk(Rc), D, gb[6], gb[7], nullptr, sd))) return rc;      // ctxn_w, ctxn_b
     {
         float* dst[8];
         for (int i = 0; i < T; ++i) dst[i] = g_temb[i];
         dst[T] = g_mask;
-        if ((rc = scatter(c, t.part_b, mmae_decoder_build_bwd_nblk(B), D, dst, T + 1, sd))) return rc;
+        if ((rc = cbat.add(c, t.part_b, MMAE_F32, mmae_decoder_build_bwd_nblk(B), (T + 1) * D, (T + 1) * D, D, dst, T + 1, sd))) return rc;
     }
     if (!grp_c.add(d_ctx_act, D, enc_act, d->Denc, gtail[2], gtail[3], D, d->Denc) &&
-        (rc = lin_dw(c, d_ctx_act, D, enc_act, gtail[2], gtail[3], Rc, D, d->Denc, sd))) return rc;
+        (rc = lin_dw(c, d_ctx_act, D, enc_act, gtail[2], gtail[3], Rc, D, d->Denc, sd, &cbat))) return rc;
     if ((rc = grp_q.flush(c, sd))) return rc;
     if ((rc = grp_c.flush(c, sd))) return rc;
+    if ((rc = cbat.flush(c, sd))) return rc;
     return lin_dx(c, d_ctx_act, D, pcw, d->d_enc, MMAE_F32, Rc, D, d->Denc, nullptr, MMAE_EPI_NONE, nullptr, st);
 }
 

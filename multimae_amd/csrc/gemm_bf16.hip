@@ -264,19 +264,20 @@ int mmae_gemm_bf16_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hi
     if (d->a_trans) MMAE_REQUIRE(d->M % 8 == 0 || d->lda >= ((d->M + 7) / 8) * 8, "gemm bf16: transposed A row too short");
     if (d->b_trans) MMAE_REQUIRE(d->N % 8 == 0 || d->ldb >= ((d->N + 7) / 8) * 8, "gemm bf16: transposed B row too short");
     // tile codes (chosen by runtime.hip's gemm_plan): 1 = 128x128 LDS-DMA, 2 = 256x128 LDS-DMA, 3 = 128x128 VGPR-staged, 4 = 256x128 VGPR-staged
-    if (code > 14) {                       // experiment / dissection builds of the newer structures (-DMMAE_EXPERIMENTS)
+#ifdef MMAE_EXPERIMENTS
+    // Round-3 structures that lost to the ping-pong kernel (profiles/r03_duo_*, r03_pp64_*) and their dissection builds: tile codes
+    // 11 / 12 ("duo", gemm_duo_body.h), 13 / 14 (64-wide K tiles, gemm_pp64_body.h), > 14 (dissections).  They exist only in
+    // experiment builds (make EXTRA=-DMMAE_EXPERIMENTS links gemm_bf16_duo.hip / gemm_bf16_pp64.hip); the production library
+    // maps those codes to the ping-pong kernel below.
+    if (code > 10) {
         const int rc = mmae_gemm_bf16_ext_impl(d, g, code, st);
         if (rc != MMAE_ESUPPORT) return rc;
-        code = 9;
     }
+#endif
+    if (code > 10) code = code == 14 ? 10 : 9;
     switch (code) {
         case 5: case 6: case 7: case 8: return mmae_gemm_bf16_pipe_impl(d, g, code, st);     // LDS-DMA ring, BK = 32
         case 9: case 10: return mmae_gemm_bf16_pp_impl(d, g, code, st);                     // 8-wave ping-pong, 256/320 x 256
-        case 11: case 12: case 13: case 14: {                                              // newer structures, dispatched in gemm_bf16_pp64.hip
-            const int rc = mmae_gemm_bf16_ext_impl(d, g, code, st);
-            if (rc != MMAE_ESUPPORT) return rc;
-            return mmae_gemm_bf16_pp_impl(d, g, code == 14 ? 10 : 9, st);
-        }
         case 2: return dispatch_layout<4, 2, true>(g, d->batch, d->a_trans != 0, d->b_trans != 0, st);
         case 3: return dispatch_layout<2, 2, false>(g, d->batch, d->a_trans != 0, d->b_trans != 0, st);
         case 4: return dispatch_layout<4, 2, false>(g, d->batch, d->a_trans != 0, d->b_trans != 0, st);

@@ -61,8 +61,15 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, char* Cz, int 
     if (g.epi == MMAE_EPI_GELU) {
         const long long ao = (long long)m * g.ldaux + n;
         float s4[4];                                     // what aux keeps: the pre-activation, or (aux_grad) GELU' of it
+        if (!g.c_f32 && !g.aux_f32) {                    // bf16 outputs: the same polynomial pair as the fast routines (one result per dtype, whatever the tile)
+            f32x4 y4, d4;
+            gelu_both_fast4((f32x4){v[0], v[1], v[2], v[3]}, y4, d4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { float y, dy; gelu_both(v[j], y, dy); s4[j] = g.aux_grad ? dy : v[j]; v[j] = y; }
+            for (int j = 0; j < 4; ++j) { s4[j] = g.aux_grad ? d4[j] : v[j]; v[j] = y4[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { float y, dy; gelu_both(v[j], y, dy); s4[j] = g.aux_grad ? dy : v[j]; v[j] = y; }
+        }
         if (g.aux_f32) {
             float* a = (float*)g.aux + ao;
             if (full) { f32x4 t = {s4[0], s4[1], s4[2], s4[3]}; st4(a, t); } else for (int j = 0; j < cnt; ++j) a[j] = s4[j];
@@ -83,6 +90,10 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, char* Cz, int 
         if (g.aux_grad) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] *= p[j];
+        } else if (!g.c_f32 && !g.aux_f32) {
+            const f32x4 g4 = gelu_grad_fast4((f32x4){p[0], p[1], p[2], p[3]});
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= g4[j];
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(p[j]);
@@ -220,8 +231,14 @@ __device__ __forceinline__ void store_tile64_fast(const GemmArgs& g, char* Cbase
                 }
                 if (EPI == MMAE_EPI_GELU) {
                     f32x4 sv;
+                    if (!C_F32 && !AUX_F32) {              // bf16 outputs: the packed polynomial pair (common.h), as the 8-column routine
+                        f32x4 y4, d4;
+                        gelu_both_fast4(v, y4, d4);
+                        sv = g.aux_grad ? d4 : v; v = y4;
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { float y, dy; gelu_both(v[j], y, dy); sv[j] = g.aux_grad ? dy : v[j]; v[j] = y; }
+                        for (int j = 0; j < 4; ++j) { float y, dy; gelu_both(v[j], y, dy); sv[j] = g.aux_grad ? dy : v[j]; v[j] = y; }
+                    }
                     if (AUX_F32) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, sv), rsAux, voff(tm, it, g.ldaux, 4), 0, 0);
                     else __builtin_amdgcn_raw_buffer_store_b64(pack4_bf16(sv), rsAux, voff(tm, it, g.ldaux, 2), 0, 0);
                 } else if (EPI == MMAE_EPI_DGELU) {
@@ -230,6 +247,10 @@ __device__ __forceinline__ void store_tile64_fast(const GemmArgs& g, char* Cbase
                     if (g.aux_grad) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] *= p[j];
+                    } else if (!C_F32 && !AUX_F32) {
+                        const f32x4 g4 = gelu_grad_fast4(p);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] *= g4[j];
                     } else {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(p[j]);
@@ -319,13 +340,12 @@ __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cba
                 }
                 if (EPI == MMAE_EPI_GELU) {
                     f32x4 s0 = v0, s1 = v1;                  // what aux keeps: the pre-activation, or (aux_grad) GELU' of it
-                    if (DBG != 1) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float y, dy;
-                            gelu_both(v0[j], y, dy); s0[j] = g.aux_grad ? dy : v0[j]; v0[j] = y;
-                            gelu_both(v1[j], y, dy); s1[j] = g.aux_grad ? dy : v1[j]; v1[j] = y;
-                        }
+                    if (DBG != 1) {                          // bf16 outputs: the packed polynomial pair (common.h)
+                        f32x4 y0, d0, y1, d1;
+                        gelu_both_fast4(v0, y0, d0);
+                        gelu_both_fast4(v1, y1, d1);
+                        if (g.aux_grad) { s0 = d0; s1 = d1; }
+                        v0 = y0; v1 = y1;
                     }
                     if (DBG != 2 && DBG != 3) __builtin_amdgcn_raw_buffer_store_b128(pack8_bf16(s0, s1), rsAux, voff(gi, g.ldaux), 0, 0);
                 } else if (EPI == MMAE_EPI_DGELU) {
@@ -336,8 +356,9 @@ __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cba
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { v0[j] *= p0[j]; v1[j] *= p1[j]; }
                     } else {
+                        const f32x4 g0 = gelu_grad_fast4(p0), g1 = gelu_grad_fast4(p1);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { v0[j] *= gelu_erf_grad(p0[j]); v1[j] *= gelu_erf_grad(p1[j]); }
+                        for (int j = 0; j < 4; ++j) { v0[j] *= g0[j]; v1[j] *= g1[j]; }
                     }
                     if (gi + PD < nsteps) pre_aux[gi % PD] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, voff(gi + PD, g.ldaux), 0, 0);
                 }

@@ -243,9 +243,22 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
     };
     // (Issuing all, or one, of the phase's DMA pieces between the MFMAs instead -- an LDS-DMA issue stalls its wave 60-180
     // cycles -- measured 0-10 % slower than keeping them in the memory half-phase.)
+    // The asm fragment reads (frag_ks) are invisible to the compiler's wait-count pass: their results are valid only behind this
+    // s_waitcnt.  Every fragment register is passed THROUGH an asm statement that follows the wait ("+v": redefined there), so
+    // no copy, live-range split or spill of a fragment can be scheduled between its read and the wait -- the
+    // dependency no longer rests on sched_barrier and the allocator's behaviour.  (volatile asms keep their order.)
+    auto frag_fence = [&](bf16x8& f) {
+        i32x4 t = __builtin_bit_cast(i32x4, f);
+        asm volatile("" : "+v"(t));
+        f = __builtin_bit_cast(bf16x8, t);
+    };
     auto mfma_phase = [&]() {
         if (AKS || BKS) {                                    // the asm fragment reads of this phase's operands (see frag_ks)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < 2; ++t) if (BKS) frag_fence(bf[t]);
+#pragma unroll
+            for (int t = 0; t < TM; ++t) if (AKS) frag_fence(af[t]);
             __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(1);
@@ -282,6 +295,12 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
     auto mfma_phase_w = [&]() {
         if (AKS || BKS) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < 2; ++t) if (BKS) { frag_fence(bf[t]); frag_fence(bf2[t]); }
+#pragma unroll
+            for (int t = 0; t < TM; ++t) if (AKS) frag_fence(af[t]);
+#pragma unroll
+            for (int t = 0; t < (WIDE ? TM : 1); ++t) if (AKS) frag_fence(af2[t]);
             __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(1);
@@ -495,7 +514,7 @@ int launch(const GemmArgs& g, int batch, hipStream_t st) {
     a.tiles_n = (g.N + BN - 1) / BN;
     a.kt_per_split = g.kt_per_split * 2;                 // runtime.hip counts 64-wide K tiles; this kernel steps by 32
     a.tiles_total = tiles_m * a.tiles_n;
-    const int n_cu = mmae_cu_count();
+    const int n_cu = mmae_cu_avail();
     static const int env_persist = mmae_env_int("MMAE_PP_PERSIST", 1);
     const int gx = (env_persist && a.tiles_total > n_cu) ? n_cu : a.tiles_total;      // one resident workgroup per CU walks the tile list
     dim3 grid(gx, batch, a.splitk), block(512);

@@ -502,7 +502,7 @@ int launch_mx(const GemmArgs& g, hipStream_t st) {
     a.tiles_n = (g.N + BN - 1) / BN;
     a.tiles_total = ((g.M + BM - 1) / BM) * a.tiles_n;
     if (a.splitk > 1) { a.C = a.ws; a.ldc = a.N; a.accumulate = 0; }      // slices write dense f32 slabs [splitk][M][N]
-    const int n_cu = mmae_cu_count();
+    const int n_cu = mmae_cu_avail();
     const long long nv = (long long)a.tiles_total * (a.splitk > 1 ? a.splitk : 1);
     const int gx = nv > n_cu ? n_cu : (int)nv;
     const size_t lds = (size_t)4 * (BM + BN) * 64 + 1024;
@@ -554,10 +554,12 @@ int mmae_gemm_mxfp8_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t
     const long long nt = (d->N + 255) / 256;
     const long long t4 = ((d->M + 255) / 256) * nt, t5 = ((d->M + 319) / 320) * nt;
     const long long c4 = ((t4 + 255) / 256) * 256, c5 = ((t5 + 255) / 256) * 320;
+    (void)c4; (void)c5;                                   // 320-row tiles spill ~35 registers in this body and measured 14 % slower:
+#ifdef MMAE_EXPERIMENTS                                   // instantiated in experiment builds only (MMAE_MX_TM=5)
     static const int env_tm = mmae_env_int("MMAE_MX_TM", 0);
-    (void)c4; (void)c5;                                   // 320-row tiles spill ~35 registers in this body and measured 14 % slower: opt-in only
-    const bool five = env_tm == 5;
-    return five ? launch_mx_fl<5>(g, fl, st) : launch_mx_fl<4>(g, fl, st);
+    if (env_tm == 5) return launch_mx_fl<5>(g, fl, st);
+#endif
+    return launch_mx_fl<4>(g, fl, st);
 }
 
 extern "C" {

@@ -2,6 +2,7 @@
 // One 64-lane wavefront per row, 16-byte vector accesses, shuffle reductions (no LDS on the
 // per-row critical path).  Roofline for all of them is HBM bytes / 8 TB/s.
 #include <stdlib.h>
+#include <mutex>
 #include "common.h"
 
 namespace {
@@ -620,6 +621,174 @@ int mmae_colsum_scatter(const void* dy, int dtype, int64_t M, int N, int64_t ld,
     for (int i = 0; i < nseg; ++i) d.dst[i] = ((float* const*)dsts)[i];
     d.seg_w = seg_w;
     return colsum_impl(dy, dtype, M, N, ld, d, accumulate, ws, stream);
+}
+
+}  // extern "C"
+
+// ---- batched column sums: several mmae_colsum_scatter jobs in one launch ----------------------------------------------------------
+namespace {
+constexpr int CB_MAX_GROUPS = 160;                 // 256-column groups per launch (a ViT-L block: 16 + 12 + 12)
+constexpr int CB_SLOTS = 64;                       // streams with a ticket slot of their own
+__device__ unsigned g_colsum_tickets[CB_SLOTS][CB_MAX_GROUPS];      // zero at module load; every launch leaves its tickets zero again
+
+struct CbJob { const void* src; long long rows, ld; int dtype, cols, seg_w, ns, group0, ws_off; float* dst[8]; };
+struct CbArgs { int n, accumulate, slot, ngroups; float* ws; CbJob j[MMAE_COLSUM_MAX_JOBS]; };
+
+template <typename DT>
+__device__ __forceinline__ f32x4 cb_rows(const DT* src, long long rows, long long ld, int c, int cols, int sp, int ns, int w, bool vec_ok) {
+    // rows sp * 4 + w, then every ns * 4 (the walk of colsum_kernel: same partial sums, same order)
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    const long long step = (long long)ns * 4;
+    long long r = (long long)sp * 4 + w;
+    if (vec_ok && cols - c >= 4) {
+        for (; r + 3 * step < rows; r += 4 * step) {
+            const f32x4 v0 = ld4(src + r * ld + c), v1 = ld4(src + (r + step) * ld + c), v2 = ld4(src + (r + 2 * step) * ld + c),
+                        v3 = ld4(src + (r + 3 * step) * ld + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s0[k] += v0[k]; s1[k] += v1[k]; s2[k] += v2[k]; s3[k] += v3[k]; }
+        }
+        for (; r < rows; r += step) {
+            const f32x4 v = ld4(src + r * ld + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s0[k] += v[k];
+        }
+    } else {                                       // rows that are not 4-element aligned / a ragged last group (class counts such as 133)
+        const int nk = cols - c < 4 ? cols - c : 4;
+        for (; r < rows; r += step)
+            for (int k = 0; k < nk; ++k) s0[k] += ActT<DT>::ld(src + r * ld + c + k);
+    }
+    f32x4 s;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = (s0[k] + s1[k]) + (s2[k] + s3[k]);
+    return s;
+}
+
+__global__ void __launch_bounds__(256) colsum_batch_kernel(const CbArgs a) {
+    __shared__ f32x4 red[4][64];
+    __shared__ unsigned last;
+    // blockIdx.x -> (job, column group, row slice)
+    int bi = blockIdx.x, ji = 0;
+    for (; ji < a.n - 1; ++ji) {
+        const int nb = ((a.j[ji].cols + 255) / 256) * a.j[ji].ns;
+        if (bi < nb) break;
+        bi -= nb;
+    }
+    const CbJob& J = a.j[ji];
+    const int ncg = (J.cols + 255) / 256, cg = bi % ncg, sp = bi / ncg;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = (cg * 64 + lane) * 4;
+    const bool vec_ok = (J.ld % 4 == 0) && (J.cols % 4 == 0);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (c < J.cols) {
+        if (J.dtype == MMAE_BF16) s = cb_rows((const uint16_t*)J.src, J.rows, J.ld, c, J.cols, sp, J.ns, w, vec_ok);
+        else s = cb_rows((const float*)J.src, J.rows, J.ld, c, J.cols, sp, J.ns, w, vec_ok);
+    }
+    red[w][lane] = s;
+    __syncthreads();
+    float* slab = a.ws + J.ws_off;                 // [ns][ncg * 256]
+    const int wcols = ncg * 256;
+    if (w == 0) {
+        f32x4 t;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = (red[0][lane][k] + red[1][lane][k]) + (red[2][lane][k] + red[3][lane][k]);
+        st4(slab + (long long)sp * wcols + c, t);
+    }
+    // the workgroup that completes a column group's last slice reduces the group (fixed order over the slices)
+    __threadfence();
+    __syncthreads();
+    unsigned* ticket = &g_colsum_tickets[a.slot][J.group0 + cg];
+    if (threadIdx.x == 0) last = (atomicAdd(ticket, 1u) == (unsigned)(J.ns - 1)) ? 1u : 0u;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r = w; r < J.ns; r += 4) {
+        const f32x4 v = ld4(slab + (long long)r * wcols + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += v[k];
+    }
+    __syncthreads();
+    red[w][lane] = acc;
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cc = c + k;
+            if (cc >= J.cols) break;
+            const float v = (red[0][lane][k] + red[1][lane][k]) + (red[2][lane][k] + red[3][lane][k]);
+            const int seg = cc / J.seg_w;
+            float* o = J.dst[seg];
+            if (o) { o += cc - seg * J.seg_w; *o = a.accumulate ? *o + v : v; }
+        }
+    }
+    if (threadIdx.x == 0) *ticket = 0u;            // ready for the next launch on this stream
+}
+
+int cb_nsplit(long long rows) { const long long s = (rows + 15) / 16; return (int)(s < 1 ? 1 : (s > 64 ? 64 : s)); }
+
+// ticket slot of a stream (launches of one stream are ordered: they may share tickets; different streams must not)
+int cb_slot(hipStream_t st) {
+    static std::mutex mu;
+    static struct { int dev; hipStream_t st; } tab[CB_SLOTS];
+    static int used = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < used; ++i) if (tab[i].dev == dev && tab[i].st == st) return i;
+    if (used == CB_SLOTS) return -1;
+    tab[used] = {dev, st};
+    return used++;
+}
+}  // namespace
+
+extern "C" {
+
+int64_t mmae_colsum_batch_ws_elems(const mmae_colsum_job* jobs, int n) {
+    if (!jobs || n < 1 || n > MMAE_COLSUM_MAX_JOBS) return -1;
+    int64_t e = 0;
+    for (int i = 0; i < n; ++i) e += (int64_t)cb_nsplit(jobs[i].rows) * ((jobs[i].cols + 255) / 256) * 256;
+    return e;
+}
+
+int mmae_colsum_batch(const mmae_colsum_job* jobs, int n, int accumulate, float* ws, int64_t ws_elems, void* stream) {
+    MMAE_REQUIRE(jobs && n >= 1 && n <= MMAE_COLSUM_MAX_JOBS && ws, "colsum_batch: bad argument");
+    MMAE_REQUIRE(ws_elems >= mmae_colsum_batch_ws_elems(jobs, n) && ((uintptr_t)ws % 16) == 0, "colsum_batch: workspace too small / unaligned");
+    hipStream_t st = (hipStream_t)stream;
+    CbArgs a = {};
+    a.n = n; a.accumulate = accumulate; a.ws = ws;
+    int groups = 0, blocks = 0;
+    long long off = 0;
+    for (int i = 0; i < n; ++i) {
+        const mmae_colsum_job& q = jobs[i];
+        MMAE_REQUIRE(q.src && q.rows > 0 && q.cols > 0 && q.seg_w > 0 && q.nseg >= 1 && q.nseg <= 8 && (int64_t)q.seg_w * q.nseg >= q.cols,
+                     "colsum_batch: bad job");
+        MMAE_REQUIRE(q.dtype == MMAE_F32 || q.dtype == MMAE_BF16, "colsum_batch: bad dtype");
+        MMAE_REQUIRE(!(q.ld % 4 == 0 && q.cols % 4 == 0) || ((uintptr_t)q.src % (q.dtype == MMAE_BF16 ? 8 : 16)) == 0, "colsum_batch: unaligned source");
+        CbJob& J = a.j[i];
+        J.src = q.src; J.rows = q.rows; J.ld = q.ld; J.dtype = q.dtype; J.cols = q.cols; J.seg_w = q.seg_w;
+        J.ns = cb_nsplit(q.rows); J.group0 = groups; J.ws_off = (int)off;
+        for (int k = 0; k < 8; ++k) J.dst[k] = k < q.nseg ? q.dst[k] : nullptr;
+        const int ncg = (q.cols + 255) / 256;
+        groups += ncg; blocks += ncg * J.ns;
+        off += (long long)J.ns * ncg * 256;
+        MMAE_REQUIRE(off < 0x7fffffffLL, "colsum_batch: workspace offset overflow");
+    }
+    a.ngroups = groups;
+    a.slot = cb_slot(st);
+    if (groups > CB_MAX_GROUPS || a.slot < 0) {    // outside the one-launch form: one scatter per job
+        for (int i = 0; i < n; ++i) {
+            const mmae_colsum_job& q = jobs[i];
+            ColDst d = {};
+            for (int k = 0; k < q.nseg; ++k) d.dst[k] = q.dst[k];
+            d.seg_w = q.seg_w;
+            MMAE_REQUIRE(ws_elems >= mmae_colsum_ws_elems(q.rows, q.cols), "colsum_batch: workspace too small for the per-job form");
+            const int rc = colsum_impl(q.src, q.dtype, q.rows, q.cols, q.ld, d, accumulate, ws, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    hipLaunchKernelGGL(colsum_batch_kernel, dim3(blocks), dim3(256), 0, st, a);
+    return mmae_check_launch("colsum_batch");
 }
 
 int mmae_softmax_fwd(const float* S, int64_t lds_, void* P, int p_dtype, int64_t ldp, int64_t rows, int n, float scale,

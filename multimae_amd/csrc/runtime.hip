@@ -26,6 +26,19 @@ int mmae_cu_count() {
     return n;
 }
 
+// compute units the persistent GEMM grids leave free (mmae_gemm_cu_reserve): a launch POLICY read on the host when a grid is sized
+static std::atomic<int> g_cu_reserve{0};
+int mmae_cu_avail() {
+    const int n = mmae_cu_count(), k = g_cu_reserve.load(std::memory_order_relaxed);
+    const int a = n - k;
+    return a < 16 ? (n < 16 ? n : 16) : a;
+}
+extern "C" int mmae_gemm_cu_reserve(int k) {
+    const int prev = g_cu_reserve.load(std::memory_order_relaxed);
+    if (k >= 0) g_cu_reserve.store(k, std::memory_order_relaxed);
+    return prev;
+}
+
 int mmae_check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -141,6 +154,7 @@ int mmae_struct_size(int which) {
         case 4: return (int)sizeof(mmae_opt_desc);
         case 5: return (int)sizeof(mmae_patch_src);
         case 6: return (int)sizeof(mmae_dw_group_desc);
+        case 7: return (int)sizeof(mmae_colsum_job);
         default: return -1;
     }
 }

@@ -196,9 +196,13 @@ __global__ void __launch_bounds__(256) tokens_assemble_bwd_kernel(const float* _
 // ------------------------------------------------------------------------------------------
 // Decoder query / context builder (output_adapters.py:160-234, use_task_queries path)
 // ------------------------------------------------------------------------------------------
+// one task-embedding row per INPUT task, by pointer (NULL = that task has none: zeros) -- the rows live wherever the parameters do,
+// no staging copy (round 3 issued one hipMemcpyAsync per task and adapter: 12 of a cfg3 step's 91 copyBuffer launches)
+struct TePtrs { const float* p[MAX_TASKS]; };
+
 __global__ void __launch_bounds__(256) decoder_build_kernel(const float* __restrict__ ctx, const long long* __restrict__ ids_keep,
                                                             const long long* __restrict__ ids_restore, const float* __restrict__ mask_token,
-                                                            const float* __restrict__ task_emb, const float* __restrict__ pos, const TaskTable tt,
+                                                            const TePtrs tep, const float* __restrict__ pos, const TaskTable tt,
                                                             int q_task, int n_keep, int G, int D, int n_q, int Ntot,
                                                             float* __restrict__ queries, float* __restrict__ context) {
     const int rows_per_b = n_q + n_keep + G;
@@ -211,7 +215,7 @@ __global__ void __launch_bounds__(256) decoder_build_kernel(const float* __restr
         // the mask_token vector the caller passes (it is added to every query row, exactly like the mask token)
         const long long rank = q_task < 0 ? (long long)n_keep : ids_restore[(long long)b * Ntot + tt.off[q_task] + j];
         const float* base = (rank < n_keep) ? ctx + ((long long)b * NC + rank) * D : mask_token;
-        const float* te = q_task < 0 ? nullptr : task_emb + (long long)q_task * D;
+        const float* te = q_task < 0 ? nullptr : tep.p[q_task];
         const float* pe = pos + (long long)j * D;
         float* o = queries + ((long long)b * n_q + j) * D;
         for (int c = threadIdx.x * 4; c < D; c += 1024) {
@@ -228,10 +232,10 @@ __global__ void __launch_bounds__(256) decoder_build_kernel(const float* __restr
         if (r >= n_keep) { for (int c = threadIdx.x * 4; c < D; c += 1024) st4(o + c, ld4(src + c)); return; }
         const int idx = (int)ids_keep[(long long)b * n_keep + r];
         const int t = task_of(tt, idx);
-        const float* te = task_emb + (long long)t * D;
+        const float* te = tep.p[t];
         const float* pe = pos + (long long)(idx - tt.off[t]) * D;
         for (int c = threadIdx.x * 4; c < D; c += 1024) {
-            const f32x4 a = ld4(src + c), t4 = ld4(te + c), p4 = ld4(pe + c);
+            const f32x4 a = ld4(src + c), t4 = te ? ld4(te + c) : f32x4{0.f, 0.f, 0.f, 0.f}, p4 = ld4(pe + c);
             f32x4 v;
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = a[k] + (t4[k] + p4[k]);
@@ -617,18 +621,36 @@ int mmae_tokens_assemble_bwd(const float* d_tok, void* d_proj, int proj_dtype, c
     return mmae_check_launch("tokens_assemble_bwd");
 }
 
-int mmae_decoder_build(const float* ctx, const int64_t* ids_keep, const int64_t* ids_restore, const float* mask_token,
-                       const float* task_emb, const float* pos, const int32_t* task_offsets_host, int T, int q_task, int B,
-                       int n_keep, int G, int D, int n_q, float* queries, float* context, void* stream) {
-    MMAE_REQUIRE(ctx && ids_keep && ids_restore && mask_token && task_emb && pos && queries && context, "decoder_build: null pointer");
+}  // extern "C"
+// the same with the task-embedding rows given one by one (device pointers, NULL = zeros); used by mmae_adapter_fwd
+int mmae_decoder_build_rows(const float* ctx, const int64_t* ids_keep, const int64_t* ids_restore, const float* mask_token,
+                            const float* const* task_emb_rows, const float* pos, const int32_t* task_offsets_host, int T, int q_task, int B,
+                            int n_keep, int G, int D, int n_q, float* queries, float* context, void* stream) {
+    MMAE_REQUIRE(ctx && ids_keep && ids_restore && mask_token && task_emb_rows && pos && queries && context, "decoder_build: null pointer");
     MMAE_REQUIRE(D % 4 == 0 && D <= 1024 && B > 0, "decoder_build: bad sizes");
     TaskTable tt;
     MMAE_REQUIRE(fill_tt(tt, task_offsets_host, T) == 0 && q_task >= -1 && q_task < T, "decoder_build: bad task table");
     MMAE_REQUIRE(n_q > 0 && (q_task < 0 || tt.off[q_task + 1] - tt.off[q_task] == n_q), "decoder_build: n_q != tokens of the query task");
+    TePtrs tep = {};
+    for (int t = 0; t < T; ++t) {
+        MMAE_REQUIRE(((uintptr_t)task_emb_rows[t] % 16) == 0, "decoder_build: unaligned task embedding");
+        tep.p[t] = task_emb_rows[t];
+    }
     hipLaunchKernelGGL(decoder_build_kernel, dim3((unsigned)((long long)B * (n_q + n_keep + G))), dim3(256), 0, (hipStream_t)stream, ctx,
-                       (const long long*)ids_keep, (const long long*)ids_restore, mask_token, task_emb, pos, tt, q_task, n_keep, G, D,
+                       (const long long*)ids_keep, (const long long*)ids_restore, mask_token, tep, pos, tt, q_task, n_keep, G, D,
                        n_q, tt.off[T], queries, context);
     return mmae_check_launch("decoder_build");
+}
+extern "C" {
+
+int mmae_decoder_build(const float* ctx, const int64_t* ids_keep, const int64_t* ids_restore, const float* mask_token,
+                       const float* task_emb, const float* pos, const int32_t* task_offsets_host, int T, int q_task, int B,
+                       int n_keep, int G, int D, int n_q, float* queries, float* context, void* stream) {
+    MMAE_REQUIRE(task_emb && T >= 1 && T <= MAX_TASKS, "decoder_build: null task embedding table / bad task count");
+    const float* rows[MAX_TASKS];
+    for (int t = 0; t < T; ++t) rows[t] = task_emb + (long long)t * D;
+    return mmae_decoder_build_rows(ctx, ids_keep, ids_restore, mask_token, rows, pos, task_offsets_host, T, q_task, B, n_keep, G, D, n_q,
+                                   queries, context, stream);
 }
 
 static int dbb_split(int B) { return B <= 512 ? 4 : 1; }

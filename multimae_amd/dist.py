@@ -66,6 +66,15 @@ class GradAllReducer:
         # force_collective: issue the all-reduces even at world size 1 (bench.py --force-dist: RCCL + the launch-stream / event
         # ordering run on a single GPU; a one-rank all-reduce is a copy)
         self.force_collective = force_collective
+        # gemm_cu_reserve: compute units the library's persistent GEMM grids leave free from the first bucket launch of a step
+        # until finish() (ops.gemm_cu_reserve).  The ping-pong GEMMs hold one 8-wave workgroup with the whole register file and
+        # 147 KiB of LDS on EVERY CU; RCCL's channel kernels cannot co-reside with one, so a bucket in flight either waits for a
+        # GEMM to end or -- once its workgroups sit on k CUs -- leaves the next full-chip persistent grid with k workgroups that
+        # start only after the first round has finished (a statically strided persistent kernel then takes twice as long).
+        # With the reserve the grids are n_cu - k workgroups wide and everything stays resident: k / n_cu of the MFMA rate
+        # while buckets fly instead of time-slicing.  0 = off (single GPU).
+        self.gemm_cu_reserve = 0
+        self._reserved = False
         self.timing = False                             # bench.py: event-time the exposed wait in finish()
         self._wait_events: List[tuple] = []
         self._bf16_tmp: Dict[int, torch.Tensor] = {}
@@ -129,6 +138,10 @@ class GradAllReducer:
             return
         s, e, _ = self.buckets[i]
         view = self.grad[s:e]
+        if self.gemm_cu_reserve > 0 and not self._reserved:
+            from . import ops
+            ops.gemm_cu_reserve(self.gemm_cu_reserve)    # GEMMs enqueued from here on leave room for the collective's kernels
+            self._reserved = True
 
         def exchange():
             if not self.bf16_buckets:
@@ -200,6 +213,10 @@ class GradAllReducer:
             ev1 = torch.cuda.Event(enable_timing=True)
             ev1.record()
             self._wait_events.append((ev0, ev1))
+        if self._reserved:
+            from . import ops
+            ops.gemm_cu_reserve(0)                       # the optimiser step and the next forward get the whole chip again
+            self._reserved = False
         self.reset()
 
     def exposed_wait_ms(self) -> float:

@@ -18,6 +18,12 @@ from .ops import AttnView, EPI_DGELU, EPI_GELU
 Tensor = torch.Tensor
 
 
+def _bound_grad(p: Tensor) -> Optional[Tensor]:
+    """p.grad of a LEAF parameter (the arena view, in direct mode), else None.  A non-leaf tensor in a parameter slot -- e.g. the
+    mask_token + task_embedding sum of the mask-token-query branch -- has no bound gradient, and reading .grad on it warns."""
+    return p.grad if p.is_leaf else None
+
+
 class GradSink:
     """Where parameter gradients go: straight into the arena-backed p.grad (direct mode, returns
     None to autograd) or into fresh tensors handed back to autograd."""
@@ -39,8 +45,9 @@ class GradSink:
             t.record_stream(self.side)          # keep the operands alive until the side stream is done with them
 
     def _target(self, p: Tensor):
-        if self.direct and p.grad is not None:
-            return p.grad, True
+        g = _bound_grad(p) if self.direct else None
+        if g is not None:
+            return g, True
         return torch.empty(p.shape, device=p.device, dtype=torch.float32), False
 
     def weight(self, p: Tensor, dy: Tensor, x: Tensor, x_off: int = 0, ldx: Optional[int] = None, K: Optional[int] = None):
@@ -100,7 +107,7 @@ class GradSink:
                 dsts.append(None)
                 accs.append(False)
                 continue
-            if self.direct and p.grad is not None:
+            if self.direct and _bound_grad(p) is not None:
                 flat, acc = p.grad.view(-1), True
             else:
                 acc = False
@@ -138,7 +145,7 @@ class GradSink:
         """g already holds the f32 gradient (any shape with p.numel() elements)."""
         if not p.requires_grad:
             return None
-        if self.direct and p.grad is not None:
+        if self.direct and _bound_grad(p) is not None:
             g = g.contiguous()
             if self.side is not None:       # same stream as the GEMM accumulations into the arena (no cross-stream races on .grad)
                 self._on_side(lambda: ops.axpy_(p.grad, g, 1.0), g)
@@ -209,7 +216,9 @@ def block_bwd(dx: Tensor, dx_act: Tensor, fc2b_done: bool, saved, P: Sequence[Te
     dm_act = dx_act if s2 is None else ops.rowscale_cast(dx, s2, N, act)
     assert not (s2 is not None and fc2b_done)
     part_h = _new(ops.dx_colsum_part_shape(R, Hd), dx, torch.float32) if fc1b.requires_grad else None
-    d_hpre = ops.linear_dx(dm_act, wc(fc2w), _new(hpre.shape, dx, act), aux=hpre, epi=EPI_DGELU, colsum_part=part_h)
+    # a composite forward with bf16 activations left GELU'(pre-activation) in hpre: multiply, do not differentiate again
+    epi_h = ops.EPI_MUL if (len(Pm) > 2 and Pm[2]) else EPI_DGELU
+    d_hpre = ops.linear_dx(dm_act, wc(fc2w), _new(hpre.shape, dx, act), aux=hpre, epi=epi_h, colsum_part=part_h)
     if fc2b_done:
         g_fc2w, g_fc2b = sink.weight(fc2w, dm_act, hact), None
     else:
@@ -248,21 +257,12 @@ def block_bwd(dx: Tensor, dx_act: Tensor, fc2b_done: bool, saved, P: Sequence[Te
 
 
 def _block_bwd_composite(dx, dx_act, fc2b_done, saved, P, wc, sink: GradSink, heads, act, B, N, cs_param):
-    """block_bwd through ONE mmae_block_bwd call; None if the gradient destinations do not allow it (mixed bound / unbound
-    .grad views)."""
+    """block_bwd through ONE mmae_block_bwd call.  A mix of bound and unbound .grad views gets fresh tensors for ALL parameters
+    (autograd accumulates them), as _grad_targets does: after a composite forward the per-op path must never run -- with bf16
+    activations that forward left GELU'(pre-activation) in `hpre`, which the per-op dGELU epilogue would differentiate again
+    (ADVICE r3)."""
     n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b = P
-    dsts: List[Optional[Tensor]] = []
-    accs = set()
-    for p in list(P) + [cs_param]:
-        if p is None or not p.requires_grad:
-            dsts.append(None)
-            continue
-        t, a = sink._target(p)
-        dsts.append(t)
-        accs.add(a)
-    if len(accs) > 1:
-        return None
-    acc = accs.pop() if accs else False
+    dsts, acc = _grad_targets(sink, list(P) + [cs_param])
     use_side = sink.side is not None and acc
     dx0, dx0_act, keep = ops.block_bwd_composite(dx, dx_act, fc2b_done, saved, P, (wc(qkvw), wc(projw), wc(fc1w), wc(fc2w)), dsts[:12],
                                                  dsts[12], acc, heads, act, B, N, sink.side.cuda_stream if use_side else None)
@@ -288,7 +288,7 @@ def _grad_targets(sink: GradSink, params: Sequence[Optional[Tensor]]):
     (accumulate) or into a fresh tensor handed to autograd.  A mix of bound and unbound parameters falls back to fresh tensors
     for all of them (autograd then accumulates), so one flag describes the whole call."""
     live = [p for p in params if p is not None and p.requires_grad]
-    direct = sink.direct and all(p.grad is not None for p in live)
+    direct = sink.direct and all(_bound_grad(p) is not None for p in live)
     dsts: List[Optional[Tensor]] = []
     for p in params:
         if p is None or not p.requires_grad:

@@ -14,7 +14,7 @@ import torch
 from . import _lib
 import contextlib
 
-from ._lib import BF16, F32, F32X3, MXFP8, EPI_NONE, EPI_GELU, EPI_DGELU, AdapterDesc, BlockDesc, DwGroupDesc, GemmDesc, OptDesc, PatchSrc, StackDesc, check
+from ._lib import BF16, F32, F32X3, MXFP8, EPI_NONE, EPI_GELU, EPI_DGELU, EPI_GELU_G, EPI_MUL, AdapterDesc, BlockDesc, DwGroupDesc, GemmDesc, OptDesc, PatchSrc, StackDesc, check
 
 Tensor = torch.Tensor
 
@@ -231,6 +231,13 @@ def gemm_mx(a: MxTensor, b: MxTensor, C: Tensor, *, bias: Optional[Tensor] = Non
     return C
 
 
+def gemm_cu_reserve(k: Optional[int] = None) -> int:
+    """Compute units the persistent GEMM grids (ping-pong bf16 / MX-fp8 kernels, grouped weight gradients) leave free: grids
+    launched afterwards are at most n_cu - k workgroups wide (mmae_gemm_cu_reserve).  Host-side launch policy, not stream
+    ordered: it applies to launches ENQUEUED after the call.  Returns the previous value; k = None only reads it."""
+    return int(_lib.load().mmae_gemm_cu_reserve(-1 if k is None else int(k)))
+
+
 def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], out: Tensor, *, resid: Optional[Tensor] = None,
                aux: Optional[Tensor] = None, epi: int = EPI_NONE, tile: int = 0) -> Tensor:
     """out[M,N] = x[M,K] @ w[N,K]^T + bias (+ epilogue).  x, w act dtype, contiguous 2-D."""
@@ -361,7 +368,9 @@ def block_fwd_composite(x: Tensor, P: Sequence[Tensor], wts: Sequence[Tensor], h
     ws = stream_workspace(st, dev)
     d.ws_main, d.ws_main_elems = ws.data_ptr(), ws.numel()
     check(_lib.load().mmae_block_fwd(ctypes.byref(d), st), 'block_fwd')
-    saved = (x, ln1, stats[0], stats[1], qkv, ('fused', lse), ao, x1, ln2, stats[2], stats[3], hpre, hact)
+    # third entry: `hpre` holds GELU'(pre-activation) (bf16 activations, mmae_gelu_grad_aux on) instead of the pre-activation
+    hpre_is_grad = act == torch.bfloat16 and bool(_lib.load().mmae_gelu_grad_aux(-1))
+    saved = (x, ln1, stats[0], stats[1], qkv, ('fused', lse, hpre_is_grad), ao, x1, ln2, stats[2], stats[3], hpre, hact)
     return x2, saved
 
 
@@ -787,6 +796,25 @@ def colsum_scatter(dy: Tensor, seg_w: int, dsts: Sequence[Optional[Tensor]], acc
     arr = (ctypes.c_void_p * len(dsts))(*[_p(d) for d in dsts])
     check(lib.mmae_colsum_scatter(dy.data_ptr(), dcode(dy.dtype), M, N, dy.stride(0), seg_w, ctypes.cast(arr, ctypes.c_void_p),
                                   len(dsts), int(accumulate), ws.data_ptr(), _stream()), 'colsum_scatter')
+
+
+def colsum_batch(jobs: Sequence[tuple], accumulate: bool) -> None:
+    """Up to 8 colsum_scatter reductions in ONE launch (mmae_colsum_batch).  jobs: (src [rows, cols] f32 / bf16 (row stride = stride(0)),
+    seg_w, [dst tensors f32 or None])."""
+    from ._lib import ColsumJob
+    assert 1 <= len(jobs) <= 8
+    arr = (ColsumJob * len(jobs))()
+    for q, (src, seg_w, dsts) in zip(arr, jobs):
+        rows, cols = src.shape
+        assert 1 <= len(dsts) <= 8 and seg_w * len(dsts) >= cols
+        q.src, q.dtype, q.cols, q.rows, q.ld, q.seg_w, q.nseg = src.data_ptr(), dcode(src.dtype), cols, rows, src.stride(0), seg_w, len(dsts)
+        for i, d in enumerate(dsts):
+            assert d is None or (d.dtype == torch.float32 and d.is_contiguous())
+            q.dst[i] = _p(d)
+    lib = _lib.load()
+    n_ws = int(lib.mmae_colsum_batch_ws_elems(ctypes.cast(arr, ctypes.c_void_p), len(jobs)))
+    ws = torch.empty((max(n_ws, 4),), device=jobs[0][0].device, dtype=torch.float32)
+    check(lib.mmae_colsum_batch(ctypes.cast(arr, ctypes.c_void_p), len(jobs), int(accumulate), ws.data_ptr(), ws.numel(), _stream()), 'colsum_batch')
 
 
 def reduce_partials(part: Tensor, out: Tensor, accumulate: bool) -> Tensor:

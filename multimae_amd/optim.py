@@ -76,11 +76,18 @@ class FusedAdamW(torch.optim.Optimizer):
         self.arena.rebind_grads()
 
     @torch.no_grad()
-    def step(self, loss: Optional[torch.Tensor] = None, closure=None) -> torch.Tensor:
+    def step(self, closure=None, *, loss: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One AdamW update in ONE library call (mmae_opt_step); returns the (device) gradient 2-norm, as the reference's
-        loss_scaler does.  lr / weight_decay are read from ``param_groups[0]`` (the reference's per-iteration cosine tables,
-        run_pretraining_multimae.py:474-480, plug in unchanged).  ``loss``: optional device scalar; a non-finite value skips
-        the update and is counted (``counters()``)."""
+        loss_scaler does.  ``torch.optim.Optimizer`` signature: ``step(closure)`` re-evaluates the model first.  lr /
+        weight_decay are read from ``param_groups[0]`` AS THEY ARE: the reference loop already writes
+        ``g['lr'] = table[it] * g['lr_scale']`` (run_pretraining_multimae.py:474-480), so ``lr_scale`` is not applied again
+        here.  ``loss``: optional device scalar (keyword, or -- the engine-native loop -- the first positional
+        argument as a Tensor); a non-finite value skips the update and is counted (``counters()``)."""
+        if isinstance(closure, torch.Tensor):            # FusedAdamW.step(loss)
+            loss, closure = closure, None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         a, g = self.arena, self.param_groups[0]
         n = a.n_trainable
         engine.join_wgrad_streams()
@@ -92,11 +99,11 @@ class FusedAdamW(torch.optim.Optimizer):
             # hipGraph capture: the schedule values come from HBM, refreshed by the host before every replay
             def hyper():
                 gg = self.param_groups[0]
-                return torch.tensor([gg['lr'] * gg.get('lr_scale', 1.0), gg['weight_decay']], dtype=torch.float32)
+                return torch.tensor([gg['lr'], gg['weight_decay']], dtype=torch.float32)
             lrwd = cap.add(hyper, a.device)
         if loss is not None:
             loss = loss.detach().float().reshape(1)
-        ops.opt_step(a.param[:n], a.grad, self.m, self.v, self._state, self._istate, self._ws, lr=g['lr'] * g.get('lr_scale', 1.0),
+        ops.opt_step(a.param[:n], a.grad, self.m, self.v, self._state, self._istate, self._ws, lr=g['lr'],
                      weight_decay=g['weight_decay'], beta1=b1, beta2=b2, eps=g['eps'], clip_grad=self.clip_grad, skip_grad=self.skip_grad,
                      grad_prescale=self.grad_prescale, lrwd_dev=lrwd, loss_dev=loss, shadow=shadow)
         if shadow is not None:

@@ -25,7 +25,7 @@ class FakeLib:
             if name == 'mmae_abi_version':
                 return 3
             if name == 'mmae_struct_size':
-                return ctypes.sizeof((_lib.GemmDesc, _lib.BlockDesc, _lib.StackDesc, _lib.AdapterDesc, _lib.OptDesc, _lib.PatchSrc, _lib.DwGroupDesc)[args[0]])
+                return ctypes.sizeof((_lib.GemmDesc, _lib.BlockDesc, _lib.StackDesc, _lib.AdapterDesc, _lib.OptDesc, _lib.PatchSrc, _lib.DwGroupDesc, _lib.ColsumJob)[args[0]])
             # slab layouts of the composite entry points: enough room for the views the host code cuts out of them
             if name in ('mmae_stack_act_bytes', 'mmae_stack_out_offset'):
                 d = args[0]._obj

@@ -210,3 +210,26 @@ def test_bench_result_line_keeps_the_measurement_contract():
     dp = {'exposed_allreduce_ms_per_step': 1.2, 'bucket_mb': 64.0, 'buckets': 7, 'rccl_ranks_seen': 8}
     d8 = bench.result_line(args, 256, 8, 36.0, 56000.0, 8.08, {'steps': 25}, roof, None, dp, 9.0, 20.0, False, 98, ['rgb', 'depth', 'semseg'])
     assert d8['n_gpus'] == 8 and d8['config']['global_batch'] == 2048 and d8['config']['parallelism'] == 'dp8' and d8['data_parallel'] == dp
+
+
+def test_isa_audit_of_the_pingpong_kernels():
+    """the transposing fragment reads of the ping-pong GEMMs are inline asm the compiler does not wait for.  On the BUILT
+    objects: no instruction touches a `ds_read_b64_tr_b16` destination before the `s_waitcnt lgkmcnt(0)` that covers it, and the
+    flavoured instantiations the training step launches use no scratch (a spill of a fragment register would be such a touch)."""
+    import importlib.util
+    import os
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('isa_audit', os.path.join(root, 'tools', 'isa_audit.py'))
+    ia = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ia)
+    objs = [o for o in ia.DEFAULT if os.path.exists(o)]
+    if len(objs) != len(ia.DEFAULT) or not os.path.exists(os.path.join(ia.LLVM, 'llvm-objdump')):
+        pytest.skip('object files of the kernel library not present (build with make -C multimae_amd/csrc)')
+    report, problems = ia.audit(objs)
+    assert not problems, problems
+    fl = [(k, r, n) for _, k, r, n in report if ia.flavoured(k)]
+    assert len(fl) >= 16
+    for k, r, _ in fl:
+        assert r['scratch'] == 0 and r['spill'] == 0, (k, r)
+    assert sum(n for k, r, n in fl) > 0 and any(n > 0 for _, k, r, n in report if 'dwgroup' in k)      # the audit did see the asm reads

@@ -1,0 +1,63 @@
+import numpy as np
+from numpy.polynomial import chebyshev as C
+from scipy.special import erf
+def Phi(x): return 0.5*(1+erf(x/np.sqrt(2)))
+def phi(x): return np.exp(-x*x/2)/np.sqrt(2*np.pi)
+def fit(f, c, deg):
+    # fit g(s) = f(sqrt(s))/sqrt(s) on s in [0, c^2] by Chebyshev interpolation then refine (Remez-lite via lstsq on dense grid weighted)
+    n=4000
+    t=np.cos(np.pi*(np.arange(n)+0.5)/n)        # cheb nodes in [-1,1]
+    s=(t+1)/2*c*c
+    x=np.sqrt(s)
+    g=np.where(x>1e-6, f(np.maximum(x,1e-6))/np.maximum(x,1e-6), f(1e-6)/1e-6)
+    # error of interest: |x * (g_hat - g)| (abs error of f), so weight by x
+    w=np.maximum(x,0.05)
+    V=C.chebvander(t,deg)
+    coef=np.linalg.lstsq(V*w[:,None], g*w, rcond=None)[0]
+    # iterate reweighting to approach minimax
+    for it in range(60):
+        err=(V@coef-g)*x
+        a=np.abs(err); 
+        w=w*(1+ 2*a/a.max())
+        w/=w.max()
+        coef=np.linalg.lstsq(V*w[:,None], g*w, rcond=None)[0]
+    err=(V@coef-g)*x
+    # convert to monomial in s
+    p=C.cheb2poly(coef)  # poly in t
+    # t = 2 s/c^2 - 1
+    from numpy.polynomial import polynomial as P
+    tt=np.array([-1.0, 2.0/(c*c)])
+    mono=np.zeros(1)
+    pw=np.ones(1)
+    for k,a in enumerate(p):
+        mono=P.polyadd(mono, a*pw)
+        pw=P.polymul(pw,tt)
+    return mono, np.abs(err).max()
+for c in (3.5,4.0,4.5,5.0):
+    for deg in (5,6,7,8,9,10):
+        m1,e1=fit(lambda x: Phi(x)-0.5, c, deg)
+        m2,e2=fit(lambda x: Phi(x)+x*phi(x)-0.5, c, deg)
+        print(f"c={c} deg={deg}: Phi err {e1:.2e} (tail {1-Phi(c):.1e})  dGELU err {e2:.2e} (tail {abs(Phi(c)+c*phi(c)-1):.1e})")
+
+print("---- fp32 Horner evaluation check")
+def horner32(coef, s):
+    # coef low->high, emulate fma in fp32: r = fl32(r*s + c)
+    r = np.full_like(s, np.float32(coef[-1]), dtype=np.float32)
+    for c in coef[-2::-1]:
+        r = (r.astype(np.float64)*s.astype(np.float64) + np.float64(np.float32(c))).astype(np.float32)
+    return r
+for c,deg in ((4.0,8),(4.0,9),(4.5,9),(4.5,10)):
+    mq,eq=fit(lambda x: Phi(x)-0.5, c, deg)
+    mr,er=fit(lambda x: Phi(x)+x*phi(x)-0.5, c, deg)
+    x=np.linspace(-c,c,400001).astype(np.float32)
+    s=(x.astype(np.float64)**2).astype(np.float32)
+    Q=horner32(mq,s); R=horner32(mr,s)
+    cdf=(0.5+x.astype(np.float64)*Q).astype(np.float32)
+    dg=(0.5+x.astype(np.float64)*R).astype(np.float32)
+    xx=x.astype(np.float64)
+    e1=np.abs(cdf-Phi(xx)).max(); e2=np.abs(dg-(Phi(xx)+xx*phi(xx))).max()
+    y=xx*cdf; yt=xx*Phi(xx)
+    rel=np.abs(y-yt)/np.maximum(np.abs(yt),1e-30)
+    print(f"c={c} deg={deg}: fp32 Phi err {e1:.2e}, dGELU err {e2:.2e}; gelu max abs err {np.abs(y-yt).max():.2e}; rel err at x>-2: {rel[x>-2].max():.2e}, x>-3: {rel[x>-3].max():.2e}")
+    print("  Q:", ", ".join(f"{v:.9e}" for v in mq))
+    print("  R:", ", ".join(f"{v:.9e}" for v in mr))
