@@ -258,7 +258,8 @@ def result_line(args, B, world, ms_per_step, img_s, final_loss, counters, roof, 
                                + f', 224^2, Dirichlet alpha=1.0, {n_vis} visible tokens, {len(doms) + 1} cross-attention decoders (dim 256, depth 2), '
                                + ('semseg adapter with fp32 activations and x3 split-bf16 GEMMs (a_hi.b_hi + a_hi.b_lo + a_lo.b_hi, fp32 accumulate), ' if 'semseg' in doms else '') + 'AdamW; fwd+losses+bwd+optimizer',
                    'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}'},
-        'final_loss': round(final_loss, 5), 'launch': 'hipGraph replay of the captured step' if use_graph else 'eager, one library call per encoder stack / output adapter / loss / optimiser step',
+        'final_loss': round(final_loss, 5), 'launch': ("the reference's loop body against the drop-in boundary: DistributedDataParallel(world 1, nccl, find_unused_parameters) + autocast + GradScaler + FusedAdamW, gradients through autograd"
+                                                      if getattr(args, 'dropin_ddp', 0) else 'hipGraph replay of the captured step' if use_graph else 'eager, one library call per encoder stack / output adapter / loss / optimiser step'),
         'host_enqueue_ms_per_step': round(host_ms, 3), 'host_throttle_wait_ms_per_step': round(host_wait_ms, 3), 'optimizer_counters': counters,
         'roofline': roof, 'cpu_baseline': cpu,
     }
@@ -311,6 +312,7 @@ def main():
     ap.add_argument('--graph', type=int, default=-1, help='1: capture the step once as a hipGraph and replay it (multimae_amd.graph.StepGraph; 1 GPU only). Default 0: on ROCm 7.2 the replay of this ~1 100-node, 10-stream graph measured 46.2 ms/step against 44.1 ms eager')
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary line (cfg5 = BASELINE configs[4] geometry, ViT-L, MX-fp8 encoder products, B = 128, a few steps) that the default single-GPU cfg3 run appends as `secondary`')
     ap.add_argument('--gemm-cu-reserve', type=int, default=-1, help='compute units the persistent GEMM grids leave free (for RCCL\'s channel kernels while gradient buckets are in flight); -1: 16 when gradient buckets are exchanged (N > 1 or --force-dist), else 0')
+    ap.add_argument('--dropin-ddp', type=int, default=0, help="1: time the REFERENCE'S loop body against the drop-in boundary instead of the native loop (VERDICT r3 item 7): the model wrapped in torch DistributedDataParallel (world 1, nccl, find_unused_parameters=True, run_pretraining_multimae.py:380-387), forward + losses inside torch.cuda.amp.autocast(), the NativeScaler sequence (GradScaler.scale(loss).backward(), unscale_, gradient norm, GradScaler.step(FusedAdamW), update()); gradients travel through autograd / DDP's reducer (engine.set_direct_grads(False))")
     ap.add_argument('--dry-run', type=int, default=0, help='1: CPU tensors and a type-checking stub of the C ABI (tests/dryrun_harness.py): exercises the LAUNCH path of this script (self-launch, process group, reducer, the JSON line) without a GPU -- the numbers are meaningless and the line says so')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -364,6 +366,12 @@ def run_once(args):
         args.no_kernel_timing = args.no_cpu_baseline = args.no_secondary = True
         args.backend = 'gloo'
     use_dist = world > 1 or bool(args.force_dist)
+    if args.dropin_ddp:
+        assert world == 1 and not args.force_dist and not dry, '--dropin-ddp times the one-GPU reference loop'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29534')
+        os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     if args.force_dist and 'MASTER_ADDR' not in os.environ:
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
     if args.gpus > 1 or use_dist:
@@ -388,7 +396,7 @@ def run_once(args):
         broadcast_parameters(arena)
         reducer = GradAllReducer.for_arena(arena, bucket_mb=args.bucket_mb, bf16_buckets=bool(args.bf16_buckets), force_collective=bool(args.force_dist))
     M.engine.set_precision(args.precision)
-    M.engine.set_direct_grads(True)
+    M.engine.set_direct_grads(not args.dropin_ddp)
     M.engine.set_adapter_streams(bool(args.adapter_streams))
     M.engine.set_wgrad_stream(bool(args.wgrad_stream))
     B = args.batch or (2 if dry else (128 if args.config == 'cfg5' else 256))
@@ -415,7 +423,34 @@ def run_once(args):
     fp32_adapters = ['semseg'] if 'semseg' in doms else []
     last = {}
 
+    net, scaler = model, None
+    if args.dropin_ddp:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=True)
+        scaler = torch.cuda.amp.GradScaler()
+
+    def dropin_step():
+        """run_pretraining_multimae.py:474-537 with utils/native_scaler.py:20-40 inlined"""
+        for g in opt.param_groups:
+            g['lr'] = lr_tab[min(it[0], n_tab - 1)] * g['lr_scale']
+            if g['weight_decay'] > 0:
+                g['weight_decay'] = wd_tab[min(it[0], n_tab - 1)]
+        it[0] += 1
+        with torch.cuda.amp.autocast():
+            preds, masks = net(x, num_encoded_tokens=n_vis, alphas=1.0, sample_tasks_uniformly=False, fp32_output_adapters=fp32_adapters)
+            mk = dict(masks, norm_rgb=masks['rgb'])
+            losses = {k: fns[k](preds[k].float(), tgt[k], mask=mk[k]) for k in preds}
+            loss = sum(losses.values())
+        opt.zero_grad()
+        scaler.scale(loss).backward()
+        scaler.unscale_(opt)
+        torch.norm(torch.stack([torch.norm(p.grad.detach(), 2.0) for p in model.parameters() if p.grad is not None]), 2.0)
+        scaler.step(opt)
+        scaler.update()
+        last['loss'] = loss
+
     def step():
+        if args.dropin_ddp:
+            return dropin_step()
         g = opt.param_groups[0]
         g['lr'], g['weight_decay'] = lr_tab[min(it[0], n_tab - 1)] * g['lr_scale'], wd_tab[min(it[0], n_tab - 1)]     # as the reference loop (:474-480)
         it[0] += 1
@@ -484,6 +519,8 @@ def run_once(args):
                    'allreduce_mb_per_step': round(sum(e - s for s, e, _ in reducer.buckets) * (2 if args.bf16_buckets else 4) / 2 ** 20, 1),
                    'rccl_ranks_seen': int(seen.item()), 'backend': args.backend, 'encoder_bwd_chunk_layers': int(getattr(model, '_bwd_chunk_layers', 0)),
                    'gemm_cu_reserved': cu_reserve}
+    if args.dropin_ddp:
+        args.no_kernel_timing = True
     final_loss = float(last['loss'].detach())
     if dry and final_loss != final_loss:
         final_loss = 0.0

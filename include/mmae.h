@@ -268,13 +268,13 @@ int mmae_colsum(const void* dy, int dtype, int64_t M, int N, int64_t ld, float* 
 int mmae_colsum_scatter(const void* dy, int dtype, int64_t M, int N, int64_t ld, int seg_w, const void* dsts_host,
                         int nseg, int accumulate, float* ws, void* stream);
 
-/* Up to MMAE_COLSUM_MAX_JOBS such reductions in ONE launch (round 4: the parameter-gradient column sums of a transformer block
- * -- LayerNorm partial blocks, the dGELU epilogue's partials, f32 bias gradients -- were 6 launches of 5-6 us, 176 per cfg3 step).
+/* Up to MMAE_COLSUM_MAX_JOBS such reductions in ONE pair of launches (round 4: the parameter-gradient column sums of a transformer
+ * block -- LayerNorm partial blocks, the dGELU epilogue's partials, f32 bias gradients -- were 6 launches of 5-6 us, 176 per cfg3 step).
  * A job is a mmae_colsum_scatter call: src act dtype [rows][ld], `cols` columns, column c delivered to dst[c / seg_w][c % seg_w].
- * Phase 1 (row slices -> ws) and phase 2 (the slices of a 256-column group summed in a fixed order by whichever workgroup
- * finishes that group last: a self-resetting ticket per group in a per-stream slot of a device-global table) run in the same
- * kernel; results are bit-identical to the two-launch form for any arrival order.  ws: mmae_colsum_batch_ws_elems() floats.
- * All jobs share `accumulate`. */
+ * Launch 1: row slices of every job -> ws; launch 2: the slices of every 256-column group summed in a fixed order and scattered.
+ * (A one-launch form with a last-workgroup reduction behind __threadfence() was built first and measured 140 us per call: an
+ * agent-scope release on gfx950 writes back the WHOLE L2 of the XCD, once per workgroup.)  Deterministic.
+ * ws: mmae_colsum_batch_ws_elems() floats.  All jobs share `accumulate`. */
 #define MMAE_COLSUM_MAX_JOBS 8
 typedef struct mmae_colsum_job {
     const void* src; int32_t dtype; int32_t cols; int64_t rows; int64_t ld;

@@ -15,16 +15,18 @@ import torch
 from torch import nn
 
 from .functions import MaskedCEFn, MaskedCEPatFn, MaskedPixelLossFn, MaskedPixelLossPatFn
+from .lazy import materialize as _materialize
 
 
 def _pat_handle(x: torch.Tensor, patch: int, ce: bool = False):
     """The adapter's patch rows behind prediction x (functions.PatHandle), if x is exactly what an output adapter returned
     (``preds[task].float()`` of an f32 tensor is the same object) and the loss's patch grid is the adapter's.  Anything else --
-    a modified prediction, or the CLONES torch DDP's output sink returns with find_unused_parameters=True -- takes the
-    image-domain loss (same value, gradient rows through the f32 image instead of the adapter's activation dtype;
-    tests/test_reference_loop_gpu.py pins the two against each other under DDP)."""
+    a modified prediction, a copy made any other way than ``clone()`` -- takes the image-domain loss (same value, gradient rows
+    through the f32 image instead of the adapter's activation dtype).  The CLONES torch DDP's output sink returns with
+    find_unused_parameters=True keep the side channel (lazy.LazyPrediction.clone), so the reference loop under DDP runs the same
+    loss kernels as the native loop (tests/test_reference_loop_gpu.py)."""
     h = getattr(x, '_mmae_pat', None)
-    if h is None or not h.matches(x, patch):
+    if h is None or not h.matches(x, patch) or not getattr(x, 'unmodified', True):
         return None
     if ce and (patch * patch > 64 or (patch * patch) & (patch * patch - 1)):
         return None
@@ -52,6 +54,7 @@ class MaskedCrossEntropyLoss(nn.Module):
         h = _pat_handle(input, self.scale_factor, ce=True)
         if h is not None:
             return MaskedCEPatFn.apply(h.token, h, target, mask, self.scale_factor, float(self.label_smoothing))
+        _materialize(input)                                 # image-domain loss: the kernels read the image itself
         return MaskedCEFn.apply(input, target, mask, self.scale_factor, float(self.label_smoothing))
 
 
@@ -71,6 +74,7 @@ class _MaskedPixelLoss(nn.Module):
         h = _pat_handle(input, self.scale_factor)
         if h is not None:
             return MaskedPixelLossPatFn.apply(h.token, h, target, mask, self.kind, bool(self.norm_pix), self.scale_factor)
+        _materialize(input)
         return MaskedPixelLossFn.apply(input, target, mask, self.kind, bool(self.norm_pix), self.scale_factor)
 
 

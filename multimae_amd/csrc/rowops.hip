@@ -628,11 +628,9 @@ int mmae_colsum_scatter(const void* dy, int dtype, int64_t M, int N, int64_t ld,
 // ---- batched column sums: several mmae_colsum_scatter jobs in one launch ----------------------------------------------------------
 namespace {
 constexpr int CB_MAX_GROUPS = 160;                 // 256-column groups per launch (a ViT-L block: 16 + 12 + 12)
-constexpr int CB_SLOTS = 64;                       // streams with a ticket slot of their own
-__device__ unsigned g_colsum_tickets[CB_SLOTS][CB_MAX_GROUPS];      // zero at module load; every launch leaves its tickets zero again
 
 struct CbJob { const void* src; long long rows, ld; int dtype, cols, seg_w, ns, group0, ws_off; float* dst[8]; };
-struct CbArgs { int n, accumulate, slot, ngroups; float* ws; CbJob j[MMAE_COLSUM_MAX_JOBS]; };
+struct CbArgs { int n, accumulate, ngroups; float* ws; CbJob j[MMAE_COLSUM_MAX_JOBS]; };
 
 template <typename DT>
 __device__ __forceinline__ f32x4 cb_rows(const DT* src, long long rows, long long ld, int c, int cols, int sp, int ns, int w, bool vec_ok) {
@@ -663,10 +661,9 @@ __device__ __forceinline__ f32x4 cb_rows(const DT* src, long long rows, long lon
     return s;
 }
 
-__global__ void __launch_bounds__(256) colsum_batch_kernel(const CbArgs a) {
+// phase 1: workgroup = (job, 256-column group, row slice) -> one row of the job's slab ws[ns][ncg * 256]
+__global__ void __launch_bounds__(256) colsum_batch_rows_kernel(const CbArgs a) {
     __shared__ f32x4 red[4][64];
-    __shared__ unsigned last;
-    // blockIdx.x -> (job, column group, row slice)
     int bi = blockIdx.x, ji = 0;
     for (; ji < a.n - 1; ++ji) {
         const int nb = ((a.j[ji].cols + 255) / 256) * a.j[ji].ns;
@@ -685,30 +682,43 @@ __global__ void __launch_bounds__(256) colsum_batch_kernel(const CbArgs a) {
     }
     red[w][lane] = s;
     __syncthreads();
-    float* slab = a.ws + J.ws_off;                 // [ns][ncg * 256]
-    const int wcols = ncg * 256;
     if (w == 0) {
         f32x4 t;
 #pragma unroll
         for (int k = 0; k < 4; ++k) t[k] = (red[0][lane][k] + red[1][lane][k]) + (red[2][lane][k] + red[3][lane][k]);
-        st4(slab + (long long)sp * wcols + c, t);
+        st4(a.ws + J.ws_off + (long long)sp * (ncg * 256) + c, t);
     }
-    // the workgroup that completes a column group's last slice reduces the group (fixed order over the slices)
-    __threadfence();
-    __syncthreads();
-    unsigned* ticket = &g_colsum_tickets[a.slot][J.group0 + cg];
-    if (threadIdx.x == 0) last = (atomicAdd(ticket, 1u) == (unsigned)(J.ns - 1)) ? 1u : 0u;
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int r = w; r < J.ns; r += 4) {
+}
+
+// phase 2: workgroup = (job, 256-column group): the group's slices summed in a fixed order, scattered to the destinations
+__global__ void __launch_bounds__(256) colsum_batch_reduce_kernel(const CbArgs a) {
+    __shared__ f32x4 red[4][64];
+    int g = blockIdx.x, ji = 0;
+    for (; ji < a.n - 1; ++ji) {
+        const int ncg = (a.j[ji].cols + 255) / 256;
+        if (g < ncg) break;
+        g -= ncg;
+    }
+    const CbJob& J = a.j[ji];
+    const int wcols = ((J.cols + 255) / 256) * 256;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = (g * 64 + lane) * 4;
+    const float* slab = a.ws + J.ws_off;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    int r = w;
+    for (; r + 4 < J.ns; r += 8) {
+        const f32x4 v0 = ld4(slab + (long long)r * wcols + c), v1 = ld4(slab + (long long)(r + 4) * wcols + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a0[k] += v0[k]; a1[k] += v1[k]; }
+    }
+    if (r < J.ns) {
         const f32x4 v = ld4(slab + (long long)r * wcols + c);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] += v[k];
+        for (int k = 0; k < 4; ++k) a0[k] += v[k];
     }
-    __syncthreads();
-    red[w][lane] = acc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a0[k] += a1[k];
+    red[w][lane] = a0;
     __syncthreads();
     if (w == 0) {
 #pragma unroll
@@ -721,24 +731,10 @@ __global__ void __launch_bounds__(256) colsum_batch_kernel(const CbArgs a) {
             if (o) { o += cc - seg * J.seg_w; *o = a.accumulate ? *o + v : v; }
         }
     }
-    if (threadIdx.x == 0) *ticket = 0u;            // ready for the next launch on this stream
 }
 
 int cb_nsplit(long long rows) { const long long s = (rows + 15) / 16; return (int)(s < 1 ? 1 : (s > 64 ? 64 : s)); }
 
-// ticket slot of a stream (launches of one stream are ordered: they may share tickets; different streams must not)
-int cb_slot(hipStream_t st) {
-    static std::mutex mu;
-    static struct { int dev; hipStream_t st; } tab[CB_SLOTS];
-    static int used = 0;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lk(mu);
-    for (int i = 0; i < used; ++i) if (tab[i].dev == dev && tab[i].st == st) return i;
-    if (used == CB_SLOTS) return -1;
-    tab[used] = {dev, st};
-    return used++;
-}
 }  // namespace
 
 extern "C" {
@@ -774,8 +770,7 @@ int mmae_colsum_batch(const mmae_colsum_job* jobs, int n, int accumulate, float*
         MMAE_REQUIRE(off < 0x7fffffffLL, "colsum_batch: workspace offset overflow");
     }
     a.ngroups = groups;
-    a.slot = cb_slot(st);
-    if (groups > CB_MAX_GROUPS || a.slot < 0) {    // outside the one-launch form: one scatter per job
+    if (groups > CB_MAX_GROUPS) {                  // outside the batched form: one scatter per job
         for (int i = 0; i < n; ++i) {
             const mmae_colsum_job& q = jobs[i];
             ColDst d = {};
@@ -787,8 +782,11 @@ int mmae_colsum_batch(const mmae_colsum_job* jobs, int n, int accumulate, float*
         }
         return 0;
     }
-    hipLaunchKernelGGL(colsum_batch_kernel, dim3(blocks), dim3(256), 0, st, a);
-    return mmae_check_launch("colsum_batch");
+    hipLaunchKernelGGL(colsum_batch_rows_kernel, dim3(blocks), dim3(256), 0, st, a);
+    int rc = mmae_check_launch("colsum_batch_rows");
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_batch_reduce_kernel, dim3(groups), dim3(256), 0, st, a);
+    return mmae_check_launch("colsum_batch_reduce");
 }
 
 int mmae_softmax_fwd(const float* S, int64_t lds_, void* P, int p_dtype, int64_t ldp, int64_t rows, int n, float scale,

@@ -78,6 +78,16 @@ def set_patch_domain_loss(flag: bool) -> None:
     _state['patch_domain_loss'] = bool(flag)
 
 
+def lazy_predictions() -> bool:
+    return _state.get('lazy_predictions', True)
+
+
+def set_lazy_predictions(flag: bool) -> None:
+    """Output adapters return their (B, C, H, W) prediction as a lazy.LazyPrediction: the image is rearranged out of the patch rows
+    the first time anything reads it (the masked losses never do).  Default on; False = written eagerly by the forward."""
+    _state['lazy_predictions'] = bool(flag)
+
+
 def adapter_streams() -> bool:
     return _state['adapter_streams']
 

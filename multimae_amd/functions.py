@@ -556,6 +556,7 @@ class SpatialAdapterFn(torch.autograd.Function):
         node in the autograd graph (see PatHandle); cfg.handle is set when the patch rows are available."""
         ctx.set_materialize_grads(False)
         cfg.handle = None
+        cfg.lazy_fill = None
         with ops.f32_gemm_mode(getattr(cfg, 'f32_gemm', 'exact')):
             img = SpatialAdapterFn._forward(ctx, cfg, enc, ids_keep, ids_restore, *params)
         token = img.new_empty(1)
@@ -598,8 +599,21 @@ class SpatialAdapterFn(torch.autograd.Function):
                 + [wc(ow), wc(pcw)]
             p_list = [qb, kvb, pb, cnw, cnb, qnw, qnb, onw, onb, f1b, f2b] \
                 + [blocks[12 * l + i] for l in range(cfg.depth) for i in (0, 1, 3, 5, 6, 7, 9, 11)] + [ob, pcb]
+            # the image is an API output nothing on the training path reads (the losses work on the patch rows): allocate it, write
+            # it on first use (lazy.LazyPrediction, wrapped around the result by SpatialOutputAdapter.forward)
+            lazy_img = engine.lazy_predictions() and engine.capturing() is None
             img, state = ops.adapter_fwd(enc.contiguous(), enc_act, ids_keep, ids_restore, cfg, w_list, p_list, mask_token.detach().reshape(D),
-                                         [None if t is None else t.detach().reshape(D) for t in temb])
+                                         [None if t is None else t.detach().reshape(D) for t in temb], want_img=not lazy_img)
+            if lazy_img:
+                img = torch.empty((B, cfg.C, cfg.nh * cfg.ph, cfg.nw * cfg.pw), device=enc.device, dtype=torch.float32)
+                ev = torch.cuda.current_stream().record_event() if enc.is_cuda else None
+                pat, slab, geom = state.pat, state.act, (B, cfg.C, cfg.nh, cfg.nw, cfg.ph, cfg.pw)
+
+                def fill(dst, pat=pat, slab=slab, ev=ev, geom=geom):     # slab: keeps the rows alive as long as the prediction lives
+                    if ev is not None:
+                        torch.cuda.current_stream().wait_event(ev)
+                    ops.unpatchify_into(pat, dst, *geom)
+                cfg.lazy_fill = fill
             ctx.comp = state if save else None
             ctx.cfg, ctx.params, ctx.ids = cfg, params, (ids_keep, ids_restore)
             ctx.dims = (B, NC, Denc, n_keep, n_q, T)

@@ -1161,6 +1161,12 @@ def unpatchify(pat: Tensor, B: int, C: int, nh: int, nw: int, ph: int, pw: int) 
     return img
 
 
+def unpatchify_into(pat: Tensor, img: Tensor, B: int, C: int, nh: int, nw: int, ph: int, pw: int) -> None:
+    """the same rearrangement into an existing (B, C, nh*ph, nw*pw) f32 tensor (lazy.LazyPrediction's deferred write)"""
+    assert img.dtype == torch.float32 and img.is_contiguous() and img.numel() == B * C * nh * ph * nw * pw
+    check(_lib.load().mmae_unpatchify(pat.data_ptr(), img.data_ptr(), B, C, nh, nw, ph, pw, _stream()), 'unpatchify')
+
+
 def patchify(img: Tensor, C: int, nh: int, nw: int, ph: int, pw: int, dtype: torch.dtype) -> Tensor:
     """(B,C,H,W) f32 -> [B*nh*nw, C*ph*pw] act dtype.  The row stride is padded to a multiple of 8 elements
     (zero-filled) so the result is a legal MFMA GEMM operand for any patch dimension; a [:, :C*ph*pw] view is

@@ -177,6 +177,12 @@ class SpatialOutputAdapter(nn.Module):
             # slot (the kernels use that slot for nothing else in this mode); autograd splits its gradient between the two
             params[0] = self.mask_token + self.task_embeddings[self.task]
         img, token = SpatialAdapterFn.apply(cfg, encoder_tokens, ids_keep.contiguous(), ids_restore.contiguous(), *params)
+        if getattr(cfg, 'lazy_fill', None) is not None or cfg.handle is not None:
+            # written when first read (the masked losses never read it); already written when the adapter ran eagerly -- the wrapper
+            # then only carries the patch-row side channel through clone() (torch DDP's output sink)
+            from .lazy import LazyPrediction
+            img = LazyPrediction.wrap(img, getattr(cfg, 'lazy_fill', None))
+            cfg.lazy_fill = None
         if cfg.handle is not None:
             img._mmae_pat = cfg.handle       # a masked loss applied to exactly this tensor works on the patch rows (criterion.py)
         return img

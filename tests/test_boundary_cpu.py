@@ -233,3 +233,45 @@ def test_isa_audit_of_the_pingpong_kernels():
     for k, r, _ in fl:
         assert r['scratch'] == 0 and r['spill'] == 0, (k, r)
     assert sum(n for k, r, n in fl) > 0 and any(n > 0 for _, k, r, n in report if 'dwgroup' in k)      # the audit did see the asm reads
+
+
+def test_lazy_prediction_is_written_on_first_read_only():
+    """lazy.LazyPrediction (round 4): the (B, C, H, W) image an output adapter returns is filled from the patch rows the first time a
+    torch function reads it; metadata, record_stream-type calls and the loop's `preds[task].float()` do not trigger the write; the
+    result of any real operation is a plain tensor; autograd through the wrapper reaches the producing node."""
+    import torch
+    from multimae_amd.lazy import LazyPrediction, materialize
+    calls = []
+    ref = torch.arange(96.).view(2, 3, 4, 4)
+
+    def fill(t):
+        calls.append(1)
+        t.detach().copy_(ref)
+    x = LazyPrediction.wrap(torch.empty(2, 3, 4, 4), fill)
+    assert tuple(x.shape) == (2, 3, 4, 4) and x.dtype == torch.float32 and x.size(1) == 3 and x.dim() == 4 and len(x) == 2 and not x.is_cuda
+    assert x.float() is x and not x.materialized and calls == []
+    x._mmae_pat = 'handle'
+    assert getattr(x.float(), '_mmae_pat') == 'handle'
+    y = x + 1
+    assert calls == [1] and type(y) is torch.Tensor and torch.equal(y, ref + 1) and x.materialized
+    assert torch.equal(x.clone(), ref) and calls == [1]                       # written once
+    z = LazyPrediction.wrap(torch.empty(2, 3, 4, 4), fill)
+    materialize(z)
+    materialize(z)
+    assert calls == [1, 1] and torch.equal(z.detach(), ref)
+    d = LazyPrediction.wrap(torch.empty(2, 3, 4, 4), fill).double()            # a real conversion reads the data
+    assert calls == [1, 1, 1] and d.dtype == torch.float64 and torch.equal(d, ref.double())
+
+    class F(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, w):
+            return torch.empty_like(w)
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 2
+    w = torch.zeros(2, 3, 4, 4, requires_grad=True)
+    lo = LazyPrediction.wrap(F.apply(w), fill)
+    assert lo.requires_grad and lo.grad_fn is not None and calls == [1, 1, 1]
+    (lo.float() * 3).sum().backward()
+    assert calls == [1, 1, 1, 1] and torch.equal(w.grad, torch.full((2, 3, 4, 4), 6.0))

@@ -14,9 +14,9 @@ exist in this torch): ``GradScaler.scale(loss).backward()``, ``unscale_``, gradi
   C  the engine-native loop: direct gradients into the arena, ``FusedAdamW.step(loss)``;
   D  driver A without the DDP wrapper, E  driver D with the patch-domain losses switched off, A2  driver A again.
 
-Findings the assertions pin: B == C and A == E == A2 bit for bit (DDP at world 1 and the power-of-two loss scale are exactly
-transparent; the only thing that separates the DDP run from the native one is that DDP's output sink clones the predictions,
-so the criterion evaluates the image-domain form of the same losses); D tracks B (torch AdamW vs the fused step).
+Findings the assertions pin: B == C and A == D == A2 bit for bit (DDP at world 1 and the power-of-two loss scale are exactly
+transparent; DDP's output sink clones the predictions, and the clones keep the adapters' patch-row side channel -- round 4 --
+so the same loss kernels run); E (image-domain losses) tracks A; D tracks B (torch AdamW vs the fused step).
 """
 import os
 import socket
@@ -144,10 +144,16 @@ def test_reference_loop_body_runs_on_the_engine_under_ddp_autocast_gradscaler():
     assert res['B'][0] == res['C'][0]
     assert all(abs(a - b) <= 2e-6 * abs(b) for a, b in zip(res['B'][1], res['C'][1])), (res['B'][1], res['C'][1])
     assert update_err(res['B'][2], res['C'][2])[0] == 0.0
-    # A == E bit for bit: DDP (world 1, RCCL) is transparent; what separates A from B is the LOSS path -- _DDPSink hands the loop
-    # clones of the predictions, so the criterion takes the image-domain form instead of the adapters' patch rows
-    assert res['A'][0] == res['E'][0] and update_err(res['E'][2], wa)[0] == 0.0
+    # A == D bit for bit: DDP (world 1, RCCL) is transparent, INCLUDING the loss path (round 4): _DDPSink hands the loop clones of the
+    # predictions, and a clone of a lazy.LazyPrediction keeps the adapter's patch-row side channel, so the criterion runs the same
+    # patch-domain kernels as without DDP (rounds 1-3: the clones fell back to the image-domain form, A == E)
+    assert res['A'][0] == res['D'][0] and update_err(res['D'][2], wa)[0] == 0.0
     assert res['A'][0] == res['A2'][0] and update_err(res['A2'][2], wa)[0] == 0.0          # and it is deterministic
+    # E (patch-domain losses off) tracks A: image-domain against patch-domain loss gradients
+    for i in range(steps):
+        assert abs(res['E'][0][i] - la[i]) < 1e-3 * abs(la[i]), (i, res['E'][0][i], la[i])
+    e_glob, e_worst = update_err(res['E'][2], wa)
+    assert 0.0 < e_glob < 6e-2 and e_worst[0] < 0.2, (e_glob, e_worst)
     # D vs B: torch.optim.AdamW against the fused step.  Step 0 sees bit-identical gradients (equal norms) and the updates agree to
     # fp32 round-off; a 1e-7 weight difference already flips a few bf16 roundings of the weight shadow, so the loss of step 1 is
     # 5e-7 ... 8e-6 apart (which weights flip depends on the last bits of the gradients), and from there the two runs are two bf16
