@@ -256,7 +256,7 @@ def result_line(args, B, world, ms_per_step, img_s, final_loss, counters, roof, 
                                + (('ViT-L (MX-fp8 encoder products), ' if args.precision == 'mxfp8' else 'ViT-L (bf16 run of the fp8 config), ') if args.config == 'cfg5' else 'ViT-B, ')
                                + ('RGB-only' if args.config == 'cfg2' else 'RGB+depth+semseg')
                                + f', 224^2, Dirichlet alpha=1.0, {n_vis} visible tokens, {len(doms) + 1} cross-attention decoders (dim 256, depth 2), '
-                               + ('semseg adapter with fp32 activations and x3 split-bf16 GEMMs (a_hi.b_hi + a_hi.b_lo + a_lo.b_hi, fp32 accumulate), ' if 'semseg' in doms else '') + 'AdamW; fwd+losses+bwd+optimizer',
+                               + (('semseg adapter with fp32 activations; its Linear products with ' + {'f16': 'fp16 operands (11-bit significand = TF32, the precision the reference got on A100 under torch 1.10; one MFMA, gradient operands pre-scaled by a power of two), attention cores split-bf16', 'x3': 'x3 split-bf16 operands (a_hi.b_hi + a_hi.b_lo + a_lo.b_hi)', 'exact': 'f32 MFMA'}[getattr(args, 'fp32_adapter_gemm', 'f16')] + ', fp32 accumulate, ') if 'semseg' in doms else '') + 'AdamW; fwd+losses+bwd+optimizer',
                    'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}'},
         'final_loss': round(final_loss, 5), 'launch': ("the reference's loop body against the drop-in boundary: DistributedDataParallel(world 1, nccl, find_unused_parameters) + autocast + GradScaler + FusedAdamW, gradients through autograd"
                                                       if getattr(args, 'dropin_ddp', 0) else 'hipGraph replay of the captured step' if use_graph else 'eager, one library call per encoder stack / output adapter / loss / optimiser step'),
@@ -312,6 +312,7 @@ def main():
     ap.add_argument('--graph', type=int, default=-1, help='1: capture the step once as a hipGraph and replay it (multimae_amd.graph.StepGraph; 1 GPU only). Default 0: on ROCm 7.2 the replay of this ~1 100-node, 10-stream graph measured 46.2 ms/step against 44.1 ms eager')
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary line (cfg5 = BASELINE configs[4] geometry, ViT-L, MX-fp8 encoder products, B = 128, a few steps) that the default single-GPU cfg3 run appends as `secondary`')
     ap.add_argument('--gemm-cu-reserve', type=int, default=-1, help='compute units the persistent GEMM grids leave free (for RCCL\'s channel kernels while gradient buckets are in flight); -1: 16 when gradient buckets are exchanged (N > 1 or --force-dist), else 0')
+    ap.add_argument('--fp32-adapter-gemm', default='f16', choices=['f16', 'x3', 'exact'], help="Linear products of the fp32 output adapter (semseg) in the bf16 speed mode: 'f16' fp16 operands (TF32-class, one MFMA; default), 'x3' split bf16 (three), 'exact' f32 MFMA (multimae_amd.engine.set_fp32_adapter_gemm)")
     ap.add_argument('--dropin-ddp', type=int, default=0, help="1: time the REFERENCE'S loop body against the drop-in boundary instead of the native loop (VERDICT r3 item 7): the model wrapped in torch DistributedDataParallel (world 1, nccl, find_unused_parameters=True, run_pretraining_multimae.py:380-387), forward + losses inside torch.cuda.amp.autocast(), the NativeScaler sequence (GradScaler.scale(loss).backward(), unscale_, gradient norm, GradScaler.step(FusedAdamW), update()); gradients travel through autograd / DDP's reducer (engine.set_direct_grads(False))")
     ap.add_argument('--dry-run', type=int, default=0, help='1: CPU tensors and a type-checking stub of the C ABI (tests/dryrun_harness.py): exercises the LAUNCH path of this script (self-launch, process group, reducer, the JSON line) without a GPU -- the numbers are meaningless and the line says so')
     args = ap.parse_args()
@@ -396,6 +397,7 @@ def run_once(args):
         broadcast_parameters(arena)
         reducer = GradAllReducer.for_arena(arena, bucket_mb=args.bucket_mb, bf16_buckets=bool(args.bf16_buckets), force_collective=bool(args.force_dist))
     M.engine.set_precision(args.precision)
+    M.engine.set_fp32_adapter_gemm(args.fp32_adapter_gemm)
     M.engine.set_direct_grads(not args.dropin_ddp)
     M.engine.set_adapter_streams(bool(args.adapter_streams))
     M.engine.set_wgrad_stream(bool(args.wgrad_stream))

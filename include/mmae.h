@@ -27,12 +27,16 @@
 extern "C" {
 #endif
 
-#define MMAE_ABI_VERSION 3
+#define MMAE_ABI_VERSION 4
 
 #define MMAE_F32  0
 #define MMAE_BF16 1
 #define MMAE_F32X3 2   /* GEMM only: f32 operands in memory, multiplied as split bf16 (hi+lo) on the bf16 MFMA:
                         a.b ~= ah.bh + ah.bl + al.bh, fp32 accumulate (~16 operand mantissa bits, > TF32) */
+#define MMAE_F32F16 3  /* GEMM only (round 4): f32 operands in memory, each rounded to fp16 -- TF32's 11-bit significand -- for ONE product
+                          per tile step on v_mfma_f32_32x32x16_f16, fp32 accumulate.  The operand precision the reference's fp32 output
+                          adapters ran at on A100 (torch 1.10: allow_tf32), at a third of MMAE_F32X3's MFMA work.  Values beyond the fp16
+                          range saturate at +-65504; a gradient operand needs mmae_gemm_desc.a_amax (see there). */
 #define MMAE_MXFP8 4   /* GEMM only: OCP MX operands -- e4m3 elements [rows][K] plus one E8M0 scale per 32 consecutive K elements in the
                           packed layout of mmae_mx_quant (a_scale / b_scale of the descriptor); block-scaled MFMA, fp32 accumulation */
 
@@ -121,6 +125,10 @@ typedef struct mmae_gemm_desc {
                                     of C (what mmae_mx_quant would produce from it: e4m3 [M][ldq] + packed scales for M rows, N cols) -- the
                                     operand of the next MX product without a separate pass.  N % 32 == 0.  NULL = off. */
     int64_t ldq;
+    const float* a_amax;         /* MMAE_F32F16 only, optional: DEVICE pointer to one f32, an upper bound m > 0 of |A| (the loss gradient's
+                                    largest element, written by the masked-loss backward kernels).  The A operand is multiplied by
+                                    2^-floor(log2 m) before its fp16 rounding and the accumulators by the inverse afterwards: gradient
+                                    operands (1e-6 .. 1e-3) keep their 11 bits instead of falling into fp16's subnormals.  NULL = as is. */
 } mmae_gemm_desc;
 
 int mmae_gemm(const mmae_gemm_desc* d, void* stream);
@@ -371,6 +379,8 @@ typedef struct mmae_block_desc {
      * mmae_x3_tmp_bytes(B * N, max(Hd, 3 D)) bytes.  Forward and dX products whose contraction is a multiple of 32 then run as
      * one bf16 product over 3 K on the ping-pong kernel; weight gradients keep the MMAE_F32X3 kernel.  NULL = off. */
     const void* const* x3_w; int32_t x3_n; void* x3_tmp; int64_t x3_tmp_bytes;
+    const float* dy_amax;                        /* f32 activations with f32_gemm = MMAE_F32F16: device scalar for the gradient operands of the
+                                                    dX / dW products (mmae_gemm_desc.a_amax); NULL: those products run as MMAE_F32X3 */
 } mmae_block_desc;
 
 int mmae_block_fwd(const mmae_block_desc* d, void* stream);
@@ -467,6 +477,7 @@ typedef struct mmae_adapter_desc {
     float* ws_side; int64_t ws_side_elems;
     const void* const* x3_w; int32_t x3_n;       /* optional pre-split weights (triples, as mmae_block_desc.x3_w) of an f32 adapter; set them
                                                     BEFORE asking for the slab sizes: the operand scratch is carved from act / tmp */
+    const float* dy_amax;                        /* as mmae_block_desc.dy_amax, for the adapter's own products and its blocks */
 } mmae_adapter_desc;
 
 int64_t mmae_adapter_act_bytes(const mmae_adapter_desc* d);
@@ -648,12 +659,14 @@ int mmae_masked_pixel_loss_pat_fwd(const float* pat, const float* target, const 
                                    int W, int patch, float* stats, float* partial, float* per_sample, float* loss, void* stream);
 int mmae_masked_pixel_loss_pat_bwd(const float* pat, const float* target, const int64_t* mask, int kind, int norm_pix, int B, int C, int H,
                                    int W, int patch, const float* stats, const float* per_sample, const float* loss, const float* upstream,
-                                   void* d_pat, int d_pat_dtype, int64_t ld_pat, void* stream);
+                                   void* d_pat, int d_pat_dtype, int64_t ld_pat, float* amax, void* stream);
 int mmae_masked_ce_pat_fwd(const float* pat, const int64_t* target, const int64_t* mask, int B, int C, int H, int W, int patch,
                            float label_smoothing, float* lse_pat, float* partial, float* per_sample, float* loss, void* stream);
 int mmae_masked_ce_pat_bwd(const float* pat, const int64_t* target, const int64_t* mask, int B, int C, int H, int W, int patch,
                            float label_smoothing, const float* lse_pat, const float* per_sample, const float* loss, const float* upstream,
-                           void* d_pat, int d_pat_dtype, int64_t ld_pat, void* stream);
+                           void* d_pat, int d_pat_dtype, int64_t ld_pat, float* amax, void* stream);
+/* (amax, optional: device f32 the kernel raises -- atomic max -- to the largest |element| it writes into d_pat; the caller zeroes it.
+ * It is what an adapter with f32 activations and MMAE_F32F16 products scales its gradient operands by: mmae_adapter_desc.dy_amax.) */
 
 /* ------------------------------------------------------------------------- *
  * Optimiser step on flat arenas.  Replaces get_grad_norm_ / clip_grad_norm_

@@ -19,7 +19,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_PKG), 'include', 'mmae.h')
 LIB_PATH = os.environ.get('MMAE_LIB') or os.path.join(_PKG, 'libmmae_hip.so')      # MMAE_LIB: an alternative build of the same ABI (A/B experiments)
 
-F32, BF16, F32X3 = 0, 1, 2
+F32, BF16, F32X3, F32F16 = 0, 1, 2, 3
 MXFP8 = 4
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_GELU_G, EPI_MUL = 0, 1, 2, 3, 4
 
@@ -44,6 +44,7 @@ class GemmDesc(ctypes.Structure):
         ('a_colsum', ctypes.c_void_p), ('a_colsum_acc', ctypes.c_int32),
         ('a_scale', ctypes.c_void_p), ('b_scale', ctypes.c_void_p),
         ('q_out', ctypes.c_void_p), ('q_scale', ctypes.c_void_p), ('ldq', ctypes.c_int64),
+        ('a_amax', ctypes.c_void_p),
     ]
 
 
@@ -64,7 +65,7 @@ class BlockDesc(ctypes.Structure):
                 + [('grad_acc', _I), ('fc2_b_done', _I), ('ws_main', _P), ('ws_main_elems', _L), ('ws_side', _P), ('ws_side_elems', _L)]
                 + [(n, _P) for n in ('dp1', 'dp2', 'branch', 'dxs_act')]
                 + [('mx_w', _P), ('mx_tmp', _P), ('mx_tmp_bytes', _L)]
-                + [('x3_w', _P), ('x3_n', _I), ('x3_tmp', _P), ('x3_tmp_bytes', _L)])
+                + [('x3_w', _P), ('x3_n', _I), ('x3_tmp', _P), ('x3_tmp_bytes', _L), ('dy_amax', _P)])
 
 
 class StackDesc(ctypes.Structure):
@@ -83,7 +84,7 @@ class AdapterDesc(ctypes.Structure):
                                      'ids_restore', 'act')] + [('act_bytes', _L), ('img', _P)]
                 + [('d_img', _P), ('d_pat', _P), ('ld_pat', _L), ('g', _P), ('d_enc', _P), ('tmp', _P), ('tmp_bytes', _L)]
                 + [('ws_main', _P), ('ws_main_elems', _L), ('ws_side', _P), ('ws_side_elems', _L)]
-                + [('x3_w', _P), ('x3_n', _I)])
+                + [('x3_w', _P), ('x3_n', _I), ('dy_amax', _P)])
 
 
 class DwProblem(ctypes.Structure):
@@ -172,7 +173,7 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = ret
         fn.argtypes = argtypes
-    if lib.mmae_abi_version() != 3:
+    if lib.mmae_abi_version() != 4:
         raise RuntimeError('libmmae_hip.so ABI version mismatch')
     for which, cls in enumerate((GemmDesc, BlockDesc, StackDesc, AdapterDesc, OptDesc, PatchSrc, DwGroupDesc, ColsumJob)):
         if lib.mmae_struct_size(which) != ctypes.sizeof(cls):

@@ -22,7 +22,11 @@ struct Ctx {
     void* mx_tmp = nullptr; int64_t mx_tmp_bytes = 0;      // scratch of the MX-fp8 activation operands (main stream only)
     const void* const* x3_w = nullptr; int x3_n = 0;       // pre-split weights of an f32 call: triples {f32 weight, [n][3k], [3n][k]}
     void* x3_tmp = nullptr; int64_t x3_tmp_bytes = 0;      // scratch of the pre-split activation operand (main stream only)
+    const float* dy_amax = nullptr;                        // MMAE_F32F16: device scalar that pre-scales gradient operands (mmae_gemm_desc.a_amax)
     int ab() const { return act_dtype == MMAE_BF16 ? MMAE_BF16 : f32_gemm; }
+    // products whose A operand is a GRADIENT: fp16 operands only with the loss gradient's amax at hand, else the split-bf16 form
+    int ab_grad() const { return act_dtype == MMAE_BF16 ? MMAE_BF16 : ((f32_gemm == MMAE_F32F16 && !dy_amax) ? MMAE_F32X3 : f32_gemm); }
+    const float* amax_for(int ab) const { return ab == MMAE_F32F16 ? dy_amax : nullptr; }
     size_t es() const { return act_dtype == MMAE_BF16 ? 2 : 4; }
 };
 
@@ -30,6 +34,7 @@ Ctx ctx_of(const mmae_block_desc* d) {
     Ctx c{d->act_dtype, d->f32_gemm, d->grad_acc, d->ws_main, d->ws_main_elems, d->ws_side, d->ws_side_elems};
     c.mx_tmp = d->mx_tmp; c.mx_tmp_bytes = d->mx_tmp_bytes;
     c.x3_w = d->x3_w; c.x3_n = d->x3_n; c.x3_tmp = d->x3_tmp; c.x3_tmp_bytes = d->x3_tmp_bytes;
+    c.dy_amax = d->dy_amax;
     return c;
 }
 
@@ -146,7 +151,7 @@ int lin_dx(const Ctx& c, const void* dy, int64_t ldy, const void* w, void* out, 
            float* colsum_part, hipStream_t st, const void* const* mxw = nullptr, int mx_in = -1, int mx_out = -1) {
     mmae_gemm_desc g = {};
     g.A = dy; g.B = w; g.C = out;
-    g.ab_dtype = c.ab();
+    g.ab_dtype = c.ab_grad(); g.a_amax = c.amax_for(g.ab_dtype);
     g.c_dtype = out_dtype;
     g.M = M; g.N = K; g.K = N;
     g.lda = ldy; g.ldb = K; g.ldc = K;
@@ -232,7 +237,7 @@ int lin_dw(const Ctx& c, const void* dy, int64_t ldy, const void* x, float* dw, 
     if (dw) {
         mmae_gemm_desc g = {};
         g.A = dy; g.B = x; g.C = dw;
-        g.ab_dtype = c.ab();
+        g.ab_dtype = c.ab_grad(); g.a_amax = c.amax_for(g.ab_dtype);
         g.c_dtype = MMAE_F32;
         g.M = N; g.N = K; g.K = M;
         g.lda = ldy; g.ldb = K; g.ldc = K;
@@ -335,8 +340,8 @@ int cast_to_act(int act, const float* src, void* dst, int64_t n, hipStream_t st)
 int check_desc(const mmae_block_desc* d) {
     MMAE_REQUIRE(d, "block: null descriptor");
     MMAE_REQUIRE(d->B > 0 && d->N > 0 && d->D > 0 && d->heads > 0 && d->Hd > 0 && d->D % d->heads == 0, "block: bad geometry");
-    MMAE_REQUIRE(d->act_dtype == MMAE_BF16 || (d->act_dtype == MMAE_F32 && d->f32_gemm == MMAE_F32X3),
-                 "block: activations must be bf16, or f32 with split-bf16 (MMAE_F32X3) products");
+    MMAE_REQUIRE(d->act_dtype == MMAE_BF16 || (d->act_dtype == MMAE_F32 && (d->f32_gemm == MMAE_F32X3 || d->f32_gemm == MMAE_F32F16)),
+                 "block: activations must be bf16, or f32 with split-bf16 (MMAE_F32X3) / fp16-operand (MMAE_F32F16) products");
     const int hd = d->D / d->heads;
     if ((hd != 32 && hd != 64) || d->N > 256) { mmae_set_error("block: geometry outside the fused attention kernel (head_dim 32/64, N <= 256)"); return MMAE_ESUPPORT; }
     MMAE_REQUIRE(d->qkv_w && d->proj_w && d->fc1_w && d->fc2_w && d->n1_w && d->n1_b && d->qkv_b && d->proj_b && d->n2_w && d->n2_b &&
@@ -427,8 +432,8 @@ bool stack_has_dp(const mmae_stack_desc* d) {
 int check_stack(const mmae_stack_desc* d) {
     MMAE_REQUIRE(d, "stack: null descriptor");
     MMAE_REQUIRE(d->L > 0 && d->B > 0 && d->N > 0 && d->D > 0 && d->heads > 0 && d->Hd > 0 && d->D % d->heads == 0, "stack: bad geometry");
-    MMAE_REQUIRE(d->act_dtype == MMAE_BF16 || (d->act_dtype == MMAE_F32 && d->f32_gemm == MMAE_F32X3),
-                 "stack: activations must be bf16, or f32 with split-bf16 (MMAE_F32X3) products");
+    MMAE_REQUIRE(d->act_dtype == MMAE_BF16 || (d->act_dtype == MMAE_F32 && (d->f32_gemm == MMAE_F32X3 || d->f32_gemm == MMAE_F32F16)),
+                 "stack: activations must be bf16, or f32 with split-bf16 (MMAE_F32X3) / fp16-operand (MMAE_F32F16) products");
     const int hd = d->D / d->heads;
     if ((hd != 32 && hd != 64) || d->N > 256) { mmae_set_error("stack: geometry outside the fused attention kernel (head_dim 32/64, N <= 256)"); return MMAE_ESUPPORT; }
     MMAE_REQUIRE(d->w && d->p && d->x && d->act, "stack: null pointer");
@@ -472,6 +477,7 @@ struct StackRun {
     float* ws_main; int64_t ws_main_elems; float* ws_side; int64_t ws_side_elems;
     const void* const* mx_w = nullptr; void* mx_tmp = nullptr; int64_t mx_tmp_bytes = 0;
     const void* const* x3_w = nullptr; int x3_n = 0; void* x3_tmp = nullptr; int64_t x3_tmp_bytes = 0;
+    const float* dy_amax = nullptr;
 };
 
 int run_blocks_bwd(const StackRun& s, int lo, int hi, const float* dx_top, const void* dx_top_act, bool top_in_sets, bool first_fc2_b_done,
@@ -514,6 +520,7 @@ int run_blocks_bwd(const StackRun& s, int lo, int hi, const float* dx_top, const
         b.ws_main = s.ws_main; b.ws_main_elems = s.ws_main_elems; b.ws_side = s.ws_side; b.ws_side_elems = s.ws_side_elems;
         if (s.mx_w) { b.mx_w = s.mx_w + 16 * l; b.mx_tmp = s.mx_tmp; b.mx_tmp_bytes = s.mx_tmp_bytes; }
         b.x3_w = s.x3_w; b.x3_n = s.x3_n; b.x3_tmp = s.x3_tmp; b.x3_tmp_bytes = s.x3_tmp_bytes;
+        b.dy_amax = s.dy_amax;
         if ((rc = mmae_block_bwd(&b, st, sd))) return rc;
         if (sd != st) {
             hipEvent_t e = g_held_ring.next();
@@ -869,8 +876,8 @@ int check_adapter(const mmae_adapter_desc* d) {
                  d->depth <= 8 && d->T >= 1 && d->T <= 7 && d->q_task >= -1 && d->q_task < d->T && d->G >= 0 && d->n_q > 0 && d->NC > d->G,
                  "adapter: bad geometry");
     MMAE_REQUIRE(d->C > 0 && d->nh > 0 && d->nw > 0 && d->ph > 0 && d->pw > 0 && d->nh * d->nw == d->n_q, "adapter: bad patch geometry");
-    MMAE_REQUIRE(d->act_dtype == MMAE_BF16 || (d->act_dtype == MMAE_F32 && d->f32_gemm == MMAE_F32X3),
-                 "adapter: activations must be bf16, or f32 with split-bf16 (MMAE_F32X3) products");
+    MMAE_REQUIRE(d->act_dtype == MMAE_BF16 || (d->act_dtype == MMAE_F32 && (d->f32_gemm == MMAE_F32X3 || d->f32_gemm == MMAE_F32F16)),
+                 "adapter: activations must be bf16, or f32 with split-bf16 (MMAE_F32X3) / fp16-operand (MMAE_F32F16) products");
     const int hd = d->D / d->heads;
     if ((hd != 32 && hd != 64) || d->n_q > 256 || d->NC > 256) { mmae_set_error("adapter: geometry outside the fused attention kernel"); return MMAE_ESUPPORT; }
     if (d->act_dtype == MMAE_F32) {
@@ -887,6 +894,7 @@ int check_adapter(const mmae_adapter_desc* d) {
 Ctx ctx_of(const mmae_adapter_desc* d, void* x3_tmp) {
     Ctx c{d->act_dtype, d->f32_gemm, d->grad_acc, d->ws_main, d->ws_main_elems, d->ws_side, d->ws_side_elems};
     if (x3_tmp) { c.x3_w = d->x3_w; c.x3_n = d->x3_n; c.x3_tmp = x3_tmp; c.x3_tmp_bytes = adapter_x3_bytes(d); }
+    c.dy_amax = d->dy_amax;
     return c;
 }
 
@@ -1021,6 +1029,7 @@ int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream
         StackRun s = {B, n_q, D, d->heads, Hd, act, d->f32_gemm, d->grad_acc, w + 5, p + 11, nullptr, gblk, a.x1, a.blocks, t.blocks, depth,
                       d->ws_main, d->ws_main_elems, d->ws_side, d->ws_side_elems};
         s.x3_w = c.x3_w; s.x3_n = c.x3_n; s.x3_tmp = c.x3_tmp; s.x3_tmp_bytes = c.x3_tmp_bytes;
+        s.dy_amax = c.dy_amax;
         const float* o; const void* oa;
         if ((rc = run_blocks_bwd(s, 0, depth, dh, dh_act, false, false, nullptr, gb[15], nullptr, st, sd, &o, &oa))) return rc;
         dh = o; dh_act = oa;

@@ -24,6 +24,7 @@ struct GemmArgs {
     int dephase;                  // experiment (env MMAE_PP_DEPHASE = n): odd workgroups of the ping-pong kernel start n x ~4 us late
     const void* scA; const void* scB;   // MX-fp8 products: packed E8M0 scales of the two operands (mxfp8.hip)
     unsigned char* qout; unsigned char* qsc; long long ldq;   // ..._Q flavours: also emit the MX-fp8 quantisation of the bf16 output C ([M][ldq] bytes + packed scales)
+    const float* a_amax;          // MMAE_F32F16 products: device scalar whose power of two pre-scales the A operand (gemm_f32x3.hip), or NULL
     int dbg;                      // epilogue dissection for profiling (env MMAE_EPI_DBG, GELU flavour only): 1 = no GELU arithmetic, 2 = no pre-activation store,
                                   // 3 = arithmetic but no stores, 4 = nothing.  0 in production.
 };

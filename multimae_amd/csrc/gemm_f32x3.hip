@@ -6,6 +6,15 @@
 // 16x slower exact-f32 MFMA.  Used for fp32_output_adapters in bf16 speed mode; the exact-f32 parity mode
 // keeps gemm_f32.hip.
 //
+// F16 = true ("f32f16", MMAE_F32F16, round 4): the same kernel with ONE product per tile step -- both operands rounded to fp16
+// (11-bit significand = TF32's; fp32 accumulation) on v_mfma_f32_32x32x16_f16.  That is exactly the operand precision the
+// reference's fp32 adapters ran at on A100 (TF32), at a third of the MFMA work and half the LDS traffic of the split form.  fp16
+// has TF32's significand but not its exponent range: forward operands (normalised activations, weights) fit as they are (values
+// beyond +-65504 saturate); a GRADIENT operand (dy of a dX / dW product, ~1e-6 at the bench batch) is multiplied by a power of two
+// read from device memory first -- 2^-floor(log2(amax)), amax = the largest |element| of the loss gradient the backward pass
+// started from, left there by the loss kernel -- and the accumulators are multiplied back before the epilogue, so nothing in
+// memory changes scale.  Without an amax the gradient products stay on the split form.
+//
 // Structure = gemm_bf16.hip's VGPR-staged kernel with BK = 32: operands are loaded as f32 (2 float4 per
 // 8-element chunk), split in registers, and written to separate hi / lo LDS tiles (same swizzled layouts,
 // same ds_read_b128 / ds_read_b64_tr_b16 fragment fetch as the bf16 kernels).
@@ -41,12 +50,30 @@ __device__ __forceinline__ void split8(const f32x4 x0, const f32x4 x1, i32x4& hi
     lo = __builtin_bit_cast(i32x4, l);
 }
 
-template <bool AKS, bool BKS>
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+// 8 consecutive f32 (times a power of two) -> fp16x8, round to nearest even, saturating
+__device__ __forceinline__ i32x4 cvt8_f16(const f32x4 x0, const f32x4 x1, float s) {
+    f16x8 h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = (_Float16)__builtin_amdgcn_fmed3f(x0[j] * s, -65504.0f, 65504.0f);
+        h[4 + j] = (_Float16)__builtin_amdgcn_fmed3f(x1[j] * s, -65504.0f, 65504.0f);
+    }
+    return __builtin_bit_cast(i32x4, h);
+}
+
+template <bool AKS, bool BKS, bool F16 = false>
 __global__ void __launch_bounds__(256) gemm_f32x3_kernel(const GemmArgs g) {
     constexpr int BM = 128, BN = 128, NT = 256;
     constexpr int LCH = BM * 4 / NT;                       // 8-element chunks per thread per operand tile (2)
-    constexpr int T_BYTES = BM * 64;                       // one bf16 tile (hi or lo) of one operand: 8 KiB
-    constexpr int STAGE = 4 * T_BYTES;                     // A_hi, A_lo, B_hi, B_lo
+    constexpr int T_BYTES = BM * 64;                       // one 16-bit tile (hi or lo / fp16) of one operand: 8 KiB
+    constexpr int STAGE = (F16 ? 2 : 4) * T_BYTES;         // A_hi, A_lo, B_hi, B_lo  |  A16, B16
+    // F16: power-of-two pre-scale of the A operand (a gradient): amax in [2^e, 2^(e+1)) -> 2^-e, undone on the accumulators
+    float a_s = 1.0f, a_inv = 1.0f;
+    if (F16 && g.a_amax) {
+        const unsigned e = (__float_as_uint(*g.a_amax) >> 23) & 0xffu;
+        if (e >= 1 && e <= 253) { a_s = __uint_as_float((254u - e) << 23); a_inv = __uint_as_float(e << 23); }
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -126,6 +153,11 @@ __global__ void __launch_bounds__(256) gemm_f32x3_kernel(const GemmArgs g) {
         char* s = smem + stage * STAGE;
 #pragma unroll
         for (int i = 0; i < LCH; ++i) {
+            if (F16) {
+                *reinterpret_cast<i32x4*>(s + a_lds[i]) = cvt8_f16(ra[i][0], ra[i][1], a_s);
+                *reinterpret_cast<i32x4*>(s + T_BYTES + b_lds[i]) = cvt8_f16(rb[i][0], rb[i][1], 1.0f);
+                continue;
+            }
             i32x4 hi, lo;
             split8(ra[i][0], ra[i][1], hi, lo);
             *reinterpret_cast<i32x4*>(s + a_lds[i]) = hi;
@@ -168,6 +200,21 @@ __global__ void __launch_bounds__(256) gemm_f32x3_kernel(const GemmArgs g) {
         const char* s = smem + ((kt - kt_begin) & 1) * STAGE;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
+            if (F16) {
+                bf16x8 a16[2], b16[2];                      // fp16 bit patterns (the fragment fetch is type-agnostic)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    a16[t] = AKS ? frag_ks(s, wm * 64 + t * 32, kk) : frag_kc(s, wm * 64 + t * 32, kk);
+                    b16[t] = BKS ? frag_ks(s + T_BYTES, wn * 64 + t * 32, kk) : frag_kc(s + T_BYTES, wn * 64 + t * 32, kk);
+                }
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, b16[tn]), __builtin_bit_cast(f16x8, a16[tm]),
+                                                                             acc[tn][tm], 0, 0, 0);
+                continue;
+            }
             bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -188,24 +235,32 @@ __global__ void __launch_bounds__(256) gemm_f32x3_kernel(const GemmArgs g) {
         if (kt + 1 < nkt) lstore((kt + 1 - kt_begin) & 1);
         __syncthreads();
     }
+    if (F16 && a_inv != 1.0f) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] *= a_inv;
+    }
     GemmArgs gs = g;                                       // the shared epilogue addresses the slab of slice blockIdx.z: point it at slice zsplit's
     if (g.splitk > 1) gs.ws = g.ws + ((long long)zsplit - (long long)blockIdx.z) * g.M * g.N;
     gemm_store_tile64(gs, Cz, smem + wave * 8192, lane, acc, m0 + wm * 64, n0 + wn * 64);   // (loop ended on a barrier)
 }
 
-template <bool AKS, bool BKS>
+template <bool AKS, bool BKS, bool F16 = false>
 int launch(const GemmArgs& g, int batch, hipStream_t st) {
     GemmArgs a = g;
     a.tiles_n = (g.N + 127) / 128;
     a.kt_per_split = g.kt_per_split * 2;           // runtime.hip counts 64-wide K tiles for 16-bit operands
     dim3 grid(((g.M + 127) / 128) * a.tiles_n, batch, a.splitk), block(256);
-    const size_t lds = 2 * 4 * 128 * 64;
+    const size_t lds = 2 * (F16 ? 2 : 4) * 128 * 64;
     static std::once_flag attr_once;
     std::call_once(attr_once, [&] {
-        (void)hipFuncSetAttribute((const void*)gemm_f32x3_kernel<AKS, BKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_f32x3_kernel<AKS, BKS, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
-    hipLaunchKernelGGL((gemm_f32x3_kernel<AKS, BKS>), grid, block, lds, st, a);
-    return mmae_check_launch("gemm_f32x3");
+    hipLaunchKernelGGL((gemm_f32x3_kernel<AKS, BKS, F16>), grid, block, lds, st, a);
+    return mmae_check_launch(F16 ? "gemm_f32f16" : "gemm_f32x3");
 }
 
 
@@ -243,6 +298,12 @@ int mmae_gemm_f32x3_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t
     const long long a_rows = d->a_trans ? d->K : d->M, b_rows = d->b_trans ? d->K : d->N;
     MMAE_REQUIRE(a_rows * d->lda * 4 < 0x7fffffffLL && b_rows * d->ldb * 4 < 0x7fffffffLL, "gemm f32x3: operand >= 2 GiB");
     const bool aks = d->a_trans != 0, bks = d->b_trans != 0;
+    if (d->ab_dtype == MMAE_F32F16) {
+        if (!aks && !bks) return launch<false, false, true>(g, d->batch, st);
+        if (!aks && bks) return launch<false, true, true>(g, d->batch, st);
+        if (aks && !bks) return launch<true, false, true>(g, d->batch, st);
+        return launch<true, true, true>(g, d->batch, st);
+    }
     if (!aks && !bks) return launch<false, false>(g, d->batch, st);
     if (!aks && bks) return launch<false, true>(g, d->batch, st);
     if (aks && !bks) return launch<true, false>(g, d->batch, st);

@@ -280,13 +280,20 @@ __global__ void __launch_bounds__(256) pixel_loss_pat_fwd_kernel(const float* __
     if (threadIdx.x == 0) partial[(long long)b * LSPLIT + blockIdx.x] = acc / (float)C;
 }
 
+// largest |gradient element| of the launch -> *amax (optional): what scales the fp16 gradient operands of an MMAE_F32F16 adapter
+// (mmae_gemm_desc.a_amax).  Non-negative floats order like their bit patterns: one atomicMax per wave that beats the value it sees.
+__device__ __forceinline__ void note_amax(float m, float* amax) {
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > *(volatile float*)amax) atomicMax((unsigned*)amax, __float_as_uint(m));
+}
+
 // one wave per patch row; 4 consecutive (c, i, j) elements per lane (P % 4 == 0: they share c, i and lie in one target row)
 template <typename DT>
 __global__ void __launch_bounds__(256) pixel_loss_pat_bwd_kernel(const float* __restrict__ pat, const float* __restrict__ target,
                                                                  const long long* __restrict__ mask, int kind, int norm_pix, int C, int H,
                                                                  int W, int P, const float* __restrict__ stats, const float* __restrict__ per_sample,
                                                                  const float* __restrict__ loss, const float* __restrict__ upstream,
-                                                                 DT* __restrict__ d_pat, long long ld, long long n_rows) {
+                                                                 DT* __restrict__ d_pat, long long ld, long long n_rows, float* __restrict__ amax) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_rows) return;
@@ -294,6 +301,7 @@ __global__ void __launch_bounds__(256) pixel_loss_pat_bwd_kernel(const float* __
     const long long b = row / np;
     const int p = (int)(row % np), py = p / nw, px = p % nw;
     const bool on = mask[row] != 0;
+    float gmax = 0.f;
     float mu = 0.f, rs = 1.f, wgt = 0.f;
     if (on) {
         if (norm_pix) { mu = stats[row * 2]; rs = stats[row * 2 + 1]; }
@@ -312,6 +320,7 @@ __global__ void __launch_bounds__(256) pixel_loss_pat_bwd_kernel(const float* __
                 for (int j = 0; j < 4; ++j) {
                     const float d = pr[j] - (tg[j] - mu) * rs;
                     g[j] = wgt * (kind == 0 ? 2.f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)));
+                    gmax = fmaxf(gmax, fabsf(g[j]));
                 }
             }
             st4(drow + e, g);
@@ -323,10 +332,12 @@ __global__ void __launch_bounds__(256) pixel_loss_pat_bwd_kernel(const float* __
                 const int c = e / npix, ij = e % npix;
                 const float d = prow[e] - (target[(((long long)b * C + c) * H + py * P + ij / P) * W + px * P + ij % P] - mu) * rs;
                 g = wgt * (kind == 0 ? 2.f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)));
+                gmax = fmaxf(gmax, fabsf(g));
             }
             ActT<DT>::st(drow + e, g);
         }
     }
+    if (amax) note_amax(gmax, amax);
 }
 
 // cross entropy on patch rows; npix = P * P <= 64, a power of two: lane = (class slot, pixel), 64 / npix class slots per pixel,
@@ -378,7 +389,7 @@ __global__ void __launch_bounds__(256) ce_pat_bwd_kernel(const float* __restrict
                                                          const long long* __restrict__ mask, int C, int H, int W, int P, float eps,
                                                          const float* __restrict__ lse_pat, const float* __restrict__ per_sample,
                                                          const float* __restrict__ loss, const float* __restrict__ upstream,
-                                                         DT* __restrict__ d_pat, long long ld, long long n_rows) {
+                                                         DT* __restrict__ d_pat, long long ld, long long n_rows, float* __restrict__ amax) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_rows) return;
@@ -397,11 +408,14 @@ __global__ void __launch_bounds__(256) ce_pat_bwd_kernel(const float* __restrict
     const long long t = target[((long long)b * H + py * P + pix / P) * W + px * P + pix % P];
     const float* prow = pat + row * nval;
     int c = slot;
+    float gmax = 0.f;
     for (int e = lane; e < (int)ld; e += 64, c += nslot) {
         float g = 0.f;
         if (e < nval) g = wgt * (expf(prow[e] - ls) - (((long long)c == t ? 1.f - eps : 0.f) + eps / (float)C));
+        gmax = fmaxf(gmax, fabsf(g));
         ActT<DT>::st(drow + e, g);
     }
+    if (amax) note_amax(gmax, amax);
 }
 
 // ---- optimiser ----------------------------------------------------------------------------
@@ -561,7 +575,7 @@ int mmae_masked_pixel_loss_pat_fwd(const float* pat, const float* target, const 
 
 int mmae_masked_pixel_loss_pat_bwd(const float* pat, const float* target, const int64_t* mask, int kind, int norm_pix, int B, int C, int H,
                                    int W, int patch, const float* stats, const float* per_sample, const float* loss, const float* upstream,
-                                   void* d_pat, int d_pat_dtype, int64_t ld_pat, void* stream) {
+                                   void* d_pat, int d_pat_dtype, int64_t ld_pat, float* amax, void* stream) {
     MMAE_REQUIRE(pat && target && mask && per_sample && loss && upstream && d_pat, "pixel_loss_pat_bwd: null pointer");
     MMAE_REQUIRE(patch > 0 && H % patch == 0 && W % patch == 0 && ld_pat >= (int64_t)C * patch * patch, "pixel_loss_pat_bwd: bad geometry");
     MMAE_REQUIRE(!norm_pix || stats, "pixel_loss_pat_bwd: norm_pix needs stats");
@@ -570,10 +584,10 @@ int mmae_masked_pixel_loss_pat_bwd(const float* pat, const float* target, const 
     const dim3 grid((unsigned)((rows + 3) / 4));
     if (d_pat_dtype == MMAE_BF16)
         hipLaunchKernelGGL((pixel_loss_pat_bwd_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, pat, target, (const long long*)mask, kind,
-                           norm_pix, C, H, W, patch, stats, per_sample, loss, upstream, (uint16_t*)d_pat, (long long)ld_pat, rows);
+                           norm_pix, C, H, W, patch, stats, per_sample, loss, upstream, (uint16_t*)d_pat, (long long)ld_pat, rows, amax);
     else
         hipLaunchKernelGGL((pixel_loss_pat_bwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, pat, target, (const long long*)mask, kind,
-                           norm_pix, C, H, W, patch, stats, per_sample, loss, upstream, (float*)d_pat, (long long)ld_pat, rows);
+                           norm_pix, C, H, W, patch, stats, per_sample, loss, upstream, (float*)d_pat, (long long)ld_pat, rows, amax);
     return mmae_check_launch("pixel_loss_pat_bwd");
 }
 
@@ -595,7 +609,7 @@ int mmae_masked_ce_pat_fwd(const float* pat, const int64_t* target, const int64_
 
 int mmae_masked_ce_pat_bwd(const float* pat, const int64_t* target, const int64_t* mask, int B, int C, int H, int W, int patch,
                            float label_smoothing, const float* lse_pat, const float* per_sample, const float* loss, const float* upstream,
-                           void* d_pat, int d_pat_dtype, int64_t ld_pat, void* stream) {
+                           void* d_pat, int d_pat_dtype, int64_t ld_pat, float* amax, void* stream) {
     MMAE_REQUIRE(pat && target && mask && lse_pat && per_sample && loss && upstream && d_pat, "ce_pat_bwd: null pointer");
     MMAE_REQUIRE(patch > 0 && H % patch == 0 && W % patch == 0 && ld_pat >= (int64_t)C * patch * patch, "ce_pat_bwd: bad geometry");
     const int npix = patch * patch;
@@ -604,10 +618,10 @@ int mmae_masked_ce_pat_bwd(const float* pat, const int64_t* target, const int64_
     const dim3 grid((unsigned)((rows + 3) / 4));
     if (d_pat_dtype == MMAE_BF16)
         hipLaunchKernelGGL((ce_pat_bwd_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, pat, (const long long*)target, (const long long*)mask,
-                           C, H, W, patch, label_smoothing, lse_pat, per_sample, loss, upstream, (uint16_t*)d_pat, (long long)ld_pat, rows);
+                           C, H, W, patch, label_smoothing, lse_pat, per_sample, loss, upstream, (uint16_t*)d_pat, (long long)ld_pat, rows, amax);
     else
         hipLaunchKernelGGL((ce_pat_bwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, pat, (const long long*)target, (const long long*)mask,
-                           C, H, W, patch, label_smoothing, lse_pat, per_sample, loss, upstream, (float*)d_pat, (long long)ld_pat, rows);
+                           C, H, W, patch, label_smoothing, lse_pat, per_sample, loss, upstream, (float*)d_pat, (long long)ld_pat, rows, amax);
     return mmae_check_launch("ce_pat_bwd");
 }
 

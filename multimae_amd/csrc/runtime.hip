@@ -170,7 +170,9 @@ int mmae_gemm_ex(const mmae_gemm_desc* d, void* stream, int timing_cls, double f
     MMAE_REQUIRE(d && d->A && d->B && d->C, "gemm: null operand");
     MMAE_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: empty problem");
     MMAE_REQUIRE(d->batch >= 1 && d->batch <= 65535 && d->batch_inner >= 1, "gemm: bad batch");
-    MMAE_REQUIRE(d->ab_dtype == MMAE_F32 || d->ab_dtype == MMAE_BF16 || d->ab_dtype == MMAE_F32X3 || d->ab_dtype == MMAE_MXFP8, "gemm: bad ab_dtype");
+    MMAE_REQUIRE(d->ab_dtype == MMAE_F32 || d->ab_dtype == MMAE_BF16 || d->ab_dtype == MMAE_F32X3 || d->ab_dtype == MMAE_F32F16 || d->ab_dtype == MMAE_MXFP8,
+                 "gemm: bad ab_dtype");
+    MMAE_REQUIRE(!d->a_amax || d->ab_dtype == MMAE_F32F16, "gemm: a_amax is an MMAE_F32F16 option");
     MMAE_REQUIRE(d->c_dtype == MMAE_F32 || d->c_dtype == MMAE_BF16, "gemm: bad c_dtype");
     MMAE_REQUIRE(!(d->accumulate && d->c_dtype != MMAE_F32), "gemm: accumulate needs f32 C");
     MMAE_REQUIRE(!(d->epi != MMAE_EPI_NONE && !d->aux), "gemm: epilogue needs aux");
@@ -201,6 +203,7 @@ int mmae_gemm_ex(const mmae_gemm_desc* d, void* stream, int timing_cls, double f
     static const int env_dephase = mmae_env_int("MMAE_PP_DEPHASE", 0);
     g.dephase = env_dephase;
     g.scA = d->a_scale; g.scB = d->b_scale;
+    g.a_amax = d->a_amax;
     g.qout = (unsigned char*)d->q_out; g.qsc = (unsigned char*)d->q_scale; g.ldq = d->ldq;
     MMAE_REQUIRE(!d->q_out || d->ab_dtype == MMAE_MXFP8, "gemm: q_out is an MX-fp8 product option");
     MMAE_REQUIRE(!d->colsum_part || ((d->epi == MMAE_EPI_DGELU || d->epi == MMAE_EPI_MUL) && !d->bias && !d->resid && !d->accumulate && d->batch == 1 && d->split_k <= 1 &&
@@ -258,7 +261,7 @@ int mmae_gemm_ex(const mmae_gemm_desc* d, void* stream, int timing_cls, double f
         return mmae_splitk_reduce(g.ws, (float*)d->C, d->M, d->N, d->ldc, g.splitk, d->accumulate, st);
     }
     int rc = (d->ab_dtype == MMAE_BF16) ? mmae_gemm_bf16_impl(d, g, code, st)
-           : (d->ab_dtype == MMAE_F32X3 ? mmae_gemm_f32x3_impl(d, g, st) : mmae_gemm_f32_impl(d, g, st));
+           : ((d->ab_dtype == MMAE_F32X3 || d->ab_dtype == MMAE_F32F16) ? mmae_gemm_f32x3_impl(d, g, st) : mmae_gemm_f32_impl(d, g, st));
     if (rc) return rc;
     if (g.acs) {
         rc = mmae_acs_reduce(g.acs, g.splitk, d->M, d->a_colsum, d->a_colsum_acc, st);

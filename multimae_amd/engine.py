@@ -28,7 +28,7 @@ _state = {
     'direct_grads': False,           # backward accumulates straight into p.grad and returns None
     'adapter_streams': False,
     'wgrad_stream': False,           # direct-grad mode: weight-gradient GEMMs / bias column sums on a side stream per compute stream        # run the independent output adapters on separate HIP streams
-    'fp32_adapter_gemm': 'x3',       # GEMMs of fp32_output_adapters in bf16 speed mode: 'x3' (split bf16) | 'exact'
+    'fp32_adapter_gemm': 'f16',      # GEMMs of fp32_output_adapters in bf16 speed mode: 'f16' (fp16 operands = TF32's significand, one MFMA) | 'x3' (split bf16, three) | 'exact'
     'patch_domain_loss': __import__('os').environ.get('MMAE_PATCH_LOSS', '1') != '0',
 }
 
@@ -229,9 +229,17 @@ def fp32_adapter_gemm() -> str:
 
 
 def set_fp32_adapter_gemm(mode: str) -> None:
-    """'x3': f32 operands multiplied as split bf16 (a_hi.b_hi + a_hi.b_lo + a_lo.b_hi, fp32 accumulate; ~16 mantissa bits,
-    above TF32).  'exact': f32-input MFMA (bit-level fmaf chain, 1/16 the bf16 rate)."""
-    assert mode in ('x3', 'exact')
+    """How the Linear products of fp32_output_adapters are multiplied in the bf16 speed mode (activations, LayerNorm, softmax, losses
+    stay f32 either way):
+    'f16' (default, round 4): both operands rounded to fp16 -- an 11-bit significand, exactly TF32's, what the reference's fp32
+          adapters ran at on A100 (torch 1.10: allow_tf32) -- ONE MFMA per tile step, fp32 accumulation.  Gradient operands are
+          pre-scaled by a power of two taken from the loss gradient's largest element (written by the masked-loss backward
+          kernel), so fp16's exponent range is no limit; when no such amax exists (a loss on the image tensor instead of the
+          adapter's patch rows) the gradient products run as 'x3'.  The attention cores stay 'x3'.
+    'x3': f32 operands multiplied as split bf16 (a_hi.b_hi + a_hi.b_lo + a_lo.b_hi, fp32 accumulate; ~16 mantissa bits,
+          above TF32), three MFMAs per tile step.
+    'exact': f32-input MFMA (bit-level fmaf chain, 1/16 the bf16 rate)."""
+    assert mode in ('f16', 'x3', 'exact')
     _state['fp32_adapter_gemm'] = mode
 
 

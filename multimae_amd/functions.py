@@ -526,11 +526,14 @@ class PatHandle:
     patch rows `pat` (f32 [B*n_q, C*ph*pw], out_proj's output before the image rearrangement), the geometry, the autograd
     `token` that links the loss node to the adapter node, and -- filled in by the loss's backward -- the gradient rows `d_pat`
     in the adapter's activation dtype."""
-    __slots__ = ('pat', 'token', 'C', 'nh', 'nw', 'ph', 'pw', 'act', 'd_pat')
+    __slots__ = ('pat', 'token', 'C', 'nh', 'nw', 'ph', 'pw', 'act', 'd_pat', 'dy_amax')
 
     def __init__(self, pat, C, nh, nw, ph, pw, act):
         self.pat, self.C, self.nh, self.nw, self.ph, self.pw, self.act = pat, C, nh, nw, ph, pw, act
         self.token, self.d_pat = None, None
+        # f32 adapter with fp16-operand products (engine.set_fp32_adapter_gemm('f16')): a zeroed device scalar the loss's backward
+        # kernel raises to the largest |element| of d_pat; the adapter's backward scales its gradient operands by its power of two
+        self.dy_amax = None
 
     def matches(self, img: Tensor, patch: int) -> bool:
         return (self.pat is not None and self.token is not None and self.ph == patch and self.pw == patch
@@ -619,6 +622,8 @@ class SpatialAdapterFn(torch.autograd.Function):
             ctx.dims = (B, NC, Denc, n_keep, n_q, T)
             if save and engine.patch_domain_loss():
                 cfg.handle = PatHandle(state.pat, cfg.C, cfg.nh, cfg.nw, cfg.ph, cfg.pw, act)
+                if act == torch.float32 and getattr(cfg, 'f32_gemm', 'exact') == 'f16':
+                    cfg.handle.dy_amax = torch.zeros(1, device=enc.device, dtype=torch.float32)
             return img
         if enc_act is None:
             enc_act = ops.cast(enc2, act)
@@ -682,6 +687,7 @@ class SpatialAdapterFn(torch.autograd.Function):
             use_side = sink.side is not None and acc
             h = getattr(ctx, 'handle', None)
             d_pat = h.d_pat if h is not None else None
+            dy_amax = h.dy_amax if (h is not None and d_pat is not None and d_img is None) else None
             if d_pat is not None:
                 if d_img is not None:
                     raise NotImplementedError('this prediction received gradient both through a patch-domain loss and through the image '
@@ -691,7 +697,7 @@ class SpatialAdapterFn(torch.autograd.Function):
             elif d_img is None:                                      # nothing reached this adapter
                 d_img = torch.zeros((B, cfg.C, cfg.nh * cfg.ph, cfg.nw * cfg.pw), device=params[0].device, dtype=torch.float32)
             d_enc, keep = ops.adapter_bwd(ctx.comp, d_img, d_pat, [None if t is None else t.view(-1) for t in dsts], acc,
-                                          sink.side.cuda_stream if use_side else None)
+                                          sink.side.cuda_stream if use_side else None, dy_amax=dy_amax)
             ctx.comp = None
             if use_side:
                 engine.mark_side_dirty(sink.side)
@@ -1029,7 +1035,7 @@ class MaskedPixelLossPatFn(torch.autograd.Function):
         up = g.contiguous().float().reshape(1)
         ops.check(_lib.load().mmae_masked_pixel_loss_pat_bwd(h.pat.data_ptr(), target.data_ptr(), mask.data_ptr(), kind, int(norm_pix), B, C, H, W,
                                                              patch, ops._p(stats), per_sample.data_ptr(), loss.data_ptr(), up.data_ptr(),
-                                                             d_pat.data_ptr(), ops.dcode(h.act), d_pat.stride(0), ops._stream()),
+                                                             d_pat.data_ptr(), ops.dcode(h.act), d_pat.stride(0), ops._p(h.dy_amax), ops._stream()),
                   'masked_pixel_loss_pat_bwd')
         h.d_pat = d_pat if h.d_pat is None else h.d_pat.add_(d_pat)        # several losses on one prediction: their gradients add
         return up.new_empty(1), None, None, None, None, None, None
@@ -1065,6 +1071,6 @@ class MaskedCEPatFn(torch.autograd.Function):
         up = g.contiguous().float().reshape(1)
         ops.check(_lib.load().mmae_masked_ce_pat_bwd(h.pat.data_ptr(), target.data_ptr(), mask.data_ptr(), B, C, H, W, patch, smooth, lse.data_ptr(),
                                                      per_sample.data_ptr(), loss.data_ptr(), up.data_ptr(), d_pat.data_ptr(), ops.dcode(h.act),
-                                                     d_pat.stride(0), ops._stream()), 'masked_ce_pat_bwd')
+                                                     d_pat.stride(0), ops._p(h.dy_amax), ops._stream()), 'masked_ce_pat_bwd')
         h.d_pat = d_pat if h.d_pat is None else h.d_pat.add_(d_pat)
         return up.new_empty(1), None, None, None, None, None

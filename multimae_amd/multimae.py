@@ -267,15 +267,15 @@ class MultiMAE(nn.Module):
         for i, domain in enumerate(self.output_adapters):
             # reference: adapters listed in fp32_output_adapters run with autocast disabled (:367-377);
             # here they run on the exact-f32 MFMA path
-            # here: f32 activations; in bf16 speed mode their GEMMs run as split-bf16 ("x3", >= TF32 precision -- what
-            # the reference's fp32 adapters got on A100 with torch 1.10's allow_tf32 default), in the fp32 parity mode
-            # on the exact-f32 MFMA path
+            # here: f32 activations; in bf16 speed mode their GEMMs run with fp16 operands ("f16": TF32's 11-bit significand -- what
+            # the reference's fp32 adapters got on A100 with torch 1.10's allow_tf32 default) or as split-bf16 ("x3", ~16 bits),
+            # engine.set_fp32_adapter_gemm; in the fp32 parity mode on the exact-f32 MFMA path
             fp32 = domain in fp32_output_adapters
             speed = engine.act_dtype() == torch.bfloat16
             kw = dict(encoder_tokens=encoder_tokens, input_info=input_info, ids_keep=ids_keep, ids_restore=ids_restore,
                       act_dtype=torch.float32 if fp32 else None, on_done=self._adapter_done_cb(domain),
                       encoder_tokens_act=None if fp32 else enc_bf16,
-                      f32_gemm='x3' if (fp32 and speed and engine.fp32_adapter_gemm() == 'x3') else 'exact')
+                      f32_gemm=engine.fp32_adapter_gemm() if (fp32 and speed and engine.fp32_adapter_gemm() in ('x3', 'f16')) else 'exact')
             if streams is None:
                 preds[domain] = self.output_adapters[domain](**kw)
             else:

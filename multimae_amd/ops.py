@@ -14,7 +14,7 @@ import torch
 from . import _lib
 import contextlib
 
-from ._lib import BF16, F32, F32X3, MXFP8, EPI_NONE, EPI_GELU, EPI_DGELU, EPI_GELU_G, EPI_MUL, AdapterDesc, BlockDesc, DwGroupDesc, GemmDesc, OptDesc, PatchSrc, StackDesc, check
+from ._lib import BF16, F32, F32X3, F32F16, MXFP8, EPI_NONE, EPI_GELU, EPI_DGELU, EPI_GELU_G, EPI_MUL, AdapterDesc, BlockDesc, DwGroupDesc, GemmDesc, OptDesc, PatchSrc, StackDesc, check
 
 Tensor = torch.Tensor
 
@@ -51,10 +51,10 @@ _F32_GEMM = ['exact']
 
 @contextlib.contextmanager
 def f32_gemm_mode(mode: str):
-    """How GEMMs with f32 operands are multiplied inside the block: 'exact' (f32-input MFMA, the parity mode)
-    or 'x3' (split-bf16 on the bf16 MFMA: >= TF32 precision at ~4x the speed; used for fp32_output_adapters
-    in bf16 speed mode)."""
-    assert mode in ('exact', 'x3')
+    """How GEMMs with f32 operands are multiplied inside the block: 'exact' (f32-input MFMA, the parity mode), 'x3' (split-bf16 on
+    the bf16 MFMA: ~16 operand bits, three MFMAs) or 'f16' (fp16 operands = TF32's significand, one MFMA; the composite adapter
+    calls only -- single launches through ops.gemm and the fused attention cores use the split form in both)."""
+    assert mode in ('exact', 'x3', 'f16')
     old = _F32_GEMM[0]
     _F32_GEMM[0] = mode
     try:
@@ -68,13 +68,23 @@ import os as _os
 _FUSED_DB = _os.environ.get('MMAE_FUSED_DB', '1') != '0'
 
 
+def _f32_split() -> bool:
+    """f32 activations on the bf16 / fp16 matrix cores (as opposed to the exact-f32 parity mode)"""
+    return _F32_GEMM[0] in ('x3', 'f16')
+
+
+def _f32_code() -> int:
+    return {'x3': F32X3, 'f16': F32F16}.get(_F32_GEMM[0], F32)
+
+
 def gemm(A: Tensor, B: Tensor, C: Tensor, M: int, N: int, K: int, *, lda: int, ldb: int, ldc: int,
          a_trans: bool = False, b_trans: bool = False, a_off: int = 0, b_off: int = 0, c_off: int = 0,
          batch: int = 1, batch_inner: int = 1, sA=(0, 0), sB=(0, 0), sC=(0, 0),
          bias: Optional[Tensor] = None, resid: Optional[Tensor] = None, ldr: int = 0,
          aux: Optional[Tensor] = None, ldaux: int = 0, epi: int = EPI_NONE, accumulate: bool = False,
          alpha: float = 1.0, tile: int = 0, split_k: int = 0, colsum_part: Optional[Tensor] = None,
-         a_colsum: Optional[Tensor] = None, a_colsum_acc: bool = False) -> bool:
+         a_colsum: Optional[Tensor] = None, a_colsum_acc: bool = False, f32_as: Optional[int] = None,
+         a_amax: Optional[Tensor] = None) -> bool:
     """C[M,N] (+)= alpha * A[M,K] . B[N,K]^T with the fused epilogue of mmae_gemm.
     *_off are element offsets into the tensors' storage views (column offsets into packed qkv etc.)."""
     _require_gpu(A, 'gemm A')
@@ -85,7 +95,10 @@ def gemm(A: Tensor, B: Tensor, C: Tensor, M: int, N: int, K: int, *, lda: int, l
     d.B = B.data_ptr() + b_off * esz_ab
     d.C = C.data_ptr() + c_off * esz_c
     d.ab_dtype, d.c_dtype = dcode(A.dtype), dcode(C.dtype)
-    if d.ab_dtype == F32 and _F32_GEMM[0] == 'x3' and lda % 4 == 0 and ldb % 4 == 0:
+    if d.ab_dtype == F32 and f32_as is not None:           # explicit: F32X3 / F32F16 (tests, probes); a_amax: device scalar that pre-scales A
+        d.ab_dtype = f32_as
+        d.a_amax = _p(a_amax)
+    elif d.ab_dtype == F32 and _f32_split() and lda % 4 == 0 and ldb % 4 == 0:
         d.ab_dtype = F32X3
     d.M, d.N, d.K = M, N, K
     d.a_trans, d.b_trans = int(a_trans), int(b_trans)
@@ -336,14 +349,14 @@ def block_composite_ok(x: Tensor, act: torch.dtype, heads: int, N: int) -> bool:
     if act == torch.bfloat16:
         return True
     lds_bwd = 4 * 2 * round_up(N, 32) * hd * 2 + 8 * round_up(N, 32)
-    return act == torch.float32 and _F32_GEMM[0] == 'x3' and lds_bwd <= 160 * 1024
+    return act == torch.float32 and _f32_split() and lds_bwd <= 160 * 1024
 
 
 def _block_desc(P: Sequence[Tensor], wts: Sequence[Tensor], heads: int, eps: float, act: torch.dtype, B: int, N: int, D: int) -> 'BlockDesc':
     n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b = P
     d = BlockDesc()
     d.B, d.N, d.D, d.heads, d.Hd = B, N, D, heads, fc1w.shape[0]
-    d.act_dtype, d.f32_gemm, d.eps = dcode(act), (F32X3 if _F32_GEMM[0] == 'x3' else F32), eps
+    d.act_dtype, d.f32_gemm, d.eps = dcode(act), _f32_code(), eps
     d.qkv_w, d.proj_w, d.fc1_w, d.fc2_w = (w.data_ptr() for w in wts)
     d.n1_w, d.n1_b, d.qkv_b, d.proj_b = n1w.data_ptr(), n1b.data_ptr(), qkvb.data_ptr(), projb.data_ptr()
     d.n2_w, d.n2_b, d.fc1_b, d.fc2_b = n2w.data_ptr(), n2b.data_ptr(), fc1b.data_ptr(), fc2b.data_ptr()
@@ -531,7 +544,7 @@ def stack_fwd(x: Tensor, params: Sequence[Tensor], wc, heads: int, eps: float, a
     Hd = params[8].shape[0]
     d = StackDesc()
     d.L, d.B, d.N, d.D, d.heads, d.Hd = L, B, N, D, heads, Hd
-    d.act_dtype, d.f32_gemm, d.eps = dcode(act), (F32X3 if _F32_GEMM[0] == 'x3' else F32), eps
+    d.act_dtype, d.f32_gemm, d.eps = dcode(act), _f32_code(), eps
     wts = [wc(params[12 * l + i]) for l in range(L) for i in (2, 4, 8, 10)]
     probe = (wts[0].data_ptr(), wts[-1].data_ptr(), params[0].data_ptr(), params[-1].data_ptr())
     w_arr, p_arr = _PTRS.get(('stack', id(params[0]), L, act), probe, lambda: (
@@ -611,7 +624,7 @@ def adapter_composite_ok(enc: Tensor, act: torch.dtype, heads: int, D: int, n_q:
     if act == torch.bfloat16:
         return True
     lds_bwd = 4 * (round_up(n_q, 32) + round_up(NC, 32)) * hd * 2 + 8 * round_up(n_q, 32)
-    return act == torch.float32 and _F32_GEMM[0] == 'x3' and lds_bwd <= 160 * 1024
+    return act == torch.float32 and _f32_split() and lds_bwd <= 160 * 1024
 
 
 class X3Weights:
@@ -674,7 +687,7 @@ def adapter_fwd(enc: Tensor, enc_act: Optional[Tensor], ids_keep: Tensor, ids_re
     d.B, d.NC, d.Denc, d.D, d.heads, d.Hd, d.depth, d.T, d.q_task, d.G, d.n_q = (B, NC, Denc, cfg.D, cfg.heads, w_list[3].shape[0], cfg.depth, T,
                                                                                   cfg.q_task, cfg.G, n_q)
     d.C, d.nh, d.nw, d.ph, d.pw = cfg.C, cfg.nh, cfg.nw, cfg.ph, cfg.pw
-    d.act_dtype, d.f32_gemm, d.eps = dcode(cfg.act), (F32X3 if _F32_GEMM[0] == 'x3' else F32), cfg.eps
+    d.act_dtype, d.f32_gemm, d.eps = dcode(cfg.act), _f32_code(), cfg.eps
     offs = _i32_array(cfg.task_offsets)
     d.task_offsets_host = ctypes.cast(offs, ctypes.c_void_p)
     probe = (w_list[0].data_ptr(), w_list[-1].data_ptr(), p_list[0].data_ptr(), p_list[-1].data_ptr(), mask_token.data_ptr())
@@ -708,7 +721,7 @@ def adapter_fwd(enc: Tensor, enc_act: Optional[Tensor], ids_keep: Tensor, ids_re
 
 
 def adapter_bwd(s: AdapterState, d_img: Optional[Tensor], d_pat: Optional[Tensor], grads: Sequence[Optional[Tensor]], grad_acc: bool,
-                side_handle: Optional[int]):
+                side_handle: Optional[int], dy_amax: Optional[Tensor] = None):
     """Backward of adapter_fwd from the image-domain gradient d_img (f32 [B,C,H,W]) or the patch-domain gradient d_pat (act
     dtype [B*n_q, ld]).  grads: destinations in mmae_adapter_desc.g order.  Returns (d_enc f32 [B, NC, Denc], keep-alives)."""
     lib = _lib.load()
@@ -718,6 +731,7 @@ def adapter_bwd(s: AdapterState, d_img: Optional[Tensor], d_pat: Optional[Tensor
         d_img = d_img.contiguous()
     d.d_img, d.d_pat = _p(d_img), _p(d_pat)
     d.ld_pat = d_pat.stride(0) if d_pat is not None else 0
+    d.dy_amax = _p(dy_amax)            # f32 adapter with fp16-operand products: scales the gradient operands (None: they run split-bf16)
     g_arr = _ptr_arr([_p(g) for g in grads])
     d.g, d.grad_acc = ctypes.cast(g_arr, ctypes.c_void_p), int(grad_acc)
     d_enc = torch.empty((d.B, d.NC, d.Denc), device=dev, dtype=torch.float32)
@@ -731,7 +745,7 @@ def adapter_bwd(s: AdapterState, d_img: Optional[Tensor], d_pat: Optional[Tensor
     wsd = stream_workspace(sd, dev) if sd != st else wm
     d.ws_side, d.ws_side_elems = wsd.data_ptr(), wsd.numel()
     check(lib.mmae_adapter_bwd(ctypes.byref(d), st, sd), 'adapter_bwd')
-    return d_enc, (tmp, s.act, s.keep, d_img, d_pat, g_arr, grads)
+    return d_enc, (tmp, s.act, s.keep, d_img, d_pat, g_arr, grads, dy_amax)
 
 
 # ------------------------------------------------------------------- row kernels --
@@ -907,7 +921,7 @@ def _fusable(q: AttnView, k: AttnView, hd: int) -> bool:
     # f32 activations: only where the surrounding GEMMs are split-bf16 too (fp32 adapters in speed mode); the backward's
     # eight hi/lo tiles must fit the 160 KB LDS
     lds_bwd = 4 * (round_up(q.N, 32) + round_up(k.N, 32)) * hd * 2 + 8 * round_up(q.N, 32)
-    return q.t.dtype == torch.float32 and _F32_GEMM[0] == 'x3' and lds_bwd <= 160 * 1024
+    return q.t.dtype == torch.float32 and _f32_split() and lds_bwd <= 160 * 1024
 
 
 def attention_fwd(q: AttnView, k: AttnView, v: AttnView, out: AttnView, B: int, H: int, hd: int, scale: float):

@@ -949,3 +949,63 @@ def test_colsum_batch_one_launch_vs_fp64_and_bit_identical_across_streams(acc):
     for a_, b_, c_ in zip(got, again, other):
         for x_, y_, z_ in zip(a_, b_, c_):
             assert torch.equal(x_, y_) and torch.equal(x_, z_)
+
+
+@pytest.mark.parametrize('a_trans,b_trans', [(False, False), (False, True), (True, True)])
+@pytest.mark.parametrize('shape', [(300, 200, 136), (520, 264, 1000), (256, 2128, 256)])
+def test_gemm_f32f16_single_product(shape, a_trans, b_trans):
+    """MMAE_F32F16 (round 4): f32 operands rounded to fp16 (11-bit significand = TF32's) for ONE MFMA product, fp32 accumulation.
+    Exactly the fp64 product of the fp16-rounded operands (to accumulation order), and TF32-class against the exact product."""
+    from multimae_amd import ops
+    from multimae_amd._lib import F32F16
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn((K, M) if a_trans else (M, K), generator=g)
+    Bm = torch.randn((K, N) if b_trans else (N, K), generator=g) * 0.05
+    C = torch.empty(M, N, device=DEV)
+    ops.gemm(A.to(DEV), Bm.to(DEV), C, M, N, K, lda=A.shape[1], ldb=Bm.shape[1], ldc=N, a_trans=a_trans, b_trans=b_trans, f32_as=F32F16)
+    a = (A.t() if a_trans else A).double()
+    b = (Bm if b_trans else Bm.t()).double()
+    a16 = (A.t() if a_trans else A).half().double()
+    b16 = (Bm if b_trans else Bm.t()).half().double()
+    assert rel_err(C.cpu().double(), a16 @ b16) < 2e-6
+    e = rel_err(C.cpu().double(), a @ b)
+    assert 1e-5 < e < 6e-4, e                              # 2^-11 per operand, averaged over the contraction
+
+
+def test_gemm_f32f16_gradient_operand_prescale_and_loss_amax():
+    """A gradient operand (~1e-7: 1 / (masked pixels x batch) at the bench geometry) would fall into fp16's subnormals; with
+    mmae_gemm_desc.a_amax it is multiplied by 2^-floor(log2 amax) first and the accumulators back afterwards -- TF32-class again.  The
+    amax is what the patch-domain loss backward kernels leave behind (atomic max over their d_pat)."""
+    from multimae_amd import ops
+    from multimae_amd._lib import F32F16
+    from multimae_amd.functions import MaskedCEPatFn, PatHandle
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 520, 264, 392
+    dy = torch.randn(M, K, generator=g) * 3e-8
+    dy[5, 7] = 4.1e-7                                      # the largest element
+    w = torch.randn(K, N, generator=g) * 0.05             # dX product: out[M, N] = dy[M, K] @ w[K, N]
+    amax = dy.abs().max().reshape(1).to(DEV)
+    ref = dy.double() @ w.double()
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm(dy.to(DEV), w.to(DEV), out, M, N, K, lda=K, ldb=N, ldc=N, b_trans=True, f32_as=F32F16, a_amax=amax)
+    e_scaled = rel_err(out.cpu().double(), ref)
+    ops.gemm(dy.to(DEV), w.to(DEV), out, M, N, K, lda=K, ldb=N, ldc=N, b_trans=True, f32_as=F32F16)
+    e_raw = rel_err(out.cpu().double(), ref)
+    assert e_scaled < 6e-4 and e_raw > 20 * e_scaled, (e_scaled, e_raw)
+    # weight-gradient shape through the split-K path: dW[N, K2] = dy^T x
+    x = torch.randn(M, 136, generator=g)
+    dw = torch.empty(K, 136, device=DEV)
+    ops.gemm(dy.to(DEV), x.to(DEV), dw, K, 136, M, lda=K, ldb=136, ldc=136, a_trans=True, b_trans=True, f32_as=F32F16, a_amax=amax)
+    assert rel_err(dw.cpu().double(), dy.double().t() @ x.double()) < 6e-4
+    # the amax the cross-entropy backward kernel reports == max |d_pat|
+    B, C, P, nh = 3, 7, 4, 2
+    lr = torch.randn(B, C, nh * P, nh * P, generator=g)
+    tgt = torch.randint(0, C, (B, nh * P, nh * P), generator=g)
+    mask = torch.tensor([[1, 0, 1, 1], [0, 0, 0, 1], [1, 1, 1, 1]])
+    h = PatHandle(ops.patchify(lr.to(DEV), C, nh, nh, P, P, torch.float32).contiguous(), C, nh, nh, P, P, torch.float32)
+    h.dy_amax = torch.zeros(1, device=DEV)
+    h.token = torch.zeros(1, device=DEV, requires_grad=True)
+    MaskedCEPatFn.apply(h.token, h, tgt.to(DEV), mask.to(DEV), P, 0.0).backward()
+    torch.cuda.synchronize()
+    assert float(h.dy_amax) == float(h.d_pat.abs().max()) > 0
