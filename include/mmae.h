@@ -308,8 +308,9 @@ int mmae_softmax_bwd(const void* P, int p_dtype, int64_t ldp, const float* dP, i
  * Attention.forward / CrossAttention.forward cores, multimae_utils.py:175-179, 206-210, and their
  * autograd.  Operands are addressed as base + b*s_b + row*s_r + h*head_dim (elements), so q/k/v
  * may be column slices of a packed qkv / kv activation.  lse f32 [B][H][Nq] = max + log(sum) of
- * the scaled scores (saved by fwd, consumed by bwd).  bwd also needs o (fwd output) for
- * delta = rowsum(dO . O); d_o shares o's strides.
+ * the scaled scores (saved by fwd, consumed by bwd).  d_o shares o's strides.  (o is no longer read by bwd: since round 4
+ * delta = sum_j P_j dP_j is formed from the kernel's own fp32 P and dP -- the flash-attention shortcut rowsum(dO . O) with the
+ * stored 16-bit O cost 22 % on dQ of the cfg5 decoders, profiles/r04_xattn_delta_probe.txt; the argument stays for ABI stability.)
  * ------------------------------------------------------------------------- */
 int mmae_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
                   int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb,
@@ -328,6 +329,15 @@ int mmae_attn_bwd_f32x3(const void* q, const void* k, const void* v, const void*
                   void* dk, void* dv, int B, int H, int Nq, int Nk, int hd, int64_t q_sb, int64_t q_sr, int64_t k_sb,
                   int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr, int64_t dq_sb, int64_t dq_sr,
                   int64_t dk_sb, int64_t dk_sr, int64_t dv_sb, int64_t dv_sr, float scale, void* stream);
+/* f32 tensors again, operands rounded to fp16 (TF32's significand; the MMAE_F32F16 precision): one MFMA per product.  bwd: dy_amax =
+ * device scalar (or NULL) whose power of two pre-scales dO on its way into LDS; dq / dk / dv are scaled back at their store. */
+int mmae_attn_fwd_f32f16(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
+                  int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb,
+                  int64_t o_sr, float scale, void* stream);
+int mmae_attn_bwd_f32f16(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, void* dq,
+                  void* dk, void* dv, int B, int H, int Nq, int Nk, int hd, int64_t q_sb, int64_t q_sr, int64_t k_sb,
+                  int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr, int64_t dq_sb, int64_t dq_sr,
+                  int64_t dk_sb, int64_t dk_sr, int64_t dv_sb, int64_t dv_sr, float scale, const float* dy_amax, void* stream);
 
 
 /* ------------------------------------------------------------------------- *

@@ -15,6 +15,11 @@
 // ("x3") GEMMs those adapters use, ~16 operand mantissa bits.  Replaces, for them, 2-5 batched x3 GEMM launches plus a
 // softmax pass over materialised (B, H, Nq, Nk) f32 scores per attention.
 //
+// MODE 2 ("f32f16", round 4): f32 activations with fp16 operands -- TF32's 11-bit significand, one MFMA per product instead of
+// three -- for adapters that run engine.set_fp32_adapter_gemm('f16').  Tiles are rounded to fp16 when they are written to LDS, P
+// and dS right before their MFMA; the backward scales dO by the power of two of the loss gradient's amax (AttnArgs.dy_amax, as
+// the GEMMs' mmae_gemm_desc.a_amax) and unscales dQ / dK / dV at their store.
+//
 // Replaces Attention.forward / CrossAttention.forward cores (multimae_utils.py:175-179, 206-210) + autograd.
 #include "common.h"
 
@@ -37,6 +42,7 @@ struct AttnArgs {
     unsigned char *mx_q, *mx_s;
     long long mx_rows;
     int mx_ld, mx_col[3];
+    const float* dy_amax;                      // MODE 2 backward: device scalar whose power of two pre-scales dO (NULL: no scaling)
 };
 
 // swizzled byte offset of 16-byte chunk c of row `row` in a row-major bf16 tile with HD columns
@@ -83,6 +89,18 @@ __device__ __forceinline__ void split8(const i32x4& a, const i32x4& b, bf16x8& h
         hi[4 + j] = (__bf16)fb[j]; lo[4 + j] = (__bf16)(fb[j] - (float)hi[4 + j]);
     }
 }
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+// 8 f32 (times a power of two) -> fp16 bit patterns, carried as bf16x8 (the LDS tiles / fragment fetches are type-agnostic)
+__device__ __forceinline__ bf16x8 cvt8_f16(const i32x4& a, const i32x4& b, float s) {
+    const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+    f16x8 h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = (_Float16)__builtin_amdgcn_fmed3f(fa[j] * s, -65504.0f, 65504.0f);
+        h[4 + j] = (_Float16)__builtin_amdgcn_fmed3f(fb[j] * s, -65504.0f, 65504.0f);
+    }
+    return __builtin_bit_cast(bf16x8, h);
+}
 // f32 rows -> a hi tile and a lo tile (same swizzled layout, `lo_off` bytes apart)
 template <int HD, int NTHR>
 struct TileLoaderF32 {
@@ -112,6 +130,14 @@ struct TileLoaderF32 {
                 *reinterpret_cast<bf16x8*>(p) = hi;
                 *reinterpret_cast<bf16x8*>(p + lo_off) = lo;
             }
+        }
+    }
+    // one fp16 tile (values times the power of two `s`, saturating)
+    __device__ __forceinline__ void commit16(char* lds, int nrows_pad, int tid, float s) {
+#pragma unroll
+        for (int i = 0; i < MAXIT; ++i) {
+            const int c = tid + i * NTHR;
+            if (c < nrows_pad * CPR) *reinterpret_cast<bf16x8*>(lds + tile_off<HD>(c / CPR, c % CPR)) = cvt8_f16(r0[i], r1[i], s);
         }
     }
 };
@@ -147,6 +173,13 @@ __device__ __forceinline__ bf16x8 pack8_lo(const f32x16& v, int s) {     // resi
     for (int j = 0; j < 8; ++j) r[j] = (__bf16)(v[8 * s + j] - (float)(__bf16)v[8 * s + j]);
     return r;
 }
+__device__ __forceinline__ bf16x8 pack8_f16(const f32x16& v, int s) {     // fp16 bit patterns of accumulator registers 8s .. 8s+7
+    f16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (_Float16)__builtin_amdgcn_fmed3f(v[8 * s + j], -65504.0f, 65504.0f);
+    return __builtin_bit_cast(bf16x8, r);
+}
+template <int MODE> __device__ __forceinline__ bf16x8 pack8m(const f32x16& v, int s) { return MODE == 2 ? pack8_f16(v, s) : pack8(v, s); }
 __device__ __forceinline__ bf16x8 load_frag_global(const __amdgpu_buffer_rsrc_t rs, bool ok, long long row, long long sr, int ks, int hi) {
     const unsigned off = ok ? (unsigned)((row * sr + ks * 16 + hi * 8) * 2) : OOB;
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
@@ -158,10 +191,17 @@ __device__ __forceinline__ void load_frag_global_f32(const __amdgpu_buffer_rsrc_
     const i32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : OOB, 0, 0);
     split8(a, b, h, l);
 }
-// c += a . b for operands given as (hi, lo) pairs; X3 = false ignores the lo parts
-template <bool X3>
+__device__ __forceinline__ void load_frag_global_f16(const __amdgpu_buffer_rsrc_t rs, bool ok, long long row, long long sr, int ks, int hi, bf16x8& h) {
+    const unsigned off = (unsigned)((row * sr + ks * 16 + hi * 8) * 4);
+    const i32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0);
+    const i32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : OOB, 0, 0);
+    h = cvt8_f16(a, b, 1.0f);
+}
+// c += a . b.  MODE 0: bf16 operands; 1: operands given as (hi, lo) bf16 pairs, three products; 2: fp16 bit patterns, one f16 product
+template <int MODE>
 __device__ __forceinline__ f32x16 mma(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x16 c) {
-    if (X3) {
+    if (MODE == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), c, 0, 0, 0);
+    if (MODE == 1) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
     }
@@ -223,9 +263,10 @@ template <bool X3> struct ActOf { typedef uint16_t T; };
 template <> struct ActOf<true> { typedef float T; };
 
 // -------------------------------------------------------------------------------------------------
-template <int HD, int NT, bool X3>
-__global__ void __launch_bounds__(256, (NT == 4 && !X3) ? 3 : (NT <= 7 ? 2 : 1)) attn_fwd_kernel(const AttnArgs a) {
-    typedef typename ActOf<X3>::T AT;
+template <int HD, int NT, int MODE>
+__global__ void __launch_bounds__(256, (NT == 4 && MODE != 1) ? 3 : (NT <= 7 ? 2 : 1)) attn_fwd_kernel(const AttnArgs a) {
+    constexpr bool X3 = MODE == 1, F32IO = MODE != 0;
+    typedef typename ActOf<F32IO>::T AT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -236,12 +277,12 @@ __global__ void __launch_bounds__(256, (NT == 4 && !X3) ? 3 : (NT <= 7 ? 2 : 1))
     char* Vs = smem + tile_b;
     const AT* kg = (const AT*)a.k + b * a.k_sb + h * HD;
     const AT* vg = (const AT*)a.v + b * a.v_sb + h * HD;
-    if constexpr (X3) {
+    if constexpr (F32IO) {
         TileLoaderF32<HD, 256> lk, lv;
         lk.issue(kg, a.k_sr, a.Nk, a.nkp, tid);
         lv.issue(vg, a.v_sr, a.Nk, a.nkp, tid);
-        lk.commit(Ks, lo, a.nkp, tid);
-        lv.commit(Vs, lo, a.nkp, tid);
+        if constexpr (X3) { lk.commit(Ks, lo, a.nkp, tid); lv.commit(Vs, lo, a.nkp, tid); }
+        else { lk.commit16(Ks, a.nkp, tid, 1.0f); lv.commit16(Vs, a.nkp, tid, 1.0f); }
     } else {
         TileLoader<HD, 256> lk, lv;
         lk.issue(kg, a.k_sr, a.Nk, a.nkp, tid);
@@ -260,6 +301,7 @@ __global__ void __launch_bounds__(256, (NT == 4 && !X3) ? 3 : (NT <= 7 ? 2 : 1))
 #pragma unroll
         for (int ks = 0; ks < HD / 16; ++ks) {
             if constexpr (X3) load_frag_global_f32(rsQ, qok, q, a.q_sr, ks, hi, qf[ks], ql[ks]);
+            else if constexpr (MODE == 2) { load_frag_global_f16(rsQ, qok, q, a.q_sr, ks, hi, qf[ks]); ql[ks] = qf[ks]; }
             else { qf[ks] = load_frag_global(rsQ, qok, q, a.q_sr, ks, hi); ql[ks] = qf[ks]; }
         }
         f32x16 s[NT];
@@ -273,7 +315,7 @@ __global__ void __launch_bounds__(256, (NT == 4 && !X3) ? 3 : (NT <= 7 ? 2 : 1))
                 for (int ks = 0; ks < HD / 16; ++ks) {
                     const bf16x8 kh = frag_rows<HD>(Ks, t * 32, ks, lane);
                     const bf16x8 kl = X3 ? frag_rows<HD>(Ks + lo, t * 32, ks, lane) : kh;
-                    s[t] = mma<X3>(kh, kl, qf[ks], ql[ks], s[t]);
+                    s[t] = mma<MODE>(kh, kl, qf[ks], ql[ks], s[t]);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -304,13 +346,13 @@ __global__ void __launch_bounds__(256, (NT == 4 && !X3) ? 3 : (NT <= 7 ? 2 : 1))
             if (t < nt) {
 #pragma unroll
                 for (int sI = 0; sI < 2; ++sI) {
-                    const bf16x8 pf = pack8(s[t], sI);
+                    const bf16x8 pf = pack8m<MODE>(s[t], sI);
                     const bf16x8 pl = X3 ? pack8_lo(s[t], sI) : pf;
 #pragma unroll
                     for (int dt = 0; dt < HD / 32; ++dt) {
                         const bf16x8 vh = frag_cols<HD>(Vs, dt * 32, t * 32 + 16 * sI, lane);
                         const bf16x8 vl = X3 ? frag_cols<HD>(Vs + lo, dt * 32, t * 32 + 16 * sI, lane) : vh;
-                        o[dt] = mma<X3>(vh, vl, pf, pl, o[dt]);
+                        o[dt] = mma<MODE>(vh, vl, pf, pl, o[dt]);
                     }
                 }
             }
@@ -319,7 +361,7 @@ __global__ void __launch_bounds__(256, (NT == 4 && !X3) ? 3 : (NT <= 7 ? 2 : 1))
             const float inv = 1.0f / l;
 #pragma unroll
             for (int dt = 0; dt < HD / 32; ++dt) store_row32(ob + q * a.o_sr + dt * 32, o[dt], inv, hi, qok);
-            if (!X3 && a.mx_q) {
+            if (MODE == 0 && a.mx_q) {
 #pragma unroll
                 for (int dt = 0; dt < HD / 32; ++dt) store_row32_mx(a, (long long)b * a.Nq + q, a.mx_col[0] + h * HD + dt * 32, o[dt], inv, hi, qok);
             }
@@ -335,10 +377,17 @@ __global__ void __launch_bounds__(256, (NT == 4 && !X3) ? 3 : (NT <= 7 ? 2 : 1))
 // prologue (tile loads, LDS commit, delta, barrier) nothing overlaps, or as TWO 4-wave workgroups that overlap each other's
 // prologue and compute: 111 vs 132 us on the encoder geometry.  At head_dim 32 (123 VGPRs, two 8-wave workgroups per CU
 // already) the 8-wave form is the faster one (107 vs 120 us).
-template <int HD, bool X3, int NW>
+template <int HD, int MODE, int NW>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(const AttnArgs a) {
     constexpr int NTH = NW * 64;
-    typedef typename ActOf<X3>::T AT;
+    constexpr bool X3 = MODE == 1, F32IO = MODE != 0;
+    typedef typename ActOf<F32IO>::T AT;
+    // MODE 2: dO is scaled by 2^-floor(log2 amax) on its way into LDS; dQ, dK, dV are scaled back at their store
+    float do_s = 1.0f, do_inv = 1.0f;
+    if (MODE == 2 && a.dy_amax) {
+        const unsigned e = (__float_as_uint(*a.dy_amax) >> 23) & 0xffu;
+        if (e >= 1 && e <= 253) { do_s = __uint_as_float((254u - e) << 23); do_inv = __uint_as_float(e << 23); }
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -354,21 +403,21 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
     const AT* dog = (const AT*)a.d_o + b * a.o_sb + h * HD;
     const AT* kg = (const AT*)a.k + b * a.k_sb + h * HD;
     const AT* vg = (const AT*)a.v + b * a.v_sb + h * HD;
-    if constexpr (X3) {
+    if constexpr (F32IO) {
         {
             TileLoaderF32<HD, NTH> lq, ld;
             lq.issue(qg, a.q_sr, a.Nq, a.nqp, tid);
             ld.issue(dog, a.o_sr, a.Nq, a.nqp, tid);
             for (int q = tid; q < a.nqp; q += NTH) lse_s[q] = q < a.Nq ? a.lse[((long long)b * a.H + h) * a.Nq + q] : 0.f;
-            lq.commit(Qs, lo, a.nqp, tid);
-            ld.commit(dOs, lo, a.nqp, tid);
+            if constexpr (X3) { lq.commit(Qs, lo, a.nqp, tid); ld.commit(dOs, lo, a.nqp, tid); }
+            else { lq.commit16(Qs, a.nqp, tid, 1.0f); ld.commit16(dOs, a.nqp, tid, do_s); }
         }
         {
             TileLoaderF32<HD, NTH> lk, lv;
             lk.issue(kg, a.k_sr, a.Nk, a.nkp, tid);
             lv.issue(vg, a.v_sr, a.Nk, a.nkp, tid);
-            lk.commit(Ks, lo, a.nkp, tid);
-            lv.commit(Vs, lo, a.nkp, tid);
+            if constexpr (X3) { lk.commit(Ks, lo, a.nkp, tid); lv.commit(Vs, lo, a.nkp, tid); }
+            else { lk.commit16(Ks, a.nkp, tid, 1.0f); lv.commit16(Vs, a.nkp, tid, 1.0f); }
         }
     } else {
         TileLoader<HD, NTH> lq, ld, lk, lv;
@@ -411,8 +460,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
             for (int ks = 0; ks < HD / 16; ++ks) {
                 const bf16x8 kh = frag_rows<HD>(Ks, t * 32, ks, lane), vh = frag_rows<HD>(Vs, t * 32, ks, lane);
                 const bf16x8 kl = X3 ? frag_rows<HD>(Ks + lo, t * 32, ks, lane) : kh, vl = X3 ? frag_rows<HD>(Vs + lo, t * 32, ks, lane) : vh;
-                st = mma<X3>(kh, kl, qf[ks], ql[ks], st);
-                dpt = mma<X3>(vh, vl, dof[ks], dol[ks], dpt);
+                st = mma<MODE>(kh, kl, qf[ks], ql[ks], st);
+                dpt = mma<MODE>(vh, vl, dof[ks], dol[ks], dpt);
             }
             // (zero-padded keys: dP is exactly 0 there, whatever exp(-lse) their P is)
 #pragma unroll
@@ -452,8 +501,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
             for (int ks = 0; ks < HD / 16; ++ks) {
                 const bf16x8 kh = frag_rows<HD>(Ks, t * 32, ks, lane), vh = frag_rows<HD>(Vs, t * 32, ks, lane);
                 const bf16x8 kl = X3 ? frag_rows<HD>(Ks + lo, t * 32, ks, lane) : kh, vl = X3 ? frag_rows<HD>(Vs + lo, t * 32, ks, lane) : vh;
-                st = mma<X3>(kh, kl, qf[ks], ql[ks], st);
-                dpt = mma<X3>(vh, vl, dof[ks], dol[ks], dpt);
+                st = mma<MODE>(kh, kl, qf[ks], ql[ks], st);
+                dpt = mma<MODE>(vh, vl, dof[ks], dol[ks], dpt);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -462,21 +511,21 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
             }
 #pragma unroll
             for (int sI = 0; sI < 2; ++sI) {
-                const bf16x8 dsf = pack8(st, sI);
+                const bf16x8 dsf = pack8m<MODE>(st, sI);
                 const bf16x8 dsl = X3 ? pack8_lo(st, sI) : dsf;
 #pragma unroll
                 for (int dt = 0; dt < HD / 32; ++dt) {
                     const bf16x8 kh = frag_cols<HD>(Ks, dt * 32, t * 32 + 16 * sI, lane);
                     const bf16x8 kl = X3 ? frag_cols<HD>(Ks + lo, dt * 32, t * 32 + 16 * sI, lane) : kh;
-                    dq[dt] = mma<X3>(kh, kl, dsf, dsl, dq[dt]);
+                    dq[dt] = mma<MODE>(kh, kl, dsf, dsl, dq[dt]);
                 }
             }
         }
         {
             AT* dst = (AT*)a.dq + b * a.dq_sb + h * HD + q * a.dq_sr;
 #pragma unroll
-            for (int dt = 0; dt < HD / 32; ++dt) store_row32(dst + dt * 32, dq[dt], 1.0f, hi, qok);
-            if (!X3 && a.mx_q) {
+            for (int dt = 0; dt < HD / 32; ++dt) store_row32(dst + dt * 32, dq[dt], do_inv, hi, qok);
+            if (MODE == 0 && a.mx_q) {
 #pragma unroll
                 for (int dt = 0; dt < HD / 32; ++dt) store_row32_mx(a, (long long)b * a.Nq + q, a.mx_col[0] + h * HD + dt * 32, dq[dt], 1.0f, hi, qok);
             }
@@ -506,8 +555,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
             for (int ks = 0; ks < HD / 16; ++ks) {
                 const bf16x8 qh = frag_rows<HD>(Qs, qt * 32, ks, lane), doh = frag_rows<HD>(dOs, qt * 32, ks, lane);
                 const bf16x8 qlo = X3 ? frag_rows<HD>(Qs + lo, qt * 32, ks, lane) : qh, dolo = X3 ? frag_rows<HD>(dOs + lo, qt * 32, ks, lane) : doh;
-                sm = mma<X3>(qh, qlo, kf[ks], kl[ks], sm);
-                dp = mma<X3>(doh, dolo, vf[ks], vl[ks], dp);
+                sm = mma<MODE>(qh, qlo, kf[ks], kl[ks], sm);
+                dp = mma<MODE>(doh, dolo, vf[ks], vl[ks], dp);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -518,15 +567,15 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
             }
 #pragma unroll
             for (int sI = 0; sI < 2; ++sI) {
-                const bf16x8 pf = pack8(sm, sI), dsf = pack8(dp, sI);
+                const bf16x8 pf = pack8m<MODE>(sm, sI), dsf = pack8m<MODE>(dp, sI);
                 const bf16x8 pl = X3 ? pack8_lo(sm, sI) : pf, dsl = X3 ? pack8_lo(dp, sI) : dsf;
 #pragma unroll
                 for (int dt = 0; dt < HD / 32; ++dt) {
                     const bf16x8 doh = frag_cols<HD>(dOs, dt * 32, qt * 32 + 16 * sI, lane), qh = frag_cols<HD>(Qs, dt * 32, qt * 32 + 16 * sI, lane);
                     const bf16x8 dolo = X3 ? frag_cols<HD>(dOs + lo, dt * 32, qt * 32 + 16 * sI, lane) : doh;
                     const bf16x8 qlo = X3 ? frag_cols<HD>(Qs + lo, dt * 32, qt * 32 + 16 * sI, lane) : qh;
-                    dv[dt] = mma<X3>(doh, dolo, pf, pl, dv[dt]);
-                    dk[dt] = mma<X3>(qh, qlo, dsf, dsl, dk[dt]);
+                    dv[dt] = mma<MODE>(doh, dolo, pf, pl, dv[dt]);
+                    dk[dt] = mma<MODE>(qh, qlo, dsf, dsl, dk[dt]);
                 }
             }
         }
@@ -536,10 +585,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
             AT* dvd = (AT*)a.dv + b * a.dv_sb + h * HD + key * a.dv_sr;
 #pragma unroll
             for (int dt = 0; dt < HD / 32; ++dt) {
-                store_row32(dkd + dt * 32, dk[dt], 1.0f, hi, kok);
-                store_row32(dvd + dt * 32, dv[dt], 1.0f, hi, kok);
+                store_row32(dkd + dt * 32, dk[dt], do_inv, hi, kok);
+                store_row32(dvd + dt * 32, dv[dt], do_inv, hi, kok);
             }
-            if (!X3 && a.mx_q) {
+            if (MODE == 0 && a.mx_q) {
 #pragma unroll
                 for (int dt = 0; dt < HD / 32; ++dt) {
                     store_row32_mx(a, (long long)b * a.Nk + key, a.mx_col[1] + h * HD + dt * 32, dk[dt], 1.0f, hi, kok);
@@ -561,9 +610,10 @@ int check_common(int B, int H, int Nq, int Nk, int hd, const long long* strides,
 
 extern "C" {
 
-static int attn_fwd_impl(bool x3, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
+static int attn_fwd_impl(int mode, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
                          int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr,
                          float scale, void* stream, void* mx_q = nullptr, void* mx_scale = nullptr) {
+    const bool x3 = mode == 1;                            // mode: 0 bf16, 1 f32 activations / split-bf16 products, 2 f32 activations / fp16 products
     MMAE_REQUIRE(q && k && v && o && lse, "attn_fwd: null pointer");
     const long long st[] = {q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr};
     const int rc = check_common(B, H, Nq, Nk, hd, st, 8);
@@ -589,21 +639,26 @@ static int attn_fwd_impl(bool x3, const void* q, const void* k, const void* v, v
     // NT = key tiles held in registers per query block: 4 (<= 128 keys), 7 (<= 224: the 196-token decoder grids; one 16-register
     // score tile less than NT = 8 is what lets two waves per SIMD fit) or 8
     const bool small = a.nkp <= 128, mid = a.nkp <= 224;
-    if (x3) {
-        if (hd == 64) { if (small) LAUNCH_FWD(64, 4, true); else if (mid) LAUNCH_FWD(64, 7, true); else LAUNCH_FWD(64, 8, true); }
-        else { if (small) LAUNCH_FWD(32, 4, true); else if (mid) LAUNCH_FWD(32, 7, true); else LAUNCH_FWD(32, 8, true); }
+    if (mode == 1) {
+        if (hd == 64) { if (small) LAUNCH_FWD(64, 4, 1); else if (mid) LAUNCH_FWD(64, 7, 1); else LAUNCH_FWD(64, 8, 1); }
+        else { if (small) LAUNCH_FWD(32, 4, 1); else if (mid) LAUNCH_FWD(32, 7, 1); else LAUNCH_FWD(32, 8, 1); }
+    } else if (mode == 2) {
+        if (hd == 64) { if (small) LAUNCH_FWD(64, 4, 2); else if (mid) LAUNCH_FWD(64, 7, 2); else LAUNCH_FWD(64, 8, 2); }
+        else { if (small) LAUNCH_FWD(32, 4, 2); else if (mid) LAUNCH_FWD(32, 7, 2); else LAUNCH_FWD(32, 8, 2); }
     } else {
-        if (hd == 64) { if (small) LAUNCH_FWD(64, 4, false); else if (mid) LAUNCH_FWD(64, 7, false); else LAUNCH_FWD(64, 8, false); }
-        else { if (small) LAUNCH_FWD(32, 4, false); else if (mid) LAUNCH_FWD(32, 7, false); else LAUNCH_FWD(32, 8, false); }
+        if (hd == 64) { if (small) LAUNCH_FWD(64, 4, 0); else if (mid) LAUNCH_FWD(64, 7, 0); else LAUNCH_FWD(64, 8, 0); }
+        else { if (small) LAUNCH_FWD(32, 4, 0); else if (mid) LAUNCH_FWD(32, 7, 0); else LAUNCH_FWD(32, 8, 0); }
     }
 #undef LAUNCH_FWD
     return mmae_check_launch("attn_fwd");
 }
 
-static int attn_bwd_impl(bool x3, const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, void* dq,
+static int attn_bwd_impl(int mode, const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, void* dq,
                          void* dk, void* dv, int B, int H, int Nq, int Nk, int hd, int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr,
                          int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr, int64_t dq_sb, int64_t dq_sr, int64_t dk_sb, int64_t dk_sr,
-                         int64_t dv_sb, int64_t dv_sr, float scale, void* stream, void* mx_q = nullptr, void* mx_scale = nullptr) {
+                         int64_t dv_sb, int64_t dv_sr, float scale, void* stream, void* mx_q = nullptr, void* mx_scale = nullptr,
+                         const float* dy_amax = nullptr) {
+    const bool x3 = mode == 1;
     MMAE_REQUIRE(q && k && v && o && d_o && lse && dq && dk && dv, "attn_bwd: null pointer");
     MMAE_REQUIRE(((uintptr_t)dq % 16 == 0) && ((uintptr_t)dk % 16 == 0) && ((uintptr_t)dv % 16 == 0), "attn_bwd: unaligned output pointer");
     const long long st[] = {q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, dq_sb, dq_sr, dk_sb, dk_sr, dv_sb, dv_sr};
@@ -616,6 +671,7 @@ static int attn_bwd_impl(bool x3, const void* q, const void* k, const void* v, c
     a.q_sb = q_sb; a.q_sr = q_sr; a.k_sb = k_sb; a.k_sr = k_sr; a.v_sb = v_sb; a.v_sr = v_sr; a.o_sb = o_sb; a.o_sr = o_sr;
     a.dq_sb = dq_sb; a.dq_sr = dq_sr; a.dk_sb = dk_sb; a.dk_sr = dk_sr; a.dv_sb = dv_sb; a.dv_sr = dv_sr;
     a.scale = scale;
+    a.dy_amax = dy_amax;
     if (mx_q) {                                           // self-attention with dq | dk | dv packed in one [B * N][3 * H * head_dim] tensor
         const int64_t Dm = (int64_t)H * hd;
         MMAE_REQUIRE(!x3 && mx_scale && Nq == Nk && dq_sr == 3 * Dm && dk_sr == 3 * Dm && dv_sr == 3 * Dm && dq_sb == Nq * 3 * Dm && dk_sb == dq_sb && dv_sb == dq_sb &&
@@ -633,9 +689,10 @@ static int attn_bwd_impl(bool x3, const void* q, const void* k, const void* v, c
         hipFuncSetAttribute((const void*)attn_bwd_kernel<HD, X3, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((attn_bwd_kernel<HD, X3, NW>), grid, dim3(NW * 64), lds, st_, a);                                 \
     } while (0)
-    if (x3) { if (hd == 64) LAUNCH_BWD(64, true, 8); else LAUNCH_BWD(32, true, 8); }
-    else if (hd == 64) { if (lds <= 80 * 1024) LAUNCH_BWD(64, false, 4); else LAUNCH_BWD(64, false, 8); }
-    else LAUNCH_BWD(32, false, 8);
+    if (mode == 1) { if (hd == 64) LAUNCH_BWD(64, 1, 8); else LAUNCH_BWD(32, 1, 8); }
+    else if (mode == 2) { if (hd == 64) { if (lds <= 80 * 1024) LAUNCH_BWD(64, 2, 4); else LAUNCH_BWD(64, 2, 8); } else LAUNCH_BWD(32, 2, 8); }
+    else if (hd == 64) { if (lds <= 80 * 1024) LAUNCH_BWD(64, 0, 4); else LAUNCH_BWD(64, 0, 8); }
+    else LAUNCH_BWD(32, 0, 8);
 #undef LAUNCH_BWD
     return mmae_check_launch("attn_bwd");
 }
@@ -643,25 +700,25 @@ static int attn_bwd_impl(bool x3, const void* q, const void* k, const void* v, c
 int mmae_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
                   int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr,
                   float scale, void* stream) {
-    return attn_fwd_impl(false, q, k, v, o, lse, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, scale, stream);
+    return attn_fwd_impl(0, q, k, v, o, lse, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, scale, stream);
 }
 int mmae_attn_fwd_mx(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
                      int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr,
                      float scale, void* mx_q, void* mx_scale, void* stream) {
     MMAE_REQUIRE(mx_q && mx_scale, "attn_fwd_mx: null MX destination");
-    return attn_fwd_impl(false, q, k, v, o, lse, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, scale, stream, mx_q, mx_scale);
+    return attn_fwd_impl(0, q, k, v, o, lse, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, scale, stream, mx_q, mx_scale);
 }
 int mmae_attn_fwd_f32x3(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
                         int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr,
                         float scale, void* stream) {
-    return attn_fwd_impl(true, q, k, v, o, lse, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, scale, stream);
+    return attn_fwd_impl(1, q, k, v, o, lse, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, scale, stream);
 }
 
 int mmae_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, void* dq, void* dk,
                   void* dv, int B, int H, int Nq, int Nk, int hd, int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb,
                   int64_t v_sr, int64_t o_sb, int64_t o_sr, int64_t dq_sb, int64_t dq_sr, int64_t dk_sb, int64_t dk_sr, int64_t dv_sb,
                   int64_t dv_sr, float scale, void* stream) {
-    return attn_bwd_impl(false, q, k, v, o, d_o, lse, dq, dk, dv, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, dq_sb,
+    return attn_bwd_impl(0, q, k, v, o, d_o, lse, dq, dk, dv, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, dq_sb,
                          dq_sr, dk_sb, dk_sr, dv_sb, dv_sr, scale, stream);
 }
 int mmae_attn_bwd_mx(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, void* dq, void* dk,
@@ -669,15 +726,29 @@ int mmae_attn_bwd_mx(const void* q, const void* k, const void* v, const void* o,
                      int64_t v_sr, int64_t o_sb, int64_t o_sr, int64_t dq_sb, int64_t dq_sr, int64_t dk_sb, int64_t dk_sr, int64_t dv_sb,
                      int64_t dv_sr, float scale, void* mx_q, void* mx_scale, void* stream) {
     MMAE_REQUIRE(mx_q && mx_scale, "attn_bwd_mx: null MX destination");
-    return attn_bwd_impl(false, q, k, v, o, d_o, lse, dq, dk, dv, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, dq_sb,
+    return attn_bwd_impl(0, q, k, v, o, d_o, lse, dq, dk, dv, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, dq_sb,
                          dq_sr, dk_sb, dk_sr, dv_sb, dv_sr, scale, stream, mx_q, mx_scale);
 }
 int mmae_attn_bwd_f32x3(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, void* dq, void* dk,
                         void* dv, int B, int H, int Nq, int Nk, int hd, int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb,
                         int64_t v_sr, int64_t o_sb, int64_t o_sr, int64_t dq_sb, int64_t dq_sr, int64_t dk_sb, int64_t dk_sr, int64_t dv_sb,
                         int64_t dv_sr, float scale, void* stream) {
-    return attn_bwd_impl(true, q, k, v, o, d_o, lse, dq, dk, dv, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, dq_sb,
+    return attn_bwd_impl(1, q, k, v, o, d_o, lse, dq, dk, dv, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, dq_sb,
                          dq_sr, dk_sb, dk_sr, dv_sb, dv_sr, scale, stream);
+}
+
+/* f32 activations, fp16 operands (engine.set_fp32_adapter_gemm('f16')): TF32-class products, one MFMA each */
+int mmae_attn_fwd_f32f16(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
+                         int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr,
+                         float scale, void* stream) {
+    return attn_fwd_impl(2, q, k, v, o, lse, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, scale, stream);
+}
+int mmae_attn_bwd_f32f16(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, void* dq, void* dk,
+                         void* dv, int B, int H, int Nq, int Nk, int hd, int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb,
+                         int64_t v_sr, int64_t o_sb, int64_t o_sr, int64_t dq_sb, int64_t dq_sr, int64_t dk_sb, int64_t dk_sr, int64_t dv_sb,
+                         int64_t dv_sr, float scale, const float* dy_amax, void* stream) {
+    return attn_bwd_impl(2, q, k, v, o, d_o, lse, dq, dk, dv, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, dq_sb,
+                         dq_sr, dk_sb, dk_sr, dv_sb, dv_sr, scale, stream, nullptr, nullptr, dy_amax);
 }
 
 }  // extern "C"

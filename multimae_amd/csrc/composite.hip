@@ -367,7 +367,7 @@ int attn_strides_fwd(const mmae_block_desc* d, hipStream_t st, void* mx_q = null
     if (mx_q)
         return mmae_attn_fwd_mx(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, d->ao, d->lse, d->B, d->heads, N, N, hd, (int64_t)N * 3 * D, 3 * D,
                                 (int64_t)N * 3 * D, 3 * D, (int64_t)N * 3 * D, 3 * D, (int64_t)N * D, D, scale, mx_q, mx_s, st);
-    auto fn = d->act_dtype == MMAE_BF16 ? mmae_attn_fwd : mmae_attn_fwd_f32x3;
+    auto fn = d->act_dtype == MMAE_BF16 ? mmae_attn_fwd : (d->f32_gemm == MMAE_F32F16 ? mmae_attn_fwd_f32f16 : mmae_attn_fwd_f32x3);
     return fn(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, d->ao, d->lse, d->B, d->heads, N, N, hd, (int64_t)N * 3 * D, 3 * D,
               (int64_t)N * 3 * D, 3 * D, (int64_t)N * 3 * D, 3 * D, (int64_t)N * D, D, scale, st);
 }
@@ -666,6 +666,11 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
         char* dq = (char*)d->d_qkv;
         const int64_t sb3 = (int64_t)N * 3 * D, sb1 = (int64_t)N * D;
         auto fn = act == MMAE_BF16 ? mmae_attn_bwd : mmae_attn_bwd_f32x3;
+        if (act == MMAE_F32 && c.ab_grad() == MMAE_F32F16) {            // fp16-operand products, dO scaled by the loss gradient's amax
+            if ((rc = mmae_attn_bwd_f32f16(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, d->ao, d->d_ao, d->lse, dq, dq + (size_t)D * es,
+                                           dq + (size_t)2 * D * es, d->B, d->heads, N, N, hd, sb3, 3 * D, sb3, 3 * D, sb3, 3 * D, sb1, D, sb3, 3 * D,
+                                           sb3, 3 * D, sb3, 3 * D, 1.0f / sqrtf((float)hd), c.dy_amax, st))) return rc;
+        } else
         if (hq >= 0) {                                    // MX mode: the kernel leaves the quantised d_qkv in half 0 for the qkv dX product
             void *gq, *gs;
             if ((rc = mx_slot(c, 0, R, 3 * D, &gq, &gs))) return rc;
@@ -948,7 +953,7 @@ int mmae_adapter_fwd(const mmae_adapter_desc* d, void* stream) {
     if ((rc = lin_fwd(c, a.qn, qw, qb, a.q, act, Rq, D, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;
     if ((rc = lin_fwd(c, a.cn, kvw, kvb, a.kv, act, Rc, 2 * D, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;
     {
-        auto fn = act == MMAE_BF16 ? mmae_attn_fwd : mmae_attn_fwd_f32x3;
+        auto fn = act == MMAE_BF16 ? mmae_attn_fwd : (d->f32_gemm == MMAE_F32F16 ? mmae_attn_fwd_f32f16 : mmae_attn_fwd_f32x3);
         const char* kv = (const char*)a.kv;
         if ((rc = fn(a.q, kv, kv + (size_t)D * es, a.xo, a.lse, B, d->heads, n_q, NC, hd, (int64_t)n_q * D, D, (int64_t)NC * 2 * D, 2 * D,
                      (int64_t)NC * 2 * D, 2 * D, (int64_t)n_q * D, D, 1.0f / sqrtf((float)hd), st))) return rc;
@@ -1053,6 +1058,11 @@ int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream
     {
         auto fn = bf ? mmae_attn_bwd : mmae_attn_bwd_f32x3;
         const char* kv = (const char*)a.kv; char* dkv = (char*)t.d_kv;
+        if (!bf && c.ab_grad() == MMAE_F32F16) {
+            if ((rc = mmae_attn_bwd_f32f16(a.q, kv, kv + (size_t)D * es, a.xo, t.d_xo, a.lse, t.d_q, dkv, dkv + (size_t)D * es, B, d->heads, n_q, NC, hd,
+                                           (int64_t)n_q * D, D, (int64_t)NC * 2 * D, 2 * D, (int64_t)NC * 2 * D, 2 * D, (int64_t)n_q * D, D, (int64_t)n_q * D, D,
+                                           (int64_t)NC * 2 * D, 2 * D, (int64_t)NC * 2 * D, 2 * D, 1.0f / sqrtf((float)hd), c.dy_amax, st))) return rc;
+        } else
         if ((rc = fn(a.q, kv, kv + (size_t)D * es, a.xo, t.d_xo, a.lse, t.d_q, dkv, dkv + (size_t)D * es, B, d->heads, n_q, NC, hd,
                      (int64_t)n_q * D, D, (int64_t)NC * 2 * D, 2 * D, (int64_t)NC * 2 * D, 2 * D, (int64_t)n_q * D, D, (int64_t)n_q * D, D,
                      (int64_t)NC * 2 * D, 2 * D, (int64_t)NC * 2 * D, 2 * D, 1.0f / sqrtf((float)hd), st))) return rc;

@@ -924,14 +924,14 @@ def _fusable(q: AttnView, k: AttnView, hd: int) -> bool:
     return q.t.dtype == torch.float32 and _f32_split() and lds_bwd <= 160 * 1024
 
 
-def attention_fwd(q: AttnView, k: AttnView, v: AttnView, out: AttnView, B: int, H: int, hd: int, scale: float):
+def attention_fwd(q: AttnView, k: AttnView, v: AttnView, out: AttnView, B: int, H: int, hd: int, scale: float, f16: bool = False):
     """softmax(q k^T * scale) v.  Returns the state backward needs: ('fused', lse) or ('gemm', P).
-    multimae_utils.py:175-179 / 206-210."""
+    multimae_utils.py:175-179 / 206-210.  f16 (f32 tensors only): fp16-operand products instead of the split-bf16 ones."""
     Nq, Nk = q.N, k.N
     dev, act = q.t.device, q.t.dtype
     if _fusable(q, k, hd):
         lse = torch.empty((B, H, Nq), device=dev, dtype=torch.float32)
-        fwd = _lib.load().mmae_attn_fwd if act == torch.bfloat16 else _lib.load().mmae_attn_fwd_f32x3
+        fwd = _lib.load().mmae_attn_fwd if act == torch.bfloat16 else (_lib.load().mmae_attn_fwd_f32f16 if f16 else _lib.load().mmae_attn_fwd_f32x3)
         check(fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), lse.data_ptr(), B, H, Nq, Nk, hd,
                                         Nq * q.ld, q.ld, Nk * k.ld, k.ld, Nk * v.ld, v.ld, Nq * out.ld, out.ld, scale, _stream()),
               'attn_fwd')
@@ -948,8 +948,13 @@ def attention_fwd(q: AttnView, k: AttnView, v: AttnView, out: AttnView, B: int, 
 
 
 def attention_bwd(q: AttnView, k: AttnView, v: AttnView, state, out: AttnView, d_out: AttnView, dq: AttnView, dk: AttnView,
-                  dv: AttnView, B: int, H: int, hd: int, scale: float) -> None:
+                  dv: AttnView, B: int, H: int, hd: int, scale: float, f16: bool = False, dy_amax: Optional[Tensor] = None) -> None:
     Nq, Nk = q.N, k.N
+    if state[0] == 'fused' and f16 and q.t.dtype == torch.float32:
+        check(_lib.load().mmae_attn_bwd_f32f16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(d_out), state[1].data_ptr(), _ptr(dq), _ptr(dk), _ptr(dv),
+                                               B, H, Nq, Nk, hd, Nq * q.ld, q.ld, Nk * k.ld, k.ld, Nk * v.ld, v.ld, Nq * out.ld, out.ld, Nq * dq.ld,
+                                               dq.ld, Nk * dk.ld, dk.ld, Nk * dv.ld, dv.ld, scale, _p(dy_amax), _stream()), 'attn_bwd_f32f16')
+        return
     if state[0] == 'fused':
         assert d_out.ld == out.ld
         bwd = _lib.load().mmae_attn_bwd if q.t.dtype == torch.bfloat16 else _lib.load().mmae_attn_bwd_f32x3

@@ -159,7 +159,10 @@ def test_reference_loop_body_runs_on_the_engine_under_ddp_autocast_gradscaler():
     # 5e-7 ... 8e-6 apart (which weights flip depends on the last bits of the gradients), and from there the two runs are two bf16
     # trajectories -- Adam normalises the resulting gradient noise -- measured 1.6 % of the update after three steps (worst matrix 5.4 %)
     assert res['D'][1][0] == res['B'][1][0]
-    assert abs(res['D'][0][1] - res['B'][0][1]) < 5e-5 * abs(res['B'][0][1]), (res['D'][0], res['B'][0])
+    # (round 4: the fp32 adapter's products round their operands to fp16 -- 11 bits, TF32-class -- so a flipped rounding of a weight
+    # is worth 2^-11 instead of the split form's 2^-16: the step-1 losses of the two optimisers are ~1e-4 apart, as they would be
+    # under TF32 on the reference's hardware)
+    assert abs(res['D'][0][1] - res['B'][0][1]) < 4e-4 * abs(res['B'][0][1]), (res['D'][0], res['B'][0])
     d_glob, d_worst = update_err(res['D'][2], res['B'][2])
     assert d_glob < 4e-2 and d_worst[0] < 0.15, (d_glob, d_worst)
     # A vs B / C: image-domain against patch-domain loss gradients (bf16 rounding at the head of the backward chain), three Adam steps on
