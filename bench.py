@@ -313,6 +313,8 @@ def main():
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary line (cfg5 = BASELINE configs[4] geometry, ViT-L, MX-fp8 encoder products, B = 128, a few steps) that the default single-GPU cfg3 run appends as `secondary`')
     ap.add_argument('--gemm-cu-reserve', type=int, default=-1, help='compute units the persistent GEMM grids leave free (for RCCL\'s channel kernels while gradient buckets are in flight); -1: 16 when gradient buckets are exchanged (N > 1 or --force-dist), else 0')
     ap.add_argument('--fp32-adapter-gemm', default='f16', choices=['f16', 'x3', 'exact'], help="Linear products of the fp32 output adapter (semseg) in the bf16 speed mode: 'f16' fp16 operands (TF32-class, one MFMA; default), 'x3' split bf16 (three), 'exact' f32 MFMA (multimae_amd.engine.set_fp32_adapter_gemm)")
+    ap.add_argument('--adapter-cu-share', type=int, default=0, help='experiment: compute units the output adapters\' persistent GEMM grids leave free while they run on separate streams (engine.set_adapter_cu_share)')
+    ap.add_argument('--enc-bwd-side-cus', type=int, default=0, help='experiment: compute units the encoder backward leaves to its weight-gradient stream (engine.set_enc_bwd_side_cus)')
     ap.add_argument('--dropin-ddp', type=int, default=0, help="1: time the REFERENCE'S loop body against the drop-in boundary instead of the native loop (VERDICT r3 item 7): the model wrapped in torch DistributedDataParallel (world 1, nccl, find_unused_parameters=True, run_pretraining_multimae.py:380-387), forward + losses inside torch.cuda.amp.autocast(), the NativeScaler sequence (GradScaler.scale(loss).backward(), unscale_, gradient norm, GradScaler.step(FusedAdamW), update()); gradients travel through autograd / DDP's reducer (engine.set_direct_grads(False))")
     ap.add_argument('--dry-run', type=int, default=0, help='1: CPU tensors and a type-checking stub of the C ABI (tests/dryrun_harness.py): exercises the LAUNCH path of this script (self-launch, process group, reducer, the JSON line) without a GPU -- the numbers are meaningless and the line says so')
     args = ap.parse_args()
@@ -398,6 +400,8 @@ def run_once(args):
         reducer = GradAllReducer.for_arena(arena, bucket_mb=args.bucket_mb, bf16_buckets=bool(args.bf16_buckets), force_collective=bool(args.force_dist))
     M.engine.set_precision(args.precision)
     M.engine.set_fp32_adapter_gemm(args.fp32_adapter_gemm)
+    M.engine.set_adapter_cu_share(args.adapter_cu_share)
+    M.engine.set_enc_bwd_side_cus(args.enc_bwd_side_cus)
     M.engine.set_direct_grads(not args.dropin_ddp)
     M.engine.set_adapter_streams(bool(args.adapter_streams))
     M.engine.set_wgrad_stream(bool(args.wgrad_stream))

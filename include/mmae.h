@@ -145,6 +145,10 @@ int mmae_gemm_auto_splitk(int M, int N, int K, int ab_dtype);
  * statically strided persistent grid run its last k workgroups as a second round.  A host-side launch policy (not stream
  * ordered, process wide).  k < 0 only reads.  Returns the previous value. */
 int mmae_gemm_cu_reserve(int k);
+/* A/B switch (default 0 = off): k > 0 splits the chip between the compute stream's persistent GEMM grids (k fewer workgroups) and the
+ * grouped weight-gradient launches (sized for k CUs: at k = the number of their output tiles they run unsplit), so that a block's dX
+ * chain and its weight gradients are resident side by side instead of time-slicing.  k < 0 only reads.  Returns the previous value. */
+int mmae_gemm_side_cus(int k);
 #ifdef MMAE_EXPERIMENTS
 /* experiment builds only: resident workgroups per CU the HIP runtime reports for the duo kernel of tile code 11 / 12 with its
  * dynamic LDS size (11 must report 2: the kernel's design is two independent workgroups per CU); < 0 on error */

@@ -17,6 +17,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 void mmae_set_error(const char* msg);
 int mmae_check_launch(const char* what);
 int mmae_cu_count();                                          // runtime.hip: compute units of the CURRENT device (cached per device)
+int mmae_cu_side();                                           // experiment: CUs set aside for the side stream's grouped weight gradients (0 = off)
 int mmae_cu_avail();                                          // ... minus the ones mmae_gemm_cu_reserve() keeps free: width of a persistent GEMM grid
 
 // A/B switches of the experiments (environment variables) exist only in builds with -DMMAE_EXPERIMENTS (make EXTRA=-DMMAE_EXPERIMENTS);

@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) dw_group_reduce_kernel(const DwReduceArgs
 }
 
 int dw_group_splits(const mmae_dw_group_desc* d, long long* tiles_out) {
-    const int n_cu = mmae_cu_avail();
+    const int n_cu = mmae_cu_side() > 0 ? mmae_cu_side() : mmae_cu_avail();
     long long tiles = 0;
     for (int i = 0; i < d->n; ++i) tiles += (long long)((d->p[i].n_out + 255) / 256) * ((d->p[i].k_in + 255) / 256);
     static const int env_split = mmae_env_int("MMAE_DW_SPLIT", 0);     // experiments: slices when the group has > 64 tiles

@@ -28,10 +28,19 @@ int mmae_cu_count() {
 
 // compute units the persistent GEMM grids leave free (mmae_gemm_cu_reserve): a launch POLICY read on the host when a grid is sized
 static std::atomic<int> g_cu_reserve{0};
+static std::atomic<int> g_side_cus{0};
 int mmae_cu_avail() {
-    const int n = mmae_cu_count(), k = g_cu_reserve.load(std::memory_order_relaxed);
+    const int n = mmae_cu_count(), k = g_cu_reserve.load(std::memory_order_relaxed) + g_side_cus.load(std::memory_order_relaxed);
     const int a = n - k;
     return a < 16 ? (n < 16 ? n : 16) : a;
+}
+// experiment (mmae_gemm_side_cus): k > 0 splits the chip between the compute stream's persistent GEMM grids (n_cu - reserve - k workgroups)
+// and the grouped weight-gradient launches of the side stream (sized for k CUs), so that both are resident at once
+int mmae_cu_side() { return g_side_cus.load(std::memory_order_relaxed); }
+extern "C" int mmae_gemm_side_cus(int k) {
+    const int prev = g_side_cus.load(std::memory_order_relaxed);
+    if (k >= 0) g_side_cus.store(k, std::memory_order_relaxed);
+    return prev;
 }
 extern "C" int mmae_gemm_cu_reserve(int k) {
     const int prev = g_cu_reserve.load(std::memory_order_relaxed);

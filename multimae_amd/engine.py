@@ -88,6 +88,25 @@ def set_lazy_predictions(flag: bool) -> None:
     _state['lazy_predictions'] = bool(flag)
 
 
+def enc_bwd_side_cus() -> int:
+    return int(_state.get('enc_bwd_side_cus', 0))
+
+
+def set_enc_bwd_side_cus(k: int) -> None:
+    """A/B switch (default 0): compute units the encoder's backward leaves to its weight-gradient stream (ops.gemm_side_cus)."""
+    _state['enc_bwd_side_cus'] = int(k)
+
+
+def adapter_cu_share() -> int:
+    return int(_state.get('adapter_cu_share', 0))
+
+
+def set_adapter_cu_share(k: int) -> None:
+    """Compute units the output adapters' persistent GEMM grids leave free while the adapters run on separate streams (A/B switch,
+    default 0; see functions._adapter_cu_share)."""
+    _state['adapter_cu_share'] = int(k)
+
+
 def adapter_streams() -> bool:
     return _state['adapter_streams']
 

@@ -361,7 +361,13 @@ class EncoderStackFn(torch.autograd.Function):
                 def on_chunk(lo, hi):
                     for l in reversed(range(lo, hi)):
                         cfg.on_layer_done(l)
-            dx, keep = ops.stack_bwd(ctx.stack, d_outs, dsts, acc, sink.side.cuda_stream if use_side else None, chunks, on_chunk)
+            side_cus = engine.enc_bwd_side_cus() if use_side else 0       # A/B switch: dX chain and weight gradients side by side
+            prev_side = ops.gemm_side_cus(side_cus) if side_cus > 0 else 0
+            try:
+                dx, keep = ops.stack_bwd(ctx.stack, d_outs, dsts, acc, sink.side.cuda_stream if use_side else None, chunks, on_chunk)
+            finally:
+                if side_cus > 0:
+                    ops.gemm_side_cus(prev_side)
             ctx.stack = None
             if use_side:
                 engine.mark_side_dirty(sink.side)
@@ -543,6 +549,25 @@ class PatHandle:
         return ops.round_up(self.C * self.ph * self.pw, 8)
 
 
+import contextlib as _contextlib
+
+
+@_contextlib.contextmanager
+def _adapter_cu_share():
+    """Experiment switch (engine.set_adapter_cu_share(k), default 0 = off): while the output adapters run on their own streams, launch
+    their persistent GEMM grids n_cu - k wide, so that the kernels of two adapters are resident side by side (one's store-bound
+    epilogue under the other's K loop) instead of time-slicing full-chip grids."""
+    k = engine.adapter_cu_share() if engine.adapter_streams() else 0
+    if k <= 0:
+        yield
+        return
+    prev = ops.gemm_cu_reserve(k)
+    try:
+        yield
+    finally:
+        ops.gemm_cu_reserve(prev)
+
+
 class SpatialAdapterFn(torch.autograd.Function):
     """forward(cfg, enc[B,NC,Denc] f32, ids_keep, ids_restore, *params)
 
@@ -560,7 +585,7 @@ class SpatialAdapterFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         cfg.handle = None
         cfg.lazy_fill = None
-        with ops.f32_gemm_mode(getattr(cfg, 'f32_gemm', 'exact')):
+        with ops.f32_gemm_mode(getattr(cfg, 'f32_gemm', 'exact')), _adapter_cu_share():
             img = SpatialAdapterFn._forward(ctx, cfg, enc, ids_keep, ids_restore, *params)
         token = img.new_empty(1)
         if cfg.handle is not None:
@@ -570,7 +595,7 @@ class SpatialAdapterFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_img: Optional[Tensor], d_token: Optional[Tensor] = None):
-        with ops.f32_gemm_mode(getattr(ctx.cfg, 'f32_gemm', 'exact')):
+        with ops.f32_gemm_mode(getattr(ctx.cfg, 'f32_gemm', 'exact')), _adapter_cu_share():
             return SpatialAdapterFn._backward(ctx, d_img)
 
     @staticmethod

@@ -251,6 +251,11 @@ def gemm_cu_reserve(k: Optional[int] = None) -> int:
     return int(_lib.load().mmae_gemm_cu_reserve(-1 if k is None else int(k)))
 
 
+def gemm_side_cus(k: Optional[int] = None) -> int:
+    """A/B switch: compute units set aside for the side stream's grouped weight gradients (mmae_gemm_side_cus); returns the previous value."""
+    return int(_lib.load().mmae_gemm_side_cus(-1 if k is None else int(k)))
+
+
 def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], out: Tensor, *, resid: Optional[Tensor] = None,
                aux: Optional[Tensor] = None, epi: int = EPI_NONE, tile: int = 0) -> Tensor:
     """out[M,N] = x[M,K] @ w[N,K]^T + bias (+ epilogue).  x, w act dtype, contiguous 2-D."""

@@ -49,12 +49,32 @@ def list_models():
     return sorted(_entrypoints)
 
 
-def create_model(model_name: str, pretrained: bool = False, checkpoint_path: str = '', **kwargs):
-    """create_model(name, input_adapters=..., output_adapters=..., num_global_tokens=..., drop_path_rate=...)."""
-    if pretrained or checkpoint_path:
-        raise NotImplementedError('pretrained / checkpoint_path loading is outside the pre-training hot path; '
-                                  'use model.load_state_dict on a reference-format checkpoint')
-    kwargs = {k: v for k, v in kwargs.items() if v is not None}
+def create_model(model_name: str, pretrained: bool = False, checkpoint_path: str = '', scriptable=None, exportable=None, no_jit=None,
+                 **kwargs):
+    """create_model(name, input_adapters=..., output_adapters=..., num_global_tokens=..., drop_path_rate=...) with the signature of
+    the reference's builder (utils/model_builder.py:29-76): the timm-era arguments are accepted -- `drop_connect_rate` is mapped to
+    `drop_path_rate` with the reference's warning, `bn_tf` / `bn_momentum` / `bn_eps` are dropped, `scriptable` / `exportable` /
+    `no_jit` are ignored (as there).  The reference builder accepts `pretrained` and `checkpoint_path` and then never uses them;
+    here `checkpoint_path` (a reference-format checkpoint file: {'model': state_dict, ...} or a bare state_dict) IS loaded after
+    construction (checkpoint.load_checkpoint: strict key match, position tables resized), `pretrained=True` has nothing to fetch
+    for these factories and is ignored with a warning."""
+    if '/' in model_name or ':' in model_name:                 # "source:name" / hub prefixes of the reference's split_model_name
+        model_name = model_name.replace(':', '/').split('/')[-1]
+    for k in ('bn_tf', 'bn_momentum', 'bn_eps'):
+        kwargs.pop(k, None)
+    drop_connect_rate = kwargs.pop('drop_connect_rate', None)
+    if drop_connect_rate is not None and kwargs.get('drop_path_rate', None) is None:
+        print("WARNING: 'drop_connect' as an argument is deprecated, please use 'drop_path'."
+              " Setting drop_path to %f." % drop_connect_rate)
+        kwargs['drop_path_rate'] = drop_connect_rate
     if not is_model(model_name):
         raise RuntimeError('Unknown model (%s)' % model_name)
-    return model_entrypoint(model_name)(**kwargs)
+    model = model_entrypoint(model_name)(**kwargs)
+    if pretrained:
+        import warnings
+        warnings.warn(f'create_model({model_name!r}, pretrained=True): no pretrained weights are registered for this factory '
+                      '(the reference builder ignores the flag too); pass checkpoint_path=... to load a checkpoint')
+    if checkpoint_path:
+        from .checkpoint import load_checkpoint
+        load_checkpoint(checkpoint_path, model)
+    return model

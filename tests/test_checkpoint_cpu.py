@@ -132,3 +132,36 @@ def test_optimizer_state_order_is_registration_order_with_readiness_arena():
     ref2.load_state_dict(out)
     for n in names:
         assert torch.equal(ref2.state[byname[n]]['exp_avg'], ref.state[byname[n]]['exp_avg']), n
+
+
+def test_create_model_builder_arguments_and_checkpoint_path(tmp_path):
+    """registry.create_model with the reference builder's signature (utils/model_builder.py:29-76): timm-era arguments accepted,
+    `drop_connect_rate` mapped to `drop_path_rate`, and `checkpoint_path` loaded after construction (reference-format file or a bare
+    state_dict) -- VERDICT r3 missing #5."""
+    import warnings
+    import multimae_amd as M
+    from helpers import MINI
+
+    def adapters():
+        ins = {'rgb': M.PatchedInputAdapter(num_channels=3, stride_level=1, patch_size_full=MINI['P'], image_size=MINI['S'])}
+        outs = {'rgb': M.SpatialOutputAdapter(num_channels=3, stride_level=1, patch_size_full=MINI['P'], dim_tokens=32, depth=1, num_heads=2,
+                                              use_task_queries=True, task='rgb', context_tasks=['rgb'], image_size=MINI['S'])}
+        return ins, outs
+    torch.manual_seed(3)
+    ins, outs = adapters()
+    src = M.create_model('pretrain_multimae_base', input_adapters=ins, output_adapters=outs, num_global_tokens=1, drop_connect_rate=0.1,
+                         bn_tf=False, bn_eps=None, scriptable=None, exportable=None, no_jit=None)
+    assert abs(src.encoder[-1].drop_path.drop_prob - 0.1) < 1e-6        # drop_connect_rate -> drop_path_rate
+    f1, f2 = str(tmp_path / 'ref_format.pth'), str(tmp_path / 'bare.pth')
+    torch.save({'model': src.state_dict(), 'epoch': 7}, f1)
+    torch.save(src.state_dict(), f2)
+    for f in (f1, f2):
+        torch.manual_seed(99)                                            # a different initialisation ...
+        ins, outs = adapters()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            m = M.create_model('pretrain_multimae_base', pretrained=True, checkpoint_path=f, input_adapters=ins, output_adapters=outs,
+                               num_global_tokens=1, drop_path_rate=0.0)
+        assert any('pretrained' in str(x.message) for x in w)
+        for (k, a), (_, b) in zip(m.state_dict().items(), src.state_dict().items()):
+            assert torch.equal(a, b), k                                  # ... replaced by the checkpoint's weights
