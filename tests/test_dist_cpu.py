@@ -227,3 +227,37 @@ def test_bf16_gradient_buckets_world2_gloo():
     for rank, ok, order, mid, nb in res:
         assert ok, f'rank {rank}: {order}'
     assert res[0][2] == res[1][2]
+
+
+def test_reducer_reserves_compute_units_only_while_buckets_are_in_flight(monkeypatch):
+    """from the first bucket launch of a step until finish() the persistent GEMM grids leave
+    `gemm_cu_reserve` CUs to the collective's kernels (ops.gemm_cu_reserve -> mmae_gemm_cu_reserve); the forward pass and the
+    optimiser step get the whole chip.  World size 1 with the collectives forced, the launch policy recorded through a stub."""
+    from multimae_amd import ops
+    calls = []
+    monkeypatch.setattr(ops, 'gemm_cu_reserve', lambda k=None: calls.append(k) or 0)
+    port = _free_port()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        grad = torch.arange(4096, dtype=torch.float32)
+        sizes = [('a', 0, 1024), ('b', 1024, 1024), ('c', 2048, 2048)]
+        r = GradAllReducer(grad, sizes, bucket_mb=1024 * 4 / 2 ** 20, force_collective=True)
+        assert len(r.buckets) >= 2
+        r.gemm_cu_reserve = 16
+        r.mark_ready(['a'])
+        assert calls == [16]                                  # first bucket in flight: reserve
+        r.mark_ready(['b'])
+        assert calls == [16]                                  # already reserved
+        r.finish()
+        assert calls == [16, 0] and not r._reserved           # everything reduced: the whole chip again
+        r.mark_ready(['a'])
+        r.finish()
+        assert calls == [16, 0, 16, 0]
+        r.gemm_cu_reserve = 0                                 # off: the policy is never touched
+        r.mark_ready(['a'])
+        r.finish()
+        assert calls == [16, 0, 16, 0]
+        assert torch.equal(grad, torch.arange(4096, dtype=torch.float32))      # one-rank sums: unchanged values
+    finally:
+        dist.destroy_process_group()
