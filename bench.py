@@ -256,7 +256,7 @@ def result_line(args, B, world, ms_per_step, img_s, final_loss, counters, roof, 
                                + (('ViT-L (MX-fp8 encoder products), ' if args.precision == 'mxfp8' else 'ViT-L (bf16 run of the fp8 config), ') if args.config == 'cfg5' else 'ViT-B, ')
                                + ('RGB-only' if args.config == 'cfg2' else 'RGB+depth+semseg')
                                + f', 224^2, Dirichlet alpha=1.0, {n_vis} visible tokens, {len(doms) + 1} cross-attention decoders (dim 256, depth 2), '
-                               + (('semseg adapter with fp32 activations; its Linear products with ' + {'f16': 'fp16 operands (11-bit significand = TF32, the precision the reference got on A100 under torch 1.10; one MFMA, gradient operands pre-scaled by a power of two), attention cores split-bf16', 'x3': 'x3 split-bf16 operands (a_hi.b_hi + a_hi.b_lo + a_lo.b_hi)', 'exact': 'f32 MFMA'}[getattr(args, 'fp32_adapter_gemm', 'f16')] + ', fp32 accumulate, ') if 'semseg' in doms else '') + 'AdamW; fwd+losses+bwd+optimizer',
+                               + (('semseg adapter (fp32_output_adapters) with ' + {'h16': 'fp16 STORAGE (activations / saved tensors / gradients of the adapter as IEEE half in HBM: every matmul input carries the 11-bit significand TF32 gave the reference on A100; gradients stored times a power of two fixed by the loss kernel; residual stream, LayerNorm statistics, softmax, loss f32)', 'f16': 'fp32 activations, Linear products on fp16 operands (11-bit significand = TF32, the precision the reference got on A100 under torch 1.10; one MFMA, gradient operands pre-scaled by a power of two), attention cores split-bf16', 'x3': 'fp32 activations, x3 split-bf16 operands (a_hi.b_hi + a_hi.b_lo + a_lo.b_hi)', 'exact': 'fp32 activations, f32 MFMA'}[getattr(args, 'fp32_adapter_gemm', 'h16')] + ', fp32 accumulate, ') if 'semseg' in doms else '') + 'AdamW; fwd+losses+bwd+optimizer',
                    'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}'},
         'final_loss': round(final_loss, 5), 'launch': ("the reference's loop body against the drop-in boundary: DistributedDataParallel(world 1, nccl, find_unused_parameters) + autocast + GradScaler + FusedAdamW, gradients through autograd"
                                                       if getattr(args, 'dropin_ddp', 0) else 'hipGraph replay of the captured step' if use_graph else 'eager, one library call per encoder stack / output adapter / loss / optimiser step'),
@@ -312,7 +312,7 @@ def main():
     ap.add_argument('--graph', type=int, default=-1, help='1: capture the step once as a hipGraph and replay it (multimae_amd.graph.StepGraph; 1 GPU only). Default 0: on ROCm 7.2 the replay of this ~1 100-node, 10-stream graph measured 46.2 ms/step against 44.1 ms eager')
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary line (cfg5 = BASELINE configs[4] geometry, ViT-L, MX-fp8 encoder products, B = 128, a few steps) that the default single-GPU cfg3 run appends as `secondary`')
     ap.add_argument('--gemm-cu-reserve', type=int, default=-1, help='compute units the persistent GEMM grids leave free (for RCCL\'s channel kernels while gradient buckets are in flight); -1: 16 when gradient buckets are exchanged (N > 1 or --force-dist), else 0')
-    ap.add_argument('--fp32-adapter-gemm', default='f16', choices=['f16', 'x3', 'exact'], help="Linear products of the fp32 output adapter (semseg) in the bf16 speed mode: 'f16' fp16 operands (TF32-class, one MFMA; default), 'x3' split bf16 (three), 'exact' f32 MFMA (multimae_amd.engine.set_fp32_adapter_gemm)")
+    ap.add_argument('--fp32-adapter-gemm', default='h16', choices=['h16', 'f16', 'x3', 'exact'], help="the fp32 output adapter (semseg) in the bf16 speed mode: 'h16' fp16 storage of its activations / gradients (bf16-pipeline kernels, TF32's significand; default), 'f16' f32 tensors with fp16 operands (one MFMA), 'x3' split bf16 (three), 'exact' f32 MFMA (multimae_amd.engine.set_fp32_adapter_gemm)")
     ap.add_argument('--adapter-cu-share', type=int, default=0, help='experiment: compute units the output adapters\' persistent GEMM grids leave free while they run on separate streams (engine.set_adapter_cu_share)')
     ap.add_argument('--enc-bwd-side-cus', type=int, default=0, help='experiment: compute units the encoder backward leaves to its weight-gradient stream (engine.set_enc_bwd_side_cus)')
     ap.add_argument('--dropin-ddp', type=int, default=0, help="1: time the REFERENCE'S loop body against the drop-in boundary instead of the native loop (VERDICT r3 item 7): the model wrapped in torch DistributedDataParallel (world 1, nccl, find_unused_parameters=True, run_pretraining_multimae.py:380-387), forward + losses inside torch.cuda.amp.autocast(), the NativeScaler sequence (GradScaler.scale(loss).backward(), unscale_, gradient norm, GradScaler.step(FusedAdamW), update()); gradients travel through autograd / DDP's reducer (engine.set_direct_grads(False))")

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMAE_ABI_VERSION 4
+#define MMAE_ABI_VERSION 5
 
 #define MMAE_F32  0
 #define MMAE_BF16 1
@@ -39,6 +39,18 @@ extern "C" {
                           range saturate at +-65504; a gradient operand needs mmae_gemm_desc.a_amax (see there). */
 #define MMAE_MXFP8 4   /* GEMM only: OCP MX operands -- e4m3 elements [rows][K] plus one E8M0 scale per 32 consecutive K elements in the
                           packed layout of mmae_mx_quant (a_scale / b_scale of the descriptor); block-scaled MFMA, fp32 accumulation */
+
+#define MMAE_F16 5     /* fp16 STORAGE (round 4, the fp32 output adapters' 'h16' mode): 16-bit activations / operands / saved tensors like
+                          MMAE_BF16, but IEEE half -- an 11-bit significand, TF32's, what every matmul input of the reference's fp32 adapters
+                          was rounded to on A100 -- so such an adapter runs on the bf16 pipeline's kernels (v_mfma_f32_32x32x16_f16, 16-bit
+                          HBM traffic) instead of f32 tensors in memory.  Residual stream, LayerNorm statistics, softmax, losses and
+                          every parameter gradient stay f32.  Forward values saturate at +-65504.  GRADIENT tensors are stored multiplied
+                          by S = 2^(4 - floor(log2 m)), m = the device scalar `dy_amax` the loss backward wrote (an upper bound of
+                          |dL/dprediction|): the largest element sits in [16, 32), 11 bits of head-room above and 2^-18..2^-28 of it
+                          below; the f32 sinks (weight / bias / LayerNorm / token gradients, d_enc) multiply by 1/S.  Accepted by:
+                          mmae_gemm (ab/c/aux dtype, ping-pong kernels with a compiled epilogue flavour only), mmae_gemm_dw_group,
+                          mmae_layernorm_*, mmae_colsum*, mmae_cast_*, mmae_patchify, mmae_attn_*_f16, the *_pat_bwd losses,
+                          mmae_block_* and mmae_adapter_* (not mmae_stack_*: the encoder stays bf16 / MX). */
 
 #define MMAE_EINVAL   (-1)   /* bad argument (shape / alignment / dtype)        */
 #define MMAE_ELAUNCH  (-2)   /* hipLaunchKernel reported an error               */
@@ -128,7 +140,9 @@ typedef struct mmae_gemm_desc {
     const float* a_amax;         /* MMAE_F32F16 only, optional: DEVICE pointer to one f32, an upper bound m > 0 of |A| (the loss gradient's
                                     largest element, written by the masked-loss backward kernels).  The A operand is multiplied by
                                     2^-floor(log2 m) before its fp16 rounding and the accumulators by the inverse afterwards: gradient
-                                    operands (1e-6 .. 1e-3) keep their 11 bits instead of falling into fp16's subnormals.  NULL = as is. */
+                                    operands (1e-6 .. 1e-3) keep their 11 bits instead of falling into fp16's subnormals.  NULL = as is.
+                                    MMAE_F16 products with an f32 C (a gradient leaving the fp16-storage domain, e.g. d_enc): the dy_amax scalar
+                                    of MMAE_F16 above; C is multiplied by 1/S.  NULL = as is. */
 } mmae_gemm_desc;
 
 int mmae_gemm(const mmae_gemm_desc* d, void* stream);
@@ -226,7 +240,7 @@ int mmae_gemm_timing_read(double* ms3, double* flop3, int64_t* calls3);
 /* ------------------------------------------------------------------------- *
  * Grouped weight gradients: up to 8 products dw_i[n_out_i][k_in_i] (+)= dy_i[rows][n_out_i]^T . x_i[rows][k_in_i] (the dW of
  * nn.Linear layers that saw the same rows, e.g. the four of a transformer block, multimae_utils.py:143-153,165-180) in ONE
- * MFMA launch + ONE reduction launch; db_i[n_out_i] (+)= column sums of dy_i ride along (NULL = not wanted).  bf16 operands
+ * MFMA launch + ONE reduction launch; db_i[n_out_i] (+)= column sums of dy_i ride along (NULL = not wanted).  bf16 / fp16 operands
  * (MMAE_ESUPPORT otherwise), widths and leading dimensions multiples of 8, dw contiguous.  Every product is cut into the
  * same number of row slices -- as many as fill the chip once (split_k = 0), at least 16 x 32 rows each -- whose f32 partials
  * go through the caller's workspace (mmae_gemm_dw_group_ws_elems) and are summed in a fixed order (deterministic).
@@ -242,6 +256,7 @@ typedef struct mmae_dw_group_desc {
     int32_t n, rows, ab_dtype, accumulate, split_k;
     mmae_dw_problem p[8];
     float* ws; int64_t ws_elems;
+    const float* unscale;        /* MMAE_F16 operands: the dy_amax device scalar -- dy is stored scaled by S (see MMAE_F16), dw / db get 1/S.  NULL = as is */
 } mmae_dw_group_desc;
 
 int64_t mmae_gemm_dw_group_ws_elems(const mmae_dw_group_desc* d);
@@ -291,6 +306,8 @@ int mmae_colsum_scatter(const void* dy, int dtype, int64_t M, int N, int64_t ld,
 typedef struct mmae_colsum_job {
     const void* src; int32_t dtype; int32_t cols; int64_t rows; int64_t ld;
     int32_t seg_w; int32_t nseg; float* dst[8];
+    const float* unscale;        /* the source holds gradients of an MMAE_F16 adapter (stored scaled by S, see MMAE_F16): its dy_amax device scalar,
+                                    the sums are multiplied by 1/S.  NULL = as is */
 } mmae_colsum_job;
 int64_t mmae_colsum_batch_ws_elems(const mmae_colsum_job* jobs, int n);
 int mmae_colsum_batch(const mmae_colsum_job* jobs, int n, int accumulate, float* ws, int64_t ws_elems, void* stream);
@@ -342,6 +359,15 @@ int mmae_attn_bwd_f32f16(const void* q, const void* k, const void* v, const void
                   void* dk, void* dv, int B, int H, int Nq, int Nk, int hd, int64_t q_sb, int64_t q_sr, int64_t k_sb,
                   int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr, int64_t dq_sb, int64_t dq_sr,
                   int64_t dk_sb, int64_t dk_sr, int64_t dv_sb, int64_t dv_sr, float scale, const float* dy_amax, void* stream);
+/* fp16 tensors in memory (MMAE_F16 storage; strides in fp16 elements): the bf16 kernels' data movement with fp16 MFMA products.  The
+ * backward takes d_o and returns dq / dk / dv in the adapter's scaled gradient units (see MMAE_F16): nothing is rescaled here. */
+int mmae_attn_fwd_f16(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
+                      int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr,
+                      float scale, void* stream);
+int mmae_attn_bwd_f16(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, void* dq, void* dk,
+                      void* dv, int B, int H, int Nq, int Nk, int hd, int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb,
+                      int64_t v_sr, int64_t o_sb, int64_t o_sr, int64_t dq_sb, int64_t dq_sr, int64_t dk_sb, int64_t dk_sr, int64_t dv_sb,
+                      int64_t dv_sr, float scale, void* stream);
 
 
 /* ------------------------------------------------------------------------- *
@@ -506,6 +532,10 @@ int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream
  * ------------------------------------------------------------------------- */
 int mmae_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int mmae_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+/* fp16 storage (MMAE_F16).  scale_amax (optional): the dy_amax device scalar of a gradient tensor -- f32 -> fp16 multiplies by S on the
+ * way (an f32 loss gradient entering the fp16-storage domain), fp16 -> f32 by 1/S. */
+int mmae_cast_f32_to_f16(const float* src, void* dst, int64_t n, const float* scale_amax, void* stream);
+int mmae_cast_f16_to_f32(const void* src, float* dst, int64_t n, const float* scale_amax, void* stream);
 /* dst[c][r] = src[r][c], src f32 [rows][cols]; dst act dtype [cols][rows] */
 int mmae_transpose_cast(const float* src, void* dst, int dst_dtype, int rows, int cols, void* stream);
 /* mean pooling over tokens, LinearOutputAdapter.forward (output_adapters.py:346-347):  y[b][:] = mean_n x[b][n][:]
@@ -679,7 +709,9 @@ int mmae_masked_ce_pat_fwd(const float* pat, const int64_t* target, const int64_
 int mmae_masked_ce_pat_bwd(const float* pat, const int64_t* target, const int64_t* mask, int B, int C, int H, int W, int patch,
                            float label_smoothing, const float* lse_pat, const float* per_sample, const float* loss, const float* upstream,
                            void* d_pat, int d_pat_dtype, int64_t ld_pat, float* amax, void* stream);
-/* (amax, optional: device f32 the kernel raises -- atomic max -- to the largest |element| it writes into d_pat; the caller zeroes it.
+/* (d_pat_dtype MMAE_F16, cross entropy only: amax is required and is WRITTEN with m = max over samples of |upstream / (n_samples * n_pixels_b)|,
+ * the bound of every element; d_pat holds the gradient times S(m) -- the units an MMAE_F16 adapter's backward runs in, mmae_adapter_desc.dy_amax.)
+ * (amax, optional: device f32 the kernel raises -- atomic max -- to the largest |element| it writes into d_pat; the caller zeroes it.
  * It is what an adapter with f32 activations and MMAE_F32F16 products scales its gradient operands by: mmae_adapter_desc.dy_amax.) */
 
 /* ------------------------------------------------------------------------- *

@@ -21,6 +21,7 @@ LIB_PATH = os.environ.get('MMAE_LIB') or os.path.join(_PKG, 'libmmae_hip.so')   
 
 F32, BF16, F32X3, F32F16 = 0, 1, 2, 3
 MXFP8 = 4
+F16 = 5            # fp16 storage (the fp32 output adapters' 'h16' mode), see mmae.h
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_GELU_G, EPI_MUL = 0, 1, 2, 3, 4
 
 
@@ -94,12 +95,12 @@ class DwProblem(ctypes.Structure):
 
 class DwGroupDesc(ctypes.Structure):
     """mirror of mmae_dw_group_desc"""
-    _fields_ = [('n', _I), ('rows', _I), ('ab_dtype', _I), ('accumulate', _I), ('split_k', _I), ('p', DwProblem * 8), ('ws', _P), ('ws_elems', _L)]
+    _fields_ = [('n', _I), ('rows', _I), ('ab_dtype', _I), ('accumulate', _I), ('split_k', _I), ('p', DwProblem * 8), ('ws', _P), ('ws_elems', _L), ('unscale', _P)]
 
 
 class ColsumJob(ctypes.Structure):
     """mirror of mmae_colsum_job"""
-    _fields_ = [('src', _P), ('dtype', _I), ('cols', _I), ('rows', _L), ('ld', _L), ('seg_w', _I), ('nseg', _I), ('dst', _P * 8)]
+    _fields_ = [('src', _P), ('dtype', _I), ('cols', _I), ('rows', _L), ('ld', _L), ('seg_w', _I), ('nseg', _I), ('dst', _P * 8), ('unscale', _P)]
 
 
 class OptDesc(ctypes.Structure):
@@ -173,7 +174,7 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = ret
         fn.argtypes = argtypes
-    if lib.mmae_abi_version() != 4:
+    if lib.mmae_abi_version() != 5:
         raise RuntimeError('libmmae_hip.so ABI version mismatch')
     for which, cls in enumerate((GemmDesc, BlockDesc, StackDesc, AdapterDesc, OptDesc, PatchSrc, DwGroupDesc, ColsumJob)):
         if lib.mmae_struct_size(which) != ctypes.sizeof(cls):

@@ -179,7 +179,7 @@ __device__ __forceinline__ bf16x8 pack8_f16(const f32x16& v, int s) {     // fp1
     for (int j = 0; j < 8; ++j) r[j] = (_Float16)__builtin_amdgcn_fmed3f(v[8 * s + j], -65504.0f, 65504.0f);
     return __builtin_bit_cast(bf16x8, r);
 }
-template <int MODE> __device__ __forceinline__ bf16x8 pack8m(const f32x16& v, int s) { return MODE == 2 ? pack8_f16(v, s) : pack8(v, s); }
+template <int MODE> __device__ __forceinline__ bf16x8 pack8m(const f32x16& v, int s) { return MODE >= 2 ? pack8_f16(v, s) : pack8(v, s); }
 __device__ __forceinline__ bf16x8 load_frag_global(const __amdgpu_buffer_rsrc_t rs, bool ok, long long row, long long sr, int ks, int hi) {
     const unsigned off = ok ? (unsigned)((row * sr + ks * 16 + hi * 8) * 2) : OOB;
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
@@ -197,10 +197,10 @@ __device__ __forceinline__ void load_frag_global_f16(const __amdgpu_buffer_rsrc_
     const i32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : OOB, 0, 0);
     h = cvt8_f16(a, b, 1.0f);
 }
-// c += a . b.  MODE 0: bf16 operands; 1: operands given as (hi, lo) bf16 pairs, three products; 2: fp16 bit patterns, one f16 product
+// c += a . b.  MODE 0: bf16 operands; 1: operands given as (hi, lo) bf16 pairs, three products; 2, 3: fp16 bit patterns, one f16 product
 template <int MODE>
 __device__ __forceinline__ f32x16 mma(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x16 c) {
-    if (MODE == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), c, 0, 0, 0);
+    if (MODE >= 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), c, 0, 0, 0);
     if (MODE == 1) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
@@ -226,11 +226,20 @@ __device__ __forceinline__ i32x2 pack4_bf16_rne(float a, float b, float c, float
     bf16x4_t v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
     return __builtin_bit_cast(i32x2, v);
 }
+__device__ __forceinline__ i32x2 pack4_f16_rne(float a, float b, float c, float d) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+    f16x4_t v = {(_Float16)__builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f), (_Float16)__builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f),
+                 (_Float16)__builtin_amdgcn_fmed3f(c, -65504.0f, 65504.0f), (_Float16)__builtin_amdgcn_fmed3f(d, -65504.0f, 65504.0f)};
+    return __builtin_bit_cast(i32x2, v);
+}
+template <bool H16 = false>
 __device__ __forceinline__ void store_row32(uint16_t* p, const f32x16& v, float s, int hi, bool ok) {    // p: column 0 of this tile's row
 #pragma unroll
     for (int g = 0; g < 4; g += 2) {
-        const i32x2 a = pack4_bf16_rne(v[g * 4] * s, v[g * 4 + 1] * s, v[g * 4 + 2] * s, v[g * 4 + 3] * s);
-        const i32x2 b = pack4_bf16_rne(v[g * 4 + 4] * s, v[g * 4 + 5] * s, v[g * 4 + 6] * s, v[g * 4 + 7] * s);
+        const i32x2 a = H16 ? pack4_f16_rne(v[g * 4] * s, v[g * 4 + 1] * s, v[g * 4 + 2] * s, v[g * 4 + 3] * s)
+                            : pack4_bf16_rne(v[g * 4] * s, v[g * 4 + 1] * s, v[g * 4 + 2] * s, v[g * 4 + 3] * s);
+        const i32x2 b = H16 ? pack4_f16_rne(v[g * 4 + 4] * s, v[g * 4 + 5] * s, v[g * 4 + 6] * s, v[g * 4 + 7] * s)
+                            : pack4_bf16_rne(v[g * 4 + 4] * s, v[g * 4 + 5] * s, v[g * 4 + 6] * s, v[g * 4 + 7] * s);
         const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
         const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
         i32x4 o; o[0] = r0[0]; o[1] = r1[0]; o[2] = r0[1]; o[3] = r1[1];
@@ -254,6 +263,7 @@ __device__ __forceinline__ void store_row32_mx(const AttnArgs& a, long long row,
         *reinterpret_cast<int*>(dst + 8 * g + 4 * hi) = mx_cvt4_e4m3(w[4 * g] * inv, w[4 * g + 1] * inv, w[4 * g + 2] * inv, w[4 * g + 3] * inv);
     if (hi == 0) a.mx_s[mx_scale_addr(a.mx_rows, row, col >> 5)] = (unsigned char)e;
 }
+template <bool H16 = false>
 __device__ __forceinline__ void store_row32(float* p, const f32x16& v, float s, int hi, bool ok) {       // f32 rows: already 16-byte stores
     if (!ok) return;
 #pragma unroll
@@ -265,7 +275,7 @@ template <> struct ActOf<true> { typedef float T; };
 // -------------------------------------------------------------------------------------------------
 template <int HD, int NT, int MODE>
 __global__ void __launch_bounds__(256, (NT == 4 && MODE != 1) ? 3 : (NT <= 7 ? 2 : 1)) attn_fwd_kernel(const AttnArgs a) {
-    constexpr bool X3 = MODE == 1, F32IO = MODE != 0;
+    constexpr bool X3 = MODE == 1, F32IO = MODE == 1 || MODE == 2;      // MODE 3: fp16 tensors in memory (MMAE_F16)
     typedef typename ActOf<F32IO>::T AT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
@@ -360,7 +370,7 @@ __global__ void __launch_bounds__(256, (NT == 4 && MODE != 1) ? 3 : (NT <= 7 ? 2
         {
             const float inv = 1.0f / l;
 #pragma unroll
-            for (int dt = 0; dt < HD / 32; ++dt) store_row32(ob + q * a.o_sr + dt * 32, o[dt], inv, hi, qok);
+            for (int dt = 0; dt < HD / 32; ++dt) store_row32<MODE == 3>(ob + q * a.o_sr + dt * 32, o[dt], inv, hi, qok);
             if (MODE == 0 && a.mx_q) {
 #pragma unroll
                 for (int dt = 0; dt < HD / 32; ++dt) store_row32_mx(a, (long long)b * a.Nq + q, a.mx_col[0] + h * HD + dt * 32, o[dt], inv, hi, qok);
@@ -380,7 +390,7 @@ __global__ void __launch_bounds__(256, (NT == 4 && MODE != 1) ? 3 : (NT <= 7 ? 2
 template <int HD, int MODE, int NW>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(const AttnArgs a) {
     constexpr int NTH = NW * 64;
-    constexpr bool X3 = MODE == 1, F32IO = MODE != 0;
+    constexpr bool X3 = MODE == 1, F32IO = MODE == 1 || MODE == 2;      // MODE 3: fp16 tensors in memory (MMAE_F16)
     typedef typename ActOf<F32IO>::T AT;
     // MODE 2: dO is scaled by 2^-floor(log2 amax) on its way into LDS; dQ, dK, dV are scaled back at their store
     float do_s = 1.0f, do_inv = 1.0f;
@@ -524,7 +534,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
         {
             AT* dst = (AT*)a.dq + b * a.dq_sb + h * HD + q * a.dq_sr;
 #pragma unroll
-            for (int dt = 0; dt < HD / 32; ++dt) store_row32(dst + dt * 32, dq[dt], do_inv, hi, qok);
+            for (int dt = 0; dt < HD / 32; ++dt) store_row32<MODE == 3>(dst + dt * 32, dq[dt], do_inv, hi, qok);
             if (MODE == 0 && a.mx_q) {
 #pragma unroll
                 for (int dt = 0; dt < HD / 32; ++dt) store_row32_mx(a, (long long)b * a.Nq + q, a.mx_col[0] + h * HD + dt * 32, dq[dt], 1.0f, hi, qok);
@@ -585,8 +595,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
             AT* dvd = (AT*)a.dv + b * a.dv_sb + h * HD + key * a.dv_sr;
 #pragma unroll
             for (int dt = 0; dt < HD / 32; ++dt) {
-                store_row32(dkd + dt * 32, dk[dt], do_inv, hi, kok);
-                store_row32(dvd + dt * 32, dv[dt], do_inv, hi, kok);
+                store_row32<MODE == 3>(dkd + dt * 32, dk[dt], do_inv, hi, kok);
+                store_row32<MODE == 3>(dvd + dt * 32, dv[dt], do_inv, hi, kok);
             }
             if (MODE == 0 && a.mx_q) {
 #pragma unroll
@@ -613,7 +623,7 @@ extern "C" {
 static int attn_fwd_impl(int mode, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
                          int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr,
                          float scale, void* stream, void* mx_q = nullptr, void* mx_scale = nullptr) {
-    const bool x3 = mode == 1;                            // mode: 0 bf16, 1 f32 activations / split-bf16 products, 2 f32 activations / fp16 products
+    const bool x3 = mode == 1;                            // mode: 0 bf16, 1 f32 activations / split-bf16 products, 2 f32 activations / fp16 products, 3 fp16 activations
     MMAE_REQUIRE(q && k && v && o && lse, "attn_fwd: null pointer");
     const long long st[] = {q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr};
     const int rc = check_common(B, H, Nq, Nk, hd, st, 8);
@@ -645,6 +655,9 @@ static int attn_fwd_impl(int mode, const void* q, const void* k, const void* v, 
     } else if (mode == 2) {
         if (hd == 64) { if (small) LAUNCH_FWD(64, 4, 2); else if (mid) LAUNCH_FWD(64, 7, 2); else LAUNCH_FWD(64, 8, 2); }
         else { if (small) LAUNCH_FWD(32, 4, 2); else if (mid) LAUNCH_FWD(32, 7, 2); else LAUNCH_FWD(32, 8, 2); }
+    } else if (mode == 3) {
+        if (hd == 64) { if (small) LAUNCH_FWD(64, 4, 3); else if (mid) LAUNCH_FWD(64, 7, 3); else LAUNCH_FWD(64, 8, 3); }
+        else { if (small) LAUNCH_FWD(32, 4, 3); else if (mid) LAUNCH_FWD(32, 7, 3); else LAUNCH_FWD(32, 8, 3); }
     } else {
         if (hd == 64) { if (small) LAUNCH_FWD(64, 4, 0); else if (mid) LAUNCH_FWD(64, 7, 0); else LAUNCH_FWD(64, 8, 0); }
         else { if (small) LAUNCH_FWD(32, 4, 0); else if (mid) LAUNCH_FWD(32, 7, 0); else LAUNCH_FWD(32, 8, 0); }
@@ -691,6 +704,7 @@ static int attn_bwd_impl(int mode, const void* q, const void* k, const void* v, 
     } while (0)
     if (mode == 1) { if (hd == 64) LAUNCH_BWD(64, 1, 8); else LAUNCH_BWD(32, 1, 8); }
     else if (mode == 2) { if (hd == 64) { if (lds <= 80 * 1024) LAUNCH_BWD(64, 2, 4); else LAUNCH_BWD(64, 2, 8); } else LAUNCH_BWD(32, 2, 8); }
+    else if (mode == 3) { if (hd == 64) { if (lds <= 80 * 1024) LAUNCH_BWD(64, 3, 4); else LAUNCH_BWD(64, 3, 8); } else LAUNCH_BWD(32, 3, 8); }
     else if (hd == 64) { if (lds <= 80 * 1024) LAUNCH_BWD(64, 0, 4); else LAUNCH_BWD(64, 0, 8); }
     else LAUNCH_BWD(32, 0, 8);
 #undef LAUNCH_BWD
@@ -749,6 +763,21 @@ int mmae_attn_bwd_f32f16(const void* q, const void* k, const void* v, const void
                          int64_t dv_sr, float scale, const float* dy_amax, void* stream) {
     return attn_bwd_impl(2, q, k, v, o, d_o, lse, dq, dk, dv, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, dq_sb,
                          dq_sr, dk_sb, dk_sr, dv_sb, dv_sr, scale, stream, nullptr, nullptr, dy_amax);
+}
+
+/* fp16 tensors in memory (MMAE_F16: an fp32 output adapter in 'h16' mode): the bf16 kernels' data movement, fp16 MFMA products.
+ * Backward: d_o arrives in the adapter's scaled gradient units and dq / dk / dv leave in them -- no scaling here. */
+int mmae_attn_fwd_f16(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
+                      int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb, int64_t o_sr,
+                      float scale, void* stream) {
+    return attn_fwd_impl(3, q, k, v, o, lse, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, scale, stream);
+}
+int mmae_attn_bwd_f16(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, void* dq, void* dk,
+                      void* dv, int B, int H, int Nq, int Nk, int hd, int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb,
+                      int64_t v_sr, int64_t o_sb, int64_t o_sr, int64_t dq_sb, int64_t dq_sr, int64_t dk_sb, int64_t dk_sr, int64_t dv_sb,
+                      int64_t dv_sr, float scale, void* stream) {
+    return attn_bwd_impl(3, q, k, v, o, d_o, lse, dq, dk, dv, B, H, Nq, Nk, hd, q_sb, q_sr, k_sb, k_sr, v_sb, v_sr, o_sb, o_sr, dq_sb,
+                         dq_sr, dk_sb, dk_sr, dv_sb, dv_sr, scale, stream);
 }
 
 }  // extern "C"

@@ -48,6 +48,27 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
 }
 
+// ---- fp16 <-> f32 (round to nearest even, saturating at +-65504): the 16-bit format of the fp32 output adapters' activations (MMAE_F16) ----
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
+    const _Float16 h = (_Float16)__builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f);
+    return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+struct h16_t { uint16_t v; };
+// Gradient scale of an fp16-storage adapter (mmae.h, MMAE_F16): S = 2^(4 - floor(log2 m)), m = *amax (the loss backward's bound of
+// |dL/dprediction|); exact powers of two from the exponent field, 1 when the scalar is missing / zero / not finite.
+__device__ __forceinline__ float h16_grad_scale(const float* amax) {
+    if (!amax) return 1.0f;
+    const unsigned e = (__float_as_uint(*amax) >> 23) & 0xffu;
+    return (e >= 8 && e <= 253) ? __uint_as_float((258u - e) << 23) : 1.0f;
+}
+__device__ __forceinline__ float h16_grad_unscale(const float* amax) {
+    if (!amax) return 1.0f;
+    const unsigned e = (__float_as_uint(*amax) >> 23) & 0xffu;
+    return (e >= 8 && e <= 253) ? __uint_as_float((e - 4u) << 23) : 1.0f;
+}                                 // element type tag of fp16 tensors in the typed row kernels
+
 // typed element access: T is float or uint16_t (bf16 bits)
 template <typename T> struct ActT;
 template <> struct ActT<float> {
@@ -57,6 +78,11 @@ template <> struct ActT<float> {
 template <> struct ActT<uint16_t> {
     static __device__ __forceinline__ float ld(const uint16_t* p) { return bf16_bits_to_f32(*p); }
     static __device__ __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_bf16_bits(v); }
+};
+
+template <> struct ActT<h16_t> {
+    static __device__ __forceinline__ float ld(const h16_t* p) { return f16_bits_to_f32(p->v); }
+    static __device__ __forceinline__ void st(h16_t* p, float v) { p->v = f32_to_f16_bits(v); }
 };
 
 // load/store 4 consecutive act elements (16-byte / 8-byte aligned)
@@ -71,6 +97,20 @@ __device__ __forceinline__ f32x4 ld4(const uint16_t* p) {
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ void st4(uint16_t* p, f32x4 v) {
     i32x2 r; r[0] = (int)pack_bf16x2(v[0], v[1]); r[1] = (int)pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<i32x2*>(p) = r;
+}
+
+__device__ __forceinline__ f32x4 ld4(const h16_t* p) {
+    i32x2 r = *reinterpret_cast<const i32x2*>(p);
+    f32x4 o;
+    o[0] = f16_bits_to_f32((uint16_t)((uint32_t)r[0] & 0xffffu)); o[1] = f16_bits_to_f32((uint16_t)((uint32_t)r[0] >> 16));
+    o[2] = f16_bits_to_f32((uint16_t)((uint32_t)r[1] & 0xffffu)); o[3] = f16_bits_to_f32((uint16_t)((uint32_t)r[1] >> 16));
+    return o;
+}
+__device__ __forceinline__ void st4(h16_t* p, f32x4 v) {
+    i32x2 r;
+    r[0] = (int)((uint32_t)f32_to_f16_bits(v[0]) | ((uint32_t)f32_to_f16_bits(v[1]) << 16));
+    r[1] = (int)((uint32_t)f32_to_f16_bits(v[2]) | ((uint32_t)f32_to_f16_bits(v[3]) << 16));
     *reinterpret_cast<i32x2*>(p) = r;
 }
 

@@ -23,12 +23,18 @@ struct Ctx {
     const void* const* x3_w = nullptr; int x3_n = 0;       // pre-split weights of an f32 call: triples {f32 weight, [n][3k], [3n][k]}
     void* x3_tmp = nullptr; int64_t x3_tmp_bytes = 0;      // scratch of the pre-split activation operand (main stream only)
     const float* dy_amax = nullptr;                        // MMAE_F32F16: device scalar that pre-scales gradient operands (mmae_gemm_desc.a_amax)
-    int ab() const { return act_dtype == MMAE_BF16 ? MMAE_BF16 : f32_gemm; }
+    bool b16() const { return act_dtype != MMAE_F32; }     // 16-bit activations: bf16, or fp16 storage (MMAE_F16: an fp32 adapter in 'h16' mode)
+    bool h16() const { return act_dtype == MMAE_F16; }
+    int ab() const { return b16() ? act_dtype : f32_gemm; }
     // products whose A operand is a GRADIENT: fp16 operands only with the loss gradient's amax at hand, else the split-bf16 form
-    int ab_grad() const { return act_dtype == MMAE_BF16 ? MMAE_BF16 : ((f32_gemm == MMAE_F32F16 && !dy_amax) ? MMAE_F32X3 : f32_gemm); }
+    int ab_grad() const { return b16() ? act_dtype : ((f32_gemm == MMAE_F32F16 && !dy_amax) ? MMAE_F32X3 : f32_gemm); }
     const float* amax_for(int ab) const { return ab == MMAE_F32F16 ? dy_amax : nullptr; }
-    size_t es() const { return act_dtype == MMAE_BF16 ? 2 : 4; }
+    // fp16 storage: every gradient tensor is stored scaled by S(dy_amax); what leaves as f32 (parameter gradients, d_enc) gets 1/S
+    const float* unscale() const { return h16() ? dy_amax : nullptr; }
+    size_t es() const { return b16() ? 2 : 4; }
 };
+inline bool is16(int act) { return act != MMAE_F32; }
+inline size_t es_of(int act) { return act == MMAE_F32 ? 4 : 2; }
 
 Ctx ctx_of(const mmae_block_desc* d) {
     Ctx c{d->act_dtype, d->f32_gemm, d->grad_acc, d->ws_main, d->ws_main_elems, d->ws_side, d->ws_side_elems};
@@ -152,6 +158,7 @@ int lin_dx(const Ctx& c, const void* dy, int64_t ldy, const void* w, void* out, 
     mmae_gemm_desc g = {};
     g.A = dy; g.B = w; g.C = out;
     g.ab_dtype = c.ab_grad(); g.a_amax = c.amax_for(g.ab_dtype);
+    if (c.h16() && out_dtype == MMAE_F32) g.a_amax = c.unscale();
     g.c_dtype = out_dtype;
     g.M = M; g.N = K; g.K = N;
     g.lda = ldy; g.ldb = K; g.ldc = K;
@@ -190,8 +197,8 @@ int lin_dx(const Ctx& c, const void* dy, int64_t ldy, const void* w, void* out, 
 // in registers anyway) and fc2-dX's epilogue multiplies by it -- no transcendental work in the backward epilogue, the largest product
 // of a block.  f32 activations (the exact parity mode) keep the pre-activation and re-evaluate, as autograd does.
 std::atomic<int> g_gelu_grad_aux{1};                                 // mmae_gelu_grad_aux(): must not change between a forward and its backward
-inline int epi_gelu(int act) { return (act == MMAE_BF16 && g_gelu_grad_aux.load(std::memory_order_relaxed)) ? MMAE_EPI_GELU_G : MMAE_EPI_GELU; }
-inline int epi_dgelu(int act) { return (act == MMAE_BF16 && g_gelu_grad_aux.load(std::memory_order_relaxed)) ? MMAE_EPI_MUL : MMAE_EPI_DGELU; }
+inline int epi_gelu(int act) { return (is16(act) && g_gelu_grad_aux.load(std::memory_order_relaxed)) ? MMAE_EPI_GELU_G : MMAE_EPI_GELU; }
+inline int epi_dgelu(int act) { return (is16(act) && g_gelu_grad_aux.load(std::memory_order_relaxed)) ? MMAE_EPI_MUL : MMAE_EPI_DGELU; }
 
 // Parameter-gradient column sums collected into ONE launch (mmae_colsum_batch): the LayerNorm partial blocks, the dGELU epilogue's
 // partials and the bias gradients that no GEMM carries.  add() queues; flush() launches on the weight-gradient stream once every
@@ -208,6 +215,7 @@ struct ColBatch {
         mmae_colsum_job& q = j[n++];
         q = mmae_colsum_job{};
         q.src = src; q.dtype = dtype; q.rows = rows; q.cols = cols; q.ld = ld; q.seg_w = seg_w; q.nseg = nseg;
+        q.unscale = c.unscale();                           // every source queued by a backward pass is a gradient
         for (int i = 0; i < nseg; ++i) q.dst[i] = dsts[i];
         return 0;
     }
@@ -234,6 +242,7 @@ struct ColBatch {
 int lin_dw(const Ctx& c, const void* dy, int64_t ldy, const void* x, float* dw, float* db, int M, int N, int K, hipStream_t st, ColBatch* cb = nullptr) {
     if (!dw && !db) return 0;
     const int acc = c.grad_acc;
+    if (c.h16() && (dw || !cb)) { mmae_set_error("composite: an fp16-storage weight gradient outside the grouped launch (widths must be multiples of 8)"); return MMAE_ESUPPORT; }
     if (dw) {
         mmae_gemm_desc g = {};
         g.A = dy; g.B = x; g.C = dw;
@@ -273,8 +282,8 @@ bool dw_group_enabled() {
 struct DwGroup {
     mmae_dw_group_desc g;
     bool on;
-    DwGroup(const Ctx& c, int rows) : g{}, on(c.act_dtype == MMAE_BF16 && dw_group_enabled()) {
-        g.rows = rows; g.ab_dtype = MMAE_BF16; g.accumulate = c.grad_acc;
+    DwGroup(const Ctx& c, int rows) : g{}, on(c.b16() && (dw_group_enabled() || c.h16())) {
+        g.rows = rows; g.ab_dtype = c.act_dtype; g.accumulate = c.grad_acc; g.unscale = c.unscale();
     }
     // queue dw (+ db); returns false if this product must be issued on its own (group off / full / no weight gradient wanted)
     bool add(const void* dy, int64_t ldy, const void* x, int64_t ldx, float* dw, float* db, int n_out, int k_in) {
@@ -333,15 +342,21 @@ bool mx_lin_dw(const Ctx& c, const void* dy, int64_t ldy, const void* x, int64_t
     return true;
 }
 
-int cast_to_act(int act, const float* src, void* dst, int64_t n, hipStream_t st) {       // f32 -> act dtype (bf16 only: f32 callers alias)
-    return act == MMAE_BF16 ? mmae_cast_f32_to_bf16(src, dst, n, st) : 0;
+int cast_to_act(int act, const float* src, void* dst, int64_t n, hipStream_t st) {       // f32 -> 16-bit act dtype, same units (f32 callers alias)
+    return act == MMAE_BF16 ? mmae_cast_f32_to_bf16(src, dst, n, st) : (act == MMAE_F16 ? mmae_cast_f32_to_f16(src, dst, n, nullptr, st) : 0);
+}
+int cast_from_act(int act, const void* src, float* dst, int64_t n, hipStream_t st) {
+    return act == MMAE_BF16 ? mmae_cast_bf16_to_f32(src, dst, n, st) : (act == MMAE_F16 ? mmae_cast_f16_to_f32(src, dst, n, nullptr, st) : 0);
 }
 
 int check_desc(const mmae_block_desc* d) {
     MMAE_REQUIRE(d, "block: null descriptor");
     MMAE_REQUIRE(d->B > 0 && d->N > 0 && d->D > 0 && d->heads > 0 && d->Hd > 0 && d->D % d->heads == 0, "block: bad geometry");
-    MMAE_REQUIRE(d->act_dtype == MMAE_BF16 || (d->act_dtype == MMAE_F32 && (d->f32_gemm == MMAE_F32X3 || d->f32_gemm == MMAE_F32F16)),
-                 "block: activations must be bf16, or f32 with split-bf16 (MMAE_F32X3) / fp16-operand (MMAE_F32F16) products");
+    MMAE_REQUIRE(d->act_dtype == MMAE_BF16 || d->act_dtype == MMAE_F16 || (d->act_dtype == MMAE_F32 && (d->f32_gemm == MMAE_F32X3 || d->f32_gemm == MMAE_F32F16)),
+                 "block: activations must be bf16, fp16 (MMAE_F16), or f32 with split-bf16 (MMAE_F32X3) / fp16-operand (MMAE_F32F16) products");
+    if (d->act_dtype == MMAE_F16 && (d->dp1 || d->dp2 || d->mx_w || (d->D % 32) || (d->Hd % 32))) {
+        mmae_set_error("block: fp16 storage needs D, Hd multiples of 32, no stochastic depth, no MX weights"); return MMAE_ESUPPORT;
+    }
     const int hd = d->D / d->heads;
     if ((hd != 32 && hd != 64) || d->N > 256) { mmae_set_error("block: geometry outside the fused attention kernel (head_dim 32/64, N <= 256)"); return MMAE_ESUPPORT; }
     MMAE_REQUIRE(d->qkv_w && d->proj_w && d->fc1_w && d->fc2_w && d->n1_w && d->n1_b && d->qkv_b && d->proj_b && d->n2_w && d->n2_b &&
@@ -361,13 +376,13 @@ int check_desc(const mmae_block_desc* d) {
 // mx_q / mx_s: also leave the MX-fp8 copy of the attention output there (bf16 activations only)
 int attn_strides_fwd(const mmae_block_desc* d, hipStream_t st, void* mx_q = nullptr, void* mx_s = nullptr) {
     const int D = d->D, N = d->N, hd = D / d->heads;
-    const size_t es = d->act_dtype == MMAE_BF16 ? 2 : 4;
+    const size_t es = es_of(d->act_dtype);
     const char* qkv = (const char*)d->qkv;
     const float scale = 1.0f / sqrtf((float)hd);
     if (mx_q)
         return mmae_attn_fwd_mx(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, d->ao, d->lse, d->B, d->heads, N, N, hd, (int64_t)N * 3 * D, 3 * D,
                                 (int64_t)N * 3 * D, 3 * D, (int64_t)N * 3 * D, 3 * D, (int64_t)N * D, D, scale, mx_q, mx_s, st);
-    auto fn = d->act_dtype == MMAE_BF16 ? mmae_attn_fwd : (d->f32_gemm == MMAE_F32F16 ? mmae_attn_fwd_f32f16 : mmae_attn_fwd_f32x3);
+    auto fn = d->act_dtype == MMAE_BF16 ? mmae_attn_fwd : (d->act_dtype == MMAE_F16 ? mmae_attn_fwd_f16 : (d->f32_gemm == MMAE_F32F16 ? mmae_attn_fwd_f32f16 : mmae_attn_fwd_f32x3));
     return fn(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, d->ao, d->lse, d->B, d->heads, N, N, hd, (int64_t)N * 3 * D, 3 * D,
               (int64_t)N * 3 * D, 3 * D, (int64_t)N * 3 * D, 3 * D, (int64_t)N * D, D, scale, st);
 }
@@ -500,7 +515,7 @@ int run_blocks_bwd(const StackRun& s, int lo, int hi, const float* dx_top, const
         }
         if (extra && l < hi - 1 && extra[l]) {                 // more gradient for this block's output: dx += extra (in place: dx is ours)
             if ((rc = mmae_axpy_f32((float*)dx, extra[l], 1.0f, R * s.D, st))) return rc;
-            if (s.act == MMAE_BF16) { if ((rc = mmae_cast_f32_to_bf16(dx, (void*)dx_act, R * s.D, st))) return rc; }
+            if ((rc = cast_to_act(s.act, dx, (void*)dx_act, R * s.D, st))) return rc;
             fc2_done = false;
         }
         mmae_block_desc b = {};
@@ -529,7 +544,7 @@ int run_blocks_bwd(const StackRun& s, int lo, int hi, const float* dx_top, const
         }
         fc2_done = b.g_cs != nullptr;
         dx = t.dx0;
-        dx_act = s.act == MMAE_BF16 ? (const void*)t.dx0_act : (const void*)t.dx0;
+        dx_act = is16(s.act) ? (const void*)t.dx0_act : (const void*)t.dx0;
     }
     *dx_out = dx; *dx_out_act = dx_act;
     return 0;
@@ -602,7 +617,8 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
     MMAE_REQUIRE(d->dx && d->dx_act && d->dx0 && d->d_hpre && d->d_ln2 && d->d_ao && d->d_qkv && d->d_ln1 && d->dx1 && d->part1 && d->part2,
                  "block_bwd: null gradient / temporary buffer");
     const int act = d->act_dtype;
-    MMAE_REQUIRE(act == MMAE_F32 || (d->dx1_act && d->dx0_act), "block_bwd: bf16 activations need dx1_act / dx0_act");
+    MMAE_REQUIRE(act == MMAE_F32 || (d->dx1_act && d->dx0_act), "block_bwd: 16-bit activations need dx1_act / dx0_act");
+    MMAE_REQUIRE(act != MMAE_F16 || d->dy_amax, "block_bwd: fp16 storage needs dy_amax (the scale its gradients are stored in)");
     MMAE_REQUIRE(!d->g_fc1_b || d->part_h, "block_bwd: part_h needed for the fc1 bias gradient");
     MMAE_REQUIRE(!(d->dp1 || d->dp2) || d->dxs_act, "block_bwd: stochastic depth needs the dxs_act scratch buffer");
     MMAE_REQUIRE(!(d->dp2 && d->fc2_b_done), "block_bwd: with a scaled MLP branch the fc2 bias gradient cannot come from the producer of dx");
@@ -661,11 +677,11 @@ int mmae_block_bwd(const mmae_block_desc* d, void* stream, void* side_stream) {
     if ((rc = cbat.add3(c, d->part2, nblk, D, d->g_n2_w, d->g_n2_b, d->dp1 ? nullptr : d->g_proj_b, sd))) return rc;
     if ((rc = wgrad(da_act, D, d->ao, D, d->g_proj_w, d->dp1 ? d->g_proj_b : nullptr, D, D))) return rc;
     {
-        const size_t es = act == MMAE_BF16 ? 2 : 4;
+        const size_t es = es_of(act);
         const char* qkv = (const char*)d->qkv;
         char* dq = (char*)d->d_qkv;
         const int64_t sb3 = (int64_t)N * 3 * D, sb1 = (int64_t)N * D;
-        auto fn = act == MMAE_BF16 ? mmae_attn_bwd : mmae_attn_bwd_f32x3;
+        auto fn = act == MMAE_BF16 ? mmae_attn_bwd : (act == MMAE_F16 ? mmae_attn_bwd_f16 : mmae_attn_bwd_f32x3);
         if (act == MMAE_F32 && c.ab_grad() == MMAE_F32F16) {            // fp16-operand products, dO scaled by the loss gradient's amax
             if ((rc = mmae_attn_bwd_f32f16(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, d->ao, d->d_ao, d->lse, dq, dq + (size_t)D * es,
                                            dq + (size_t)2 * D * es, d->B, d->heads, N, N, hd, sb3, 3 * D, sb3, 3 * D, sb3, 3 * D, sb1, D, sb3, 3 * D,
@@ -823,11 +839,11 @@ int64_t adapter_x3_bytes(const mmae_adapter_desc* d) {
 }
 
 AdapterAct carve_adapter_act(Carver& cv, const mmae_adapter_desc* d) {
-    const size_t es = d->act_dtype == MMAE_BF16 ? 2 : 4;
+    const size_t es = es_of(d->act_dtype);
     const int64_t Rq = (int64_t)d->B * d->n_q, Rc = (int64_t)d->B * d->NC;
     const int D = d->D;
     AdapterAct a;
-    a.enc_act = (d->act_dtype == MMAE_BF16 && !d->enc_act) ? cv.take(Rc * d->Denc * es) : nullptr;
+    a.enc_act = (is16(d->act_dtype) && !d->enc_act) ? cv.take(Rc * d->Denc * es) : nullptr;
     a.ctx_tok = cv.takeT<float>(Rc * D); a.te = cv.takeT<float>((int64_t)d->T * D);
     a.queries = cv.takeT<float>(Rq * D); a.context = cv.takeT<float>(Rc * D);
     a.qn = cv.take(Rq * D * es); a.cn = cv.take(Rc * D * es);
@@ -837,7 +853,7 @@ AdapterAct carve_adapter_act(Carver& cv, const mmae_adapter_desc* d) {
     a.x = cv.takeT<float>(Rq * D); a.on = cv.take(Rq * D * es); a.omean = cv.takeT<float>(Rq); a.orstd = cv.takeT<float>(Rq);
     a.hpre = cv.take(Rq * d->Hd * es); a.hact = cv.take(Rq * d->Hd * es); a.x1 = cv.takeT<float>(Rq * D);
     for (int l = 0; l < d->depth; ++l) a.blocks[l] = carve_block_act(cv, d->B, d->n_q, D, d->heads, d->Hd, es);
-    a.h_act = d->act_dtype == MMAE_BF16 ? cv.take(Rq * D * es) : nullptr;
+    a.h_act = is16(d->act_dtype) ? cv.take(Rq * D * es) : nullptr;
     a.pat = cv.takeT<float>(Rq * kp_of(d));
     a.x3_tmp = adapter_x3_bytes(d) ? cv.take(adapter_x3_bytes(d)) : nullptr;
     return a;
@@ -852,8 +868,8 @@ struct AdapterTmp {
 int64_t ldpat_of(const mmae_adapter_desc* d) { return (kp_of(d) + 7) / 8 * 8; }
 
 AdapterTmp carve_adapter_tmp(Carver& cv, const mmae_adapter_desc* d) {
-    const size_t es = d->act_dtype == MMAE_BF16 ? 2 : 4;
-    const bool bf = d->act_dtype == MMAE_BF16;
+    const size_t es = es_of(d->act_dtype);
+    const bool bf = is16(d->act_dtype);
     const int64_t Rq = (int64_t)d->B * d->n_q, Rc = (int64_t)d->B * d->NC;
     const int D = d->D;
     AdapterTmp t;
@@ -881,8 +897,11 @@ int check_adapter(const mmae_adapter_desc* d) {
                  d->depth <= 8 && d->T >= 1 && d->T <= 7 && d->q_task >= -1 && d->q_task < d->T && d->G >= 0 && d->n_q > 0 && d->NC > d->G,
                  "adapter: bad geometry");
     MMAE_REQUIRE(d->C > 0 && d->nh > 0 && d->nw > 0 && d->ph > 0 && d->pw > 0 && d->nh * d->nw == d->n_q, "adapter: bad patch geometry");
-    MMAE_REQUIRE(d->act_dtype == MMAE_BF16 || (d->act_dtype == MMAE_F32 && (d->f32_gemm == MMAE_F32X3 || d->f32_gemm == MMAE_F32F16)),
-                 "adapter: activations must be bf16, or f32 with split-bf16 (MMAE_F32X3) / fp16-operand (MMAE_F32F16) products");
+    MMAE_REQUIRE(d->act_dtype == MMAE_BF16 || d->act_dtype == MMAE_F16 || (d->act_dtype == MMAE_F32 && (d->f32_gemm == MMAE_F32X3 || d->f32_gemm == MMAE_F32F16)),
+                 "adapter: activations must be bf16, fp16 (MMAE_F16), or f32 with split-bf16 (MMAE_F32X3) / fp16-operand (MMAE_F32F16) products");
+    if (d->act_dtype == MMAE_F16 && ((d->D % 32) || (d->Denc % 32) || (d->Hd % 32) || (kp_of(d) % 8))) {
+        mmae_set_error("adapter: fp16 storage needs D, Denc, Hd multiples of 32 and C * ph * pw a multiple of 8"); return MMAE_ESUPPORT;
+    }
     const int hd = d->D / d->heads;
     if ((hd != 32 && hd != 64) || d->n_q > 256 || d->NC > 256) { mmae_set_error("adapter: geometry outside the fused attention kernel"); return MMAE_ESUPPORT; }
     if (d->act_dtype == MMAE_F32) {
@@ -892,7 +911,7 @@ int check_adapter(const mmae_adapter_desc* d) {
     if ((d->D % 8) || (d->Denc % 8) || (d->Hd % 8) || (kp_of(d) % 4)) { mmae_set_error("adapter: widths must be multiples of 8 (patch row of 4)"); return MMAE_ESUPPORT; }
     MMAE_REQUIRE(d->task_offsets_host && d->w && d->p && d->mask_token && d->task_emb && d->pos && d->enc && d->ids_keep && d->ids_restore && d->act,
                  "adapter: null pointer");
-    MMAE_REQUIRE(d->act_dtype == MMAE_BF16 || d->enc_act == nullptr || d->enc_act == (const void*)d->enc, "adapter: enc_act must alias enc for f32 activations");
+    MMAE_REQUIRE(is16(d->act_dtype) || d->enc_act == nullptr || d->enc_act == (const void*)d->enc, "adapter: enc_act must alias enc for f32 activations");
     return 0;
 }
 
@@ -941,7 +960,7 @@ int mmae_adapter_fwd(const mmae_adapter_desc* d, void* stream) {
                 *f2b = p[10], *ob = p[11 + 8 * depth], *pcb = p[12 + 8 * depth];
     const void* enc_act = act == MMAE_F32 ? (const void*)d->enc : d->enc_act;
     if (!enc_act) {
-        if ((rc = mmae_cast_f32_to_bf16(d->enc, a.enc_act, (int64_t)Rc * d->Denc, st))) return rc;
+        if ((rc = cast_to_act(act, d->enc, a.enc_act, (int64_t)Rc * d->Denc, st))) return rc;
         enc_act = a.enc_act;
     }
     if ((rc = lin_fwd(c, enc_act, pcw, pcb, a.ctx_tok, MMAE_F32, Rc, D, d->Denc, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;      // :258
@@ -953,7 +972,7 @@ int mmae_adapter_fwd(const mmae_adapter_desc* d, void* stream) {
     if ((rc = lin_fwd(c, a.qn, qw, qb, a.q, act, Rq, D, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;
     if ((rc = lin_fwd(c, a.cn, kvw, kvb, a.kv, act, Rc, 2 * D, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;
     {
-        auto fn = act == MMAE_BF16 ? mmae_attn_fwd : (d->f32_gemm == MMAE_F32F16 ? mmae_attn_fwd_f32f16 : mmae_attn_fwd_f32x3);
+        auto fn = act == MMAE_BF16 ? mmae_attn_fwd : (act == MMAE_F16 ? mmae_attn_fwd_f16 : (d->f32_gemm == MMAE_F32F16 ? mmae_attn_fwd_f32f16 : mmae_attn_fwd_f32x3));
         const char* kv = (const char*)a.kv;
         if ((rc = fn(a.q, kv, kv + (size_t)D * es, a.xo, a.lse, B, d->heads, n_q, NC, hd, (int64_t)n_q * D, D, (int64_t)NC * 2 * D, 2 * D,
                      (int64_t)NC * 2 * D, 2 * D, (int64_t)n_q * D, D, 1.0f / sqrtf((float)hd), st))) return rc;
@@ -973,7 +992,7 @@ int mmae_adapter_fwd(const mmae_adapter_desc* d, void* stream) {
         h = a.blocks[l].x2;
     }
     const void* h_act = h;
-    if (act == MMAE_BF16) { if ((rc = mmae_cast_f32_to_bf16(h, a.h_act, (int64_t)Rq * D, st))) return rc; h_act = a.h_act; }
+    if (is16(act)) { if ((rc = cast_to_act(act, h, a.h_act, (int64_t)Rq * D, st))) return rc; h_act = a.h_act; }
     if ((rc = lin_fwd(c, h_act, ow, ob, a.pat, MMAE_F32, Rq, KP, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;                  // :274
     if (d->img) return mmae_unpatchify(a.pat, d->img, B, d->C, d->nh, d->nw, d->ph, d->pw, st);                                       // :277-280
     return 0;
@@ -989,7 +1008,8 @@ int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream
     hipStream_t sd = side_stream ? (hipStream_t)side_stream : st;
     const int act = d->act_dtype, D = d->D, Hd = d->Hd, B = d->B, NC = d->NC, n_q = d->n_q, T = d->T, depth = d->depth;
     const int Rq = B * n_q, Rc = B * NC, hd = D / d->heads, KP = kp_of(d);
-    const bool bf = act == MMAE_BF16;
+    const bool bf = is16(act);                               // 16-bit activations (bf16 / fp16 storage)
+    MMAE_REQUIRE(act != MMAE_F16 || (d->d_pat && d->dy_amax), "adapter_bwd: fp16 storage takes the loss gradient as fp16 patch rows (d_pat) in the units of dy_amax");
     Carver ca(d->act);
     AdapterAct a = carve_adapter_act(ca, d);
     Carver ct(d->tmp);
@@ -1025,7 +1045,7 @@ int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream
     if (!grp_q.add(d_pat, ldp, h_act, D, gtail[0], gtail[1], KP, D) && (rc = lin_dw(c, d_pat, ldp, h_act, gtail[0], gtail[1], Rq, KP, D, sd, &cbat))) return rc;
     if ((rc = lin_dx(c, d_pat, ldp, ow, t.dh_act, act, Rq, KP, D, nullptr, MMAE_EPI_NONE, nullptr, st))) return rc;
     const float* dh = (const float*)t.dh_act;
-    if (bf) { if ((rc = mmae_cast_bf16_to_f32(t.dh_act, t.dh, (int64_t)Rq * D, st))) return rc; dh = t.dh; }
+    if (bf) { if ((rc = cast_from_act(act, t.dh_act, t.dh, (int64_t)Rq * D, st))) return rc; dh = t.dh; }
     const void* dh_act = t.dh_act;
     // ---- decoder_transformer blocks
     bool fc2_done = false;
@@ -1056,7 +1076,7 @@ int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream
     if ((rc = cbat.add3(c, t.part_o, mmae_layernorm_bwd_nblk(Rq), D, gb[10], gb[11], gb[5], sd))) return rc;      // outn_w, outn_b, proj_b
     if (!grp_q.add(dx_act, D, a.xo, D, gb[4], nullptr, D, D) && (rc = lin_dw(c, dx_act, D, a.xo, gb[4], nullptr, Rq, D, D, sd))) return rc;
     {
-        auto fn = bf ? mmae_attn_bwd : mmae_attn_bwd_f32x3;
+        auto fn = act == MMAE_BF16 ? mmae_attn_bwd : (act == MMAE_F16 ? mmae_attn_bwd_f16 : mmae_attn_bwd_f32x3);
         const char* kv = (const char*)a.kv; char* dkv = (char*)t.d_kv;
         if (!bf && c.ab_grad() == MMAE_F32F16) {
             if ((rc = mmae_attn_bwd_f32f16(a.q, kv, kv + (size_t)D * es, a.xo, t.d_xo, a.lse, t.d_q, dkv, dkv + (size_t)D * es, B, d->heads, n_q, NC, hd,
@@ -1077,7 +1097,7 @@ int mmae_adapter_bwd(const mmae_adapter_desc* d, void* stream, void* side_stream
     if ((rc = mmae_decoder_build_bwd(t.d_queries, t.d_context, d->ids_keep, d->ids_restore, d->task_offsets_host, T, d->q_task, B, NC - d->G, d->G, D,
                                      n_q, t.d_ctx, t.part_b, st))) return rc;
     const void* d_ctx_act = t.d_ctx;
-    if (bf) { if ((rc = mmae_cast_f32_to_bf16(t.d_ctx, t.d_ctx_act, (int64_t)Rc * D, st))) return rc; d_ctx_act = t.d_ctx_act; }
+    if (bf) { if ((rc = cast_to_act(act, t.d_ctx, t.d_ctx_act, (int64_t)Rc * D, st))) return rc; d_ctx_act = t.d_ctx_act; }
     if ((rc = fork_to(st, sd))) return rc;
     if ((rc = cbat.add3(c, t.part_q, mmae_layernorm_bwd_nblk(Rq), D, gb[8], gb[9], nullptr, sd))) return rc;      // qn_w, qn_b
     if ((rc = cbat.add3(c, t.part_c, mmae_layernorm_bwd_nblk(Rc), D, gb[6], gb[7], nullptr, sd))) return rc;      // ctxn_w, ctxn_b

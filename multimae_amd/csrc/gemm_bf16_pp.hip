@@ -22,7 +22,7 @@ struct DwGroupArgs {
     DwProblem p[8];
 };
 
-template <bool KF, bool WIDE = false>
+template <bool KF, bool WIDE = false, bool H16 = false>
 __global__ void __launch_bounds__(512) gemm_bf16_pp_dwgroup_kernel(const DwGroupArgs ga) {
     // XCD-aware order (workgroup b runs on XCD b % 8): every XCD takes a contiguous range of the concatenated tile lists, so the
     // tiles resident on one XCD share dY / X column panels in its L2 instead of every XCD streaming every panel
@@ -52,7 +52,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_dwgroup_kernel(const DwGroup
     g.colpart = nullptr;
     g.wide_st = 0;
     g.dbg = 0; g.dephase = 0;
-    pp_body<4, true, true, 0, KF, KF, WIDE>(g, local, 1 << 30);
+    g.h16 = H16 ? 1 : 0; g.a_amax = nullptr;              // (the partial slabs stay in the operands' units; the reduction applies 1/S)
+    pp_body<4, true, true, 0, KF, KF, WIDE, H16>(g, local, 1 << 30);
 }
 
 }  // namespace
@@ -67,6 +68,12 @@ int mmae_gemm_bf16_pp_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code,
     // epilogue flavour known before the launch: use the instantiation that contains only that epilogue (fewer live registers:
     // no spills in the 320-row kernels, whose per-tile scratch reloads cost a full vmcnt(0) drain of the prefetched K tiles)
     static const int env_fl = mmae_env_int("MMAE_PP_FL", 1);
+    if (g.h16) {                                  // fp16 storage: only the compiled flavours of the 256 x 256 tile (gemm_bf16_pp_fl.hip)
+        const int fl = (code == 9 && !aks) ? gemm_flavour(g, d->batch) : 0;
+        const int rc = fl ? mmae_gemm_bf16_pp_fl_impl(d, g, 9, fl, st) : MMAE_ESUPPORT;
+        if (rc == MMAE_ESUPPORT) mmae_set_error("gemm(f16): this operand layout / epilogue has no fp16 instantiation (k-contiguous A, K % 32 == 0, 8-aligned widths)");
+        return rc;
+    }
     if (env_fl && !aks) {
         const int fl = gemm_flavour(g, d->batch);
         if (fl) {
@@ -89,10 +96,11 @@ int mmae_gemm_bf16_pp_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code,
 namespace {
 
 struct DwReduceProblem { const float* ws; float* C; const float* acs; float* bias; long long mn; int M; long long begin4; };
-struct DwReduceArgs { int n, splits, accumulate; long long total4; DwReduceProblem p[8]; };
+struct DwReduceArgs { int n, splits, accumulate; long long total4; const float* unscale; DwReduceProblem p[8]; };
 
 // C_p (+)= sum_z ws_p[z] (fixed order: deterministic); bias_p (+)= sum_z acs_p[z]
 __global__ void __launch_bounds__(256) dw_group_reduce_kernel(const DwReduceArgs ra) {
+    const float us = h16_grad_unscale(ra.unscale);         // fp16-storage gradients: the slabs are in scaled units (1 otherwise)
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < ra.total4; i += (long long)gridDim.x * 256) {
         int pi = 0;
 #pragma unroll
@@ -100,11 +108,19 @@ __global__ void __launch_bounds__(256) dw_group_reduce_kernel(const DwReduceArgs
         const DwReduceProblem& pr = ra.p[pi];
         const long long e = (i - pr.begin4) * 4;
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        if (ra.accumulate) a = ld4(pr.C + e);
         for (int z = 0; z < ra.splits; ++z) {
             const f32x4 v = ld4(pr.ws + z * pr.mn + e);
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[j] += v[j];
+        }
+        if (ra.unscale) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] *= us;
+        }
+        if (ra.accumulate) {
+            const f32x4 c0 = ld4(pr.C + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] += c0[j];
         }
         st4(pr.C + e, a);
     }
@@ -113,9 +129,10 @@ __global__ void __launch_bounds__(256) dw_group_reduce_kernel(const DwReduceArgs
             const DwReduceProblem& pr = ra.p[pi];
             if (!pr.bias) continue;
             for (int m = threadIdx.x; m < pr.M; m += 256) {
-                float a = ra.accumulate ? pr.bias[m] : 0.f;
+                float a = 0.f;
                 for (int z = 0; z < ra.splits; ++z) a += pr.acs[(long long)z * pr.M + m];
-                pr.bias[m] = a;
+                if (ra.unscale) a *= us;
+                pr.bias[m] = ra.accumulate ? pr.bias[m] + a : a;
             }
         }
     }
@@ -151,7 +168,9 @@ extern "C" int64_t mmae_gemm_dw_group_ws_elems(const mmae_dw_group_desc* d) {
 
 extern "C" int mmae_gemm_dw_group(const mmae_dw_group_desc* d, void* stream) {
     MMAE_REQUIRE(d && d->n >= 1 && d->n <= 8 && d->rows > 0, "dw_group: bad descriptor");
-    if (d->ab_dtype != MMAE_BF16) { mmae_set_error("dw_group: bf16 operands only"); return MMAE_ESUPPORT; }
+    if (d->ab_dtype != MMAE_BF16 && d->ab_dtype != MMAE_F16) { mmae_set_error("dw_group: bf16 / fp16 operands only"); return MMAE_ESUPPORT; }
+    MMAE_REQUIRE(!d->unscale || d->ab_dtype == MMAE_F16, "dw_group: unscale is an MMAE_F16 option");
+    const bool h16 = d->ab_dtype == MMAE_F16;
     for (int i = 0; i < d->n; ++i) {
         const mmae_dw_problem& q = d->p[i];
         MMAE_REQUIRE(q.dy && q.x && q.dw && q.n_out > 0 && q.k_in > 0, "dw_group: null / empty problem");
@@ -167,7 +186,7 @@ extern "C" int mmae_gemm_dw_group(const mmae_dw_group_desc* d, void* stream) {
     DwGroupArgs ga = {};
     DwReduceArgs ra = {};
     ga.n = d->n; ga.K = d->rows; ga.splitk = s; ga.kt_per_split = kt_per;
-    ra.n = d->n; ra.splits = s; ra.accumulate = d->accumulate;
+    ra.n = d->n; ra.splits = s; ra.accumulate = d->accumulate; ra.unscale = d->unscale;
     float* w = d->ws;
     int tb = 0;
     long long b4 = 0;
@@ -195,6 +214,8 @@ extern "C" int mmae_gemm_dw_group(const mmae_dw_group_desc* d, void* stream) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_dwgroup_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_dwgroup_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_dwgroup_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_dwgroup_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_dwgroup_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
 #ifdef MMAE_NO_KF
     static const int env_kf = 0;
@@ -205,15 +226,19 @@ extern "C" int mmae_gemm_dw_group(const mmae_dw_group_desc* d, void* stream) {
     for (int i = 0; i < d->n; ++i) flop += 2.0 * d->rows * d->p[i].n_out * d->p[i].k_in;
     hipEvent_t t_ev = mmae_timing_begin(st);
     static const int env_wide = mmae_env_int("MMAE_DW_WIDE", 0);      // one phase pair per K tile: measured neutral (421 vs 411-436 us per block), off
+    if (h16) {
+        if (env_kf && (d->rows & 31) == 0) hipLaunchKernelGGL((gemm_bf16_pp_dwgroup_kernel<true, false, true>), dim3(tb, 1, s), dim3(512), lds, st, ga);
+        else hipLaunchKernelGGL((gemm_bf16_pp_dwgroup_kernel<false, false, true>), dim3(tb, 1, s), dim3(512), lds, st, ga);
+    } else
     if (env_kf && env_wide && (d->rows & 31) == 0) hipLaunchKernelGGL((gemm_bf16_pp_dwgroup_kernel<true, true>), dim3(tb, 1, s), dim3(512), lds, st, ga);
     else if (env_kf && (d->rows & 31) == 0) hipLaunchKernelGGL(gemm_bf16_pp_dwgroup_kernel<true>, dim3(tb, 1, s), dim3(512), lds, st, ga);
     else hipLaunchKernelGGL(gemm_bf16_pp_dwgroup_kernel<false>, dim3(tb, 1, s), dim3(512), lds, st, ga);
     int rc = mmae_check_launch("gemm_bf16_pp_dwgroup");
-    if (rc) { mmae_timing_end(t_ev, st, flop, 0); return rc; }
+    if (rc) { mmae_timing_end(t_ev, st, flop, h16 ? 1 : 0); return rc; }
     long long nb = (b4 + 255) / 256;
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(dw_group_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, ra);
-    mmae_timing_end(t_ev, st, flop, 0);
+    mmae_timing_end(t_ev, st, flop, h16 ? 1 : 0);
     return mmae_check_launch("dw_group_reduce");
 }

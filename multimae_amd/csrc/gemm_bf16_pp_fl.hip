@@ -14,7 +14,28 @@ constexpr bool KFV = true;
 int mmae_gemm_bf16_pp_fl_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, int fl, hipStream_t st) {
     const bool bks = d->b_trans != 0;
     const bool t10 = code == 10;
+    if (g.h16 && !d->a_trans && bks && fl == FL_BF16 && (g.K & 31))    // out_proj's dX of the semseg adapter contracts over C * ph * pw = 2128 columns:
+        return launch<4, false, true, FL_BF16, false, true>(g, d->batch, st);   // the general address walk (zero-filled K tail)
     if (d->a_trans || (KFV && (g.K & 31))) return MMAE_ESUPPORT;       // these instantiations carry the K % 32 == 0 address walk (KF)
+    if (g.h16) {                                  // fp16 storage (MMAE_F16): the 256 x 256 tile, the flavours an output adapter launches
+        if (t10) return MMAE_ESUPPORT;
+        if (!bks) {
+            switch (fl) {
+                case FL_BF16_BIAS: return launch<4, false, false, FL_BF16_BIAS, KFV, true>(g, d->batch, st);
+                case FL_BF16_BIAS_GELU: return launch<4, false, false, FL_BF16_BIAS_GELU, KFV, true>(g, d->batch, st);
+                case FL_F32_BIAS_RESID: return launch<4, false, false, FL_F32_BIAS_RESID, KFV, true>(g, d->batch, st);
+                case FL_F32_BIAS: return launch<4, false, false, FL_F32_BIAS, KFV, true>(g, d->batch, st);
+                default: return MMAE_ESUPPORT;
+            }
+        }
+        switch (fl) {
+            case FL_BF16: return launch<4, false, true, FL_BF16, KFV, true>(g, d->batch, st);
+            case FL_BF16_DGELU_CS: return launch<4, false, true, FL_BF16_DGELU_CS, KFV, true>(g, d->batch, st);
+            case FL_BF16_DGELU: return launch<4, false, true, FL_BF16_DGELU, KFV, true>(g, d->batch, st);
+            case FL_F32: return launch<4, false, true, FL_F32, KFV, true>(g, d->batch, st);
+            default: return MMAE_ESUPPORT;
+        }
+    }
     if (!bks) {                                   // forward products: A [M][K], W [N][K]
         if (t10) {
             switch (fl) {

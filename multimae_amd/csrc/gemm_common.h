@@ -24,6 +24,7 @@ struct GemmArgs {
     int dephase;                  // experiment (env MMAE_PP_DEPHASE = n): odd workgroups of the ping-pong kernel start n x ~4 us late
     const void* scA; const void* scB;   // MX-fp8 products: packed E8M0 scales of the two operands (mxfp8.hip)
     unsigned char* qout; unsigned char* qsc; long long ldq;   // ..._Q flavours: also emit the MX-fp8 quantisation of the bf16 output C ([M][ldq] bytes + packed scales)
+    int h16;                      // the 16-bit operands / outputs / aux of this product are fp16 (MMAE_F16), not bf16: flavoured ping-pong kernels only
     const float* a_amax;          // MMAE_F32F16 products: device scalar whose power of two pre-scales the A operand (gemm_f32x3.hip), or NULL
     int dbg;                      // epilogue dissection for profiling (env MMAE_EPI_DBG, GELU flavour only): 1 = no GELU arithmetic, 2 = no pre-activation store,
                                   // 3 = arithmetic but no stores, 4 = nothing.  0 in production.
@@ -170,6 +171,21 @@ __device__ __forceinline__ f32x4 unpack4_bf16(i32x2 r) {
     o[2] = __uint_as_float(((uint32_t)r[1]) << 16); o[3] = __uint_as_float(((uint32_t)r[1]) & 0xffff0000u);
     return o;
 }
+// the same two for the 16-bit format of the instantiation: bf16 (H16 = false) or fp16
+template <bool H16> __device__ __forceinline__ i32x2 pack4_16(f32x4 v) {
+    if constexpr (!H16) return pack4_bf16(v);
+    i32x2 r;
+    r[0] = (int)((uint32_t)f32_to_f16_bits(v[0]) | ((uint32_t)f32_to_f16_bits(v[1]) << 16));
+    r[1] = (int)((uint32_t)f32_to_f16_bits(v[2]) | ((uint32_t)f32_to_f16_bits(v[3]) << 16));
+    return r;
+}
+template <bool H16> __device__ __forceinline__ f32x4 unpack4_16(i32x2 r) {
+    if constexpr (!H16) return unpack4_bf16(r);
+    f32x4 o;
+    o[0] = f16_bits_to_f32((uint16_t)((uint32_t)r[0] & 0xffffu)); o[1] = f16_bits_to_f32((uint16_t)((uint32_t)r[0] >> 16));
+    o[2] = f16_bits_to_f32((uint16_t)((uint32_t)r[1] & 0xffffu)); o[3] = f16_bits_to_f32((uint16_t)((uint32_t)r[1] >> 16));
+    return o;
+}
 template <typename T>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(T* base, long long row, long long ld) {
     const unsigned long long v = (unsigned long long)(base + row * ld);       // wave-uniform: keep it in SGPRs
@@ -301,7 +317,12 @@ __device__ __forceinline__ i32x4 pack8_bf16(const f32x4 a, const f32x4 b) {
     return r;
 }
 // MXQ: additionally write the MX-fp8 quantisation of the (bf16-rounded) output -- a 32-column block is four adjacent lanes
-template <bool BIAS, int EPI, bool COLSUM, int DBG = 0, int PDEPTH = 4, bool MXQ = false>
+template <bool H16> __device__ __forceinline__ i32x4 pack8_16(const f32x4 a, const f32x4 b) {
+    const i32x2 lo = pack4_16<H16>(a), hi = pack4_16<H16>(b);
+    i32x4 r; r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
+    return r;
+}
+template <bool BIAS, int EPI, bool COLSUM, int DBG = 0, int PDEPTH = 4, bool MXQ = false, bool H16 = false>
 __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cbase, char* wave_lds, int lane, const f32x16 (&acc)[2][2],
                                                     int m_base, int n_base, int ntm) {
     constexpr unsigned OOB_OFF = 0x80000000u;
@@ -348,11 +369,11 @@ __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cba
                         if (g.aux_grad) { s0 = d0; s1 = d1; }
                         v0 = y0; v1 = y1;
                     }
-                    if (DBG != 2 && DBG != 3) __builtin_amdgcn_raw_buffer_store_b128(pack8_bf16(s0, s1), rsAux, voff(gi, g.ldaux), 0, 0);
+                    if (DBG != 2 && DBG != 3) __builtin_amdgcn_raw_buffer_store_b128(pack8_16<H16>(s0, s1), rsAux, voff(gi, g.ldaux), 0, 0);
                 } else if (EPI == MMAE_EPI_DGELU) {
                     const i32x4 pa = pre_aux[gi % PD];
                     i32x2 lo2, hi2; lo2[0] = pa[0]; lo2[1] = pa[1]; hi2[0] = pa[2]; hi2[1] = pa[3];
-                    const f32x4 p0 = unpack4_bf16(lo2), p1 = unpack4_bf16(hi2);
+                    const f32x4 p0 = unpack4_16<H16>(lo2), p1 = unpack4_16<H16>(hi2);
                     if (g.aux_grad) {                        // the forward stored GELU' itself: no transcendental work here
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { v0[j] *= p0[j]; v1[j] *= p1[j]; }
@@ -368,7 +389,7 @@ __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cba
                     for (int j = 0; j < 4; ++j) { cs0[j] += ok ? v0[j] : 0.f; cs1[j] += ok ? v1[j] : 0.f; }
                 }
                 if (MXQ) {
-                    const i32x4 pk = pack8_bf16(v0, v1);
+                    const i32x4 pk = pack8_16<H16>(v0, v1);
                     __builtin_amdgcn_raw_buffer_store_b128(pk, rsC, voff(gi, g.ldc), 0, 0);
                     float w[8];
 #pragma unroll
@@ -389,8 +410,8 @@ __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cba
                         if ((c8 & 3) == 0) g.qsc[mx_scale_addr(g.M, grow, n >> 5)] = (unsigned char)e;
                     }
                 } else
-                if (DBG != 3) __builtin_amdgcn_raw_buffer_store_b128(pack8_bf16(v0, v1), rsC, voff(gi, g.ldc), 0, 0);
-                else if (v0[0] == 1234.5678f) __builtin_amdgcn_raw_buffer_store_b128(pack8_bf16(v0, v1), rsC, voff(gi, g.ldc), 0, 0);   // keeps the arithmetic alive
+                if (DBG != 3) __builtin_amdgcn_raw_buffer_store_b128(pack8_16<H16>(v0, v1), rsC, voff(gi, g.ldc), 0, 0);
+                else if (v0[0] == 1234.5678f) __builtin_amdgcn_raw_buffer_store_b128(pack8_16<H16>(v0, v1), rsC, voff(gi, g.ldc), 0, 0);   // keeps the arithmetic alive
             }
             if (COLSUM) {       // the 8 lanes that share a column group (r8 = 0..7) -> one partial per column and 32-row block
 #pragma unroll
@@ -513,15 +534,15 @@ static inline int gemm_flavour(const GemmArgs& g, int batch) {
     return FL_GENERIC;
 }
 
-template <int FL>
+template <int FL, bool H16 = false>
 __device__ __forceinline__ void gemm_store_tile64_fl(const GemmArgs& g, char* Cz, char* wave_lds, int lane, f32x16 (&acc)[2][2], int m_base, int n_base,
                                                      int ntm = 2) {
-    if (FL == FL_BF16_BIAS) store_tile64_bf16x8<true, MMAE_EPI_NONE, false>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
-    else if (FL == FL_BF16) store_tile64_bf16x8<false, MMAE_EPI_NONE, false>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
-    else if (FL == FL_BF16_BIAS_GELU) store_tile64_bf16x8<true, MMAE_EPI_GELU, false>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
+    if (FL == FL_BF16_BIAS) store_tile64_bf16x8<true, MMAE_EPI_NONE, false, 0, 4, false, H16>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
+    else if (FL == FL_BF16) store_tile64_bf16x8<false, MMAE_EPI_NONE, false, 0, 4, false, H16>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
+    else if (FL == FL_BF16_BIAS_GELU) store_tile64_bf16x8<true, MMAE_EPI_GELU, false, 0, 4, false, H16>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
     // (with one flavour per instantiation there are registers to spare: all 8 pre-activation loads of a 64-row tile go out before its first use)
-    else if (FL == FL_BF16_DGELU_CS) store_tile64_bf16x8<false, MMAE_EPI_DGELU, true, 0, 4>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
-    else if (FL == FL_BF16_DGELU) store_tile64_bf16x8<false, MMAE_EPI_DGELU, false, 0, 8>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
+    else if (FL == FL_BF16_DGELU_CS) store_tile64_bf16x8<false, MMAE_EPI_DGELU, true, 0, 4, false, H16>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
+    else if (FL == FL_BF16_DGELU) store_tile64_bf16x8<false, MMAE_EPI_DGELU, false, 0, 8, false, H16>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
     else if (FL == FL_BF16_BIAS_GELU_Q) store_tile64_bf16x8<true, MMAE_EPI_GELU, false, 0, 4, true>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
     else if (FL == FL_BF16_DGELU_CS_Q) store_tile64_bf16x8<false, MMAE_EPI_DGELU, true, 0, 4, true>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
     else if (FL == FL_BF16_DGELU_Q) store_tile64_bf16x8<false, MMAE_EPI_DGELU, false, 0, 8, true>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);

@@ -84,7 +84,20 @@ __device__ __forceinline__ void wg_barrier() {
 // both slices' fragments in registers): half the workgroup barriers per K tile.  Schedule: G0: MEM(u) b_2u MFMA(u) b_2u+1, G1: b_2u
 // MEM(u) b_2u+1 MFMA(u); MEM(u) reads tile u and issues the pieces of tile u+2 (its slot held tile u-2, whose last reads were
 // drained before b_2u-1); every wave waits for its pieces of tile u+2 -- those of tile u+3 may still fly -- before b_2u+3.
-template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false, bool UNR = false, bool WIDE = false>
+// H16: the 16-bit operands are fp16 (v_mfma_f32_32x32x16_f16, fp16 conversions in the epilogue) instead of bf16: the activations of an fp32
+// output adapter in engine.set_fp32_adapter_gemm('h16') mode (MMAE_F16).  LDS images, DMA pieces and fragment reads are type-agnostic.
+template <bool H16>
+__device__ __forceinline__ f32x16 mfma16(bf16x8 b, bf16x8 a, f32x16 c) {
+    if constexpr (H16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, b), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c, 0, 0, 0);
+}
+template <bool H16>
+__device__ __forceinline__ void dot2_ones(float& acc, int w) {          // acc += the two 16-bit halves of w
+    if constexpr (H16) asm("v_dot2c_f32_f16 %0, %1, %2" : "+v"(acc) : "v"(w), "v"(0x3c003c00));
+    else asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(w), "v"(0x3f803f80));
+}
+
+template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false, bool UNR = false, bool WIDE = false, bool H16 = false>
 __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const int vstep) {
     constexpr int WMR = TM * 32;                         // output rows per wave
     constexpr int BM = 2 * WMR, BN = 256, NW = 8;
@@ -266,14 +279,14 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
-                acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+                acc[tn][tm] = mfma16<H16>(bf[tn], af[tm], acc[tn][tm]);
         __builtin_amdgcn_s_setprio(0);
         if (AKS && do_acs) {
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
                 const i32x4 w = __builtin_bit_cast(i32x4, af[tm]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acs[tm]) : "v"(w[j]), "v"(0x3f803f80));
+                for (int j = 0; j < 4; ++j) dot2_ones<H16>(acs[tm], w[j]);
             }
         }
     };
@@ -308,12 +321,12 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
-                acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+                acc[tn][tm] = mfma16<H16>(bf[tn], af[tm], acc[tn][tm]);
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
             for (int tm = 0; tm < (WIDE ? TM : 1); ++tm)
-                acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf2[tn], af2[tm], acc[tn][tm], 0, 0, 0);
+                acc[tn][tm] = mfma16<H16>(bf2[tn], af2[tm], acc[tn][tm]);
         __builtin_amdgcn_s_setprio(0);
         if (AKS && do_acs) {
 #pragma unroll
@@ -321,8 +334,8 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
                 const i32x4 w = __builtin_bit_cast(i32x4, af[tm]), w2 = __builtin_bit_cast(i32x4, af2[tm]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acs[tm]) : "v"(w[j]), "v"(0x3f803f80));
-                    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acs[tm]) : "v"(w2[j]), "v"(0x3f803f80));
+                    dot2_ones<H16>(acs[tm], w[j]);
+                    dot2_ones<H16>(acs[tm], w2[j]);
                 }
             }
         }
@@ -469,6 +482,17 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
         wait_vm<0>();                                        // the zero-fill tail pieces must not land on live data
         __syncthreads();                                     // every wave is out of the ring
 
+        if constexpr (H16) {                                 // a gradient leaving the fp16-storage domain (f32 C): 1/S, mmae.h MMAE_F16
+            if (g.a_amax) {
+                const float us = h16_grad_unscale(g.a_amax);
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[tn][tm][r] *= us;
+            }
+        }
         const int mw = m0 + wm * WMR, nw = n0 + wn * 64;
         const bool has_next = v + vstep < g.tiles_total;
         if (has_next) {                                      // next tile: K tiles 0, 1 -> slots 0, 1 (in flight during the epilogue)
@@ -479,15 +503,15 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
         }
         {
             f32x16 sub[2][2] = {{acc[0][0], acc[0][1]}, {acc[1][0], acc[1][1]}};
-            gemm_store_tile64_fl<FL>(g, Cz, stage, lane, sub, mw, nw);
+            gemm_store_tile64_fl<FL, H16>(g, Cz, stage, lane, sub, mw, nw);
         }
         {
             f32x16 sub[2][2] = {{acc[0][2], acc[0][3]}, {acc[1][2], acc[1][3]}};
-            gemm_store_tile64_fl<FL>(g, Cz, stage, lane, sub, mw + 64, nw);
+            gemm_store_tile64_fl<FL, H16>(g, Cz, stage, lane, sub, mw + 64, nw);
         }
         if (TM & 1) {
             f32x16 sub[2][2] = {{acc[0][TM - 1], acc[0][TM - 1]}, {acc[1][TM - 1], acc[1][TM - 1]}};
-            gemm_store_tile64_fl<FL>(g, Cz, stage, lane, sub, mw + (TM - 1) * 32, nw, 1);
+            gemm_store_tile64_fl<FL, H16>(g, Cz, stage, lane, sub, mw + (TM - 1) * 32, nw, 1);
         }
         if (has_next) {
             // loads and stores share vmcnt and may retire out of order with respect to each other: drain everything (the
@@ -500,13 +524,13 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
     }
 }
 
-template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false>
+template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false, bool H16 = false>
 __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
     // unrolled wherever the flavoured instantiation has the registers for it (measured: no scratch)
-    pp_body<TM, AKS, BKS, FL, KF, (FL != 0 && KF && !(TM == 5 && BKS))>(g, blockIdx.x, gridDim.x);
+    pp_body<TM, AKS, BKS, FL, KF, (FL != 0 && KF && !(TM == 5 && BKS)), false, H16>(g, blockIdx.x, gridDim.x);
 }
 
-template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false>
+template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false, bool H16 = false>
 int launch(const GemmArgs& g, int batch, hipStream_t st) {
     constexpr int BM = TM * 64, BN = 256;
     const int tiles_m = (g.M + BM - 1) / BM;
@@ -521,9 +545,9 @@ int launch(const GemmArgs& g, int batch, hipStream_t st) {
     const size_t lds = (size_t)4 * (BM + BN) * 64 + 1024;
     static std::once_flag attr_once;
     std::call_once(attr_once, [&] {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<TM, AKS, BKS, FL, KF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<TM, AKS, BKS, FL, KF, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
-    hipLaunchKernelGGL((gemm_bf16_pp_kernel<TM, AKS, BKS, FL, KF>), grid, block, lds, st, a);
+    hipLaunchKernelGGL((gemm_bf16_pp_kernel<TM, AKS, BKS, FL, KF, H16>), grid, block, lds, st, a);
     return mmae_check_launch("gemm_bf16_pp");
 }
 

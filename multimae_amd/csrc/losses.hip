@@ -4,6 +4,7 @@
 // sum over masked pixels of the channel-mean error divided by the number of masked pixels;
 // the loss is the mean of that over samples that have at least one masked token (nanmean).
 #include <math.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -461,18 +462,36 @@ __global__ void __launch_bounds__(256) ce_pat_bwd_kernel(const float* __restrict
                                                          DT* __restrict__ d_pat, long long ld, long long n_rows, float* __restrict__ amax) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n_rows) return;
     const int nw = W / P, np = (H / P) * nw, npix = P * P, nval = npix * C;
     const long long b = row / np;
     const int p = (int)(row % np), py = p / nw, px = p % nw;
     const int pix = lane % npix, slot = lane / npix, nslot = 64 / npix;
+    // fp16 storage (MMAE_F16): |gradient| <= max_b |weight_b| -- the bound every workgroup derives for itself from the B per-sample
+    // counts; it fixes the scale S the adapter's whole backward is stored in (mmae.h) and is what `amax` receives
+    float gs = 1.0f;
+    if constexpr (std::is_same<DT, h16_t>::value) {
+        __shared__ float wred[4];
+        const int B = (int)(n_rows / np);
+        float wm = 0.f;
+        for (int i = threadIdx.x; i < B; i += 256) {
+            const float cnt = per_sample[i * 2 + 1];
+            if (cnt > 0.f) wm = fmaxf(wm, fabsf(upstream[0] / (loss[1] * cnt)));
+        }
+        wm = wave_max(wm);
+        if (lane == 0) wred[threadIdx.x >> 6] = wm;
+        __syncthreads();
+        wm = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+        if (blockIdx.x == 0 && threadIdx.x == 0 && amax) *amax = wm;
+        gs = h16_grad_scale(&wm);
+    }
+    if (row >= n_rows) return;
     const bool on = mask[row] != 0;
     DT* drow = d_pat + row * ld;
     if (!on) {
         for (int e = lane; e < (int)ld; e += 64) ActT<DT>::st(drow + e, 0.f);
         return;
     }
-    const float wgt = upstream[0] / (loss[1] * per_sample[b * 2 + 1]);
+    const float wgt = gs * upstream[0] / (loss[1] * per_sample[b * 2 + 1]);
     const float ls = lse_pat[row * npix + pix];
     const long long t = target[((long long)b * H + py * P + pix / P) * W + px * P + pix % P];
     const float* prow = pat + row * nval;
@@ -484,7 +503,7 @@ __global__ void __launch_bounds__(256) ce_pat_bwd_kernel(const float* __restrict
         gmax = fmaxf(gmax, fabsf(g));
         ActT<DT>::st(drow + e, g);
     }
-    if (amax) note_amax(gmax, amax);
+    if (!std::is_same<DT, h16_t>::value && amax) note_amax(gmax, amax);
 }
 
 // ---- optimiser ----------------------------------------------------------------------------
@@ -685,7 +704,11 @@ int mmae_masked_ce_pat_bwd(const float* pat, const int64_t* target, const int64_
     if (npix > 64 || (npix & (npix - 1))) { mmae_set_error("ce_pat_bwd: patch_size^2 must be a power of two <= 64"); return MMAE_ESUPPORT; }
     const long long rows = (long long)B * (H / patch) * (W / patch);
     const dim3 grid((unsigned)((rows + 3) / 4));
-    if (d_pat_dtype == MMAE_BF16)
+    if (d_pat_dtype == MMAE_F16) {
+        MMAE_REQUIRE(amax, "ce_pat_bwd: fp16 patch rows need the amax scalar (it carries their scale)");
+        hipLaunchKernelGGL((ce_pat_bwd_kernel<h16_t>), grid, dim3(256), 0, (hipStream_t)stream, pat, (const long long*)target, (const long long*)mask,
+                           C, H, W, patch, label_smoothing, lse_pat, per_sample, loss, upstream, (h16_t*)d_pat, (long long)ld_pat, rows, amax);
+    } else if (d_pat_dtype == MMAE_BF16)
         hipLaunchKernelGGL((ce_pat_bwd_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, pat, (const long long*)target, (const long long*)mask,
                            C, H, W, patch, label_smoothing, lse_pat, per_sample, loss, upstream, (uint16_t*)d_pat, (long long)ld_pat, rows, amax);
     else

@@ -3,6 +3,7 @@
 // per-row critical path).  Roofline for all of them is HBM bytes / 8 TB/s.
 #include <stdlib.h>
 #include <mutex>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -191,7 +192,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const DT* __restrict__ dy, 
 
 // Up to 8 destination segments for a column-sum result: column c goes to dst[c / seg_w][c % seg_w] (a null segment is
 // dropped).  Lets ONE reduction feed several parameter gradients (LayerNorm dgamma | dbeta | the bias gradient riding along).
-struct ColDst { float* dst[8]; int seg_w; };
+struct ColDst { float* dst[8]; int seg_w; const float* unscale; };      // unscale: mmae_colsum_job.unscale (fp16-storage gradients)
 
 // out[c] (+)= sum_r part[r][c].  Workgroup = 64 columns x 4 row phases (coalesced 256-B rows, 4-way
 // unrolled so 16 loads are in flight per lane), fixed summation order (deterministic).
@@ -212,7 +213,7 @@ __global__ void __launch_bounds__(256) colsum_partials_kernel(const float* __res
     red[ty][tx] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (ty == 0 && c < ncols) {
-        const float s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        const float s = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) * h16_grad_unscale(out.unscale);
         const int seg = c / out.seg_w;
         float* o = out.dst[seg];
         if (o) { o += c - seg * out.seg_w; *o = accumulate ? *o + s : s; }
@@ -377,6 +378,20 @@ __global__ void cast_bf16_f32_kernel(const uint16_t* __restrict__ s, float* __re
         else for (long long j = i; j < n; ++j) d[j] = bf16_bits_to_f32(s[j]);
     }
 }
+// fp16 storage (MMAE_F16); UP: true f32 -> fp16 * S, false fp16 -> f32 * 1/S (S from the adapter's dy_amax scalar, 1 without)
+template <bool UP>
+__global__ void cast_f16_kernel(const void* __restrict__ sv, void* __restrict__ dv, long long n, const float* __restrict__ amax) {
+    const float sc = UP ? h16_grad_scale(amax) : h16_grad_unscale(amax);
+    const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const long long step = (long long)gridDim.x * blockDim.x * 4;
+    typedef typename std::conditional<UP, float, h16_t>::type ST;
+    typedef typename std::conditional<UP, h16_t, float>::type DT;
+    const ST* s = (const ST*)sv; DT* d = (DT*)dv;
+    for (long long i = i4; i < n; i += step) {
+        if (i + 4 <= n) { f32x4 v = ld4(s + i); v[0] *= sc; v[1] *= sc; v[2] *= sc; v[3] *= sc; st4(d + i, v); }
+        else for (long long j = i; j < n; ++j) ActT<DT>::st(d + j, ActT<ST>::ld(s + j) * sc);
+    }
+}
 // dst[c][r] = src[r][c]; 64x64 tiles through LDS (+1 pad), coalesced on both sides.
 template <typename DT>
 __global__ void __launch_bounds__(256) transpose_cast_kernel(const float* __restrict__ src, DT* __restrict__ dst, int rows,
@@ -505,6 +520,8 @@ int mmae_layernorm_fwd(const float* x, const float* gamma, const float* beta, vo
 #define LN_FWD(NV)                                                                                                        \
     if (y_dtype == MMAE_BF16) hipLaunchKernelGGL((ln_fwd_kernel<NV, uint16_t>), grid, block, 0, st, x, gamma, beta,       \
                                                   (uint16_t*)y, mean, rstd, (long long)R, D, eps);                       \
+    else if (y_dtype == MMAE_F16) hipLaunchKernelGGL((ln_fwd_kernel<NV, h16_t>), grid, block, 0, st, x, gamma, beta,      \
+                                                      (h16_t*)y, mean, rstd, (long long)R, D, eps);                      \
     else hipLaunchKernelGGL((ln_fwd_kernel<NV, float>), grid, block, 0, st, x, gamma, beta, (float*)y, mean, rstd,        \
                             (long long)R, D, eps);
     switch (nv) { case 1: LN_FWD(1) break; case 2: LN_FWD(2) break; case 3: LN_FWD(3) break; default: LN_FWD(4) break; }
@@ -554,11 +571,14 @@ int mmae_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float
     dim3 grid(part_rows < resident ? part_rows : resident), block(256);
     hipStream_t st = (hipStream_t)stream;
     const bool dyb = dy_dtype == MMAE_BF16, axb = dx_act_dtype == MMAE_BF16;
+    const bool dyh = dy_dtype == MMAE_F16, axh = dx_act_dtype == MMAE_F16;       // fp16 storage: the gradient's scale passes through (linear in dy, dx_in)
+    MMAE_REQUIRE(!(dyh && axb) && !(dyb && axh), "layernorm_bwd: bf16 and fp16 tensors do not mix");
 #define LN_BWD(NV, DT, AT)                                                                                                \
     hipLaunchKernelGGL((ln_bwd_kernel<NV, DT, AT>), grid, block, 0, st, (const DT*)dy, x, gamma, mean, rstd, dx_in, dx_out, \
                        (AT*)dx_act, part, (long long)R, D, part_rows)
 #define LN_BWD_T(NV)                                                                                                      \
-    if (dyb && axb) LN_BWD(NV, uint16_t, uint16_t); else if (dyb) LN_BWD(NV, uint16_t, float);                           \
+    if (dyh && axh) LN_BWD(NV, h16_t, h16_t); else if (dyh) LN_BWD(NV, h16_t, float);                                    \
+    else if (dyb && axb) LN_BWD(NV, uint16_t, uint16_t); else if (dyb) LN_BWD(NV, uint16_t, float);                      \
     else if (axb) LN_BWD(NV, float, uint16_t); else LN_BWD(NV, float, float);
     switch (nv) { case 1: LN_BWD_T(1) break; case 2: LN_BWD_T(2) break; case 3: LN_BWD_T(3) break; default: LN_BWD_T(4) break; }
 #undef LN_BWD_T
@@ -592,6 +612,7 @@ static int colsum_impl(const void* dy, int dtype, int64_t M, int N, int64_t ld, 
     if (N % 4 != 0 || ld % 4 != 0) {
         dim3 g1((N + 63) / 64, ns);
         if (dtype == MMAE_BF16) hipLaunchKernelGGL((colsum_scalar_kernel<uint16_t>), g1, dim3(256), 0, st, (const uint16_t*)dy, (long long)M, N, (long long)ld, ws);
+        else if (dtype == MMAE_F16) hipLaunchKernelGGL((colsum_scalar_kernel<h16_t>), g1, dim3(256), 0, st, (const h16_t*)dy, (long long)M, N, (long long)ld, ws);
         else hipLaunchKernelGGL((colsum_scalar_kernel<float>), g1, dim3(256), 0, st, (const float*)dy, (long long)M, N, (long long)ld, ws);
         int rc1 = mmae_check_launch("colsum");
         if (rc1) return rc1;
@@ -599,6 +620,7 @@ static int colsum_impl(const void* dy, int dtype, int64_t M, int N, int64_t ld, 
     }
     dim3 grid((N + 255) / 256, ns), block(256);
     if (dtype == MMAE_BF16) hipLaunchKernelGGL((colsum_kernel<uint16_t>), grid, block, 0, st, (const uint16_t*)dy, (long long)M, N, (long long)ld, ws);
+    else if (dtype == MMAE_F16) hipLaunchKernelGGL((colsum_kernel<h16_t>), grid, block, 0, st, (const h16_t*)dy, (long long)M, N, (long long)ld, ws);
     else hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, st, (const float*)dy, (long long)M, N, (long long)ld, ws);
     int rc = mmae_check_launch("colsum");
     if (rc) return rc;
@@ -629,7 +651,7 @@ int mmae_colsum_scatter(const void* dy, int dtype, int64_t M, int N, int64_t ld,
 namespace {
 constexpr int CB_MAX_GROUPS = 160;                 // 256-column groups per launch (a ViT-L block: 16 + 12 + 12)
 
-struct CbJob { const void* src; long long rows, ld; int dtype, cols, seg_w, ns, group0, ws_off; float* dst[8]; };
+struct CbJob { const void* src; long long rows, ld; int dtype, cols, seg_w, ns, group0, ws_off; float* dst[8]; const float* unscale; };
 struct CbArgs { int n, accumulate, ngroups; float* ws; CbJob j[MMAE_COLSUM_MAX_JOBS]; };
 
 template <typename DT>
@@ -678,6 +700,7 @@ __global__ void __launch_bounds__(256) colsum_batch_rows_kernel(const CbArgs a) 
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (c < J.cols) {
         if (J.dtype == MMAE_BF16) s = cb_rows((const uint16_t*)J.src, J.rows, J.ld, c, J.cols, sp, J.ns, w, vec_ok);
+        else if (J.dtype == MMAE_F16) s = cb_rows((const h16_t*)J.src, J.rows, J.ld, c, J.cols, sp, J.ns, w, vec_ok);
         else s = cb_rows((const float*)J.src, J.rows, J.ld, c, J.cols, sp, J.ns, w, vec_ok);
     }
     red[w][lane] = s;
@@ -721,11 +744,12 @@ __global__ void __launch_bounds__(256) colsum_batch_reduce_kernel(const CbArgs a
     red[w][lane] = a0;
     __syncthreads();
     if (w == 0) {
+        const float us = h16_grad_unscale(J.unscale);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int cc = c + k;
             if (cc >= J.cols) break;
-            const float v = (red[0][lane][k] + red[1][lane][k]) + (red[2][lane][k] + red[3][lane][k]);
+            const float v = ((red[0][lane][k] + red[1][lane][k]) + (red[2][lane][k] + red[3][lane][k])) * us;
             const int seg = cc / J.seg_w;
             float* o = J.dst[seg];
             if (o) { o += cc - seg * J.seg_w; *o = a.accumulate ? *o + v : v; }
@@ -758,11 +782,11 @@ int mmae_colsum_batch(const mmae_colsum_job* jobs, int n, int accumulate, float*
         const mmae_colsum_job& q = jobs[i];
         MMAE_REQUIRE(q.src && q.rows > 0 && q.cols > 0 && q.seg_w > 0 && q.nseg >= 1 && q.nseg <= 8 && (int64_t)q.seg_w * q.nseg >= q.cols,
                      "colsum_batch: bad job");
-        MMAE_REQUIRE(q.dtype == MMAE_F32 || q.dtype == MMAE_BF16, "colsum_batch: bad dtype");
-        MMAE_REQUIRE(!(q.ld % 4 == 0 && q.cols % 4 == 0) || ((uintptr_t)q.src % (q.dtype == MMAE_BF16 ? 8 : 16)) == 0, "colsum_batch: unaligned source");
+        MMAE_REQUIRE(q.dtype == MMAE_F32 || q.dtype == MMAE_BF16 || q.dtype == MMAE_F16, "colsum_batch: bad dtype");
+        MMAE_REQUIRE(!(q.ld % 4 == 0 && q.cols % 4 == 0) || ((uintptr_t)q.src % (q.dtype == MMAE_F32 ? 16 : 8)) == 0, "colsum_batch: unaligned source");
         CbJob& J = a.j[i];
         J.src = q.src; J.rows = q.rows; J.ld = q.ld; J.dtype = q.dtype; J.cols = q.cols; J.seg_w = q.seg_w;
-        J.ns = cb_nsplit(q.rows); J.group0 = groups; J.ws_off = (int)off;
+        J.ns = cb_nsplit(q.rows); J.group0 = groups; J.ws_off = (int)off; J.unscale = q.unscale;
         for (int k = 0; k < 8; ++k) J.dst[k] = k < q.nseg ? q.dst[k] : nullptr;
         const int ncg = (q.cols + 255) / 256;
         groups += ncg; blocks += ncg * J.ns;
@@ -775,7 +799,7 @@ int mmae_colsum_batch(const mmae_colsum_job* jobs, int n, int accumulate, float*
             const mmae_colsum_job& q = jobs[i];
             ColDst d = {};
             for (int k = 0; k < q.nseg; ++k) d.dst[k] = q.dst[k];
-            d.seg_w = q.seg_w;
+            d.seg_w = q.seg_w; d.unscale = q.unscale;
             MMAE_REQUIRE(ws_elems >= mmae_colsum_ws_elems(q.rows, q.cols), "colsum_batch: workspace too small for the per-job form");
             const int rc = colsum_impl(q.src, q.dtype, q.rows, q.cols, q.ld, d, accumulate, ws, stream);
             if (rc) return rc;
@@ -824,6 +848,20 @@ int mmae_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream) 
     if (n == 0) return 0;
     hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, dst, (long long)n);
     return mmae_check_launch("cast_bf16_to_f32");
+}
+int mmae_cast_f32_to_f16(const float* src, void* dst, int64_t n, const float* scale_amax, void* stream) {
+    MMAE_REQUIRE(src && dst && n >= 0, "cast: bad argument");
+    MMAE_REQUIRE(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 8 == 0), "cast: unaligned");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(cast_f16_kernel<true>, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const void*)src, dst, (long long)n, scale_amax);
+    return mmae_check_launch("cast_f32_to_f16");
+}
+int mmae_cast_f16_to_f32(const void* src, float* dst, int64_t n, const float* scale_amax, void* stream) {
+    MMAE_REQUIRE(src && dst && n >= 0, "cast: bad argument");
+    MMAE_REQUIRE(((uintptr_t)src % 8 == 0) && ((uintptr_t)dst % 16 == 0), "cast: unaligned");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(cast_f16_kernel<false>, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, src, (void*)dst, (long long)n, scale_amax);
+    return mmae_check_launch("cast_f16_to_f32");
 }
 int mmae_transpose_cast(const float* src, void* dst, int dst_dtype, int rows, int cols, void* stream) {
     MMAE_REQUIRE(src && dst && rows > 0 && cols > 0, "transpose_cast: bad argument");

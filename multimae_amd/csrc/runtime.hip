@@ -58,6 +58,7 @@ int mmae_check_launch(const char* what) {
 }
 
 int mmae_gemm_bf16_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hipStream_t st);
+int mmae_gemm_bf16_pp_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hipStream_t st);
 int mmae_gemm_f32_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st);
 int mmae_gemm_f32x3_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st);
 int mmae_gemm_mxfp8_impl(const mmae_gemm_desc* d, const GemmArgs& g, hipStream_t st);
@@ -179,10 +180,13 @@ int mmae_gemm_ex(const mmae_gemm_desc* d, void* stream, int timing_cls, double f
     MMAE_REQUIRE(d && d->A && d->B && d->C, "gemm: null operand");
     MMAE_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: empty problem");
     MMAE_REQUIRE(d->batch >= 1 && d->batch <= 65535 && d->batch_inner >= 1, "gemm: bad batch");
-    MMAE_REQUIRE(d->ab_dtype == MMAE_F32 || d->ab_dtype == MMAE_BF16 || d->ab_dtype == MMAE_F32X3 || d->ab_dtype == MMAE_F32F16 || d->ab_dtype == MMAE_MXFP8,
-                 "gemm: bad ab_dtype");
-    MMAE_REQUIRE(!d->a_amax || d->ab_dtype == MMAE_F32F16, "gemm: a_amax is an MMAE_F32F16 option");
-    MMAE_REQUIRE(d->c_dtype == MMAE_F32 || d->c_dtype == MMAE_BF16, "gemm: bad c_dtype");
+    MMAE_REQUIRE(d->ab_dtype == MMAE_F32 || d->ab_dtype == MMAE_BF16 || d->ab_dtype == MMAE_F32X3 || d->ab_dtype == MMAE_F32F16 || d->ab_dtype == MMAE_MXFP8 ||
+                 d->ab_dtype == MMAE_F16, "gemm: bad ab_dtype");
+    const bool h16 = d->ab_dtype == MMAE_F16;
+    MMAE_REQUIRE(!d->a_amax || d->ab_dtype == MMAE_F32F16 || (h16 && d->c_dtype == MMAE_F32), "gemm: a_amax is an MMAE_F32F16 option (MMAE_F16: with an f32 C)");
+    MMAE_REQUIRE(d->c_dtype == MMAE_F32 || d->c_dtype == (h16 ? MMAE_F16 : MMAE_BF16), "gemm: bad c_dtype (16-bit C: the operands' format)");
+    MMAE_REQUIRE(!d->aux || d->aux_dtype == MMAE_F32 || d->aux_dtype == (h16 ? MMAE_F16 : MMAE_BF16), "gemm: bad aux_dtype (16-bit aux: the operands' format)");
+    if (h16 && (d->batch != 1 || d->split_k > 1 || d->a_colsum || d->a_trans)) { mmae_set_error("gemm(f16): unbatched, unsplit products with k-contiguous A only"); return MMAE_ESUPPORT; }
     MMAE_REQUIRE(!(d->accumulate && d->c_dtype != MMAE_F32), "gemm: accumulate needs f32 C");
     MMAE_REQUIRE(!(d->epi != MMAE_EPI_NONE && !d->aux), "gemm: epilogue needs aux");
     MMAE_REQUIRE(!(d->resid && d->batch != 1), "gemm: residual is unbatched only");
@@ -213,6 +217,7 @@ int mmae_gemm_ex(const mmae_gemm_desc* d, void* stream, int timing_cls, double f
     g.dephase = env_dephase;
     g.scA = d->a_scale; g.scB = d->b_scale;
     g.a_amax = d->a_amax;
+    g.h16 = h16 ? 1 : 0;
     g.qout = (unsigned char*)d->q_out; g.qsc = (unsigned char*)d->q_scale; g.ldq = d->ldq;
     MMAE_REQUIRE(!d->q_out || d->ab_dtype == MMAE_MXFP8, "gemm: q_out is an MX-fp8 product option");
     MMAE_REQUIRE(!d->colsum_part || ((d->epi == MMAE_EPI_DGELU || d->epi == MMAE_EPI_MUL) && !d->bias && !d->resid && !d->accumulate && d->batch == 1 && d->split_k <= 1 &&
@@ -232,7 +237,7 @@ int mmae_gemm_ex(const mmae_gemm_desc* d, void* stream, int timing_cls, double f
         hipEvent_t a; hipStream_t st; double flop; int cls;
         ~TimingGuard() { mmae_timing_end(a, st, flop, cls); }
     } t_guard{t_ev, st, 2.0 * d->M * d->N * d->K * d->batch * flop_scale,
-              timing_cls >= 0 ? timing_cls : (d->ab_dtype == MMAE_BF16 ? 0 : (d->ab_dtype == MMAE_MXFP8 ? 2 : 1))};
+              timing_cls >= 0 ? timing_cls : (d->ab_dtype == MMAE_BF16 ? 0 : (d->ab_dtype == MMAE_MXFP8 ? 2 : 1))};      // (MMAE_F16: the fp32 adapters' class)
     // split-K: the dW-type products (small M x N, K = all rows of the batch) would otherwise occupy
     // a handful of the 256 CUs.  Each K slice writes a dense f32 partial slab into the caller's
     // workspace; a second launch sums the slabs into C in a fixed order (deterministic).
@@ -252,6 +257,7 @@ int mmae_gemm_ex(const mmae_gemm_desc* d, void* stream, int timing_cls, double f
     int code = 0, unused = 0;
     gemm_plan(d, &code, &unused);
     g.acs = nullptr;
+    if (h16) return mmae_gemm_bf16_pp_impl(d, g, 9, st);    // fp16 storage: the 256 x 256 ping-pong tile, compiled flavours only
     if (d->a_colsum) {
         MMAE_REQUIRE(d->ab_dtype == MMAE_BF16 && d->a_trans && d->batch == 1 && code == 9,
                      "gemm: a_colsum needs a bf16, a_trans, unbatched product on the 256x256 ping-pong kernel (see mmae_gemm_plan)");

@@ -28,7 +28,7 @@ _state = {
     'direct_grads': False,           # backward accumulates straight into p.grad and returns None
     'adapter_streams': False,
     'wgrad_stream': False,           # direct-grad mode: weight-gradient GEMMs / bias column sums on a side stream per compute stream        # run the independent output adapters on separate HIP streams
-    'fp32_adapter_gemm': 'f16',      # GEMMs of fp32_output_adapters in bf16 speed mode: 'f16' (fp16 operands = TF32's significand, one MFMA) | 'x3' (split bf16, three) | 'exact'
+    'fp32_adapter_gemm': 'h16',      # fp32_output_adapters in bf16 speed mode: 'h16' (fp16 STORAGE: the bf16 pipeline's kernels with TF32's significand) | 'f16' (f32 tensors, fp16 operands) | 'x3' (split bf16) | 'exact'
     'patch_domain_loss': __import__('os').environ.get('MMAE_PATCH_LOSS', '1') != '0',
 }
 
@@ -248,17 +248,26 @@ def fp32_adapter_gemm() -> str:
 
 
 def set_fp32_adapter_gemm(mode: str) -> None:
-    """How the Linear products of fp32_output_adapters are multiplied in the bf16 speed mode (activations, LayerNorm, softmax, losses
-    stay f32 either way):
-    'f16' (default, round 4): both operands rounded to fp16 -- an 11-bit significand, exactly TF32's, what the reference's fp32
-          adapters ran at on A100 (torch 1.10: allow_tf32) -- ONE MFMA per tile step, fp32 accumulation.  Gradient operands are
+    """How fp32_output_adapters run in the bf16 speed mode (residual stream, LayerNorm statistics, softmax, losses and every parameter
+    gradient are f32 in all of them):
+    'h16' (default, round 4): fp16 STORAGE (mmae.h MMAE_F16).  The reference runs these adapters with autocast off, i.e. f32 tensors whose
+          matmul inputs the A100 rounded to TF32's 11-bit significand (torch 1.10: allow_tf32).  Here everything that is only ever a
+          matmul / attention input -- LayerNorm outputs, q / k / v, attention output, the MLP's hidden activations, and the matching
+          gradient tensors -- is STORED with that significand (IEEE half) instead of rounded on every read, so the adapter runs on the
+          bf16 pipeline's kernels (ping-pong GEMMs with fused epilogues, the grouped weight-gradient launch, LDS-DMA attention) with half
+          the HBM traffic: -1.5 ms of a 30.9 ms cfg3 step, per-tensor gradient parity unchanged (profiles/r04_h16_*).  Gradients are kept in
+          units of S = 2^(4 - floor(log2 m)), m = max_b |d loss / d logit| as the cross-entropy kernel bounds it before writing (any other
+          gradient source: its largest element), and multiplied by 1/S where they leave as f32.  Needs the composite adapter call and
+          widths that are multiples of 32 (patch row: of 8); anything else runs as 'f16'.
+    'f16': f32 tensors in memory, both operands of every Linear product rounded to fp16 -- an 11-bit significand, exactly TF32's, what the reference's fp32
+          on their way into ONE MFMA per tile step, fp32 accumulation.  Gradient operands are
           pre-scaled by a power of two taken from the loss gradient's largest element (written by the masked-loss backward
           kernel), so fp16's exponent range is no limit; when no such amax exists (a loss on the image tensor instead of the
           adapter's patch rows) the gradient products run as 'x3'.  The attention cores stay 'x3'.
     'x3': f32 operands multiplied as split bf16 (a_hi.b_hi + a_hi.b_lo + a_lo.b_hi, fp32 accumulate; ~16 mantissa bits,
           above TF32), three MFMAs per tile step.
     'exact': f32-input MFMA (bit-level fmaf chain, 1/16 the bf16 rate)."""
-    assert mode in ('f16', 'x3', 'exact')
+    assert mode in ('h16', 'f16', 'x3', 'exact')
     _state['fp32_adapter_gemm'] = mode
 
 

@@ -568,6 +568,13 @@ def _adapter_cu_share():
         ops.gemm_cu_reserve(prev)
 
 
+def _f32_mode(cfg) -> str:
+    """ops.f32_gemm_mode of an adapter call: 'h16' (fp16 storage) is a property of the composite call; whatever runs outside it (a geometry
+    the composite does not take, single launches) uses the fp16-operand products on f32 tensors"""
+    m = getattr(cfg, 'f32_gemm', 'exact')
+    return 'f16' if m == 'h16' else m
+
+
 class SpatialAdapterFn(torch.autograd.Function):
     """forward(cfg, enc[B,NC,Denc] f32, ids_keep, ids_restore, *params)
 
@@ -585,7 +592,7 @@ class SpatialAdapterFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         cfg.handle = None
         cfg.lazy_fill = None
-        with ops.f32_gemm_mode(getattr(cfg, 'f32_gemm', 'exact')), _adapter_cu_share():
+        with ops.f32_gemm_mode(_f32_mode(cfg)), _adapter_cu_share():
             img = SpatialAdapterFn._forward(ctx, cfg, enc, ids_keep, ids_restore, *params)
         token = img.new_empty(1)
         if cfg.handle is not None:
@@ -595,7 +602,7 @@ class SpatialAdapterFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_img: Optional[Tensor], d_token: Optional[Tensor] = None):
-        with ops.f32_gemm_mode(getattr(ctx.cfg, 'f32_gemm', 'exact')), _adapter_cu_share():
+        with ops.f32_gemm_mode(_f32_mode(ctx.cfg)), _adapter_cu_share():
             return SpatialAdapterFn._backward(ctx, d_img)
 
     @staticmethod
@@ -621,17 +628,26 @@ class SpatialAdapterFn(torch.autograd.Function):
         ctx.comp = None
         KP = cfg.C * cfg.ph * cfg.pw
         xattn = bool(getattr(cfg, 'use_xattn', True))
-        if xattn and ops.adapter_composite_ok(enc2, act, heads, D, n_q, NC, cfg.depth, T, KP):
+        # fp32 adapter, engine.set_fp32_adapter_gemm('h16'): activations / saved tensors / gradients of the composite call stored as fp16
+        # (mmae.h MMAE_F16) -- the bf16 pipeline's kernels and traffic with TF32's significand; residual stream, statistics, losses f32
+        h16 = (act == torch.float32 and getattr(cfg, 'f32_gemm', 'exact') == 'h16' and xattn
+               and ops.adapter_h16_ok(enc2, heads, D, f1w.shape[0], n_q, NC, cfg.depth, T, KP))
+        ctx.h16 = h16
+        if xattn and (h16 or ops.adapter_composite_ok(enc2, act, heads, D, n_q, NC, cfg.depth, T, KP)):
             # the whole adapter as ONE library call (same kernels, same order)
             w_list = [wc(qw), wc(kvw), wc(pw_), wc(f1w), wc(f2w)] + [wc(blocks[12 * l + i]) for l in range(cfg.depth) for i in (2, 4, 8, 10)] \
                 + [wc(ow), wc(pcw)]
+            store = None
+            if h16:
+                store, enc_act = torch.float16, None
+                w_list = list(ops.h16_weights([w.detach() for w in w_list]).refresh())
             p_list = [qb, kvb, pb, cnw, cnb, qnw, qnb, onw, onb, f1b, f2b] \
                 + [blocks[12 * l + i] for l in range(cfg.depth) for i in (0, 1, 3, 5, 6, 7, 9, 11)] + [ob, pcb]
             # the image is an API output nothing on the training path reads (the losses work on the patch rows): allocate it, write
             # it on first use (lazy.LazyPrediction, wrapped around the result by SpatialOutputAdapter.forward)
             lazy_img = engine.lazy_predictions() and engine.capturing() is None
             img, state = ops.adapter_fwd(enc.contiguous(), enc_act, ids_keep, ids_restore, cfg, w_list, p_list, mask_token.detach().reshape(D),
-                                         [None if t is None else t.detach().reshape(D) for t in temb], want_img=not lazy_img)
+                                         [None if t is None else t.detach().reshape(D) for t in temb], want_img=not lazy_img, store=store)
             if lazy_img:
                 img = torch.empty((B, cfg.C, cfg.nh * cfg.ph, cfg.nw * cfg.pw), device=enc.device, dtype=torch.float32)
                 ev = torch.cuda.current_stream().record_event() if enc.is_cuda else None
@@ -646,8 +662,8 @@ class SpatialAdapterFn(torch.autograd.Function):
             ctx.cfg, ctx.params, ctx.ids = cfg, params, (ids_keep, ids_restore)
             ctx.dims = (B, NC, Denc, n_keep, n_q, T)
             if save and engine.patch_domain_loss():
-                cfg.handle = PatHandle(state.pat, cfg.C, cfg.nh, cfg.nw, cfg.ph, cfg.pw, act)
-                if act == torch.float32 and getattr(cfg, 'f32_gemm', 'exact') == 'f16':
+                cfg.handle = PatHandle(state.pat, cfg.C, cfg.nh, cfg.nw, cfg.ph, cfg.pw, torch.float16 if h16 else act)
+                if h16 or (act == torch.float32 and getattr(cfg, 'f32_gemm', 'exact') == 'f16'):
                     cfg.handle.dy_amax = torch.zeros(1, device=enc.device, dtype=torch.float32)
             return img
         if enc_act is None:
@@ -721,6 +737,12 @@ class SpatialAdapterFn(torch.autograd.Function):
                 h.d_pat, h.pat = None, None
             elif d_img is None:                                      # nothing reached this adapter
                 d_img = torch.zeros((B, cfg.C, cfg.nh * cfg.ph, cfg.nw * cfg.pw), device=params[0].device, dtype=torch.float32)
+            if getattr(ctx, 'h16', False) and (d_pat is None or d_pat.dtype != torch.float16):
+                # the gradient did not come from a loss kernel that writes scaled fp16 rows (image-domain gradient, a pixel loss,
+                # several losses added up): bring it into the adapter's units here -- rows, their largest element, one scaled cast
+                rows = d_pat if d_pat is not None else ops.patchify(d_img.contiguous().float(), cfg.C, cfg.nh, cfg.nw, cfg.ph, cfg.pw, torch.float32)
+                dy_amax = rows.detach().abs().amax().reshape(1).float()
+                d_pat, d_img = ops.cast_f16(rows, scale_amax=dy_amax), None
             d_enc, keep = ops.adapter_bwd(ctx.comp, d_img, d_pat, [None if t is None else t.view(-1) for t in dsts], acc,
                                           sink.side.cuda_stream if use_side else None, dy_amax=dy_amax)
             ctx.comp = None
@@ -1028,6 +1050,12 @@ class MaskedCEFn(torch.autograd.Function):
         return d, None, None, None, None
 
 
+def _h16_rows_to_f32(h: PatHandle) -> None:
+    """gradient rows an fp16-storage adapter already received (scaled fp16, from the cross-entropy kernel) back to plain f32"""
+    if h.d_pat is not None and h.d_pat.dtype == torch.float16:
+        h.d_pat = ops.cast_f16(h.d_pat, scale_amax=h.dy_amax)
+
+
 class MaskedPixelLossPatFn(torch.autograd.Function):
     """MaskedMSELoss / MaskedL1Loss on an output adapter's patch rows (PatHandle): same per-pixel arithmetic as
     MaskedPixelLossFn, gradient handed to the adapter as patch rows in its activation dtype."""
@@ -1056,11 +1084,16 @@ class MaskedPixelLossPatFn(torch.autograd.Function):
         kind, norm_pix, patch, B, C, H, W = ctx.args
         if (target._version, mask._version) != versions:
             raise RuntimeError('a tensor saved for the masked-loss backward was modified in place')
-        d_pat = torch.empty((h.pat.shape[0], h.ld()), device=h.pat.device, dtype=h.act)
+        # (fp16-storage adapter: f32 rows here, the adapter's backward scales them into its units -- only the cross entropy bounds its
+        # gradient before computing it)
+        row_t = torch.float32 if h.act == torch.float16 else h.act
+        _h16_rows_to_f32(h)
+        d_pat = torch.empty((h.pat.shape[0], h.ld()), device=h.pat.device, dtype=row_t)
         up = g.contiguous().float().reshape(1)
         ops.check(_lib.load().mmae_masked_pixel_loss_pat_bwd(h.pat.data_ptr(), target.data_ptr(), mask.data_ptr(), kind, int(norm_pix), B, C, H, W,
                                                              patch, ops._p(stats), per_sample.data_ptr(), loss.data_ptr(), up.data_ptr(),
-                                                             d_pat.data_ptr(), ops.dcode(h.act), d_pat.stride(0), ops._p(h.dy_amax), ops._stream()),
+                                                             d_pat.data_ptr(), ops.dcode(row_t), d_pat.stride(0),
+                                                             None if h.act == torch.float16 else ops._p(h.dy_amax), ops._stream()),
                   'masked_pixel_loss_pat_bwd')
         h.d_pat = d_pat if h.d_pat is None else h.d_pat.add_(d_pat)        # several losses on one prediction: their gradients add
         return up.new_empty(1), None, None, None, None, None, None
@@ -1092,10 +1125,17 @@ class MaskedCEPatFn(torch.autograd.Function):
         patch, B, C, H, W, smooth = ctx.args
         if (target._version, mask._version) != versions:
             raise RuntimeError('a tensor saved for the masked-loss backward was modified in place')
-        d_pat = torch.empty((h.pat.shape[0], h.ld()), device=h.pat.device, dtype=h.act)
+        # fp16-storage adapter: the first (normally the only) loss writes scaled fp16 rows and the bound they are scaled by (dy_amax);
+        # a second loss on the same prediction continues in f32 rows
+        row_t = h.act
+        if h.act == torch.float16 and h.d_pat is not None:
+            _h16_rows_to_f32(h)
+            row_t = torch.float32
+        d_pat = torch.empty((h.pat.shape[0], h.ld()), device=h.pat.device, dtype=row_t)
         up = g.contiguous().float().reshape(1)
         ops.check(_lib.load().mmae_masked_ce_pat_bwd(h.pat.data_ptr(), target.data_ptr(), mask.data_ptr(), B, C, H, W, patch, smooth, lse.data_ptr(),
-                                                     per_sample.data_ptr(), loss.data_ptr(), up.data_ptr(), d_pat.data_ptr(), ops.dcode(h.act),
-                                                     d_pat.stride(0), ops._p(h.dy_amax), ops._stream()), 'masked_ce_pat_bwd')
+                                                     per_sample.data_ptr(), loss.data_ptr(), up.data_ptr(), d_pat.data_ptr(), ops.dcode(row_t),
+                                                     d_pat.stride(0), None if (h.act == torch.float16 and row_t == torch.float32) else ops._p(h.dy_amax),
+                                                     ops._stream()), 'masked_ce_pat_bwd')
         h.d_pat = d_pat if h.d_pat is None else h.d_pat.add_(d_pat)
         return up.new_empty(1), None, None, None, None, None

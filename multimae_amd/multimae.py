@@ -275,7 +275,7 @@ class MultiMAE(nn.Module):
             kw = dict(encoder_tokens=encoder_tokens, input_info=input_info, ids_keep=ids_keep, ids_restore=ids_restore,
                       act_dtype=torch.float32 if fp32 else None, on_done=self._adapter_done_cb(domain),
                       encoder_tokens_act=None if fp32 else enc_bf16,
-                      f32_gemm=engine.fp32_adapter_gemm() if (fp32 and speed and engine.fp32_adapter_gemm() in ('x3', 'f16')) else 'exact')
+                      f32_gemm=engine.fp32_adapter_gemm() if (fp32 and speed and engine.fp32_adapter_gemm() in ('x3', 'f16', 'h16')) else 'exact')
             if streams is None:
                 preds[domain] = self.output_adapters[domain](**kw)
             else:

@@ -14,7 +14,7 @@ import torch
 from . import _lib
 import contextlib
 
-from ._lib import BF16, F32, F32X3, F32F16, MXFP8, EPI_NONE, EPI_GELU, EPI_DGELU, EPI_GELU_G, EPI_MUL, AdapterDesc, BlockDesc, DwGroupDesc, GemmDesc, OptDesc, PatchSrc, StackDesc, check
+from ._lib import BF16, F16, F32, F32X3, F32F16, MXFP8, EPI_NONE, EPI_GELU, EPI_DGELU, EPI_GELU_G, EPI_MUL, AdapterDesc, BlockDesc, DwGroupDesc, GemmDesc, OptDesc, PatchSrc, StackDesc, check
 
 Tensor = torch.Tensor
 
@@ -30,6 +30,8 @@ def dcode(dtype: torch.dtype) -> int:
         return F32
     if dtype == torch.bfloat16:
         return BF16
+    if dtype == torch.float16:           # fp16 storage: an fp32 output adapter in engine.set_fp32_adapter_gemm('h16') mode
+        return F16
     raise TypeError(f'unsupported activation dtype {dtype}')
 
 
@@ -100,6 +102,9 @@ def gemm(A: Tensor, B: Tensor, C: Tensor, M: int, N: int, K: int, *, lda: int, l
         d.a_amax = _p(a_amax)
     elif d.ab_dtype == F32 and _f32_split() and lda % 4 == 0 and ldb % 4 == 0:
         d.ab_dtype = F32X3
+    elif d.ab_dtype == F16:                                 # f32 C of a gradient product: multiplied by 1/S(a_amax)
+        d.a_amax = _p(a_amax)
+        split_k = 1
     d.M, d.N, d.K = M, N, K
     d.a_trans, d.b_trans = int(a_trans), int(b_trans)
     d.lda, d.ldb, d.ldc = lda, ldb, ldc
@@ -283,13 +288,15 @@ def linear_dx(dy: Tensor, w: Tensor, out: Tensor, *, aux: Optional[Tensor] = Non
     return out
 
 
-def gemm_dw_group(problems: Sequence[tuple], accumulate: bool, split_k: int = 0) -> None:
-    """Up to 8 weight gradients in one launch (mmae_gemm_dw_group).  problems: (dy [rows, n_out] bf16, x [rows, k_in] bf16,
-    dw f32 [n_out, k_in] contiguous, db f32 [n_out] or None); all share `rows`."""
+def gemm_dw_group(problems: Sequence[tuple], accumulate: bool, split_k: int = 0, unscale: Optional[Tensor] = None) -> None:
+    """Up to 8 weight gradients in one launch (mmae_gemm_dw_group).  problems: (dy [rows, n_out] bf16 / fp16, x [rows, k_in] same,
+    dw f32 [n_out, k_in] contiguous, db f32 [n_out] or None); all share `rows`.  unscale (fp16 operands): the dy_amax scalar dy is scaled by."""
     d = DwGroupDesc()
-    d.n, d.rows, d.ab_dtype, d.accumulate, d.split_k = len(problems), problems[0][0].shape[0], BF16, int(accumulate), split_k
+    ab = problems[0][0].dtype
+    d.n, d.rows, d.ab_dtype, d.accumulate, d.split_k = len(problems), problems[0][0].shape[0], dcode(ab), int(accumulate), split_k
+    d.unscale = _p(unscale)
     for i, (dy, x, dw, db) in enumerate(problems):
-        assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32 and dw.is_contiguous()
+        assert ab in (torch.bfloat16, torch.float16) and dy.dtype == ab and x.dtype == ab and dw.dtype == torch.float32 and dw.is_contiguous()
         assert dy.shape[0] == d.rows and x.shape[0] == d.rows and dw.shape == (dy.shape[1], x.shape[1])
         q = d.p[i]
         q.dy, q.ldy, q.x, q.ldx, q.dw, q.db, q.n_out, q.k_in = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), _p(db), dy.shape[1], x.shape[1]
@@ -681,9 +688,12 @@ def x3_weights(w_list: Sequence[Tensor]) -> X3Weights:
 
 
 def adapter_fwd(enc: Tensor, enc_act: Optional[Tensor], ids_keep: Tensor, ids_restore: Tensor, cfg, w_list: Sequence[Tensor],
-                p_list: Sequence[Tensor], mask_token: Tensor, temb: Sequence[Optional[Tensor]], want_img: bool = True):
+                p_list: Sequence[Tensor], mask_token: Tensor, temb: Sequence[Optional[Tensor]], want_img: bool = True,
+                store: Optional[torch.dtype] = None):
     """SpatialOutputAdapter.forward in one library call.  enc f32 [B, NC, Denc]; w_list / p_list in mmae_adapter_desc order.
+    store: the activation dtype in memory when it is not cfg.act (torch.float16: an fp32 adapter in 'h16' mode, w_list fp16 copies).
     Returns (img or None, AdapterState)."""
+    act = store if store is not None else cfg.act
     lib = _lib.load()
     B, NC, Denc = enc.shape
     T = len(cfg.task_offsets) - 1
@@ -692,19 +702,19 @@ def adapter_fwd(enc: Tensor, enc_act: Optional[Tensor], ids_keep: Tensor, ids_re
     d.B, d.NC, d.Denc, d.D, d.heads, d.Hd, d.depth, d.T, d.q_task, d.G, d.n_q = (B, NC, Denc, cfg.D, cfg.heads, w_list[3].shape[0], cfg.depth, T,
                                                                                   cfg.q_task, cfg.G, n_q)
     d.C, d.nh, d.nw, d.ph, d.pw = cfg.C, cfg.nh, cfg.nw, cfg.ph, cfg.pw
-    d.act_dtype, d.f32_gemm, d.eps = dcode(cfg.act), _f32_code(), cfg.eps
+    d.act_dtype, d.f32_gemm, d.eps = dcode(act), _f32_code(), cfg.eps
     offs = _i32_array(cfg.task_offsets)
     d.task_offsets_host = ctypes.cast(offs, ctypes.c_void_p)
     probe = (w_list[0].data_ptr(), w_list[-1].data_ptr(), p_list[0].data_ptr(), p_list[-1].data_ptr(), mask_token.data_ptr())
-    w_arr, p_arr, te_arr = _PTRS.get(('adapter', id(p_list[0]), len(w_list), cfg.act), probe, lambda: (
+    w_arr, p_arr, te_arr = _PTRS.get(('adapter', id(p_list[0]), len(w_list), act), probe, lambda: (
         _ptr_arr([w.data_ptr() for w in w_list]), _ptr_arr([t.data_ptr() for t in p_list]), _ptr_arr([_p(t) for t in temb])))
     d.w, d.p, d.task_emb = ctypes.cast(w_arr, ctypes.c_void_p), ctypes.cast(p_arr, ctypes.c_void_p), ctypes.cast(te_arr, ctypes.c_void_p)
     d.mask_token, d.pos = mask_token.data_ptr(), cfg.pos.data_ptr()
     d.enc = enc.data_ptr()
-    d.enc_act = enc.data_ptr() if cfg.act == torch.float32 else _p(enc_act)
+    d.enc_act = enc.data_ptr() if act == torch.float32 else _p(enc_act)
     d.ids_keep, d.ids_restore = ids_keep.data_ptr(), ids_restore.data_ptr()
     x3 = None
-    if _X3_PRESPLIT and cfg.act == torch.float32 and _F32_GEMM[0] == 'x3' and all(w.dtype == torch.float32 and w.is_contiguous() and w.numel() % (8 * w.shape[0]) == 0 for w in w_list):
+    if _X3_PRESPLIT and act == torch.float32 and _F32_GEMM[0] == 'x3' and all(w.dtype == torch.float32 and w.is_contiguous() and w.numel() % (8 * w.shape[0]) == 0 for w in w_list):
         x3 = x3_weights(w_list)                 # forward / dX products of this fp32 adapter as ONE bf16 product over 3 K each
         x3.refresh()
         d.x3_w, d.x3_n = ctypes.cast(x3.triples, ctypes.c_void_p), len(w_list)
@@ -817,9 +827,9 @@ def colsum_scatter(dy: Tensor, seg_w: int, dsts: Sequence[Optional[Tensor]], acc
                                   len(dsts), int(accumulate), ws.data_ptr(), _stream()), 'colsum_scatter')
 
 
-def colsum_batch(jobs: Sequence[tuple], accumulate: bool) -> None:
-    """Up to 8 colsum_scatter reductions in ONE launch (mmae_colsum_batch).  jobs: (src [rows, cols] f32 / bf16 (row stride = stride(0)),
-    seg_w, [dst tensors f32 or None])."""
+def colsum_batch(jobs: Sequence[tuple], accumulate: bool, unscale: Optional[Tensor] = None) -> None:
+    """Up to 8 colsum_scatter reductions in ONE launch (mmae_colsum_batch).  jobs: (src [rows, cols] f32 / bf16 / fp16 (row stride = stride(0)),
+    seg_w, [dst tensors f32 or None]).  unscale: the dy_amax scalar of an fp16-storage adapter whose (scaled) gradients the sources hold."""
     from ._lib import ColsumJob
     assert 1 <= len(jobs) <= 8
     arr = (ColsumJob * len(jobs))()
@@ -830,6 +840,7 @@ def colsum_batch(jobs: Sequence[tuple], accumulate: bool) -> None:
         for i, d in enumerate(dsts):
             assert d is None or (d.dtype == torch.float32 and d.is_contiguous())
             q.dst[i] = _p(d)
+        q.unscale = _p(unscale)
     lib = _lib.load()
     n_ws = int(lib.mmae_colsum_batch_ws_elems(ctypes.cast(arr, ctypes.c_void_p), len(jobs)))
     ws = torch.empty((max(n_ws, 4),), device=jobs[0][0].device, dtype=torch.float32)
@@ -867,6 +878,76 @@ def cast(x: Tensor, dtype: torch.dtype) -> Tensor:
     else:
         check(lib.mmae_cast_bf16_to_f32(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), 'cast_bf16_to_f32')
     return y
+
+
+def cast_f16(x: Tensor, scale_amax: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """fp16 storage (mmae.h MMAE_F16): f32 -> fp16 (times S(scale_amax): a loss gradient entering an 'h16' adapter's backward) or
+    fp16 -> f32 (times 1/S).  scale_amax: the adapter's dy_amax device scalar, None = values as they are."""
+    _require_gpu(x, 'cast input')
+    x = x.contiguous()
+    lib = _lib.load()
+    if x.dtype == torch.float32:
+        y = out if out is not None else torch.empty(x.shape, device=x.device, dtype=torch.float16)
+        assert y.dtype == torch.float16 and y.numel() == x.numel() and y.is_contiguous()
+        check(lib.mmae_cast_f32_to_f16(x.data_ptr(), y.data_ptr(), x.numel(), _p(scale_amax), _stream()), 'cast_f32_to_f16')
+        return y
+    assert x.dtype == torch.float16
+    y = out if out is not None else torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    check(lib.mmae_cast_f16_to_f32(x.data_ptr(), y.data_ptr(), x.numel(), _p(scale_amax), _stream()), 'cast_f16_to_f32')
+    return y
+
+
+class H16Weights:
+    """fp16 copies of the f32 weights of an fp32 output adapter in 'h16' mode, refreshed once per forward.  The weights of one adapter
+    sit close together in the parameter arena: one cast launch over the range that spans them (biases and LayerNorm vectors in
+    between are cast along, unused) instead of one per weight; scattered weights fall back to a launch each."""
+
+    def __init__(self, w_list: Sequence[Tensor]):
+        self.ws = list(w_list)
+        dev = self.ws[0].device
+        self.probe = tuple(w.data_ptr() for w in self.ws)
+        lo = min(self.probe)
+        hi = max(w.data_ptr() + w.numel() * 4 for w in self.ws)
+        total = sum(w.numel() for w in self.ws)
+        same = all(w.dtype == torch.float32 and w.is_contiguous() and w.untyped_storage().data_ptr() == self.ws[0].untyped_storage().data_ptr()
+                   for w in self.ws)
+        self.span = same and lo % 16 == 0 and (hi - lo) // 4 <= 2 * total + 4096
+        if self.span:
+            n = (hi - lo) // 4
+            self.src = torch.empty(0, device=dev, dtype=torch.float32).set_(self.ws[0].untyped_storage(), (lo - self.ws[0].untyped_storage().data_ptr()) // 4, (n,))
+            self.buf = torch.empty((n,), device=dev, dtype=torch.float16)
+            self.copies = [self.buf[(w.data_ptr() - lo) // 4:(w.data_ptr() - lo) // 4 + w.numel()].view(w.shape) for w in self.ws]
+        else:
+            self.copies = [torch.empty(w.shape, device=dev, dtype=torch.float16) for w in self.ws]
+
+    def matches(self, w_list: Sequence[Tensor]) -> bool:
+        return self.probe == tuple(w.data_ptr() for w in w_list)
+
+    def refresh(self) -> Sequence[Tensor]:
+        if self.span:
+            cast_f16(self.src, out=self.buf)
+        else:
+            for w, c in zip(self.ws, self.copies):
+                cast_f16(w.detach(), out=c)
+        return self.copies
+
+
+_H16_SETS = {}
+
+
+def h16_weights(w_list: Sequence[Tensor]) -> H16Weights:
+    key = id(w_list[0])
+    s = _H16_SETS.get(key)
+    if s is None or not s.matches(w_list):
+        s = H16Weights(w_list)
+        _H16_SETS[key] = s
+    return s
+
+
+def adapter_h16_ok(enc: Tensor, heads: int, D: int, Hd: int, n_q: int, NC: int, depth: int, T: int, KP: int) -> bool:
+    """fp16 storage for an fp32 output adapter: the composite call with every width on the fp16 ping-pong kernels' grid"""
+    return (adapter_composite_ok(enc, torch.bfloat16, heads, D, n_q, NC, depth, T, KP) and D % 32 == 0 and Hd % 32 == 0
+            and enc.shape[-1] % 32 == 0 and KP % 8 == 0)
 
 
 def cast_into(src: Tensor, dst: Tensor) -> None:
@@ -921,7 +1002,7 @@ def _ptr(v: AttnView) -> int:
 def _fusable(q: AttnView, k: AttnView, hd: int) -> bool:
     if not (_FUSED_ATTN[0] and hd in (32, 64) and q.N <= 256 and k.N <= 256):
         return False
-    if q.t.dtype == torch.bfloat16:
+    if q.t.dtype in (torch.bfloat16, torch.float16):
         return True
     # f32 activations: only where the surrounding GEMMs are split-bf16 too (fp32 adapters in speed mode); the backward's
     # eight hi/lo tiles must fit the 160 KB LDS
@@ -936,7 +1017,8 @@ def attention_fwd(q: AttnView, k: AttnView, v: AttnView, out: AttnView, B: int, 
     dev, act = q.t.device, q.t.dtype
     if _fusable(q, k, hd):
         lse = torch.empty((B, H, Nq), device=dev, dtype=torch.float32)
-        fwd = _lib.load().mmae_attn_fwd if act == torch.bfloat16 else (_lib.load().mmae_attn_fwd_f32f16 if f16 else _lib.load().mmae_attn_fwd_f32x3)
+        fwd = _lib.load().mmae_attn_fwd if act == torch.bfloat16 else (_lib.load().mmae_attn_fwd_f16 if act == torch.float16 else (
+            _lib.load().mmae_attn_fwd_f32f16 if f16 else _lib.load().mmae_attn_fwd_f32x3))
         check(fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), lse.data_ptr(), B, H, Nq, Nk, hd,
                                         Nq * q.ld, q.ld, Nk * k.ld, k.ld, Nk * v.ld, v.ld, Nq * out.ld, out.ld, scale, _stream()),
               'attn_fwd')
@@ -962,7 +1044,7 @@ def attention_bwd(q: AttnView, k: AttnView, v: AttnView, state, out: AttnView, d
         return
     if state[0] == 'fused':
         assert d_out.ld == out.ld
-        bwd = _lib.load().mmae_attn_bwd if q.t.dtype == torch.bfloat16 else _lib.load().mmae_attn_bwd_f32x3
+        bwd = _lib.load().mmae_attn_bwd if q.t.dtype == torch.bfloat16 else (_lib.load().mmae_attn_bwd_f16 if q.t.dtype == torch.float16 else _lib.load().mmae_attn_bwd_f32x3)
         check(bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(d_out), state[1].data_ptr(), _ptr(dq), _ptr(dk),
                                         _ptr(dv), B, H, Nq, Nk, hd, Nq * q.ld, q.ld, Nk * k.ld, k.ld, Nk * v.ld, v.ld, Nq * out.ld,
                                         out.ld, Nq * dq.ld, dq.ld, Nk * dk.ld, dk.ld, Nk * dv.ld, dv.ld, scale, _stream()), 'attn_bwd')

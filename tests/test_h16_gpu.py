@@ -1,0 +1,265 @@
+"""fp16 STORAGE (mmae.h MMAE_F16, engine.set_fp32_adapter_gemm('h16')): the kernels of the bf16 pipeline instantiated for IEEE-half tensors,
+each against an fp64 evaluation of the same fp16-rounded inputs; the gradient scale S = 2^(4 - floor(log2 amax)) and its removal at every
+f32 sink; the whole adapter against its f32-activation form."""
+import math
+
+import pytest
+import torch
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _S(amax: float) -> float:
+    return 2.0 ** (4 - math.floor(math.log2(amax)))
+
+
+def _gelu(x):
+    return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
+
+
+def _dgelu(x):
+    return 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+
+
+@pytest.mark.parametrize('shape', [(520, 264, 256), (50176 // 8, 1024, 256), (300, 2128, 256)])
+def test_gemm_f16_forward_flavours(shape):
+    from multimae_amd import ops
+    from multimae_amd._lib import EPI_GELU_G
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M)
+    A = torch.randn(M, K, generator=g).half()
+    W = (torch.randn(N, K, generator=g) * 0.05).half()
+    bias = torch.randn(N, generator=g) * 0.1
+    ref = A.double() @ W.double().t() + bias.double()
+    Ad, Wd, bd = A.to(DEV), W.to(DEV), bias.to(DEV)
+    # bias -> fp16
+    C = torch.empty(M, N, device=DEV, dtype=torch.float16)
+    ops.gemm(Ad, Wd, C, M, N, K, lda=K, ldb=K, ldc=N, bias=bd)
+    assert rel_err(C.cpu().double(), ref) < 4e-4                      # one fp16 rounding of the output
+    # bias + residual -> f32
+    R = torch.randn(M, N, generator=g)
+    C32 = torch.empty(M, N, device=DEV)
+    ops.gemm(Ad, Wd, C32, M, N, K, lda=K, ldb=K, ldc=N, bias=bd, resid=R.to(DEV), ldr=N)
+    assert rel_err(C32.cpu().double(), ref + R.double()) < 2e-6
+    ops.gemm(Ad, Wd, C32, M, N, K, lda=K, ldb=K, ldc=N, bias=bd)
+    assert rel_err(C32.cpu().double(), ref) < 2e-6
+    # bias + GELU -> fp16 activations, GELU'(pre-activation) -> fp16 aux
+    aux = torch.empty(M, N, device=DEV, dtype=torch.float16)
+    ops.gemm(Ad, Wd, C, M, N, K, lda=K, ldb=K, ldc=N, bias=bd, aux=aux, ldaux=N, epi=EPI_GELU_G)
+    assert rel_err(C.cpu().double(), _gelu(ref)) < 5e-4
+    assert rel_err(aux.cpu().double(), _dgelu(ref)) < 5e-4
+
+
+def test_gemm_f16_input_gradient_flavours_and_unscale():
+    from multimae_amd import ops
+    from multimae_amd._lib import EPI_MUL
+    M, N, K = 1000, 1024, 256                                     # dx[M, K] = dy[M, N] @ W[N, K]
+    g = torch.Generator().manual_seed(3)
+    amax = torch.tensor([3.3e-7])
+    S = _S(float(amax))
+    dy_true = torch.randn(M, N, generator=g) * 4e-8
+    dy = (dy_true * S).half()                                     # as the producers store it
+    W = (torch.randn(N, K, generator=g) * 0.05).half()
+    ref = dy.double() @ W.double()
+    dyd, Wd = dy.to(DEV), W.to(DEV)
+    out = torch.empty(M, K, device=DEV, dtype=torch.float16)
+    ops.gemm(dyd, Wd, out, M, K, N, lda=N, ldb=K, ldc=K, b_trans=True)
+    assert rel_err(out.cpu().double(), ref) < 4e-4
+    # x GELU' (stored derivative) + column-sum partials of the result
+    dg = torch.rand(M, K, generator=g).half()
+    part = torch.empty(ops.dx_colsum_part_shape(M, K), device=DEV)
+    ops.gemm(dyd, Wd, out, M, K, N, lda=N, ldb=K, ldc=K, b_trans=True, aux=dg.to(DEV), ldaux=K, epi=EPI_MUL, colsum_part=part)
+    r2 = ref * dg.double()
+    assert rel_err(out.cpu().double(), r2) < 5e-4
+    assert rel_err(part.sum(0).cpu().double(), r2.sum(0)) < 2e-4
+    # f32 output leaving the fp16-storage domain: times 1/S
+    o32 = torch.empty(M, K, device=DEV)
+    ops.gemm(dyd, Wd, o32, M, K, N, lda=N, ldb=K, ldc=K, b_trans=True, a_amax=amax.to(DEV))
+    assert rel_err(o32.cpu().double(), ref / S) < 2e-6
+    assert rel_err(o32.cpu().double(), dy_true.double() @ W.double()) < 6e-4      # TF32-class against the unrounded gradient
+
+
+def test_gemm_f16_contraction_not_a_multiple_of_32():
+    """out_proj's input gradient of the semseg adapter: dh[M, 256] = d_pat[M, 2128] @ W[2128, 256] -- the general address walk"""
+    from multimae_amd import ops
+    M, N, K = 1000, 2128, 256
+    g = torch.Generator().manual_seed(8)
+    dy = torch.randn(M, N, generator=g).half()
+    W = (torch.randn(N, K, generator=g) * 0.05).half()
+    out = torch.empty(M, K, device=DEV, dtype=torch.float16)
+    ops.gemm(dy.to(DEV), W.to(DEV), out, M, K, N, lda=N, ldb=K, ldc=K, b_trans=True)
+    assert rel_err(out.cpu().double(), dy.double() @ W.double()) < 4e-4
+
+
+def test_gemm_f16_rejects_what_is_not_compiled():
+    from multimae_amd import ops
+    A = torch.randn(300, 72, device=DEV).half()                  # forward product with K % 32 != 0
+    W = torch.randn(64, 72, device=DEV).half()
+    C = torch.empty(300, 64, device=DEV, dtype=torch.float16)
+    with pytest.raises(RuntimeError):
+        ops.gemm(A, W, C, 300, 64, 72, lda=72, ldb=72, ldc=64)
+
+
+@pytest.mark.parametrize('rows', [50176 // 4, 1000])
+def test_dw_group_f16_unscaled_weight_and_bias_gradients(rows):
+    from multimae_amd import ops
+    g = torch.Generator().manual_seed(rows)
+    amax = torch.tensor([1.7e-6])
+    S = _S(float(amax))
+    probs, refs = [], []
+    for n_out, k_in in [(256, 1024), (768, 256), (2128, 256)]:
+        dy = (torch.randn(rows, n_out, generator=g) * 1e-7 * S).half()
+        x = torch.randn(rows, k_in, generator=g).half()
+        dw = torch.full((n_out, k_in), 2e-5, device=DEV)
+        db = torch.full((n_out,), -1e-4, device=DEV)
+        probs.append((dy.to(DEV), x.to(DEV), dw, db))
+        refs.append((dy.double().t() @ x.double() / S, dy.double().sum(0) / S))
+    ops.gemm_dw_group(probs, accumulate=True, unscale=amax.to(DEV))
+    for (dy, x, dw, db), (rw, rb) in zip(probs, refs):
+        assert rel_err(dw.cpu().double() - 2e-5, rw) < 1e-4         # (f32 cancellation against what was there)
+        assert rel_err(db.cpu().double() + 1e-4, rb) < 1e-4
+    for p in probs:
+        p[2].zero_(); p[3].zero_()
+    ops.gemm_dw_group(probs, accumulate=False, unscale=amax.to(DEV))
+    for (dy, x, dw, db), (rw, rb) in zip(probs, refs):
+        assert rel_err(dw.cpu().double(), rw) < 3e-6
+        assert rel_err(db.cpu().double(), rb) < 3e-6
+
+
+def test_layernorm_colsum_and_casts_f16():
+    from multimae_amd import ops
+    g = torch.Generator().manual_seed(5)
+    R, D = 1001, 256
+    x = torch.randn(R, D, generator=g) * 2 + 0.3
+    w, b = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    y, mean, rstd = ops.layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, torch.float16)
+    xd = x.double()
+    mu, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+    xh = (xd - mu) / torch.sqrt(var + 1e-6)
+    assert y.dtype == torch.float16 and rel_err(y.cpu().double(), xh * w.double() + b.double()) < 4e-4
+    # backward: fp16 dy (scaled units), f32 residual gradient in, f32 + fp16 out; linear in the scale
+    dy = (torch.randn(R, D, generator=g) * 20).half()
+    dx_in = torch.randn(R, D, generator=g) * 20
+    dx, dx_act, part = ops.layernorm_bwd_part(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd, dx_in.to(DEV), torch.float16)
+    dh = dy.double() * w.double()
+    rs = 1 / torch.sqrt(var + 1e-6)
+    ref = rs * (dh - dh.mean(1, keepdim=True) - xh * (dh * xh).mean(1, keepdim=True)) + dx_in.double()
+    assert rel_err(dx.cpu().double(), ref) < 2e-5
+    assert dx_act.dtype == torch.float16 and rel_err(dx_act.cpu().double(), ref) < 4e-4
+    # the partial block reduced with the scale removed
+    amax = torch.tensor([0.9e-6], device=DEV)
+    S = _S(0.9e-6)
+    outs = [torch.zeros(D, device=DEV) for _ in range(3)]
+    bias_g = torch.zeros(D, device=DEV)
+    ops.colsum_batch([(part, D, outs), (dy.to(DEV), D, [bias_g])], False, unscale=amax)
+    assert rel_err(outs[0].cpu().double(), (dy.double() * xh).sum(0) / S) < 2e-5
+    assert rel_err(outs[1].cpu().double(), dy.double().sum(0) / S) < 2e-5
+    assert rel_err(outs[2].cpu().double(), ref.sum(0) / S) < 2e-4
+    assert rel_err(bias_g.cpu().double(), dy.double().sum(0) / S) < 2e-5
+    # casts: scale in, scale out
+    v = torch.randn(3001, generator=g) * 2e-7
+    h = ops.cast_f16(v.to(DEV), scale_amax=amax)
+    assert h.dtype == torch.float16 and rel_err(h.cpu().double(), v.double() * S) < 4e-4
+    back = ops.cast_f16(h, scale_amax=amax)
+    assert back.dtype == torch.float32 and rel_err(back.cpu().double(), v.double()) < 4e-4
+    big = ops.cast_f16(torch.tensor([1e6, -1e6, 1.0], device=DEV))
+    assert big.cpu().tolist() == [65504.0, -65504.0, 1.0]              # saturating
+
+
+@pytest.mark.parametrize('hd,Nq,Nk', [(32, 196, 98), (64, 98, 98), (32, 196, 196)])
+def test_attention_f16_storage_vs_fp64(hd, Nq, Nk):
+    from multimae_amd import ops
+    from multimae_amd.ops import AttnView
+    B, H = 3, 4
+    D = H * hd
+    g = torch.Generator().manual_seed(hd + Nq)
+    q = torch.randn(B * Nq, D, generator=g).half()
+    kv = torch.randn(B * Nk, 2 * D, generator=g).half()
+    d_o = (torch.randn(B * Nq, D, generator=g) * 8).half()
+    qd, kvd, dod = q.to(DEV), kv.to(DEV), d_o.to(DEV)
+    o = torch.empty(B * Nq, D, device=DEV, dtype=torch.float16)
+    scale = hd ** -0.5
+    st = ops.attention_fwd(AttnView(qd, 0, D, Nq), AttnView(kvd, 0, 2 * D, Nk), AttnView(kvd, D, 2 * D, Nk), AttnView(o, 0, D, Nq), B, H, hd, scale)
+    assert st[0] == 'fused'
+    Q = q.double().view(B, Nq, H, hd).transpose(1, 2).requires_grad_()
+    K = kv[:, :D].double().reshape(B, Nk, H, hd).transpose(1, 2).requires_grad_()
+    V = kv[:, D:].double().reshape(B, Nk, H, hd).transpose(1, 2).requires_grad_()
+    P = torch.softmax(Q @ K.transpose(-1, -2) * scale, -1)
+    O = (P @ V).transpose(1, 2).reshape(B * Nq, D)
+    assert rel_err(o.cpu().double(), O.detach()) < 1.5e-3
+    O.backward(d_o.double())
+    dq = torch.empty(B * Nq, D, device=DEV, dtype=torch.float16)
+    dkv = torch.empty(B * Nk, 2 * D, device=DEV, dtype=torch.float16)
+    ops.attention_bwd(AttnView(qd, 0, D, Nq), AttnView(kvd, 0, 2 * D, Nk), AttnView(kvd, D, 2 * D, Nk), st, AttnView(o, 0, D, Nq),
+                      AttnView(dod, 0, D, Nq), AttnView(dq, 0, D, Nq), AttnView(dkv, 0, 2 * D, Nk), AttnView(dkv, D, 2 * D, Nk), B, H, hd, scale)
+    f = lambda t, n: t.transpose(1, 2).reshape(B * n, D)
+    assert rel_err(dq.cpu().double(), f(Q.grad, Nq)) < 3e-3
+    assert rel_err(dkv[:, :D].cpu().double(), f(K.grad, Nk)) < 3e-3
+    assert rel_err(dkv[:, D:].cpu().double(), f(V.grad, Nk)) < 3e-3
+
+
+def test_cross_entropy_rows_in_fp16_units():
+    """The cross-entropy backward writes fp16 rows times S(m), m = the largest per-sample weight (written to dy_amax): equal to the f32 rows
+    of the same kernel times S, to fp16 rounding; no element exceeds 32."""
+    from multimae_amd import ops
+    from multimae_amd.functions import MaskedCEPatFn, PatHandle
+    g = torch.Generator().manual_seed(11)
+    B, C, P, nh = 4, 21, 4, 3
+    lr = torch.randn(B, C, nh * P, nh * P, generator=g) * 3
+    tgt = torch.randint(0, C, (B, nh * P, nh * P), generator=g)
+    mask = (torch.rand(B, nh * nh, generator=g) < 0.6).long()
+    mask[1] = 0                                                       # a sample without masked patches
+    mask[2, :] = 0; mask[2, 4] = 1                                    # and one with a single patch: the largest weight
+    pat = ops.patchify(lr.to(DEV), C, nh, nh, P, P, torch.float32).contiguous()
+    rows = {}
+    for act in (torch.float32, torch.float16):
+        h = PatHandle(pat, C, nh, nh, P, P, act)
+        h.dy_amax = torch.zeros(1, device=DEV)
+        h.token = torch.zeros(1, device=DEV, requires_grad=True)
+        (MaskedCEPatFn.apply(h.token, h, tgt.to(DEV), mask.to(DEV), P, 0.1) * 0.37).backward()
+        torch.cuda.synchronize()
+        rows[act] = (h.d_pat.float().cpu(), float(h.dy_amax))
+    r32, m32 = rows[torch.float32]
+    r16, m16 = rows[torch.float16]
+    n_valid = int((mask.sum(1) > 0).sum())
+    assert abs(m16 - 0.37 / (n_valid * P * P)) < 1e-7 * m16 + 1e-12    # upstream / (samples with a mask x pixels of the smallest mask)
+    assert m16 >= m32 > 0
+    S = _S(m16)
+    assert rel_err(r16.double(), r32.double() * S) < 4e-4
+    assert 4.0 < float(r16.abs().max()) < 32.0
+
+
+def test_adapter_fp16_storage_vs_f32_activations():
+    """The whole semseg adapter (cfg3 geometry, B = 4) in 'h16' mode against the same adapter with f32 activations and exact-f32 products:
+    prediction, d_enc and every parameter gradient; and against the 'f16' (f32 storage, fp16 operands) mode it replaces."""
+    import multimae_amd as M
+    from test_parity_geometry_gpu import _seeded_case, _fwd_bwd
+    doms = ['rgb', 'depth', 'semseg']
+    res = {}
+    for mode in ('x3', 'f16', 'h16'):
+        model, x, mask_all, ik, ir, ntok = _seeded_case(doms)
+        model.to(DEV)
+        model.build_arena()
+        tm = {d: mask_all[:, i * ntok:(i + 1) * ntok].to(DEV) for i, d in enumerate(doms)}
+        xd = {k: v.to(DEV) for k, v in x.items()}
+        old = M.engine.fp32_adapter_gemm()
+        M.engine.set_fp32_adapter_gemm(mode)
+        try:
+            preds, losses = _fwd_bwd(model, xd, doms, tm, ik.to(DEV), ir.to(DEV), 98, 'bf16', ('semseg',))
+        finally:
+            M.engine.set_fp32_adapter_gemm(old)
+        res[mode] = (preds['semseg'].float().cpu().double(), float(losses['semseg']),
+                     {n: p.grad.detach().cpu().double() for n, p in model.named_parameters() if p.grad is not None and n.startswith('output_adapters.semseg.')},
+                     {n: p.grad.detach().cpu().double() for n, p in model.named_parameters() if p.grad is not None and n.startswith('encoder.11.')})
+    ref = res['x3']                                                # split-bf16 products on f32 tensors: ~16 operand bits
+    for mode in ('f16', 'h16'):
+        p, l, ga, ge = res[mode]
+        assert rel_err(p, ref[0]) < 3e-3, (mode, rel_err(p, ref[0]))
+        assert abs(l - ref[1]) < 2e-3 * abs(ref[1]), (mode, l, ref[1])
+        worst = max(rel_err(ga[n], ref[2][n]) for n in ga)
+        assert worst < 6e-3, (mode, sorted(((rel_err(ga[n], ref[2][n]), n) for n in ga), reverse=True)[:5])
+        worst_e = max(rel_err(ge[n], ref[3][n]) for n in ge)          # what reaches the encoder through d_enc (summed with the bf16 adapters')
+        assert worst_e < 6e-3, (mode, worst_e)
