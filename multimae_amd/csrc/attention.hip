@@ -387,8 +387,12 @@ __global__ void __launch_bounds__(256, (NT == 4 && MODE != 1) ? 3 : (NT <= 7 ? 2
 // prologue (tile loads, LDS commit, delta, barrier) nothing overlaps, or as TWO 4-wave workgroups that overlap each other's
 // prologue and compute: 111 vs 132 us on the encoder geometry.  At head_dim 32 (123 VGPRs, two 8-wave workgroups per CU
 // already) the 8-wave form is the faster one (107 vs 120 us).
-template <int HD, int MODE, int NW>
+// RS (NW = 4, at most 4 key tiles = 128 keys: the encoder's 98-token self-attention): pass 1 keeps the S and dP tiles of its query block
+// in registers (8 x 16 accumulators), forms delta from them and goes straight on to dS and dQ -- the separate delta sweep (a second
+// evaluation of the same S / dP products and exponentials: 32 of a wave's 144 MFMAs, 64 of its 192 v_exp) disappears.
+template <int HD, int MODE, int NW, bool RS = false>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(const AttnArgs a) {
+    static_assert(!RS || NW == 4, "register-resident pass 1: the passes run one after the other");
     constexpr int NTH = NW * 64;
     constexpr bool X3 = MODE == 1, F32IO = MODE == 1 || MODE == 2;      // MODE 3: fp16 tensors in memory (MMAE_F16)
     typedef typename ActOf<F32IO>::T AT;
@@ -451,7 +455,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
     // for both, that was 22 % on dQ of the decoders' cross-attention and 4.8 % on decoder.q.weight, against 0.7 % / 0.4 % with
     // this delta: tools/xattn_delta_probe.py)  One extra S / dP sweep per query block, spread over all waves;
     // O is no longer read.
-    for (int qblk = wave; qblk < nqb; qblk += NW) {
+    for (int qblk = wave; !RS && qblk < nqb; qblk += NW) {
         const int q = qblk * 32 + (lane & 31);
         bf16x8 qf[HD / 16], dof[HD / 16], ql[HD / 16], dol[HD / 16];
 #pragma unroll
@@ -484,10 +488,80 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
         d += __shfl_xor(d, 32, 64);
         if (hi == 0) delta_s[q] = d;
     }
-    __syncthreads();
+    if (!RS) __syncthreads();
+
+    // ---- pass 1, register-resident form
+    for (int qblk = wave; RS && qblk < nqb; qblk += 4) {
+        const int q = qblk * 32 + (lane & 31);
+        const bool qok = q < a.Nq;
+        f32x16 st[4], dpt[4];
+        {
+            bf16x8 qf[HD / 16], dof[HD / 16];
+#pragma unroll
+            for (int ks = 0; ks < HD / 16; ++ks) { qf[ks] = frag_rows<HD>(Qs, qblk * 32, ks, lane); dof[ks] = frag_rows<HD>(dOs, qblk * 32, ks, lane); }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < nt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { st[t][r] = 0.f; dpt[t][r] = 0.f; }
+#pragma unroll
+                    for (int ks = 0; ks < HD / 16; ++ks) {
+                        const bf16x8 kh = frag_rows<HD>(Ks, t * 32, ks, lane), vh = frag_rows<HD>(Vs, t * 32, ks, lane);
+                        st[t] = mma<MODE>(kh, kh, qf[ks], qf[ks], st[t]);
+                        dpt[t] = mma<MODE>(vh, vh, dof[ks], dof[ks], dpt[t]);
+                    }
+                }
+            }
+        }
+        const float lse_q = lse_s[q];
+        float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < nt) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float p0 = __expf(st[t][r] * a.scale - lse_q), p1 = __expf(st[t][r + 1] * a.scale - lse_q);
+                    st[t][r] = p0; st[t][r + 1] = p1;
+                    d0 += p0 * dpt[t][r]; d1 += p1 * dpt[t][r + 1];
+                }
+            }
+        }
+        float delta_q = d0 + d1;
+        delta_q += __shfl_xor(delta_q, 32, 64);
+        if (hi == 0) delta_s[q] = delta_q;                               // for pass 2, behind the barrier below
+        f32x16 dq[HD / 32];
+#pragma unroll
+        for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[t][r] = st[t][r] * (dpt[t][r] - delta_q) * a.scale;      // dS^T
+#pragma unroll
+                for (int sI = 0; sI < 2; ++sI) {
+                    const bf16x8 dsf = pack8m<MODE>(st[t], sI);
+#pragma unroll
+                    for (int dt = 0; dt < HD / 32; ++dt) {
+                        const bf16x8 kh = frag_cols<HD>(Ks, dt * 32, t * 32 + 16 * sI, lane);
+                        dq[dt] = mma<MODE>(kh, kh, dsf, dsf, dq[dt]);
+                    }
+                }
+            }
+        }
+        AT* dst = (AT*)a.dq + b * a.dq_sb + h * HD + q * a.dq_sr;
+#pragma unroll
+        for (int dt = 0; dt < HD / 32; ++dt) store_row32<MODE == 3>(dst + dt * 32, dq[dt], do_inv, hi, qok);
+        if (MODE == 0 && a.mx_q) {
+#pragma unroll
+            for (int dt = 0; dt < HD / 32; ++dt) store_row32_mx(a, (long long)b * a.Nq + q, a.mx_col[0] + h * HD + dt * 32, dq[dt], 1.0f, hi, qok);
+        }
+    }
+    if (RS) __syncthreads();                                             // delta of every query block
 
     // ---- pass 1 (waves 0-3): lane = query row -> dQ
-    for (int qblk = wave; (NW == 4 || wave < 4) && qblk < nqb; qblk += 4) {
+    for (int qblk = wave; !RS && (NW == 4 || wave < 4) && qblk < nqb; qblk += 4) {
         const int q = qblk * 32 + (lane & 31);
         const bool qok = q < a.Nq;
         bf16x8 qf[HD / 16], dof[HD / 16], ql[HD / 16], dol[HD / 16];
@@ -697,15 +771,17 @@ static int attn_bwd_impl(int mode, const void* q, const void* k, const void* v, 
     if (lds > 160 * 1024) { mmae_set_error("attn_bwd: tiles exceed the 160 KB LDS (f32 split path: (Nq + Nk) * head_dim too large)"); return MMAE_ESUPPORT; }
     hipStream_t st_ = (hipStream_t)stream;
     dim3 grid(B * H);
-#define LAUNCH_BWD(HD, X3, NW)                                                                                               \
-    do {                                                                                                                     \
-        hipFuncSetAttribute((const void*)attn_bwd_kernel<HD, X3, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((attn_bwd_kernel<HD, X3, NW>), grid, dim3(NW * 64), lds, st_, a);                                 \
+#define LAUNCH_BWD(HD, X3, NW, ...)                                                                                                       \
+    do {                                                                                                                                  \
+        hipFuncSetAttribute((const void*)attn_bwd_kernel<HD, X3, NW, ##__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((attn_bwd_kernel<HD, X3, NW, ##__VA_ARGS__>), grid, dim3(NW * 64), lds, st_, a);                                 \
     } while (0)
+    static const int env_rs = mmae_env_int("MMAE_ATTN_BWD_RS", 1);      // 0: the separate delta sweep everywhere (A/B)
+    const bool rs = env_rs && a.nkp <= 128 && lds <= 80 * 1024;
     if (mode == 1) { if (hd == 64) LAUNCH_BWD(64, 1, 8); else LAUNCH_BWD(32, 1, 8); }
     else if (mode == 2) { if (hd == 64) { if (lds <= 80 * 1024) LAUNCH_BWD(64, 2, 4); else LAUNCH_BWD(64, 2, 8); } else LAUNCH_BWD(32, 2, 8); }
     else if (mode == 3) { if (hd == 64) { if (lds <= 80 * 1024) LAUNCH_BWD(64, 3, 4); else LAUNCH_BWD(64, 3, 8); } else LAUNCH_BWD(32, 3, 8); }
-    else if (hd == 64) { if (lds <= 80 * 1024) LAUNCH_BWD(64, 0, 4); else LAUNCH_BWD(64, 0, 8); }
+    else if (hd == 64) { if (rs) LAUNCH_BWD(64, 0, 4, true); else if (lds <= 80 * 1024) LAUNCH_BWD(64, 0, 4); else LAUNCH_BWD(64, 0, 8); }
     else LAUNCH_BWD(32, 0, 8);
 #undef LAUNCH_BWD
     return mmae_check_launch("attn_bwd");

@@ -35,6 +35,11 @@ class FusedAdamW(torch.optim.Optimizer):
     norm or loss, skip_grad) does not advance Adam's t -- the reference never calls optimizer.step() for it
     (utils/native_scaler.py:27-31, GradScaler.step)."""
 
+    # torch.amp.GradScaler.step(): hands over `found_inf` / `grad_scale` as DEVICE tensors (attributes set around the step() call) instead
+    # of deciding on the host with found_inf.item() -- the one synchronisation per iteration of the reference's loss-scaler sequence
+    # (utils/native_scaler.py:33) that kept the host from running ahead of the GPU through the drop-in path (VERDICT r3 item 7)
+    _step_supports_amp_scaling = True
+
     def __init__(self, model: nn.Module, lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.95), eps: float = 1e-8,
                  weight_decay: float = 0.05, clip_grad: Optional[float] = None, skip_grad: Optional[float] = None):
         self.arena = engine.arena_of(model) or engine.ParamArena(model)
@@ -103,6 +108,12 @@ class FusedAdamW(torch.optim.Optimizer):
             lrwd = cap.add(hyper, a.device)
         if loss is not None:
             loss = loss.detach().float().reshape(1)
+        found_inf, grad_scale = getattr(self, 'found_inf', None), getattr(self, 'grad_scale', None)
+        if grad_scale is not None:                       # GradScaler.step() without a preceding unscale_(): the arena still holds scaled gradients
+            a.grad.div_(grad_scale.to(a.grad.device).float())
+        if found_inf is not None:                        # an inf / nan gradient seen by GradScaler: skip on the device, as a non-finite loss does
+            bad = torch.where(found_inf.to(a.grad.device).reshape(1) > 0, float('nan'), 0.0).float()
+            loss = bad if loss is None else loss + bad
         ops.opt_step(a.param[:n], a.grad, self.m, self.v, self._state, self._istate, self._ws, lr=g['lr'],
                      weight_decay=g['weight_decay'], beta1=b1, beta2=b2, eps=g['eps'], clip_grad=self.clip_grad, skip_grad=self.skip_grad,
                      grad_prescale=self.grad_prescale, lrwd_dev=lrwd, loss_dev=loss, shadow=shadow)

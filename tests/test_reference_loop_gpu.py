@@ -224,6 +224,44 @@ def _rccl_rank(rank, world, port, q):
         q.put((rank, False, traceback.format_exc(), 0.0))
 
 
+def test_gradscaler_overflow_skips_the_fused_step_on_the_device():
+    """GradScaler.step(FusedAdamW): the optimiser takes the scaler's found_inf as a device tensor (``_step_supports_amp_scaling``) -- no
+    found_inf.item() on the host.  An overflowing iteration leaves the weights and Adam's step count untouched and halves the scale, as
+    GradScaler.step / update do for torch.optim.AdamW (utils/native_scaler.py:27-33); the next iteration updates again."""
+    import multimae_amd as M
+    from multimae_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    model = build_mini_engine()
+    model.to(DEV)
+    model.build_arena()
+    x = {k: v.to(DEV) for k, v in make_inputs(MINI['doms'], 2, MINI['S']).items()}
+    opt = FusedAdamW(model, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
+    assert getattr(opt, '_step_supports_amp_scaling', False)
+    scaler = torch.cuda.amp.GradScaler()
+
+    def iteration(poison):
+        torch.manual_seed(7)
+        with torch.cuda.amp.autocast():
+            preds, masks = model(x, num_encoded_tokens=MINI['nvis'], alphas=1.0, sample_tasks_uniformly=False, fp32_output_adapters=['semseg'])
+            loss = sum(_losses(M, preds, masks, x).values())
+            if poison:
+                loss = loss * float('inf')
+        opt.zero_grad()
+        _native_scaler_call(scaler, loss, opt, list(model.parameters()))
+
+    iteration(False)
+    torch.cuda.synchronize()
+    w1 = opt.arena.param.clone()
+    assert opt.step_count == 1 and float(scaler.get_scale()) == 65536.0
+    iteration(True)
+    torch.cuda.synchronize()
+    assert torch.equal(opt.arena.param, w1) and opt.step_count == 1
+    assert float(scaler.get_scale()) == 32768.0
+    iteration(False)
+    torch.cuda.synchronize()
+    assert opt.step_count == 2 and not torch.equal(opt.arena.param, w1) and bool(torch.isfinite(opt.arena.param).all())
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs (the driver scaling node); the 1-GPU box skips it')
 def test_two_rank_rccl_step_keeps_the_replicas_identical():
     """a real 2-rank RCCL data-parallel step -- broadcast_parameters, readiness-ordered bucketed all-reduce from
