@@ -633,7 +633,13 @@ class SpatialAdapterFn(torch.autograd.Function):
         h16 = (act == torch.float32 and getattr(cfg, 'f32_gemm', 'exact') == 'h16' and xattn
                and ops.adapter_h16_ok(enc2, heads, D, f1w.shape[0], n_q, NC, cfg.depth, T, KP))
         ctx.h16 = h16
-        if xattn and (h16 or ops.adapter_composite_ok(enc2, act, heads, D, n_q, NC, cfg.depth, T, KP)):
+        # stochastic depth in decoder_transformer (SpatialOutputAdapter(drop_path_rate > 0), training): per-sample scales [(attention
+        # branch, MLP branch)] * depth; the one-call adapter has no such option, the per-block sequence below folds them into the residual adds
+        dps = getattr(cfg, 'dp', None)
+        dp_of = (lambda l: (dps[2 * l], dps[2 * l + 1])) if dps is not None else (lambda l: (None, None))
+        if dps is not None:
+            h16 = ctx.h16 = False
+        if xattn and dps is None and (h16 or ops.adapter_composite_ok(enc2, act, heads, D, n_q, NC, cfg.depth, T, KP)):
             # the whole adapter as ONE library call (same kernels, same order)
             w_list = [wc(qw), wc(kvw), wc(pw_), wc(f1w), wc(f2w)] + [wc(blocks[12 * l + i]) for l in range(cfg.depth) for i in (2, 4, 8, 10)] \
                 + [wc(ow), wc(pcw)]
@@ -678,7 +684,7 @@ class SpatialAdapterFn(torch.autograd.Function):
         if not xattn:                                # use_xattn=False (output_adapters.py:264-268): x = queries
             h, bsaved = queries, []
             for l in range(cfg.depth):
-                h, s = block_fwd(h, blocks[12 * l:12 * l + 12], wc, heads, eps, act, B, n_q, save)
+                h, s = block_fwd(h, blocks[12 * l:12 * l + 12], wc, heads, eps, act, B, n_q, save, dp=dp_of(l))
                 bsaved.append(s)
             h_act = ops.cast(h, act)
             pat = _lin_fwd(h_act, ow, ob, wc, torch.float32)
@@ -703,7 +709,7 @@ class SpatialAdapterFn(torch.autograd.Function):
         x1 = _lin_fwd(hact, f2w, f2b, wc, torch.float32, resid=x)                       # :266
         h, bsaved = x1, []
         for l in range(cfg.depth):
-            h, s = block_fwd(h, blocks[12 * l:12 * l + 12], wc, heads, eps, act, B, n_q, save)   # :271
+            h, s = block_fwd(h, blocks[12 * l:12 * l + 12], wc, heads, eps, act, B, n_q, save, dp=dp_of(l))   # :271
             bsaved.append(s)
         h_act = ops.cast(h, act)
         pat = _lin_fwd(h_act, ow, ob, wc, torch.float32)                                # :274
@@ -775,10 +781,13 @@ class SpatialAdapterFn(torch.autograd.Function):
         dh = ops.cast(dh_act, torch.float32)
         bgrads: List[Optional[Tensor]] = [None] * (12 * cfg.depth)
         fc2b_done, g_cs = False, None
+        dps = getattr(cfg, 'dp', None)
         for l in reversed(range(cfg.depth)):
             cs_param = blocks[12 * (l - 1) + 11] if l > 0 else (f2b if xattn else None)
+            if dps is not None and l > 0 and dps[2 * (l - 1) + 1] is not None:
+                cs_param = None                      # the block below rescales its MLP branch: colsum(dx0) is not its fc2 bias gradient
             dh, dh_act, g_cs_next, g = block_bwd(dh, dh_act, fc2b_done, bsaved[l], blocks[12 * l:12 * l + 12], wc, sink, heads, act, B,
-                                                 n_q, cs_param)
+                                                 n_q, cs_param, dp=(dps[2 * l], dps[2 * l + 1]) if dps is not None else (None, None))
             bgrads[12 * l:12 * l + 12] = g
             if fc2b_done:
                 bgrads[12 * l + 11] = g_cs

@@ -53,8 +53,10 @@ class SpatialOutputAdapter(nn.Module):
             # (the reference allocates this table as (1, h, w, D) but resizes it with F.interpolate as if it were (1, D, h, w),
             # output_adapters.py:108-111,172: not a behaviour worth mirroring)
             raise NotImplementedError('learnable decoder positional embeddings are not built in the HIP engine')
-        if drop_path_rate != 0.0 or drop_rate != 0.0 or attn_drop_rate != 0.0:
-            raise NotImplementedError('decoder dropout / drop-path > 0 is not built in the HIP engine')
+        if drop_rate != 0.0 or attn_drop_rate != 0.0:
+            raise NotImplementedError('decoder dropout / attention dropout > 0 is not built in the HIP engine')
+        # (drop_path_rate > 0: stochastic depth in decoder_transformer, output_adapters.py:126-132 -- the per-sample scales are drawn in
+        # forward() in the reference's order and folded into the blocks' residual adds, as in the encoder)
 
         self.P_H = max(1, self.patch_size_full[0] // stride_level)
         self.P_W = max(1, self.patch_size_full[1] // stride_level)
@@ -171,6 +173,9 @@ class SpatialOutputAdapter(nn.Module):
                    q_task=in_tasks.index(self.task) if task_queries else -1, G=G, D=self.dim_tokens, pos=self._pos_tokens(nh, nw), depth=self.depth,
                    C=self.num_channels, nh=nh, nw=nw, ph=self.P_H, pw=self.P_W, on_done=on_done, f32_gemm=f32_gemm,
                    enc_act=encoder_tokens_act)
+        if self.depth > 0:                                   # two draws per block with a rate > 0, as the blocks execute (multimae_utils.py:229-232)
+            from .multimae_utils import _stack_drop_path
+            cfg.dp = _stack_drop_path(list(self.decoder_transformer), encoder_tokens.shape[0], encoder_tokens.device)
         params = self._params(in_tasks)
         if not task_queries and self.task_embeddings is not None and self.task in self.task_embeddings:
             # the query rows are mask_token + task_embeddings[task] + pos: one vector added to every row, passed in the mask-token

@@ -153,3 +153,53 @@ def test_mxfp8_mode_and_option_plumbing(stubbed):
     ad = M.PatchedInputAdapter(num_channels=3, stride_level=1, patch_size_full=8, dim_tokens=64, learnable_pos_emb=True, image_size=32)
     ad(torch.randn(2, 3, 32, 32)).sum().backward()
     assert ad.pos_emb.grad is not None and ad.pos_emb.grad.shape == ad.pos_emb.shape
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_decoder_drop_path_and_fp16_storage_control_flow(stubbed, mode):
+    """Host logic of two round-4 adapter options against the type-checking stub: stochastic depth in decoder_transformer (the adapters
+    leave the one-call composite, every block draws two per-sample scales while training, none in eval mode) and the 'h16' / 'f16'
+    modes of an fp32 output adapter (the mini model's 532-column patch rows are outside the fp16-storage grid: the call must fall back)."""
+    import multimae_amd as M
+    from functools import partial
+    from torch import nn
+    from multimae_amd import multimae_utils as mu
+    doms, P, S = MINI['doms'], MINI['P'], MINI['S']
+    torch.manual_seed(0)
+    ins = {d: (M.SemSegInputAdapter(num_classes=133, dim_class_emb=16, interpolate_class_emb=False, stride_level=4, patch_size_full=P, image_size=S)
+               if d == 'semseg' else M.PatchedInputAdapter(num_channels=3 if d == 'rgb' else 1, stride_level=1, patch_size_full=P, image_size=S))
+           for d in doms}
+    outs = {}
+    for key, task in [(d, d) for d in doms] + [('norm_rgb', 'rgb')]:
+        ch = {'rgb': 3, 'depth': 1, 'semseg': 133}[task]
+        outs[key] = M.SpatialOutputAdapter(num_channels=ch, stride_level=4 if task == 'semseg' else 1, patch_size_full=P, dim_tokens=64, depth=3,
+                                           num_heads=2, use_task_queries=True, task=task, context_tasks=list(doms), use_xattn=True, image_size=S,
+                                           drop_path_rate=0.3)
+    model = M.MultiMAE(ins, outs, num_global_tokens=1, dim_tokens=128, depth=2, num_heads=2, mlp_ratio=4, qkv_bias=True,
+                       norm_layer=partial(nn.LayerNorm, eps=1e-6)).train()
+    draws = []
+    real = mu._drop_path_rand
+    mu._drop_path_rand = lambda shape, device: (draws.append(shape), real(shape, device))[1]
+    try:
+        g = load_mini()
+        for gemm in ('h16', 'f16'):
+            old = M.engine.fp32_adapter_gemm()
+            M.engine.set_fp32_adapter_gemm(gemm)
+            try:
+                draws.clear()
+                _step(model, mode, False, g['x'], fp32_adapters=('semseg',))
+            finally:
+                M.engine.set_fp32_adapter_gemm(old)
+            assert len(draws) == 4 * 2 * 2, draws            # four adapters x the two blocks with a rate > 0 x two branches
+            for n, p in model.named_parameters():
+                assert (p.grad is not None) == p.requires_grad, n
+            model.zero_grad()
+        model.eval()
+        draws.clear()
+        with torch.no_grad(), M.engine.precision(mode):
+            model(g['x'], num_encoded_tokens=MINI['nvis'], alphas=1.0)
+        assert draws == []
+    finally:
+        mu._drop_path_rand = real
+    with pytest.raises(NotImplementedError):
+        M.SpatialOutputAdapter(num_channels=3, stride_level=1, patch_size_full=P, dim_tokens=64, drop_rate=0.1)
