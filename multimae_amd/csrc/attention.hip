@@ -302,6 +302,7 @@ __global__ void __launch_bounds__(256, (NT == 4 && MODE != 1) ? 3 : (NT <= 7 ? 2
     }
     __syncthreads();
     const int nt = a.nkp >> 5, nqb = (a.Nq + 31) >> 5;
+    const float sc2 = a.scale * 1.44269504089f;            // v_exp_f32 is 2^x: fold log2(e) into the score scale (one VALU op per score less)
     const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)((const AT*)a.q + b * a.q_sb + h * HD), 0, 0x80000000, 0x00020000);
     AT* ob = (AT*)a.out + b * a.o_sb + h * HD;
     for (int qblk = wave; qblk < nqb; qblk += 4) {
@@ -330,7 +331,7 @@ __global__ void __launch_bounds__(256, (NT == 4 && MODE != 1) ? 3 : (NT <= 7 ? 2
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const float v = key < a.Nk ? s[t][r] * a.scale : -INFINITY;
+                    const float v = key < a.Nk ? s[t][r] * sc2 : -INFINITY;          // scores in the base-2 domain: exp(x) = 2^(x log2 e)
                     s[t][r] = v;
                     m = fmaxf(m, v);
                 }
@@ -342,7 +343,7 @@ __global__ void __launch_bounds__(256, (NT == 4 && MODE != 1) ? 3 : (NT <= 7 ? 2
         for (int t = 0; t < NT; ++t) {
             if (t < nt) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { const float p = __expf(s[t][r] - m); s[t][r] = p; l += p; }
+                for (int r = 0; r < 16; ++r) { const float p = __builtin_amdgcn_exp2f(s[t][r] - m); s[t][r] = p; l += p; }
             }
         }
         l += __shfl_xor(l, 32, 64);
@@ -375,7 +376,7 @@ __global__ void __launch_bounds__(256, (NT == 4 && MODE != 1) ? 3 : (NT <= 7 ? 2
 #pragma unroll
                 for (int dt = 0; dt < HD / 32; ++dt) store_row32_mx(a, (long long)b * a.Nq + q, a.mx_col[0] + h * HD + dt * 32, o[dt], inv, hi, qok);
             }
-            if (qok && hi == 0) a.lse[((long long)b * a.H + h) * a.Nq + q] = m + __logf(l);
+            if (qok && hi == 0) a.lse[((long long)b * a.H + h) * a.Nq + q] = m * 0.69314718056f + __logf(l);     // natural-log lse, as before
         }
     }
 }
@@ -422,7 +423,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
             TileLoaderF32<HD, NTH> lq, ld;
             lq.issue(qg, a.q_sr, a.Nq, a.nqp, tid);
             ld.issue(dog, a.o_sr, a.Nq, a.nqp, tid);
-            for (int q = tid; q < a.nqp; q += NTH) lse_s[q] = q < a.Nq ? a.lse[((long long)b * a.H + h) * a.Nq + q] : 0.f;
+            for (int q = tid; q < a.nqp; q += NTH) lse_s[q] = q < a.Nq ? a.lse[((long long)b * a.H + h) * a.Nq + q] * 1.44269504089f : 0.f;
             if constexpr (X3) { lq.commit(Qs, lo, a.nqp, tid); ld.commit(dOs, lo, a.nqp, tid); }
             else { lq.commit16(Qs, a.nqp, tid, 1.0f); ld.commit16(dOs, a.nqp, tid, do_s); }
         }
@@ -439,13 +440,16 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
         ld.issue(dog, a.o_sr, a.Nq, a.nqp, tid);
         lk.issue(kg, a.k_sr, a.Nk, a.nkp, tid);
         lv.issue(vg, a.v_sr, a.Nk, a.nkp, tid);
-        for (int q = tid; q < a.nqp; q += NTH) lse_s[q] = q < a.Nq ? a.lse[((long long)b * a.H + h) * a.Nq + q] : 0.f;
+        for (int q = tid; q < a.nqp; q += NTH) lse_s[q] = q < a.Nq ? a.lse[((long long)b * a.H + h) * a.Nq + q] * 1.44269504089f : 0.f;
         lq.commit(Qs, a.nqp, tid);
         ld.commit(dOs, a.nqp, tid);
         lk.commit(Ks, a.nkp, tid);
         lv.commit(Vs, a.nkp, tid);
     }
     const int nt = a.nkp >> 5, nqb = a.nqp >> 5;
+    // base-2 softmax recomputation: lse_s holds lse * log2(e), P = 2^(s * sc2 - lse_s) (fma + v_exp_f32); delta_s holds delta * scale, so that
+    // dS = P * fma(dP, scale, -delta_s): five VALU operations per score where the natural-base form took seven
+    const float sc2 = a.scale * 1.44269504089f;
     __syncthreads();
     // delta[q] = sum_j P[q][j] dP[q][j], from the SAME fp32 P and dP the two passes form dS = P (dP - delta) with -- exactly what
     // autograd's softmax backward computes.  (Rounds 1-3 used the flash-attention shortcut delta = rowsum(dO . O) with the STORED
@@ -480,13 +484,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
             // (zero-padded keys: dP is exactly 0 there, whatever exp(-lse) their P is)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                d0 += __expf(st[r] * a.scale - lse_q) * dpt[r];
-                d1 += __expf(st[r + 1] * a.scale - lse_q) * dpt[r + 1];
+                d0 += __builtin_amdgcn_exp2f(st[r] * sc2 - lse_q) * dpt[r];
+                d1 += __builtin_amdgcn_exp2f(st[r + 1] * sc2 - lse_q) * dpt[r + 1];
             }
         }
         float d = d0 + d1;
         d += __shfl_xor(d, 32, 64);
-        if (hi == 0) delta_s[q] = d;
+        if (hi == 0) delta_s[q] = d * a.scale;
     }
     if (!RS) __syncthreads();
 
@@ -520,7 +524,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
             if (t < nt) {
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const float p0 = __expf(st[t][r] * a.scale - lse_q), p1 = __expf(st[t][r + 1] * a.scale - lse_q);
+                    const float p0 = __builtin_amdgcn_exp2f(st[t][r] * sc2 - lse_q), p1 = __builtin_amdgcn_exp2f(st[t][r + 1] * sc2 - lse_q);
                     st[t][r] = p0; st[t][r + 1] = p1;
                     d0 += p0 * dpt[t][r]; d1 += p1 * dpt[t][r + 1];
                 }
@@ -528,6 +532,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
         }
         float delta_q = d0 + d1;
         delta_q += __shfl_xor(delta_q, 32, 64);
+        delta_q *= a.scale;
         if (hi == 0) delta_s[q] = delta_q;                               // for pass 2, behind the barrier below
         f32x16 dq[HD / 32];
 #pragma unroll
@@ -538,7 +543,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
         for (int t = 0; t < 4; ++t) {
             if (t < nt) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) st[t][r] = st[t][r] * (dpt[t][r] - delta_q) * a.scale;      // dS^T
+                for (int r = 0; r < 16; ++r) st[t][r] = st[t][r] * (dpt[t][r] * a.scale - delta_q);      // dS^T
 #pragma unroll
                 for (int sI = 0; sI < 2; ++sI) {
                     const bf16x8 dsf = pack8m<MODE>(st[t], sI);
@@ -590,8 +595,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __expf(st[r] * a.scale - lse_q);
-                st[r] = p * (dpt[r] - delta_q) * a.scale;            // dS^T
+                const float p = __builtin_amdgcn_exp2f(st[r] * sc2 - lse_q);
+                st[r] = p * (dpt[r] * a.scale - delta_q);            // dS^T
             }
 #pragma unroll
             for (int sI = 0; sI < 2; ++sI) {
@@ -645,9 +650,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qr = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float p = __expf(sm[r] * a.scale - lse_s[qr]);
+                const float p = __builtin_amdgcn_exp2f(sm[r] * sc2 - lse_s[qr]);
                 sm[r] = p;                                            // P
-                dp[r] = p * (dp[r] - delta_s[qr]) * a.scale;          // dS
+                dp[r] = p * (dp[r] * a.scale - delta_s[qr]);          // dS
             }
 #pragma unroll
             for (int sI = 0; sI < 2; ++sI) {

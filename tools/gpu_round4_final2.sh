@@ -34,8 +34,6 @@ timeout 300 python bench.py --no-cpu-baseline --no-kernel-timing --no-secondary 
 echo "cfg3, data-parallel path over RCCL at world size 1, collectives issued (--force-dist 1): $(grep 'timed region' gpurun_out/x.err | sed 's/.*done: //' | cut -c1-120)" >> gpurun_out/summary.txt
 grep "^{" gpurun_out/dist_world1.log | tail -1 > gpurun_out/dist_world1_rccl.json
 run "cfg3, the reference's loop body through the drop-in boundary (--dropin-ddp 1)" timeout 300 $B --dropin-ddp 1
-run "cfg3 hipGraph replay" timeout 300 $B --graph 1
-run "cfg3 default, once more" timeout 300 $B
 PROF="--steps 5 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-secondary"
 for mode in default serialized; do
   EXTRA=""; [ $mode = serialized ] && EXTRA="--adapter-streams 0 --wgrad-stream 0"
