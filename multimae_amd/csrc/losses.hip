@@ -408,31 +408,24 @@ __global__ void __launch_bounds__(256) ce_pat_fwd_kernel(const float* __restrict
         const float* prow = pat + row * nval;
         const long long t = target[((long long)b * H + py * P + pix / P) * W + px * P + pix % P];
         float mx = -3.0e38f, s = 0.f, lt = 0.f, sx = 0.f;
-        int c = slot;
-        if (nval <= 64 * 40) {
-            // (round 4) the row's values -- at most 40 per lane: 133 classes x 16 pixels = 34 -- are loaded up front, all loads in
-            // flight together, then max and sum in two passes over registers: one exp per element instead of the online form's
-            // dependent chain (174 us = 2.4 TB/s for the semseg loss of a cfg3 step)
-            float v[40];
+        // online softmax over groups of eight values per lane: eight independent loads in flight, one rescale per group (rounds 1-3 loaded one
+        // value per iteration: 2.4 TB/s; round 4's first form held the whole row -- 40 values per lane -- in registers and came out at 223 VGPRs,
+        // two waves per SIMD: 2.9 TB/s).  ~30 VGPRs: the workgroups of a whole sample row are resident at once.
+        for (int e0 = lane; e0 < nval; e0 += 512) {
+            float v[8];
 #pragma unroll
-            for (int k = 0; k < 40; ++k) v[k] = (lane + 64 * k < nval) ? prow[lane + 64 * k] : -3.0e38f;
+            for (int k = 0; k < 8; ++k) { const int e = e0 + 64 * k; v[k] = e < nval ? prow[e] : -3.0e38f; }
+            float gm = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+            if (gm > mx) { s *= expf(mx - gm); mx = gm; }
 #pragma unroll
-            for (int k = 0; k < 40; ++k) mx = fmaxf(mx, v[k]);
-#pragma unroll
-            for (int k = 0; k < 40; ++k) {
-                if (lane + 64 * k < nval) {
+            for (int k = 0; k < 8; ++k) {
+                const int e = e0 + 64 * k;
+                if (e < nval) {
                     s += expf(v[k] - mx);
                     sx += v[k];
-                    if ((long long)(c + k * nslot) == t) lt = v[k];
+                    if ((long long)(slot + (e >> 6) * nslot) == t) lt = v[k];
                 }
             }
-        } else
-        for (int e = lane; e < nval; e += 64, c += nslot) {
-            const float v = prow[e];
-            if (v > mx) { s *= expf(mx - v); mx = v; }
-            s += expf(v - mx);
-            sx += v;
-            if ((long long)c == t) lt = v;
         }
         // combine the class slots of a pixel (lanes pix, pix + npix, ...)
         for (int o = npix; o < 64; o <<= 1) {
@@ -495,13 +488,23 @@ __global__ void __launch_bounds__(256) ce_pat_bwd_kernel(const float* __restrict
     const float ls = lse_pat[row * npix + pix];
     const long long t = target[((long long)b * H + py * P + pix / P) * W + px * P + pix % P];
     const float* prow = pat + row * nval;
-    int c = slot;
     float gmax = 0.f;
-    for (int e = lane; e < (int)ld; e += 64, c += nslot) {
-        float g = 0.f;
-        if (e < nval) g = wgt * (expf(prow[e] - ls) - (((long long)c == t ? 1.f - eps : 0.f) + eps / (float)C));
-        gmax = fmaxf(gmax, fabsf(g));
-        ActT<DT>::st(drow + e, g);
+    // four independent loads in flight per lane (one per iteration left the kernel at 22 VGPRs and latency-bound: 3.5 TB/s)
+    for (int e0 = lane; e0 < (int)ld; e0 += 256) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int e = e0 + 64 * k; v[k] = e < nval ? prow[e] : 0.f; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = e0 + 64 * k;
+            if (e < (int)ld) {
+                const int c = slot + (e >> 6) * nslot;
+                float g = 0.f;
+                if (e < nval) g = wgt * (expf(v[k] - ls) - (((long long)c == t ? 1.f - eps : 0.f) + eps / (float)C));
+                gmax = fmaxf(gmax, fabsf(g));
+                ActT<DT>::st(drow + e, g);
+            }
+        }
     }
     if (!std::is_same<DT, h16_t>::value && amax) note_amax(gmax, amax);
 }

@@ -263,3 +263,55 @@ def test_adapter_fp16_storage_vs_f32_activations():
         assert worst < 6e-3, (mode, sorted(((rel_err(ga[n], ref[2][n]), n) for n in ga), reverse=True)[:5])
         worst_e = max(rel_err(ge[n], ref[3][n]) for n in ge)          # what reaches the encoder through d_enc (summed with the bf16 adapters')
         assert worst_e < 6e-3, (mode, worst_e)
+
+
+def test_standalone_adapter_fp16_storage_from_an_image_gradient_vs_oracle():
+    """One SpatialOutputAdapter in 'h16' mode on its own -- parameters NOT in an arena (the fp16 weight copies are cast one by one), the gradient
+    arriving on the IMAGE tensor (no loss kernel fixed its units: the adapter's backward takes rows -> their largest element -> one scaled
+    cast), twice the same magnitude 1e-6 apart -- against the oracle: prediction, encoder-token gradient, every parameter gradient, TF32 class."""
+    import multimae_amd as M
+    import multimae_oracle as orc
+    torch.manual_seed(5)
+    B, Denc, D, P, S, C = 3, 96, 64, 4, 32, 3
+    ad = M.SpatialOutputAdapter(num_channels=C, stride_level=1, patch_size_full=P, dim_tokens=D, depth=1, num_heads=2, use_task_queries=True,
+                                task='rgb', context_tasks=['rgb', 'depth'], use_xattn=True, image_size=S, dim_tokens_enc=Denc)
+    g0 = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for n_, p in ad.named_parameters():
+            if p.requires_grad and (n_.endswith('bias') or 'mask_token' in n_):
+                p.copy_(0.05 * torch.randn(p.shape, generator=g0))
+    n, nkeep, G = (S // P) ** 2, 40, 1
+    ids_shuffle = torch.argsort(torch.rand(B, 2 * n), dim=1)
+    ids_restore = torch.argsort(ids_shuffle, dim=1)
+    ids_keep = ids_shuffle[:, :nkeep]
+    enc = torch.randn(B, nkeep + G, Denc)
+    info = {'tasks': {'rgb': {'num_tokens': n, 'has_2d_posemb': True, 'start_idx': 0, 'end_idx': n},
+                      'depth': {'num_tokens': n, 'has_2d_posemb': True, 'start_idx': n, 'end_idx': 2 * n}},
+            'image_size': (S, S), 'num_task_tokens': 2 * n, 'num_global_tokens': G}
+    cfg = orc.standard_config(['rgb', 'depth'], patch_size=P, image_size=S, dim_tokens=Denc, depth=1, num_heads=2, dec_dim=D, dec_depth=1,
+                              dec_heads=2, extra_norm_pix=False)
+    sd = {'output_adapters.rgb.' + k: v.detach().clone() for k, v in ad.state_dict().items()}
+    for k, p in ad.named_parameters():
+        sd['output_adapters.rgb.' + k].requires_grad_(p.requires_grad)
+    ad = ad.to(DEV)
+    rel = lambda a, b: float((a.cpu().double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    for scale in (1.0, 1e-6):                               # the second: gradients that plain fp16 would flush to zero
+        g = torch.randn(B, C, S, S) * scale
+        for v in sd.values():
+            v.grad = None
+        eo = enc.clone().requires_grad_(True)
+        po = orc.spatial_adapter(eo, sd, cfg, 'rgb', 'rgb', {'rgb': n, 'depth': n}, ids_keep, ids_restore, (S, S))
+        po.backward(g)
+        ad.zero_grad()
+        eg = enc.to(DEV).requires_grad_(True)
+        with M.engine.precision('bf16'):
+            pred = ad(eg, info, ids_keep.to(DEV), ids_restore.to(DEV), act_dtype=torch.float32, f32_gemm='h16')
+            assert pred._mmae_pat.act == torch.float16, 'the call must have taken the fp16-storage path'
+            pred.backward(g.to(DEV))
+        torch.cuda.synchronize()
+        assert rel(pred.detach(), po.detach()) < 4e-3, rel(pred.detach(), po.detach())
+        assert rel(eg.grad, eo.grad) < 6e-3, (scale, rel(eg.grad, eo.grad))
+        for k, p in ad.named_parameters():
+            if p.requires_grad:
+                assert p.grad is not None, k
+                assert rel(p.grad, sd['output_adapters.rgb.' + k].grad) < 8e-3, (scale, k, rel(p.grad, sd['output_adapters.rgb.' + k].grad))
