@@ -204,9 +204,15 @@ __global__ void __launch_bounds__(256) decoder_build_kernel(const float* __restr
                                                             const long long* __restrict__ ids_restore, const float* __restrict__ mask_token,
                                                             const TePtrs tep, const float* __restrict__ pos, const TaskTable tt,
                                                             int q_task, int n_keep, int G, int D, int n_q, int Ntot,
-                                                            float* __restrict__ queries, float* __restrict__ context) {
+                                                            float* __restrict__ queries, float* __restrict__ context, long long total_rows) {
+    // a row per group of `lpr` lanes: four rows per workgroup at the decoders' D = 256 (one workgroup per 1 KB row with 192 idle lanes, as
+    // built in round 1, ran at 2.4 TB/s: every row is two dependent round trips -- index, then data)
+    const int lpr = D <= 256 ? 64 : (D <= 512 ? 128 : 256);
     const int rows_per_b = n_q + n_keep + G;
-    const int b = blockIdx.x / rows_per_b, rr = blockIdx.x % rows_per_b;
+    const long long grow = (long long)blockIdx.x * (256 / lpr) + threadIdx.x / lpr;
+    if (grow >= total_rows) return;                              // (the grid is rounded up to whole workgroups)
+    const int b = (int)(grow / rows_per_b), rr = (int)(grow % rows_per_b);
+    const int tl = threadIdx.x % lpr, cstep = lpr * 4;
     const int NC = n_keep + G;
     if (rr < n_q) {
         const int j = rr;
@@ -218,7 +224,7 @@ __global__ void __launch_bounds__(256) decoder_build_kernel(const float* __restr
         const float* te = q_task < 0 ? nullptr : tep.p[q_task];
         const float* pe = pos + (long long)j * D;
         float* o = queries + ((long long)b * n_q + j) * D;
-        for (int c = threadIdx.x * 4; c < D; c += 1024) {
+        for (int c = tl * 4; c < D; c += cstep) {
             const f32x4 a = ld4(base + c), t4 = te ? ld4(te + c) : f32x4{0.f, 0.f, 0.f, 0.f}, p4 = ld4(pe + c);
             f32x4 v;
 #pragma unroll
@@ -229,12 +235,12 @@ __global__ void __launch_bounds__(256) decoder_build_kernel(const float* __restr
         const int r = rr - n_q;
         const float* src = ctx + ((long long)b * NC + r) * D;
         float* o = context + ((long long)b * NC + r) * D;
-        if (r >= n_keep) { for (int c = threadIdx.x * 4; c < D; c += 1024) st4(o + c, ld4(src + c)); return; }
+        if (r >= n_keep) { for (int c = tl * 4; c < D; c += cstep) st4(o + c, ld4(src + c)); return; }
         const int idx = (int)ids_keep[(long long)b * n_keep + r];
         const int t = task_of(tt, idx);
         const float* te = tep.p[t];
         const float* pe = pos + (long long)(idx - tt.off[t]) * D;
-        for (int c = threadIdx.x * 4; c < D; c += 1024) {
+        for (int c = tl * 4; c < D; c += cstep) {
             const f32x4 a = ld4(src + c), t4 = te ? ld4(te + c) : f32x4{0.f, 0.f, 0.f, 0.f}, p4 = ld4(pe + c);
             f32x4 v;
 #pragma unroll
@@ -636,9 +642,11 @@ int mmae_decoder_build_rows(const float* ctx, const int64_t* ids_keep, const int
         MMAE_REQUIRE(((uintptr_t)task_emb_rows[t] % 16) == 0, "decoder_build: unaligned task embedding");
         tep.p[t] = task_emb_rows[t];
     }
-    hipLaunchKernelGGL(decoder_build_kernel, dim3((unsigned)((long long)B * (n_q + n_keep + G))), dim3(256), 0, (hipStream_t)stream, ctx,
+    const int rpw = D <= 256 ? 4 : (D <= 512 ? 2 : 1);
+    const long long total_rows = (long long)B * (n_q + n_keep + G);
+    hipLaunchKernelGGL(decoder_build_kernel, dim3((unsigned)((total_rows + rpw - 1) / rpw)), dim3(256), 0, (hipStream_t)stream, ctx,
                        (const long long*)ids_keep, (const long long*)ids_restore, mask_token, tep, pos, tt, q_task, n_keep, G, D,
-                       n_q, tt.off[T], queries, context);
+                       n_q, tt.off[T], queries, context, total_rows);
     return mmae_check_launch("decoder_build");
 }
 extern "C" {
