@@ -273,8 +273,11 @@ template <bool X3> struct ActOf { typedef uint16_t T; };
 template <> struct ActOf<true> { typedef float T; };
 
 // -------------------------------------------------------------------------------------------------
-template <int HD, int NT, int MODE>
+// GRP (with NT = 4): more than 128 keys are walked in groups of four key tiles with the running (max, sum) rescale of flash attention -- 64
+// score registers instead of 112 / 128, so three waves per SIMD fit where the single-group form of the 196-key decoder grids (NT = 7) holds two.
+template <int HD, int NT, int MODE, bool GRP = false>
 __global__ void __launch_bounds__(256, (NT == 4 && MODE != 1) ? 3 : (NT <= 7 ? 2 : 1)) attn_fwd_kernel(const AttnArgs a) {
+    static_assert(!GRP || NT == 4, "grouped form: four key tiles per group");
     constexpr bool X3 = MODE == 1, F32IO = MODE == 1 || MODE == 2;      // MODE 3: fp16 tensors in memory (MMAE_F16)
     typedef typename ActOf<F32IO>::T AT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -316,54 +319,69 @@ __global__ void __launch_bounds__(256, (NT == 4 && MODE != 1) ? 3 : (NT <= 7 ? 2
             else { qf[ks] = load_frag_global(rsQ, qok, q, a.q_sr, ks, hi); ql[ks] = qf[ks]; }
         }
         f32x16 s[NT];
-        float m = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t < nt) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < HD / 16; ++ks) {
-                    const bf16x8 kh = frag_rows<HD>(Ks, t * 32, ks, lane);
-                    const bf16x8 kl = X3 ? frag_rows<HD>(Ks + lo, t * 32, ks, lane) : kh;
-                    s[t] = mma<MODE>(kh, kl, qf[ks], ql[ks], s[t]);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const float v = key < a.Nk ? s[t][r] * sc2 : -INFINITY;          // scores in the base-2 domain: exp(x) = 2^(x log2 e)
-                    s[t][r] = v;
-                    m = fmaxf(m, v);
-                }
-            }
-        }
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float l = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t < nt) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { const float p = __builtin_amdgcn_exp2f(s[t][r] - m); s[t][r] = p; l += p; }
-            }
-        }
-        l += __shfl_xor(l, 32, 64);
+        float m = -INFINITY, l = 0.f;
         f32x16 o[HD / 32];
 #pragma unroll
         for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+        for (int t0 = 0; t0 < (GRP ? nt : 1); t0 += NT) {                  // one pass unless GRP
+            float mg = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t < nt) {
+            for (int t = 0; t < NT; ++t) {
+                if (t0 + t < nt) {
 #pragma unroll
-                for (int sI = 0; sI < 2; ++sI) {
-                    const bf16x8 pf = pack8m<MODE>(s[t], sI);
-                    const bf16x8 pl = X3 ? pack8_lo(s[t], sI) : pf;
+                    for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
 #pragma unroll
-                    for (int dt = 0; dt < HD / 32; ++dt) {
-                        const bf16x8 vh = frag_cols<HD>(Vs, dt * 32, t * 32 + 16 * sI, lane);
-                        const bf16x8 vl = X3 ? frag_cols<HD>(Vs + lo, dt * 32, t * 32 + 16 * sI, lane) : vh;
-                        o[dt] = mma<MODE>(vh, vl, pf, pl, o[dt]);
+                    for (int ks = 0; ks < HD / 16; ++ks) {
+                        const bf16x8 kh = frag_rows<HD>(Ks, (t0 + t) * 32, ks, lane);
+                        const bf16x8 kl = X3 ? frag_rows<HD>(Ks + lo, (t0 + t) * 32, ks, lane) : kh;
+                        s[t] = mma<MODE>(kh, kl, qf[ks], ql[ks], s[t]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = (t0 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const float v = key < a.Nk ? s[t][r] * sc2 : -INFINITY;          // scores in the base-2 domain: exp(x) = 2^(x log2 e)
+                        s[t][r] = v;
+                        mg = fmaxf(mg, v);
+                    }
+                }
+            }
+            mg = fmaxf(mg, __shfl_xor(mg, 32, 64));
+            const float mn = fmaxf(m, mg);                                 // (every group holds at least one real key: mn is finite)
+            float lg = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (t0 + t < nt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const float p = __builtin_amdgcn_exp2f(s[t][r] - mn); s[t][r] = p; lg += p; }
+                }
+            }
+            lg += __shfl_xor(lg, 32, 64);
+            if (GRP) {                                                     // running rescale (first group: m = -inf -> alpha = 0 on zeros)
+                const float alpha = __builtin_amdgcn_exp2f(m - mn);
+                l = l * alpha + lg;
+#pragma unroll
+                for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            } else {
+                l = lg;
+            }
+            m = mn;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (t0 + t < nt) {
+#pragma unroll
+                    for (int sI = 0; sI < 2; ++sI) {
+                        const bf16x8 pf = pack8m<MODE>(s[t], sI);
+                        const bf16x8 pl = X3 ? pack8_lo(s[t], sI) : pf;
+#pragma unroll
+                        for (int dt = 0; dt < HD / 32; ++dt) {
+                            const bf16x8 vh = frag_cols<HD>(Vs, dt * 32, (t0 + t) * 32 + 16 * sI, lane);
+                            const bf16x8 vl = X3 ? frag_cols<HD>(Vs + lo, dt * 32, (t0 + t) * 32 + 16 * sI, lane) : vh;
+                            o[dt] = mma<MODE>(vh, vl, pf, pl, o[dt]);
+                        }
                     }
                 }
             }
@@ -720,11 +738,12 @@ static int attn_fwd_impl(int mode, const void* q, const void* k, const void* v, 
     const size_t lds = (size_t)2 * a.nkp * hd * 2 * (x3 ? 2 : 1);
     hipStream_t st_ = (hipStream_t)stream;
     dim3 grid(B * H), block(256);
-#define LAUNCH_FWD(HD, NT, X3)                                                                                               \
-    do {                                                                                                                     \
-        hipFuncSetAttribute((const void*)attn_fwd_kernel<HD, NT, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((attn_fwd_kernel<HD, NT, X3>), grid, block, lds, st_, a);                                         \
+#define LAUNCH_FWD(HD, NT, X3, ...)                                                                                                       \
+    do {                                                                                                                                  \
+        hipFuncSetAttribute((const void*)attn_fwd_kernel<HD, NT, X3, ##__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((attn_fwd_kernel<HD, NT, X3, ##__VA_ARGS__>), grid, block, lds, st_, a);                                         \
     } while (0)
+    static const int env_grp = mmae_env_int("MMAE_ATTN_FWD_GRP", 1);    // 0: all key tiles of a query block in registers at once (A/B)
     // NT = key tiles held in registers per query block: 4 (<= 128 keys), 7 (<= 224: the 196-token decoder grids; one 16-register
     // score tile less than NT = 8 is what lets two waves per SIMD fit) or 8
     const bool small = a.nkp <= 128, mid = a.nkp <= 224;
@@ -735,11 +754,11 @@ static int attn_fwd_impl(int mode, const void* q, const void* k, const void* v, 
         if (hd == 64) { if (small) LAUNCH_FWD(64, 4, 2); else if (mid) LAUNCH_FWD(64, 7, 2); else LAUNCH_FWD(64, 8, 2); }
         else { if (small) LAUNCH_FWD(32, 4, 2); else if (mid) LAUNCH_FWD(32, 7, 2); else LAUNCH_FWD(32, 8, 2); }
     } else if (mode == 3) {
-        if (hd == 64) { if (small) LAUNCH_FWD(64, 4, 3); else if (mid) LAUNCH_FWD(64, 7, 3); else LAUNCH_FWD(64, 8, 3); }
-        else { if (small) LAUNCH_FWD(32, 4, 3); else if (mid) LAUNCH_FWD(32, 7, 3); else LAUNCH_FWD(32, 8, 3); }
+        if (hd == 64) { if (small) LAUNCH_FWD(64, 4, 3); else if (mid) LAUNCH_FWD(64, 7, 3); else LAUNCH_FWD(64, 8, 3); }      // (grouped form at head_dim 64: 168 VGPRs + scratch)
+        else { if (small) LAUNCH_FWD(32, 4, 3); else if (env_grp) LAUNCH_FWD(32, 4, 3, true); else if (mid) LAUNCH_FWD(32, 7, 3); else LAUNCH_FWD(32, 8, 3); }
     } else {
-        if (hd == 64) { if (small) LAUNCH_FWD(64, 4, 0); else if (mid) LAUNCH_FWD(64, 7, 0); else LAUNCH_FWD(64, 8, 0); }
-        else { if (small) LAUNCH_FWD(32, 4, 0); else if (mid) LAUNCH_FWD(32, 7, 0); else LAUNCH_FWD(32, 8, 0); }
+        if (hd == 64) { if (small) LAUNCH_FWD(64, 4, 0); else if (mid) LAUNCH_FWD(64, 7, 0); else LAUNCH_FWD(64, 8, 0); }      // (grouped form at head_dim 64: 168 VGPRs + scratch)
+        else { if (small) LAUNCH_FWD(32, 4, 0); else if (env_grp) LAUNCH_FWD(32, 4, 0, true); else if (mid) LAUNCH_FWD(32, 7, 0); else LAUNCH_FWD(32, 8, 0); }
     }
 #undef LAUNCH_FWD
     return mmae_check_launch("attn_fwd");
