@@ -936,9 +936,12 @@ _H16_SETS = {}
 
 
 def h16_weights(w_list: Sequence[Tensor]) -> H16Weights:
-    key = id(w_list[0])
+    # keyed by where the first weight LIVES (the callers hand in fresh detach() views every forward: their id() is not stable)
+    key = (w_list[0].data_ptr(), len(w_list))
     s = _H16_SETS.get(key)
     if s is None or not s.matches(w_list):
+        if len(_H16_SETS) > 16:
+            _H16_SETS.clear()
         s = H16Weights(w_list)
         _H16_SETS[key] = s
     return s

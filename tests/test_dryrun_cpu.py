@@ -203,3 +203,16 @@ def test_decoder_drop_path_and_fp16_storage_control_flow(stubbed, mode):
         mu._drop_path_rand = real
     with pytest.raises(NotImplementedError):
         M.SpatialOutputAdapter(num_channels=3, stride_level=1, patch_size_full=P, dim_tokens=64, drop_rate=0.1)
+
+
+def test_fp16_weight_copies_are_cached_by_storage_not_by_object():
+    """ops.h16_weights: the fp16 copies of an fp32 adapter's weights are allocated once per set of weights -- the callers pass fresh detach()
+    views every forward, so the cache must key on where the weights live (a key on id() allocated a new copy every step)."""
+    from multimae_amd import ops
+    ws = [torch.nn.Parameter(torch.randn(8, 8)) for _ in range(3)]
+    a = ops.h16_weights([w.detach() for w in ws])
+    b = ops.h16_weights([w.detach() for w in ws])
+    assert a is b and len(a.copies) == 3 and a.copies[0].dtype == torch.float16
+    other = [torch.nn.Parameter(torch.randn(8, 8)) for _ in range(3)]
+    assert ops.h16_weights([w.detach() for w in other]) is not a
+    assert ops.h16_weights([w.detach() for w in ws]) is a
