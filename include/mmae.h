@@ -49,8 +49,9 @@ extern "C" {
                           |dL/dprediction|): the largest element sits in [16, 32), 11 bits of head-room above and 2^-18..2^-28 of it
                           below; the f32 sinks (weight / bias / LayerNorm / token gradients, d_enc) multiply by 1/S.  Accepted by:
                           mmae_gemm (ab/c/aux dtype, ping-pong kernels with a compiled epilogue flavour only), mmae_gemm_dw_group,
-                          mmae_layernorm_*, mmae_colsum*, mmae_cast_*, mmae_patchify, mmae_attn_*_f16, the *_pat_bwd losses,
-                          mmae_block_* and mmae_adapter_* (not mmae_stack_*: the encoder stays bf16 / MX). */
+                          mmae_layernorm_*, mmae_colsum*, mmae_cast_f32_to_f16 / _f16_to_f32, mmae_attn_*_f16, mmae_masked_ce_pat_bwd (the
+                          one loss whose gradient is bounded before it is written; any other gradient enters through the scaled cast),
+                          mmae_block_* and mmae_adapter_* (not mmae_stack_*: the encoder stays bf16 / MX; adapter_bwd takes d_pat, not d_img). */
 
 #define MMAE_EINVAL   (-1)   /* bad argument (shape / alignment / dtype)        */
 #define MMAE_ELAUNCH  (-2)   /* hipLaunchKernel reported an error               */
