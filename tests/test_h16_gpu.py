@@ -315,3 +315,40 @@ def test_standalone_adapter_fp16_storage_from_an_image_gradient_vs_oracle():
             if p.requires_grad:
                 assert p.grad is not None, k
                 assert rel(p.grad, sd['output_adapters.rgb.' + k].grad) < 8e-3, (scale, k, rel(p.grad, sd['output_adapters.rgb.' + k].grad))
+
+
+def test_fp16_storage_adapter_under_a_pixel_loss_and_two_losses():
+    """An fp32 output adapter in 'h16' mode whose gradient does NOT come from the cross-entropy kernel: a masked MSE on its patch rows (f32 rows,
+    the adapter's backward finds their largest element and casts them into its units), and two losses on the same prediction (the rows add up
+    in f32 first).  Against the same adapter with f32 tensors and split-bf16 products."""
+    import multimae_amd as M
+    from test_parity_geometry_gpu import _seeded_case
+    doms = ['rgb', 'depth', 'semseg']
+    res = {}
+    for mode in ('x3', 'h16'):
+        model, x, mask_all, ik, ir, ntok = _seeded_case(doms)
+        model.to(DEV)
+        model.build_arena()
+        tm = {d: mask_all[:, i * ntok:(i + 1) * ntok].to(DEV) for i, d in enumerate(doms)}
+        xd = {k: v.to(DEV) for k, v in x.items()}
+        model.generate_random_masks = lambda *a, **k: (tm, ik.to(DEV), ir.to(DEV))
+        old = M.engine.fp32_adapter_gemm()
+        M.engine.set_fp32_adapter_gemm(mode)
+        try:
+            with M.engine.precision('bf16'):
+                preds, masks = model(xd, num_encoded_tokens=98, alphas=1.0, fp32_output_adapters=['rgb'])
+                if mode == 'h16':
+                    assert preds['rgb']._mmae_pat.act == torch.float16
+                l1 = M.MaskedMSELoss(16, 1)(preds['rgb'].float(), xd['rgb'], mask=masks['rgb'])
+                l2 = M.MaskedL1Loss(16, 1)(preds['rgb'].float(), xd['rgb'], mask=masks['rgb'])
+                (l1 + 0.5 * l2).backward()
+        finally:
+            M.engine.set_fp32_adapter_gemm(old)
+        torch.cuda.synchronize()
+        res[mode] = (float(l1.detach()), float(l2.detach()), {n: p.grad.detach().cpu().double() for n, p in model.named_parameters()
+                                           if p.grad is not None and (n.startswith('output_adapters.rgb.') or n.startswith('encoder.11.'))})
+    a, b = res['x3'], res['h16']
+    assert abs(a[0] - b[0]) < 2e-3 * abs(a[0]) and abs(a[1] - b[1]) < 2e-3 * abs(a[1])
+    assert len(b[2]) > 30
+    worst = max((rel_err(b[2][n], a[2][n]), n) for n in a[2])
+    assert worst[0] < 6e-3, worst
