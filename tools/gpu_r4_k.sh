@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4, visit k: decoder GEMM shapes with the workgroup de-phasing experiment (MMAE_PP_DEPHASE), GradScaler overflow test
+# NOTE: the MMAE_* switches below are read only by the EXPERIMENTS library (common.h mmae_env_int); this script ran them against the production library, where they are no-ops -- its 'A/B' lines compare a build with itself.  The valid A/B of the same switches is tools/gpu_r4_p.sh (MMAE_LIB=.../libmmae_hip_exp.so).
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$PWD

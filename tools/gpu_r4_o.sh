@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4, visit o: attention forward, grouped online-softmax form for > 128 keys at head_dim 32 (A/B via MMAE_ATTN_FWD_GRP)
+# NOTE: the MMAE_* switches below are read only by the EXPERIMENTS library (common.h mmae_env_int); this script ran them against the production library, where they are no-ops -- its 'A/B' lines compare a build with itself.  The valid A/B of the same switches is tools/gpu_r4_p.sh (MMAE_LIB=.../libmmae_hip_exp.so).
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$PWD
