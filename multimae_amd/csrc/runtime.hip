@@ -129,6 +129,9 @@ void gemm_plan(const mmae_gemm_desc* d, int* tile_out, int* split_out) {
             }
         }
     }
+    // experiments: the two-workgroups-per-CU structure (tile 11) for short contractions (the output adapters' D = 256 products)
+    static const int env_duo_k = mmae_env_int("MMAE_DUO_MAX_K", 0);
+    if (env_duo_k && !d->tile && (tile == 9 || tile == 10) && d->K <= env_duo_k && !d->a_trans && d->split_k <= 1 && (d->K % 32) == 0) tile = 11;
     int s = 1;
     // workgroups a split product should reach (ping-pong kernel: one per CU).  Below 256 the dW launches leave CUs to the dX
     // chain they run beside, write fewer partial slabs and run longer K loops; tunable for experiments.

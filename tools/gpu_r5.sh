@@ -1,0 +1,36 @@
+#!/bin/bash
+# Round 5: ONE parameterised collection script (replaces the per-visit gpu_r4_*.sh files).  Usage on the GPU box:
+#   gpurun -- 'bash tools/gpu_r5.sh <visit> [...]'      visits: duo | baseline | tests | final | ...
+# Everything lands under gpurun_out/r5_<visit>_*; what is worth keeping is copied to profiles/ by hand (profiles/INDEX.md).
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+R=$PWD
+V=${1:-baseline}; shift
+S=gpurun_out/r5_${V}_summary.txt
+: > $S
+EXP=$R/multimae_amd/libmmae_hip_exp.so
+B="python bench.py --no-cpu-baseline --no-kernel-timing --no-secondary --steps 20 --warmup 5"
+# run <label> <cmd...>: one bench run, its step time into the summary
+run() { label=$1; shift; ( "$@" > gpurun_out/x.log 2> gpurun_out/x.err ); echo "$label: $(grep 'timed region' gpurun_out/x.err | sed 's/.*done: //' | cut -c1-70)" >> $S; grep -i "error\|Traceback" gpurun_out/x.err | tail -3 >> $S; }
+# table <tool.py> <label> [tool args]: a per-product GEMM table under rocprofv3 --kernel-trace
+table() { tool=$1; label=$2; shift 2; rm -rf gpurun_out/tbl; (cd /tmp && timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/tbl -o p --output-format csv -- python $R/tools/$tool "$@" > $R/gpurun_out/tbl.log 2>&1); echo "== $label" >> $S; python tools/$tool --parse gpurun_out/tbl "$@" >> $S 2>&1; rm -rf gpurun_out/tbl; }
+# kstats <tag> [bench args]: serialized kernel stats of the bench command -> gpurun_out/r5_<visit>_kernel_stats_<tag>.csv
+kstats() { tag=$1; shift; rm -rf gpurun_out/prof; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o p --output-format csv -- python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-secondary --adapter-streams 0 --wgrad-stream 0 "$@" > $R/gpurun_out/prof.log 2>&1); f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r5_${V}_kernel_stats_$tag.csv; rm -rf gpurun_out/prof; }
+
+case $V in
+duo)   # the two-workgroups-per-CU GEMM (tile 11, experiments library) on the output adapters' short-K products
+  run "production library, defaults" timeout 300 $B
+  export MMAE_LIB=$EXP
+  run "exp library, defaults" timeout 300 $B
+  MMAE_DUO_MAX_K=256 run "exp, duo for K <= 256" timeout 300 $B
+  MMAE_DUO_MAX_K=1024 run "exp, duo for K <= 1024" timeout 300 $B
+  run "exp library, defaults again" timeout 300 $B
+  table decoder_gemms.py "decoder GEMMs, tiles 9 10 11 12" 9 10 11 12
+  ;;
+baseline)
+  run "production library, defaults" timeout 300 $B
+  table encoder_gemms.py "encoder GEMMs"
+  ;;
+*) echo "unknown visit $V" >> $S ;;
+esac
+cat $S
