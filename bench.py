@@ -518,13 +518,17 @@ def run_once(args):
     if reducer is not None:
         # self-diagnosis of the data-parallel run: how much of the gradient exchange was NOT hidden by backward
         reducer.timing = False
+        bt = reducer.bucket_timings()          # per bucket: last gradient kernel done -> all-reduce done, while backward kept running
         seen = torch.ones(1, device=device)
         dist.all_reduce(seen)
         dp_diag = {'exposed_allreduce_ms_per_step': round(reducer.exposed_wait_ms() / args.steps, 3), 'bucket_mb': args.bucket_mb,
                    'buckets': len(reducer.buckets), 'bucket_dtype': 'bf16' if args.bf16_buckets else 'f32',
                    'allreduce_mb_per_step': round(sum(e - s for s, e, _ in reducer.buckets) * (2 if args.bf16_buckets else 4) / 2 ** 20, 1),
                    'rccl_ranks_seen': int(seen.item()), 'backend': args.backend, 'encoder_bwd_chunk_layers': int(getattr(model, '_bwd_chunk_layers', 0)),
-                   'gemm_cu_reserved': cu_reserve}
+                   'gemm_cu_reserved': cu_reserve, 'per_bucket': bt['buckets'],
+                   'backward_ms_on_reduced_width_grids': bt['backward_ms_on_reduced_width_grids'],
+                   'reading': 'a bucket whose launch_to_done_ms approaches the reduced-width stretch is what finish() waits for; exposed_allreduce_ms_per_step '
+                              'is that wait; algbw_gb_s is per bucket under the load of the concurrent backward (8 GPUs, 7 xGMI links x ~153 GB/s: ring bound ~2 x 64 MiB x 7/8 / 153 GB/s = 0.77 ms per bucket unloaded)'}
     if args.dropin_ddp:
         args.no_kernel_timing = True
     final_loss = float(last['loss'].detach())

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMAE_ABI_VERSION 5
+#define MMAE_ABI_VERSION 6
 
 #define MMAE_F32  0
 #define MMAE_BF16 1
@@ -36,7 +36,8 @@ extern "C" {
 #define MMAE_F32F16 3  /* GEMM only (round 4): f32 operands in memory, each rounded to fp16 -- TF32's 11-bit significand -- for ONE product
                           per tile step on v_mfma_f32_32x32x16_f16, fp32 accumulate.  The operand precision the reference's fp32 output
                           adapters ran at on A100 (torch 1.10: allow_tf32), at a third of MMAE_F32X3's MFMA work.  Values beyond the fp16
-                          range saturate at +-65504; a gradient operand needs mmae_gemm_desc.a_amax (see there). */
+                          range round to +-inf (never silently clamped: the inf reaches the loss / gradient norm and mmae_opt_step skips
+                          and counts the update, the GradScaler contract of fp16 training); a gradient operand needs mmae_gemm_desc.a_amax (see there). */
 #define MMAE_MXFP8 4   /* GEMM only: OCP MX operands -- e4m3 elements [rows][K] plus one E8M0 scale per 32 consecutive K elements in the
                           packed layout of mmae_mx_quant (a_scale / b_scale of the descriptor); block-scaled MFMA, fp32 accumulation */
 
@@ -44,7 +45,8 @@ extern "C" {
                           MMAE_BF16, but IEEE half -- an 11-bit significand, TF32's, what every matmul input of the reference's fp32 adapters
                           was rounded to on A100 -- so such an adapter runs on the bf16 pipeline's kernels (v_mfma_f32_32x32x16_f16, 16-bit
                           HBM traffic) instead of f32 tensors in memory.  Residual stream, LayerNorm statistics, softmax, losses and
-                          every parameter gradient stay f32.  Forward values saturate at +-65504.  GRADIENT tensors are stored multiplied
+                          every parameter gradient stay f32.  Values beyond +-65504 are stored as +-inf -- not clamped -- so an overflow ends in a skipped,
+                          counted optimiser step (mmae_opt_step's non-finite test), as under fp16 autocast.  GRADIENT tensors are stored multiplied
                           by S = 2^(4 - floor(log2 m)), m = the device scalar `dy_amax` the loss backward wrote (an upper bound of
                           |dL/dprediction|): the largest element sits in [16, 32), 11 bits of head-room above and 2^-18..2^-28 of it
                           below; the f32 sinks (weight / bias / LayerNorm / token gradients, d_enc) multiply by 1/S.  Accepted by:
@@ -160,6 +162,10 @@ int mmae_gemm_auto_splitk(int M, int N, int K, int ab_dtype);
  * statically strided persistent grid run its last k workgroups as a second round.  A host-side launch policy (not stream
  * ordered, process wide).  k < 0 only reads.  Returns the previous value. */
 int mmae_gemm_cu_reserve(int k);
+/* A second, independent slot of the same policy for callers that want narrower grids for their own reasons (the output adapters'
+ * side-by-side experiment, multimae_amd/functions.py): the grids leave max(reserve, share) CUs free, so saving / restoring one slot
+ * never disturbs what the other requester set.  k < 0 only reads.  Returns the previous value. */
+int mmae_gemm_cu_share(int k);
 /* A/B switch (default 0 = off): k > 0 splits the chip between the compute stream's persistent GEMM grids (k fewer workgroups) and the
  * grouped weight-gradient launches (sized for k CUs: at k = the number of their output tiles they run unsplit), so that a block's dX
  * chain and its weight gradients are resident side by side instead of time-slicing.  k < 0 only reads.  Returns the previous value. */
@@ -519,6 +525,10 @@ typedef struct mmae_adapter_desc {
     const void* const* x3_w; int32_t x3_n;       /* optional pre-split weights (triples, as mmae_block_desc.x3_w) of an f32 adapter; set them
                                                     BEFORE asking for the slab sizes: the operand scratch is carved from act / tmp */
     const float* dy_amax;                        /* as mmae_block_desc.dy_amax, for the adapter's own products and its blocks */
+    float* pat;                                  /* optional caller-owned home of the prediction rows f32 [B * n_q][C * ph * pw] (out_proj's output, what
+                                                    the patch-domain losses and a deferred unpatchify read); NULL = carved from `act`.  Set it BEFORE asking
+                                                    for the slab sizes.  With its own allocation the rows outlive the activation slab (a lazily
+                                                    written prediction image no longer pins the whole slab until it is read or dropped) */
 } mmae_adapter_desc;
 
 int64_t mmae_adapter_act_bytes(const mmae_adapter_desc* d);
@@ -741,15 +751,20 @@ int mmae_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, cons
  * utils/native_scaler.py:49-62), clip / skip decision (:22-35), the non-finite guards (GradScaler.step skipping an
  * update with inf / NaN gradients; the loop's isfinite(loss) check, run_pretraining_multimae.py:529-531) and AdamW --
  * with every decision taken ON THE DEVICE (no host synchronisation):
- *   norm   = grad_prescale * |g|_2                       (grad_prescale = 1 / world_size for SUMMED data-parallel gradients)
+ *   pre    = grad_prescale / (grad_scale_dev ? *grad_scale_dev : 1)   (grad_prescale = 1 / world_size for SUMMED data-parallel
+ *            gradients; grad_scale_dev = torch.amp.GradScaler's loss scale when the arena still holds SCALED gradients -- the
+ *            un-scaling is folded into the step's existing multiply, no pass over the arena)
+ *   norm   = pre * |g|_2
  *   skip   = !finite(norm) || (skip_grad > 0 && norm >= skip_grad) || (loss_dev && !finite(*loss_dev))
- *   scale  = grad_prescale * (clip_grad > 0 ? min(1, clip_grad / (norm + 1e-6)) : 1)
+ *            || (found_inf_dev && *found_inf_dev > 0)       (GradScaler's own inf / NaN verdict, counted apart from a bad loss)
+ *   scale  = pre * (clip_grad > 0 ? min(1, clip_grad / (norm + 1e-6)) : 1)
  *   !skip: step += 1;  AdamW with lr, weight_decay (host values, or lrwd_dev[0..1] when given -- the per-iteration cosine
  *          tables of run_pretraining_multimae.py:474-480) and the bias corrections of the DEVICE step counter, so a skipped
  *          iteration does not advance Adam's step (the reference never calls optimizer.step() for it).
  * state  f32 [8]:  [0] sum of squares  [1] norm  [2] scale  [3..6] lr, weight_decay, 1 - beta1^t, sqrt(1 - beta2^t)
- * istate i32 [4]:  [0] skip flag of this step  [1] t = updates applied so far  [2] steps whose loss was not finite
- *                  [3] steps skipped for any reason.     ws: f32 scratch >= 1024.
+ * istate i32 [8]:  [0] skip flag of this step  [1] t = updates applied so far  [2] steps whose loss was not finite
+ *                  [3] steps skipped for any reason  [4] steps skipped because found_inf_dev was set (AMP overflow)
+ *                  [5] steps whose gradient norm was not finite  [6..7] reserved.     ws: f32 scratch >= 1024.
  * ------------------------------------------------------------------------- */
 typedef struct mmae_opt_desc {
     float* p; const float* g; float* m; float* v; int64_t n;
@@ -759,6 +774,8 @@ typedef struct mmae_opt_desc {
     float clip_grad, skip_grad, grad_prescale;
     const float* loss_dev;
     float* state; int32_t* istate; float* ws;
+    const float* found_inf_dev;                  /* optional: GradScaler.step()'s found_inf (> 0: skip, istate[4] += 1) */
+    const float* grad_scale_dev;                 /* optional: the loss scale the gradients still carry */
 } mmae_opt_desc;
 int mmae_opt_step(const mmae_opt_desc* d, void* stream);
 

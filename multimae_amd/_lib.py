@@ -85,7 +85,7 @@ class AdapterDesc(ctypes.Structure):
                                      'ids_restore', 'act')] + [('act_bytes', _L), ('img', _P)]
                 + [('d_img', _P), ('d_pat', _P), ('ld_pat', _L), ('g', _P), ('d_enc', _P), ('tmp', _P), ('tmp_bytes', _L)]
                 + [('ws_main', _P), ('ws_main_elems', _L), ('ws_side', _P), ('ws_side_elems', _L)]
-                + [('x3_w', _P), ('x3_n', _I), ('dy_amax', _P)])
+                + [('x3_w', _P), ('x3_n', _I), ('dy_amax', _P), ('pat', _P)])
 
 
 class DwProblem(ctypes.Structure):
@@ -108,7 +108,7 @@ class OptDesc(ctypes.Structure):
     _fields_ = [('p', _P), ('g', _P), ('m', _P), ('v', _P), ('n', _L), ('shadow', _P), ('shadow_dtype', _I),
                 ('lr', _F), ('weight_decay', _F), ('beta1', _F), ('beta2', _F), ('eps', _F), ('lrwd_dev', _P),
                 ('clip_grad', _F), ('skip_grad', _F), ('grad_prescale', _F), ('loss_dev', _P),
-                ('state', _P), ('istate', _P), ('ws', _P)]
+                ('state', _P), ('istate', _P), ('ws', _P), ('found_inf_dev', _P), ('grad_scale_dev', _P)]
 
 
 class PatchSrc(ctypes.Structure):
@@ -174,7 +174,7 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = ret
         fn.argtypes = argtypes
-    if lib.mmae_abi_version() != 5:
+    if lib.mmae_abi_version() != 6:
         raise RuntimeError('libmmae_hip.so ABI version mismatch')
     for which, cls in enumerate((GemmDesc, BlockDesc, StackDesc, AdapterDesc, OptDesc, PatchSrc, DwGroupDesc, ColsumJob)):
         if lib.mmae_struct_size(which) != ctypes.sizeof(cls):

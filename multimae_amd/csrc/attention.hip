@@ -96,8 +96,8 @@ __device__ __forceinline__ bf16x8 cvt8_f16(const i32x4& a, const i32x4& b, float
     f16x8 h;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        h[j] = (_Float16)__builtin_amdgcn_fmed3f(fa[j] * s, -65504.0f, 65504.0f);
-        h[4 + j] = (_Float16)__builtin_amdgcn_fmed3f(fb[j] * s, -65504.0f, 65504.0f);
+        h[j] = f16_cvt(fa[j] * s);
+        h[4 + j] = f16_cvt(fb[j] * s);
     }
     return __builtin_bit_cast(bf16x8, h);
 }
@@ -176,7 +176,7 @@ __device__ __forceinline__ bf16x8 pack8_lo(const f32x16& v, int s) {     // resi
 __device__ __forceinline__ bf16x8 pack8_f16(const f32x16& v, int s) {     // fp16 bit patterns of accumulator registers 8s .. 8s+7
     f16x8 r;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (_Float16)__builtin_amdgcn_fmed3f(v[8 * s + j], -65504.0f, 65504.0f);
+    for (int j = 0; j < 8; ++j) r[j] = f16_cvt(v[8 * s + j]);
     return __builtin_bit_cast(bf16x8, r);
 }
 template <int MODE> __device__ __forceinline__ bf16x8 pack8m(const f32x16& v, int s) { return MODE >= 2 ? pack8_f16(v, s) : pack8(v, s); }
@@ -228,8 +228,8 @@ __device__ __forceinline__ i32x2 pack4_bf16_rne(float a, float b, float c, float
 }
 __device__ __forceinline__ i32x2 pack4_f16_rne(float a, float b, float c, float d) {
     typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
-    f16x4_t v = {(_Float16)__builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f), (_Float16)__builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f),
-                 (_Float16)__builtin_amdgcn_fmed3f(c, -65504.0f, 65504.0f), (_Float16)__builtin_amdgcn_fmed3f(d, -65504.0f, 65504.0f)};
+    f16x4_t v = {f16_cvt(a), f16_cvt(b),
+                 f16_cvt(c), f16_cvt(d)};
     return __builtin_bit_cast(i32x2, v);
 }
 template <bool H16 = false>

@@ -48,11 +48,15 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
 }
 
-// ---- fp16 <-> f32 (round to nearest even, saturating at +-65504): the 16-bit format of the fp32 output adapters' activations (MMAE_F16) ----
+// ---- fp16 <-> f32 (round to nearest even): the 16-bit format of the fp32 output adapters' activations (MMAE_F16) ----
+// NOT saturating (round 5): a value beyond +-65504 becomes +-inf (and a NaN stays a NaN), exactly as under fp16 autocast.
+// The inf then reaches the loss / the gradient norm, mmae_opt_step's non-finite test skips the update and counts it
+// (FusedAdamW.counters()['skipped']) -- the GradScaler contract of the reference's own fp16 runs -- instead of a silently clamped
+// activation training on.  f16_cvt() is the one conversion every fp16 store and operand rounding of the library goes through.
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ _Float16 f16_cvt(float f) { return (_Float16)f; }
 __device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
-    const _Float16 h = (_Float16)__builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f);
-    return __builtin_bit_cast(uint16_t, h);
+    return __builtin_bit_cast(uint16_t, f16_cvt(f));
 }
 __device__ __forceinline__ float f16_bits_to_f32(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
 struct h16_t { uint16_t v; };
@@ -132,14 +136,16 @@ __device__ __forceinline__ void gelu_both(float x, float& y, float& dy) { float 
 __device__ __forceinline__ float gelu_erf_grad(float x) { float c, e; gelu_cdf_exp(x, c, e); return c + x * e * 0.39894228040143268f; }
 
 // ---- the same pair for bf16 OUTPUTS: no transcendental, packed fp32 math ---------------------------------------------------------
-// Phi(x) - 1/2 and GELU'(x) - 1/2 are odd: x Q(x^2) and x R(x^2) with degree-8 minimax polynomials in s = x^2 on |x| <= 4, x clamped
-// to that range first (Phi(4) = 1 - 3.2e-5: beyond it gelu(x) = x Phi(+-4), GELU' = GELU'(+-4) = 1 + 5e-4 | -5e-4).  Evaluated in
-// fp32 Horner form (measured against fp64, tools/gelu_poly_fit.py): |Phi error| 6.6e-6, |GELU' error| 8.4e-5, gelu relative
-// error 1.3e-4 for x > -2 and an absolute error <= 2.7e-5 everywhere -- all below the bf16 rounding (2^-9 = 2e-3) the result gets
-// anyway.  Two elements per instruction (v_pk_fma_f32 / v_pk_mul_f32): 8 + 8 packed FMAs per pair against one v_exp, one v_rcp and
-// ~17 scalar FMA-class operations per ELEMENT of the exact form, which kept the bias + GELU epilogue of fc1 VALU-bound behind its
-// two store streams (profiles/r02_epilogue_dissection.txt: 17-30 us of 166).  The exact form above stays for every f32 output
-// (the parity mode, the fp32 output adapters).
+// Phi(x) - 1/2 and GELU'(x) - 1/2 are odd: x Q(x^2) and x R(x^2) with degree-8 minimax polynomials in s = x^2 on |x| <= 4.  Beyond
+// |x| = 4 (round 5) the pair is the limit itself -- Phi = GELU' = step(x), i.e. gelu(x) = max(x, 0) -- instead of the
+// polynomial held at +-4, which left gelu(x) = x Phi(-4) = -3.2e-5 |x| on the negative tail and GELU' = -5e-4 / 1 + 5e-4: the true
+// values there are |gelu(x) - max(x, 0)| <= 1.3e-4 and |GELU' - step| <= 5.1e-4 (at |x| = 4, falling like the Gaussian tail).
+// Evaluated in fp32 Horner form (measured against fp64 over |x| <= 20, tools/gelu_poly_fit.py): |Phi error| 3.2e-5 (the cut at 4;
+// 6.6e-6 inside), |GELU' error| 5.1e-4 at the cut (8.4e-5 inside), |gelu error| <= 1.3e-4 everywhere -- all below the bf16 rounding
+// (2^-9 = 2e-3 relative) the result gets anyway.  Two elements per instruction (v_pk_fma_f32 / v_pk_mul_f32): 8 + 8 packed FMAs
+// per pair against one v_exp, one v_rcp and ~17 scalar FMA-class operations per ELEMENT of the exact form, which kept the bias +
+// GELU epilogue of fc1 VALU-bound behind its two store streams (profiles/r02_epilogue_dissection.txt: 17-30 us of 166).  The exact
+// form above stays for every f32 output (the parity mode) and for the fp16-storage adapters (H16 epilogues).
 __device__ __forceinline__ void gelu_both_fast2(f32x2 x, f32x2& y, f32x2& dy) {
     f32x2 t;
     t[0] = __builtin_amdgcn_fmed3f(x[0], -4.0f, 4.0f);
@@ -157,9 +163,16 @@ __device__ __forceinline__ void gelu_both_fast2(f32x2 x, f32x2& y, f32x2& dy) {
     MMAE_PK_STEP(q, 3.989227094e-01f);  MMAE_PK_STEP(r, 7.976095497e-01f);
 #undef MMAE_PK_STEP
     const f32x2 half = {0.5f, 0.5f};
-    const f32x2 cdf = __builtin_elementwise_fma(t, q, half);
-    y = x * cdf;
+    f32x2 cdf = __builtin_elementwise_fma(t, q, half);
     dy = __builtin_elementwise_fma(t, r, half);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {                          // the tails: step(x) (one clamped multiply, one compare, two selects per element)
+        const float st = __builtin_amdgcn_fmed3f(x[j] * 1e30f, 0.0f, 1.0f);
+        const bool out = fabsf(x[j]) > 4.0f;
+        cdf[j] = out ? st : cdf[j];
+        dy[j] = out ? st : dy[j];
+    }
+    y = x * cdf;
 }
 __device__ __forceinline__ void gelu_both_fast4(f32x4 x, f32x4& y, f32x4& dy) {
     f32x2 ya, da, yb, db;

@@ -854,7 +854,7 @@ AdapterAct carve_adapter_act(Carver& cv, const mmae_adapter_desc* d) {
     a.hpre = cv.take(Rq * d->Hd * es); a.hact = cv.take(Rq * d->Hd * es); a.x1 = cv.takeT<float>(Rq * D);
     for (int l = 0; l < d->depth; ++l) a.blocks[l] = carve_block_act(cv, d->B, d->n_q, D, d->heads, d->Hd, es);
     a.h_act = is16(d->act_dtype) ? cv.take(Rq * D * es) : nullptr;
-    a.pat = cv.takeT<float>(Rq * kp_of(d));
+    a.pat = d->pat ? d->pat : cv.takeT<float>(Rq * kp_of(d));
     a.x3_tmp = adapter_x3_bytes(d) ? cv.take(adapter_x3_bytes(d)) : nullptr;
     return a;
 }
@@ -940,7 +940,7 @@ int64_t mmae_adapter_pat_offset(const mmae_adapter_desc* d) {
     if (!d || d->depth < 0 || d->depth > 8) return -1;
     Carver cv(nullptr);
     AdapterAct a = carve_adapter_act(cv, d);
-    return (int64_t)(uintptr_t)a.pat;
+    return d->pat ? -1 : (int64_t)(uintptr_t)a.pat;       // caller-owned rows: not in the slab
 }
 
 int mmae_adapter_fwd(const mmae_adapter_desc* d, void* stream) {

@@ -362,10 +362,19 @@ __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cba
                 }
                 if (EPI == MMAE_EPI_GELU) {
                     f32x4 s0 = v0, s1 = v1;                  // what aux keeps: the pre-activation, or (aux_grad) GELU' of it
-                    if (DBG != 1) {                          // bf16 outputs: the packed polynomial pair (common.h)
-                        f32x4 y0, d0, y1, d1;
-                        gelu_both_fast4(v0, y0, d0);
-                        gelu_both_fast4(v1, y1, d1);
+                    if (DBG != 1) {                          // bf16 outputs: the packed polynomial pair (common.h); fp16-storage adapters (the
+                        f32x4 y0, d0, y1, d1;                // reference's fp32 adapters): the exact erf form, as every f32 output
+                        if constexpr (H16) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                float ya, da, yb, db;
+                                gelu_both(v0[j], ya, da); gelu_both(v1[j], yb, db);
+                                y0[j] = ya; d0[j] = da; y1[j] = yb; d1[j] = db;
+                            }
+                        } else {
+                            gelu_both_fast4(v0, y0, d0);
+                            gelu_both_fast4(v1, y1, d1);
+                        }
                         if (g.aux_grad) { s0 = d0; s1 = d1; }
                         v0 = y0; v1 = y1;
                     }
@@ -377,6 +386,9 @@ __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cba
                     if (g.aux_grad) {                        // the forward stored GELU' itself: no transcendental work here
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { v0[j] *= p0[j]; v1[j] *= p1[j]; }
+                    } else if constexpr (H16) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { v0[j] *= gelu_erf_grad(p0[j]); v1[j] *= gelu_erf_grad(p1[j]); }
                     } else {
                         const f32x4 g0 = gelu_grad_fast4(p0), g1 = gelu_grad_fast4(p1);
 #pragma unroll

@@ -10,7 +10,7 @@
 // (11-bit significand = TF32's; fp32 accumulation) on v_mfma_f32_32x32x16_f16.  That is exactly the operand precision the
 // reference's fp32 adapters ran at on A100 (TF32), at a third of the MFMA work and half the LDS traffic of the split form.  fp16
 // has TF32's significand but not its exponent range: forward operands (normalised activations, weights) fit as they are (values
-// beyond +-65504 saturate); a GRADIENT operand (dy of a dX / dW product, ~1e-6 at the bench batch) is multiplied by a power of two
+// beyond +-65504 become inf, which the optimiser step's non-finite test turns into a skipped, counted update: common.h f16_cvt); a GRADIENT operand (dy of a dX / dW product, ~1e-6 at the bench batch) is multiplied by a power of two
 // read from device memory first -- 2^-floor(log2(amax)), amax = the largest |element| of the loss gradient the backward pass
 // started from, left there by the loss kernel -- and the accumulators are multiplied back before the epilogue, so nothing in
 // memory changes scale.  Without an amax the gradient products stay on the split form.
@@ -56,8 +56,8 @@ __device__ __forceinline__ i32x4 cvt8_f16(const f32x4 x0, const f32x4 x1, float 
     f16x8 h;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        h[j] = (_Float16)__builtin_amdgcn_fmed3f(x0[j] * s, -65504.0f, 65504.0f);
-        h[4 + j] = (_Float16)__builtin_amdgcn_fmed3f(x1[j] * s, -65504.0f, 65504.0f);
+        h[j] = f16_cvt(x0[j] * s);
+        h[4 + j] = f16_cvt(x1[j] * s);
     }
     return __builtin_bit_cast(i32x4, h);
 }

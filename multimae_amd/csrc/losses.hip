@@ -529,11 +529,14 @@ __global__ void __launch_bounds__(256) sumsq_stage2(const float* __restrict__ ws
 // Every decision of the optimiser step on the device (mmae_opt_step): norm, clip / skip, non-finite guards, Adam's step
 // counter and bias corrections.  One thread.
 __global__ void opt_finalize_kernel(float* __restrict__ state, int* __restrict__ istate, float lr, float wd, const float* __restrict__ lrwd,
-                                    float b1, float b2, float clip, float skip_at, float prescale, const float* __restrict__ loss) {
+                                    float b1, float b2, float clip, float skip_at, float prescale, const float* __restrict__ loss,
+                                    const float* __restrict__ found_inf, const float* __restrict__ grad_scale) {
+    if (grad_scale) prescale /= grad_scale[0];             // GradScaler's loss scale, still on the gradients (mmae.h)
     const float norm = sqrtf(state[0]) * prescale;
     const bool loss_bad = loss && !isfinite(loss[0]);
+    const bool amp_bad = found_inf && found_inf[0] > 0.f;
     // clip and skip are exclusive, clip first: utils/native_scaler.py:24-32 is `if clip_grad ... elif skip_grad`
-    const bool skip = !isfinite(norm) || (clip <= 0.f && skip_at > 0.f && norm >= skip_at) || loss_bad;
+    const bool skip = !isfinite(norm) || (clip <= 0.f && skip_at > 0.f && norm >= skip_at) || loss_bad || amp_bad;
     float scale = prescale;
     if (clip > 0.f) { const float cc = clip / (norm + 1e-6f); scale *= cc < 1.f ? cc : 1.f; }
     int t = istate[1];
@@ -542,6 +545,8 @@ __global__ void opt_finalize_kernel(float* __restrict__ state, int* __restrict__
     istate[1] = t;
     if (loss_bad) istate[2] += 1;
     if (skip) istate[3] += 1;
+    if (amp_bad) istate[4] += 1;
+    if (!isfinite(norm)) istate[5] += 1;
     state[1] = norm; state[2] = scale;
     state[3] = lrwd ? lrwd[0] : lr;
     state[4] = lrwd ? lrwd[1] : wd;
@@ -773,7 +778,7 @@ int mmae_opt_step(const mmae_opt_desc* d, void* stream) {
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(opt_finalize_kernel, dim3(1), dim3(1), 0, st, d->state, d->istate, d->lr, d->weight_decay, d->lrwd_dev, d->beta1, d->beta2,
-                       d->clip_grad, d->skip_grad, d->grad_prescale, d->loss_dev);
+                       d->clip_grad, d->skip_grad, d->grad_prescale, d->loss_dev, d->found_inf_dev, d->grad_scale_dev);
     if ((rc = mmae_check_launch("opt_finalize"))) return rc;
     return mmae_adamw_dev(d->p, d->g, d->m, d->v, d->n, d->state + 3, d->beta1, d->beta2, d->eps, d->state + 2, d->istate, d->shadow,
                           d->shadow_dtype, stream);

@@ -27,10 +27,15 @@ int mmae_cu_count() {
 }
 
 // compute units the persistent GEMM grids leave free (mmae_gemm_cu_reserve): a launch POLICY read on the host when a grid is sized
+// Two independent requesters, one slot each (a save / restore of ONE shared value let an enclosing context wipe what the
+// gradient reducer had set mid-backward): `reserve` belongs to the data-parallel gradient exchange (dist.GradAllReducer),
+// `share` to the output adapters' side-by-side experiment (functions._adapter_cu_share); the grids leave max(reserve, share) free.
 static std::atomic<int> g_cu_reserve{0};
+static std::atomic<int> g_cu_share{0};
 static std::atomic<int> g_side_cus{0};
 int mmae_cu_avail() {
-    const int n = mmae_cu_count(), k = g_cu_reserve.load(std::memory_order_relaxed) + g_side_cus.load(std::memory_order_relaxed);
+    const int r = g_cu_reserve.load(std::memory_order_relaxed), sh = g_cu_share.load(std::memory_order_relaxed);
+    const int n = mmae_cu_count(), k = (r > sh ? r : sh) + g_side_cus.load(std::memory_order_relaxed);
     const int a = n - k;
     return a < 16 ? (n < 16 ? n : 16) : a;
 }
@@ -45,6 +50,11 @@ extern "C" int mmae_gemm_side_cus(int k) {
 extern "C" int mmae_gemm_cu_reserve(int k) {
     const int prev = g_cu_reserve.load(std::memory_order_relaxed);
     if (k >= 0) g_cu_reserve.store(k, std::memory_order_relaxed);
+    return prev;
+}
+extern "C" int mmae_gemm_cu_share(int k) {
+    const int prev = g_cu_share.load(std::memory_order_relaxed);
+    if (k >= 0) g_cu_share.store(k, std::memory_order_relaxed);
     return prev;
 }
 

@@ -75,8 +75,11 @@ class GradAllReducer:
         # while buckets fly instead of time-slicing.  0 = off (single GPU).
         self.gemm_cu_reserve = 0
         self._reserved = False
-        self.timing = False                             # bench.py: event-time the exposed wait in finish()
-        self._wait_events: List[tuple] = []
+        self.timing = False                             # bench.py: event-time the exposed wait in finish(), every bucket's launch -> done, and
+        self._wait_events: List[tuple] = []             # the stretch of backward that ran on the reduced-width GEMM grids
+        self._bucket_events: List[tuple] = []           # (bucket, issue event, done event) on the launch stream
+        self._reserve_events: List[tuple] = []          # (first bucket launch, finish()) on the compute stream
+        self._reserve_ev0 = None
         self._bf16_tmp: Dict[int, torch.Tensor] = {}
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -112,6 +115,13 @@ class GradAllReducer:
         return 1.0 if self.average_in_place else 1.0 / self.world
 
     def reset(self) -> None:
+        """Back to "no bucket launched".  Also the recovery path after a step that raised between the first bucket launch and
+        finish(): the CUs reserved for the collective go back to the GEMMs (ADVICE r4 -- the reserve used to stay for the rest
+        of the process)."""
+        if getattr(self, '_reserved', False):
+            from . import ops
+            ops.gemm_cu_reserve(0)
+            self._reserved = False
         self._remaining = [len(names) for _, _, names in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._events = [[] for _ in self.buckets]
@@ -142,6 +152,9 @@ class GradAllReducer:
             from . import ops
             ops.gemm_cu_reserve(self.gemm_cu_reserve)    # GEMMs enqueued from here on leave room for the collective's kernels
             self._reserved = True
+            if self.timing and self.grad.is_cuda:
+                self._reserve_ev0 = torch.cuda.Event(enable_timing=True)
+                self._reserve_ev0.record()               # on the compute stream: backward from here runs n_cu - k wide
 
         def exchange():
             if not self.bf16_buckets:
@@ -160,7 +173,15 @@ class GradAllReducer:
             for ev in self._events[i]:
                 ls.wait_event(ev)
             with torch.cuda.stream(ls):
+                if self.timing:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record()                          # every contributing gradient kernel has finished: the bucket could start
                 h = exchange()
+                if self.timing:
+                    h.wait()                             # orders the launch stream (only) behind the collective
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    self._bucket_events.append((i, e0, e1))
         else:
             h = exchange()
         self._handles.append((h, i))
@@ -199,6 +220,11 @@ class GradAllReducer:
         for i in pending:
             self._launch(i)
         ev0 = None
+        if self.timing and self.grad.is_cuda and self._reserve_ev0 is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()                                  # end of backward on the compute stream
+            self._reserve_events.append((self._reserve_ev0, ev))
+            self._reserve_ev0 = None
         if self.timing and self.grad.is_cuda and self._handles:
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -213,11 +239,7 @@ class GradAllReducer:
             ev1 = torch.cuda.Event(enable_timing=True)
             ev1.record()
             self._wait_events.append((ev0, ev1))
-        if self._reserved:
-            from . import ops
-            ops.gemm_cu_reserve(0)                       # the optimiser step and the next forward get the whole chip again
-            self._reserved = False
-        self.reset()
+        self.reset()                                     # also lifts the CU reserve: the optimiser step and the next forward get the whole chip
 
     def exposed_wait_ms(self) -> float:
         """Sum of the event-timed waits finish() put on the calling stream since the last call (timing = True): the part of the
@@ -228,6 +250,32 @@ class GradAllReducer:
             tot += a.elapsed_time(b)
         self._wait_events = []
         return tot
+
+    def bucket_timings(self) -> dict:
+        """Self-diagnosis of an N > 1 run (timing = True; call after the timed region, synchronises): per bucket the mean time from
+        "its last gradient kernel finished" to "its all-reduce finished" on the launch stream (size / that = the algorithm bandwidth the
+        bucket saw while backward kept running), and the mean stretch of backward -- first bucket launch to finish() -- that ran on
+        GEMM grids `gemm_cu_reserve` CUs narrower.  A bucket whose launch-to-done time approaches that stretch is the one finish()
+        ends up waiting for."""
+        per: Dict[int, List[float]] = {}
+        for i, a, b in self._bucket_events:
+            b.synchronize()
+            per.setdefault(i, []).append(a.elapsed_time(b))
+        self._bucket_events = []
+        res = []
+        for a, b in self._reserve_events:
+            b.synchronize()
+            res.append(a.elapsed_time(b))
+        self._reserve_events = []
+        out = []
+        for i in sorted(per):
+            s, e, names = self.buckets[i]
+            ms = sum(per[i]) / len(per[i])
+            mb = (e - s) * (2 if self.bf16_buckets else 4) / 1e6
+            out.append(dict(bucket=i, mb=round(mb, 1), first=names[0], launch_to_done_ms=round(ms, 3),
+                            algbw_gb_s=round(mb / ms, 1) if ms > 0 else None, n=len(per[i])))
+        return dict(buckets=out, backward_ms_on_reduced_width_grids=round(sum(res) / len(res), 3) if res else 0.0,
+                    gemm_cu_reserved=self.gemm_cu_reserve)
 
     def _join_all(self, buckets: Sequence[int]) -> None:
         from . import engine

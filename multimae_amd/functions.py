@@ -561,11 +561,11 @@ def _adapter_cu_share():
     if k <= 0:
         yield
         return
-    prev = ops.gemm_cu_reserve(k)
+    prev = ops.gemm_cu_share(k)                      # its own slot: the gradient reducer's reserve is untouched
     try:
         yield
     finally:
-        ops.gemm_cu_reserve(prev)
+        ops.gemm_cu_share(prev)
 
 
 def _f32_mode(cfg) -> str:
@@ -657,11 +657,13 @@ class SpatialAdapterFn(torch.autograd.Function):
             if lazy_img:
                 img = torch.empty((B, cfg.C, cfg.nh * cfg.ph, cfg.nw * cfg.pw), device=enc.device, dtype=torch.float32)
                 ev = torch.cuda.current_stream().record_event() if enc.is_cuda else None
-                pat, slab, geom = state.pat, state.act, (B, cfg.C, cfg.nh, cfg.nw, cfg.ph, cfg.pw)
+                pat, geom = state.pat, (B, cfg.C, cfg.nh, cfg.nw, cfg.ph, cfg.pw)
 
-                def fill(dst, pat=pat, slab=slab, ev=ev, geom=geom):     # slab: keeps the rows alive as long as the prediction lives
+                def fill(dst, pat=pat, ev=ev, geom=geom):     # holds the prediction ROWS (their own allocation), not the activation slab
                     if ev is not None:
-                        torch.cuda.current_stream().wait_event(ev)
+                        cur = torch.cuda.current_stream()
+                        cur.wait_event(ev)
+                        pat.record_stream(cur)               # written on the adapter's stream, read here on the consumer's
                     ops.unpatchify_into(pat, dst, *geom)
                 cfg.lazy_fill = fill
             ctx.comp = state if save else None

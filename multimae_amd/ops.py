@@ -256,6 +256,11 @@ def gemm_cu_reserve(k: Optional[int] = None) -> int:
     return int(_lib.load().mmae_gemm_cu_reserve(-1 if k is None else int(k)))
 
 
+def gemm_cu_share(k: Optional[int] = None) -> int:
+    """The second slot of the same launch policy (mmae_gemm_cu_share): grids leave max(reserve, share) CUs free; returns the previous value."""
+    return int(_lib.load().mmae_gemm_cu_share(-1 if k is None else int(k)))
+
+
 def gemm_side_cus(k: Optional[int] = None) -> int:
     """A/B switch: compute units set aside for the side stream's grouped weight gradients (mmae_gemm_side_cus); returns the previous value."""
     return int(_lib.load().mmae_gemm_side_cus(-1 if k is None else int(k)))
@@ -718,6 +723,11 @@ def adapter_fwd(enc: Tensor, enc_act: Optional[Tensor], ids_keep: Tensor, ids_re
         x3 = x3_weights(w_list)                 # forward / dX products of this fp32 adapter as ONE bf16 product over 3 K each
         x3.refresh()
         d.x3_w, d.x3_n = ctypes.cast(x3.triples, ctypes.c_void_p), len(w_list)
+    # the prediction rows in their own allocation (mmae_adapter_desc.pat): a lazily written image / a patch-domain loss keep THEM
+    # alive, not the whole activation slab
+    KP = cfg.C * cfg.ph * cfg.pw
+    pat = torch.empty((B * n_q, KP), device=enc.device, dtype=torch.float32)
+    d.pat = pat.data_ptr()
     slab = _slab(lib.mmae_adapter_act_bytes(ctypes.byref(d)), enc.device)
     d.act, d.act_bytes = slab.data_ptr(), slab.numel()
     img = torch.empty((B, cfg.C, cfg.nh * cfg.ph, cfg.nw * cfg.pw), device=enc.device, dtype=torch.float32) if want_img else None
@@ -727,9 +737,7 @@ def adapter_fwd(enc: Tensor, enc_act: Optional[Tensor], ids_keep: Tensor, ids_re
     d.ws_main, d.ws_main_elems = ws.data_ptr(), ws.numel()
     check(lib.mmae_adapter_fwd(ctypes.byref(d), st), 'adapter_fwd')
     s = AdapterState()
-    KP = cfg.C * cfg.ph * cfg.pw
-    off = lib.mmae_adapter_pat_offset(ctypes.byref(d))
-    s.pat = slab[off:off + B * n_q * KP * 4].view(torch.float32).view(B * n_q, KP)
+    s.pat = pat
     s.desc, s.act, s.ld_pat = d, slab, KP
     s.keep = (offs, w_arr, p_arr, te_arr, w_list, p_list, temb, mask_token, enc, enc_act, ids_keep, ids_restore, cfg.pos, x3)
     return img, s
@@ -1312,14 +1320,18 @@ def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, *, lr: float, beta1: float
 
 def opt_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, state: Tensor, istate: Tensor, ws: Tensor, *, lr: float, weight_decay: float,
              beta1: float, beta2: float, eps: float, clip_grad: Optional[float], skip_grad: Optional[float], grad_prescale: float = 1.0,
-             lrwd_dev: Optional[Tensor] = None, loss_dev: Optional[Tensor] = None, shadow: Optional[Tensor] = None) -> None:
-    """mmae_opt_step: grad-norm, clip / skip / non-finite decisions, step counter and AdamW -- all on the device."""
+             lrwd_dev: Optional[Tensor] = None, loss_dev: Optional[Tensor] = None, shadow: Optional[Tensor] = None,
+             found_inf_dev: Optional[Tensor] = None, grad_scale_dev: Optional[Tensor] = None) -> None:
+    """mmae_opt_step: grad-norm, clip / skip / non-finite decisions, step counter and AdamW -- all on the device.
+    ``found_inf_dev`` / ``grad_scale_dev``: torch.amp.GradScaler's device scalars (an overflow verdict that skips the update and is
+    counted on its own, istate[4]; the loss scale still on the gradients, folded into the step's multiply)."""
     d = OptDesc()
     d.p, d.g, d.m, d.v, d.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
     d.shadow, d.shadow_dtype = _p(shadow), (dcode(shadow.dtype) if shadow is not None else F32)
     d.lr, d.weight_decay, d.beta1, d.beta2, d.eps = lr, weight_decay, beta1, beta2, eps
     d.lrwd_dev, d.loss_dev = _p(lrwd_dev), _p(loss_dev)
+    d.found_inf_dev, d.grad_scale_dev = _p(found_inf_dev), _p(grad_scale_dev)
     d.clip_grad, d.skip_grad, d.grad_prescale = (clip_grad or 0.0), (skip_grad or 0.0), grad_prescale
-    assert state.dtype == torch.float32 and state.numel() >= 8 and istate.dtype == torch.int32 and istate.numel() >= 4
+    assert state.dtype == torch.float32 and state.numel() >= 8 and istate.dtype == torch.int32 and istate.numel() >= 8
     d.state, d.istate, d.ws = state.data_ptr(), istate.data_ptr(), ws.data_ptr()
     check(_lib.load().mmae_opt_step(ctypes.byref(d), _stream()), 'opt_step')

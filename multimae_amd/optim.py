@@ -30,8 +30,9 @@ class FusedAdamW(torch.optim.Optimizer):
     views (``zero_grad()`` re-binds them; AccumulateGrad / DDP write into them in place).
 
     state (device, mmae_opt_desc): ``_state`` f32[8] = [sum of squares, gradient norm, applied gradient scale, lr, weight
-    decay, 1 - beta1^t, sqrt(1 - beta2^t), -]; ``_istate`` i32[4] = [skip flag of the last step, t = updates applied, steps
-    with a non-finite loss, skipped steps].  The step counter lives on the device: a skipped iteration (non-finite gradient
+    decay, 1 - beta1^t, sqrt(1 - beta2^t), -]; ``_istate`` i32[8] = [skip flag of the last step, t = updates applied, steps
+    with a non-finite loss, skipped steps, steps skipped on GradScaler's found_inf (AMP overflow), steps with a non-finite
+    gradient norm, -, -].  The step counter lives on the device: a skipped iteration (non-finite gradient
     norm or loss, skip_grad) does not advance Adam's t -- the reference never calls optimizer.step() for it
     (utils/native_scaler.py:27-31, GradScaler.step)."""
 
@@ -52,7 +53,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.clip_grad, self.skip_grad = clip_grad, skip_grad
         self.grad_prescale = 1.0          # 1 / world_size when the gradient arena holds rank SUMS (dist.GradAllReducer sets it)
         self._state = torch.zeros(8, device=a.device, dtype=torch.float32)
-        self._istate = torch.zeros(4, device=a.device, dtype=torch.int32)
+        self._istate = torch.zeros(8, device=a.device, dtype=torch.int32)
         self._ws = torch.empty(1024, device=a.device, dtype=torch.float32)
         self.grad_norm = self._state[1:2]
         self.max_steps_in_flight = 2      # the host may enqueue at most this many steps ahead of the GPU (see step())
@@ -68,11 +69,16 @@ class FusedAdamW(torch.optim.Optimizer):
     def step_count(self, t: int) -> None:
         self._istate[1] = int(t)
 
-    def counters(self) -> dict:
+    def counters(self, detail: bool = False) -> dict:
         """{'steps', 'nonfinite_loss', 'skipped'} (one host read; poll at logging time to mirror the reference's
-        isfinite(loss) exit, run_pretraining_multimae.py:529-531, without a per-step synchronisation)."""
+        isfinite(loss) exit, run_pretraining_multimae.py:529-531, without a per-step synchronisation).  ``detail=True`` adds
+        'amp_overflow' (steps GradScaler's found_inf skipped -- NOT a diverged loss) and 'nonfinite_grad' (steps
+        whose gradient norm was inf / NaN: an fp16-storage adapter that overflowed lands here)."""
         c = self._istate.tolist()
-        return dict(steps=c[1], nonfinite_loss=c[2], skipped=c[3])
+        out = dict(steps=c[1], nonfinite_loss=c[2], skipped=c[3])
+        if detail:
+            out.update(amp_overflow=c[4], nonfinite_grad=c[5])
+        return out
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         """One memset of the gradient arena; ``p.grad`` stays (or becomes again) the arena view, whatever ``set_to_none`` says."""
@@ -108,15 +114,18 @@ class FusedAdamW(torch.optim.Optimizer):
             lrwd = cap.add(hyper, a.device)
         if loss is not None:
             loss = loss.detach().float().reshape(1)
+        # torch.amp.GradScaler.step() (_step_supports_amp_scaling): device scalars, consumed by the library call itself -- the overflow
+        # verdict skips the update under its own counter, the loss scale (set only when unscale_() was not called, i.e. the arena still
+        # holds scaled gradients) is folded into the step's gradient multiply instead of a pass over the arena
         found_inf, grad_scale = getattr(self, 'found_inf', None), getattr(self, 'grad_scale', None)
-        if grad_scale is not None:                       # GradScaler.step() without a preceding unscale_(): the arena still holds scaled gradients
-            a.grad.div_(grad_scale.to(a.grad.device).float())
-        if found_inf is not None:                        # an inf / nan gradient seen by GradScaler: skip on the device, as a non-finite loss does
-            bad = torch.where(found_inf.to(a.grad.device).reshape(1) > 0, float('nan'), 0.0).float()
-            loss = bad if loss is None else loss + bad
+        if found_inf is not None:
+            found_inf = found_inf.to(a.grad.device).float().reshape(1)
+        if grad_scale is not None:
+            grad_scale = grad_scale.to(a.grad.device).float().reshape(1)
         ops.opt_step(a.param[:n], a.grad, self.m, self.v, self._state, self._istate, self._ws, lr=g['lr'],
                      weight_decay=g['weight_decay'], beta1=b1, beta2=b2, eps=g['eps'], clip_grad=self.clip_grad, skip_grad=self.skip_grad,
-                     grad_prescale=self.grad_prescale, lrwd_dev=lrwd, loss_dev=loss, shadow=shadow)
+                     grad_prescale=self.grad_prescale, lrwd_dev=lrwd, loss_dev=loss, shadow=shadow, found_inf_dev=found_inf,
+                     grad_scale_dev=grad_scale)
         if shadow is not None:
             a.mark_shadow_fresh()
         if cap is None and a.param.is_cuda and self.max_steps_in_flight:

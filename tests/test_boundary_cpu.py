@@ -16,7 +16,7 @@ def test_cabi_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f'libmmae_hip.so does not export {n}'
-    assert _lib.load().mmae_abi_version() == 5        # load() also checks every ctypes struct mirror against mmae_struct_size()
+    assert _lib.load().mmae_abi_version() == 6        # load() also checks every ctypes struct mirror against mmae_struct_size()
 
 
 def test_state_dict_contract_and_seeded_init_base():

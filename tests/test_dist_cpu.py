@@ -261,3 +261,69 @@ def test_reducer_reserves_compute_units_only_while_buckets_are_in_flight(monkeyp
         assert torch.equal(grad, torch.arange(4096, dtype=torch.float32))      # one-rank sums: unchanged values
     finally:
         dist.destroy_process_group()
+
+
+def _skew_worker(rank, world, port, q):
+    try:
+        import time
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        from multimae_amd import ops
+        state = {'reserve': 0, 'log': []}
+
+        def fake_reserve(k=None):
+            prev = state['reserve']
+            if k is not None and k >= 0:
+                state['reserve'] = k
+                state['log'].append(k)
+            return prev
+        ops.gemm_cu_reserve = fake_reserve
+        grad = torch.full((4096,), float(rank + 1))
+        sizes = [('a', 0, 1024), ('b', 1024, 1024), ('c', 2048, 1024), ('d', 3072, 1024)]
+        r = GradAllReducer(grad, sizes, bucket_mb=1024 * 4 / 2 ** 20)
+        r.gemm_cu_reserve = 16
+        seen_at_step = []
+        for step in range(3):
+            grad.fill_(float(rank + 1))
+            # the same readiness ORDER on every rank (the backward pass is the same program), different TIMING: the ranks reach each
+            # report -- and finish() -- at different moments
+            for j, n in enumerate(['a', 'b', 'c', 'd']):
+                time.sleep(0.02 * ((rank + step + j) % 3))
+                r.mark_ready([n])
+                assert state['reserve'] == 16, (rank, step, n)       # from the first bucket launch on
+            time.sleep(0.03 * ((rank + step) % 2))
+            r.finish()
+            seen_at_step.append(state['reserve'])                    # what the optimiser step would see on THIS rank
+            assert torch.allclose(grad, torch.full((4096,), float(sum(range(1, world + 1)))))
+        # a step that dies between the first bucket launch and finish(): reset() gives the CUs back
+        r.mark_ready(['a'])
+        assert state['reserve'] == 16
+        for h, _ in r._handles:
+            h.wait()
+        r.reset()
+        q.put((rank, seen_at_step, state['reserve'], state['log']))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:                     # pragma: no cover
+        import traceback
+        q.put((rank, 'error', repr(e), traceback.format_exc()))
+
+
+def test_cu_reserve_is_lifted_before_the_optimizer_step_on_every_rank_under_timing_skew_world2_gloo():
+    """the CUs reserved for the collective are returned by finish() -- i.e. before opt.step -- on EVERY rank, also
+    when the ranks reach their readiness reports and finish() at different times; and by reset() after a step that raised."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_skew_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] != 'error', r
+        rank, seen, final, log = r
+        assert seen == [0, 0, 0], (rank, seen)
+        assert final == 0, (rank, final)
+        assert log == [16, 0] * 4, (rank, log)

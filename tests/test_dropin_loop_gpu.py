@@ -1,0 +1,146 @@
+"""GPU: the reference's ``train_one_epoch`` body (run_pretraining_multimae.py:472-540) driven by the services of
+``dropin/amd_loop.py`` -- ``wrap_model`` instead of DistributedDataParallel, ``create_optimizer`` -> FusedAdamW, ``LossScaler``
+instead of NativeScalerWithGradNormCount -- at the BENCH geometry (cfg3, B = 256), against the engine-native loop of bench.py
+(through the plain seam the reference loop costs 25 % more than the native step; with the three services swapped
+it must be within 5 %).  The loop body is replayed line by line, host reads included (``.item()`` on every task loss, the
+``torch.cuda.synchronize()`` at :540): those are the reference's, and they stay."""
+import json
+import math
+import os
+import sys
+import time
+import types
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'dropin'))
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda', 0)
+OUT = os.path.join(ROOT, 'gpurun_out')
+
+
+def _reference_loop_body(model, batches, tasks_loss_fn, optimizer, loss_scaler, lr_tab, wd_tab, *, num_encoded_tokens, in_domains,
+                         fp32_output_adapters, max_norm=None, max_skip_norm=None):
+    """run_pretraining_multimae.py:472-540 (loss_on_unmasked=False, extra_norm_pix_loss=True, NoWeightingStrategy, no depth
+    standardisation: the synthetic depth is already standardised), metric logging reduced to the values it reads."""
+    model.train()
+    seen = []
+    for step, x in enumerate(batches):
+        it = step
+        for param_group in optimizer.param_groups:                                        # :474-480
+            param_group['lr'] = lr_tab[it] * param_group['lr_scale']
+            if param_group['weight_decay'] > 0:
+                param_group['weight_decay'] = wd_tab[it]
+        tasks_dict = {task: tensor.to(DEV, non_blocking=True) for task, tensor in x.items()}          # :482-485
+        input_dict = {task: tensor for task, tensor in tasks_dict.items() if task in in_domains}       # :494-498
+        with torch.cuda.amp.autocast():                                                   # :500
+            preds, masks = model(input_dict, num_encoded_tokens=num_encoded_tokens, alphas=1.0, sample_tasks_uniformly=False,
+                                 fp32_output_adapters=fp32_output_adapters)
+            tasks_dict['norm_rgb'] = tasks_dict['rgb']                                    # :509-511
+            masks['norm_rgb'] = masks.get('rgb', None)
+            task_losses = {task: tasks_loss_fn[task](preds[task].float(), tasks_dict[task], mask=masks.get(task, None)) for task in preds}
+            loss = sum(task_losses.values())                                             # NoWeightingStrategy: identity
+        loss_value = sum(task_losses.values()).item()                                     # :525
+        task_loss_values = {f'{task}_loss': l.item() for task, l in task_losses.items()}   # :526
+        if not math.isfinite(loss_value):                                                 # :529-531
+            raise SystemExit(1)
+        optimizer.zero_grad()                                                             # :533
+        grad_norm = loss_scaler(loss, optimizer, clip_grad=max_norm, skip_grad=max_skip_norm, parameters=model.parameters(),
+                                create_graph=False)                                       # :536-537
+        loss_scale_value = loss_scaler.state_dict()['scale']                              # :538
+        torch.cuda.synchronize()                                                          # :540
+        seen.append((loss_value, task_loss_values, float(grad_norm), loss_scale_value))
+    return seen
+
+
+def _native_loop(model, batches, fns, opt, lr_tab, wd_tab, nvis):
+    out = []
+    for it, x in enumerate(batches):
+        g = opt.param_groups[0]
+        g['lr'], g['weight_decay'] = lr_tab[it], wd_tab[it]
+        opt.zero_grad()
+        preds, masks = model(x, num_encoded_tokens=nvis, alphas=1.0, sample_tasks_uniformly=False, fp32_output_adapters=['semseg'])
+        tgt = dict(x, norm_rgb=x['rgb'])
+        mk = dict(masks, norm_rgb=masks['rgb'])
+        loss = sum(fns[k](preds[k].float(), tgt[k], mask=mk[k]) for k in preds)
+        loss.backward()
+        opt.step(loss)
+        out.append(loss.detach())
+    torch.cuda.synchronize()
+    return [float(v) for v in out]
+
+
+def _fresh(B):
+    import multimae_amd as M
+    import bench
+    torch.manual_seed(0)
+    model, doms = bench.build_model('cfg3')
+    model.to(DEV)
+    x = bench.synthetic_batch(doms, B, DEV, seed=0)
+    return M, bench, model, doms, x
+
+
+@pytest.mark.parametrize('B', [256])
+def test_reference_loop_with_engine_services_runs_at_the_native_step_time(B):
+    import amd_loop
+    warm, steps = 4, 12
+    n = warm + steps
+    lr_tab = [1e-4 * min(1.0, (i + 1) / 10) for i in range(n)]
+    wd_tab = [0.05] * n
+    args = types.SimpleNamespace(opt='adamw', lr=lr_tab[0], weight_decay=0.05, opt_eps=1e-8, opt_betas=[0.9, 0.95], task_balancer='none')
+
+    def seeds():
+        torch.manual_seed(4321)
+        torch.cuda.manual_seed(4321)
+
+    # ---- engine-native loop (bench.py's) -------------------------------------------------------------------------------------
+    M, bench, model, doms, x = _fresh(B)
+    model.build_arena()
+    M.engine.set_direct_grads(True); M.engine.set_adapter_streams(True); M.engine.set_wgrad_stream(True)
+    from multimae_amd.optim import FusedAdamW
+    opt = FusedAdamW(model, lr=lr_tab[0], betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    fns = bench.loss_fns()
+    try:
+        seeds()
+        _native_loop(model, [x] * warm, fns, opt, lr_tab, wd_tab, 98)
+        t0 = time.perf_counter()
+        native_losses = _native_loop(model, [x] * steps, fns, opt, lr_tab[warm:], wd_tab[warm:], 98)
+        native_ms = (time.perf_counter() - t0) * 1e3 / steps
+    finally:
+        M.engine.set_direct_grads(False); M.engine.set_adapter_streams(False); M.engine.set_wgrad_stream(False)
+    del opt, model
+    torch.cuda.empty_cache()
+
+    # ---- the reference loop body on amd_loop's services ------------------------------------------------------------------------
+    M, bench, model, doms, x = _fresh(B)
+    try:
+        model, reducer = amd_loop.wrap_model(model, args)
+        assert reducer is None                                   # one process: no gradient exchange
+        optimizer = amd_loop.create_optimizer(args, model, reducer)
+        loss_scaler = amd_loop.LossScaler()
+        fns = bench.loss_fns()
+        kw = dict(num_encoded_tokens=98, in_domains=doms, fp32_output_adapters=['semseg'])
+        seeds()
+        _reference_loop_body(model, [x] * warm, fns, optimizer, loss_scaler, lr_tab, wd_tab, **kw)
+        t0 = time.perf_counter()
+        seen = _reference_loop_body(model, [x] * steps, fns, optimizer, loss_scaler, lr_tab[warm:], wd_tab[warm:], **kw)
+        ref_ms = (time.perf_counter() - t0) * 1e3 / steps
+        counters = optimizer.counters(detail=True)
+    finally:
+        M.engine.set_direct_grads(False); M.engine.set_adapter_streams(False); M.engine.set_wgrad_stream(False)
+    try:
+        os.makedirs(OUT, exist_ok=True)
+        with open(os.path.join(OUT, 'dropin_fast_loop.json'), 'w') as f:
+            json.dump({'geometry': f'cfg3, B = {B}, bf16, {steps} timed steps after {warm}', 'native_loop_ms_per_step': native_ms,
+                       'reference_loop_body_on_amd_loop_services_ms_per_step': ref_ms, 'ratio': ref_ms / native_ms,
+                       'losses_native': native_losses, 'losses_reference_loop': [s[0] for s in seen], 'counters': counters}, f, indent=1)
+    except OSError:
+        pass
+    # the same kernels in the same order from the same seeds: identical losses
+    assert [s[0] for s in seen] == pytest.approx(native_losses, rel=1e-6), (seen, native_losses)
+    assert all(s[3] == 1.0 and math.isfinite(s[2]) and s[2] > 0 for s in seen)
+    assert counters['steps'] == warm + steps and counters['skipped'] == 0
+    assert ref_ms <= 1.05 * native_ms, (ref_ms, native_ms)

@@ -165,8 +165,10 @@ def test_layernorm_colsum_and_casts_f16():
     assert h.dtype == torch.float16 and rel_err(h.cpu().double(), v.double() * S) < 4e-4
     back = ops.cast_f16(h, scale_amax=amax)
     assert back.dtype == torch.float32 and rel_err(back.cpu().double(), v.double()) < 4e-4
-    big = ops.cast_f16(torch.tensor([1e6, -1e6, 1.0], device=DEV))
-    assert big.cpu().tolist() == [65504.0, -65504.0, 1.0]              # saturating
+    # beyond the fp16 range: +-inf, never a silent clamp (round 5) -- the inf reaches the gradient norm and the fused
+    # optimiser step skips and counts the update (test_h16_overflow_surfaces_as_a_skipped_counted_step)
+    big = ops.cast_f16(torch.tensor([1e6, -1e6, 1.0, 65504.0, float('nan')], device=DEV)).cpu()
+    assert big[:4].tolist() == [float('inf'), float('-inf'), 1.0, 65504.0] and bool(torch.isnan(big[4]))
 
 
 @pytest.mark.parametrize('hd,Nq,Nk', [(32, 196, 98), (64, 98, 98), (32, 196, 196)])
@@ -352,3 +354,47 @@ def test_fp16_storage_adapter_under_a_pixel_loss_and_two_losses():
     assert len(b[2]) > 30
     worst = max((rel_err(b[2][n], a[2][n]), n) for n in a[2])
     assert worst[0] < 6e-3, worst
+
+
+def test_h16_overflow_surfaces_as_a_skipped_counted_step():
+    """An fp16-storage adapter whose activations leave the fp16 range must not train on clamped values: the overflow becomes inf,
+    travels to the loss / gradient norm, and mmae_opt_step skips the update and counts it -- the GradScaler contract of the
+    reference's own fp16 runs.  Forced here by scaling one MLP weight of the semseg adapter by 1e6."""
+    import multimae_amd as M
+    from multimae_amd.optim import FusedAdamW
+    from helpers import MINI, build_mini_engine, make_inputs
+    torch.manual_seed(0)
+    model = build_mini_engine().to(DEV)
+    model.build_arena()
+    torch.manual_seed(5)
+    x = {k: v.to(DEV) for k, v in make_inputs(MINI['doms'], 4, MINI['S']).items()}
+    P = MINI['P']
+    fns = {'rgb': M.MaskedMSELoss(P, 1), 'depth': M.MaskedL1Loss(P, 1), 'semseg': M.MaskedCrossEntropyLoss(P, 4), 'norm_rgb': M.MaskedMSELoss(P, 1, norm_pix=True)}
+    prev = M.engine.fp32_adapter_gemm()
+    M.engine.set_fp32_adapter_gemm('h16')
+    M.engine.set_direct_grads(True)
+    opt = FusedAdamW(model, lr=1e-3)
+    try:
+        def step():
+            opt.zero_grad()
+            preds, masks = model(x, num_encoded_tokens=MINI['nvis'], alphas=1.0, fp32_output_adapters=['semseg'])
+            mk = dict(masks, norm_rgb=masks['rgb'])
+            tgt = dict(x, norm_rgb=x['rgb'])
+            loss = sum(fns[k](preds[k].float(), tgt[k], mask=mk[k]) for k in preds)
+            loss.backward()
+            opt.step(loss)
+            return float(loss)
+        l0 = step()
+        assert l0 == l0 and opt.counters(detail=True) == dict(steps=1, nonfinite_loss=0, skipped=0, amp_overflow=0, nonfinite_grad=0)
+        w = model.output_adapters['semseg'].mlp.fc1.weight
+        before = model.encoder[0].attn.qkv.weight.detach().clone()
+        with torch.no_grad():
+            w.mul_(1e6)
+        l1 = step()
+        c = opt.counters(detail=True)
+        assert c['steps'] == 1 and c['skipped'] == 1, (l1, c)          # the update was NOT applied ...
+        assert c['nonfinite_loss'] + c['nonfinite_grad'] >= 1, c        # ... because the overflow was seen, not clamped away
+        assert torch.equal(model.encoder[0].attn.qkv.weight.detach(), before)
+    finally:
+        M.engine.set_direct_grads(False)
+        M.engine.set_fp32_adapter_gemm(prev)

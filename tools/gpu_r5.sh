@@ -27,6 +27,23 @@ duo)   # the two-workgroups-per-CU GEMM (tile 11, experiments library) on the ou
   run "exp library, defaults again" timeout 300 $B
   table decoder_gemms.py "decoder GEMMs, tiles 9 10 11 12" 9 10 11 12
   ;;
+probe)   # HBM ceilings by direction, the encoder table and the serialized kernel statistics of this box
+  python tools/hbm_probe.py >> $S 2>&1
+  table encoder_gemms.py "encoder GEMMs"
+  kstats base
+  python - >> $S <<'PY'
+import csv
+rows = list(csv.DictReader(open('gpurun_out/r5_probe_kernel_stats_base.csv')))
+print('== serialized ms/step', round(sum(float(r['TotalDurationNs']) for r in rows) / 8e6, 3))
+for r in sorted(rows, key=lambda r: -float(r['TotalDurationNs']))[:45]:
+    print(f"{float(r['TotalDurationNs']) / 8e6:7.3f} ms/step  {int(r['Calls']) / 8:6.1f} calls  {float(r['AverageNs']) / 1e3:8.1f} us  {r['Name'][:150]}")
+PY
+  ;;
+newtests)   # the tests added this round + the default bench line
+  timeout 1500 python -m pytest tests/test_curves_gpu.py tests/test_dropin_loop_gpu.py tests/test_h16_gpu.py -x -q 2>&1 | tail -25 >> $S
+  for f in curve_cfg3_bf16_h16.json curve_cfg3_bf16_f16.json curve_cfg3_bf16_x3.json adapter_modes_train_cfg3.json mxfp8_trains_cfg5.json dropin_fast_loop.json; do [ -f gpurun_out/$f ] && cp gpurun_out/$f gpurun_out/r5_$f; done
+  run "production library, defaults" timeout 300 $B
+  ;;
 baseline)
   run "production library, defaults" timeout 300 $B
   table encoder_gemms.py "encoder GEMMs"
