@@ -233,13 +233,30 @@ def cpu_baseline(cfg: str, sample_B: int, steps: int, threads: int = 0):
         cores = min(sweep, key=sweep.get)
     med = timed(cores, steps)
     log(f'cpu_baseline: {kind}, {cores} of {avail} cores, B={sample_B}: median {med:.2f} s/step = {sample_B / med:.2f} img/s')
-    return {'value': round(sample_B / med, 3), 'unit': 'images/s', 'cores': cores, 'kind': kind, 'cpu': cpu_model_name(),
+    # batch sweep: a larger CPU batch amortises the per-step overheads -- B = 4 x sample_B at the best thread count and
+    # at twice it, 2 timed steps each; the best img/s over (B, threads) is the reported value, so the baseline is not under-stated
+    best = dict(img_s=sample_B / med, B=sample_B, cores=cores)
+    batch_sweep = {f'B={sample_B},threads={cores}': round(sample_B / med, 2)}
+    big_B = 4 * sample_B
+    try:
+        step_big = (_reference_step_fn(cfg, big_B) if kind == 'reference' else None) or _oracle_step_fn(cfg, big_B)
+        step = step_big
+        for c in sorted({cores, min(2 * cores, avail)}):
+            t = timed(c, 2)
+            batch_sweep[f'B={big_B},threads={c}'] = round(big_B / t, 2)
+            log(f'cpu_baseline batch sweep: B={big_B}, {c} threads -> {t:.2f} s/step ({big_B / t:.2f} img/s)')
+            if big_B / t > best['img_s']:
+                best = dict(img_s=big_B / t, B=big_B, cores=c)
+    except Exception as e:      # noqa: BLE001 -- memory / time on a small host: keep the B = sample_B figure
+        batch_sweep['error'] = repr(e)[:200]
+    return {'value': round(best['img_s'], 3), 'unit': 'images/s', 'cores': best['cores'], 'kind': kind, 'cpu': cpu_model_name(),
             'cores_available': avail, 'thread_sweep_img_s': {str(c): round(sample_B / t, 2) for c, t in sweep.items()},
-            'sample': f'BASELINE.md section 3 protocol: median of {steps} timed steps after 1 warm-up of the same {cfg} step (fwd, 4 losses, '
-                      f'backward, AdamW) at B={sample_B}, fp32, '
+            'batch_sweep_img_s': batch_sweep,
+            'sample': f'BASELINE.md section 3 protocol: the same {cfg} step (fwd, 4 losses, backward, AdamW) in fp32, '
                       + ('the reference classes (/root/reference, Appendix B import)' if kind == 'reference'
-                         else 'oracle/multimae_oracle.py + torch autograd (the reference checkout does not exist on this box)')
-                      + f', {cores} threads (best of the 8/16/32/64 sweep)'}
+                         else 'oracle/multimae_oracle.py + torch autograd (the reference checkout does not exist on this box; ~15 % slower than the reference classes on equal cores, DESIGN section 8)')
+                      + f'; threads = best of the 8/16/32/64 sweep at B={sample_B} (median of {steps} timed steps after 1 warm-up), then B={big_B} at that count and twice it '
+                        f'(2 timed steps each); value = the best img/s seen: B={best["B"]}, {best["cores"]} threads'}
 
 
 def result_line(args, B, world, ms_per_step, img_s, final_loss, counters, roof, cpu, dp_diag, host_ms, host_wait_ms, use_graph, n_vis, doms):
@@ -338,6 +355,21 @@ def main():
             out['secondary'] = {k: o2[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config', 'final_loss', 'roofline')}
         except Exception as e:      # noqa: BLE001 -- the secondary line must never cost the primary one
             out['secondary'] = {'error': repr(e)[:300]}
+        # ... and two more short runs beside it: the headline step with the fp32 (semseg) adapter as f32 tensors and
+        # split-bf16 ('x3', ~16-bit operand significand, 8-bit exponent) products instead of fp16 storage -- the strictest of the speed-mode
+        # adapter forms, so that the driver's line shows what the default's storage format buys -- and BASELINE configs[1] (RGB only)
+        for key, mods in (('secondary_x3_adapter', dict(fp32_adapter_gemm='x3')), ('secondary_cfg2', dict(config='cfg2'))):
+            a3 = copy.copy(args)
+            a3.steps, a3.warmup, a3.no_cpu_baseline, a3.no_kernel_timing = 10, 3, True, True
+            for k, v in mods.items():
+                setattr(a3, k, v)
+            gc.collect()
+            torch.cuda.empty_cache()
+            try:
+                o3 = run_once(a3)
+                out[key] = {k: o3[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config', 'final_loss')}
+            except Exception as e:      # noqa: BLE001
+                out[key] = {'error': repr(e)[:300]}
     if out is not None:
         print(json.dumps(out))
     import torch.distributed as dist

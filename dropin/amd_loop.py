@@ -40,8 +40,9 @@ def wrap_model(model: torch.nn.Module, args=None, bucket_mb: float = 64.0):
     torch.distributed.  Rank 0's parameters are broadcast as DDP's constructor does (the script seeds every rank differently, :300-302)."""
     arena = model.build_arena()
     M.engine.set_direct_grads(True)              # backward writes straight into the gradient arena: no AccumulateGrad per parameter
-    M.engine.set_adapter_streams(True)
-    M.engine.set_wgrad_stream(True)
+    on_gpu = arena.param.is_cuda                 # (a CPU dry run of the host logic has no streams)
+    M.engine.set_adapter_streams(on_gpu)
+    M.engine.set_wgrad_stream(on_gpu)
     reducer = None
     if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
         mdist.broadcast_parameters(arena)

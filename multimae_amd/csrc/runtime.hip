@@ -228,6 +228,8 @@ int mmae_gemm_ex(const mmae_gemm_desc* d, void* stream, int timing_cls, double f
     g.dbg = env_dbg;
     static const int env_dephase = mmae_env_int("MMAE_PP_DEPHASE", 0);
     g.dephase = env_dephase;
+    static const int env_dephase_sel = mmae_env_int("MMAE_PP_DEPHASE_SEL", 0);     // 1: only the two-stream epilogues of the encoder (fc1 + GELU, fc2-dX x aux)
+    if (env_dephase_sel == 1 && (d->epi == MMAE_EPI_NONE || d->K < 512)) g.dephase = 0;
     g.scA = d->a_scale; g.scB = d->b_scale;
     g.a_amax = d->a_amax;
     g.h16 = h16 ? 1 : 0;

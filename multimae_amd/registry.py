@@ -23,6 +23,11 @@ def register_model(fn: Callable) -> Callable:
             mod.__all__ = [fn.__name__]
         elif fn.__name__ not in names:
             names.append(fn.__name__)
+    _into_reference_registry(fn)
+    return fn
+
+
+def _reference_registry():
     ext = sys.modules.get('utils.registry')
     if ext is None:
         # deployed next to the reference tree: its registry is importable as utils.registry (the reference's own
@@ -32,9 +37,26 @@ def register_model(fn: Callable) -> Callable:
             ext = importlib.import_module('utils.registry')
         except Exception:
             ext = None
-    if ext is not None and hasattr(ext, '_model_entrypoints'):
+    return ext if ext is not None and hasattr(ext, '_model_entrypoints') else None
+
+
+def _into_reference_registry(fn: Callable) -> None:
+    ext = _reference_registry()
+    if ext is not None:
         ext._model_entrypoints[fn.__name__] = fn        # live reference registry: take over the name
-    return fn
+
+
+def sync_reference_registry() -> int:
+    """(Re-)insert every registered factory into the reference's ``utils.registry`` if it is importable NOW.  ``register_model`` does
+    this at decoration time, which is too early when the engine was imported before the reference tree was on ``sys.path`` (found by
+    running the unmodified script, tools/run_reference_script_dryrun.py); the drop-in ``multimae.multimae`` module calls this when the
+    training script imports it -- run_pretraining_multimae.py:34-36 imports ``utils`` first.  Returns the number of names placed."""
+    ext = _reference_registry()
+    if ext is None:
+        return 0
+    for name, fn in _entrypoints.items():
+        ext._model_entrypoints[name] = fn
+    return len(_entrypoints)
 
 
 def is_model(name: str) -> bool:

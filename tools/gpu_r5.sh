@@ -44,6 +44,24 @@ newtests)   # the tests added this round + the default bench line
   for f in curve_cfg3_bf16_h16.json curve_cfg3_bf16_f16.json curve_cfg3_bf16_x3.json adapter_modes_train_cfg3.json mxfp8_trains_cfg5.json dropin_fast_loop.json; do [ -f gpurun_out/$f ] && cp gpurun_out/$f gpurun_out/r5_$f; done
   run "production library, defaults" timeout 300 $B
   ;;
+pmcdec)   # HBM bytes per launch of the decoder / encoder products (tile 10 or the planner's choice), FETCH and WRITE passes
+  for c in FETCH_SIZE WRITE_SIZE; do rm -rf gpurun_out/pmc_$c; (cd /tmp && timeout 300 rocprofv3 --pmc $c -d $R/gpurun_out/pmc_$c -o p --output-format csv -- python $R/tools/decoder_gemms.py 10 > $R/gpurun_out/pmc_$c.log 2>&1); done
+  echo "== decoder products, tile 10: HBM bytes per launch" >> $S
+  python tools/pmc_cases.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE 8 "fwd qkv" "fwd proj" "fwd fc1" "fwd fc2" "dx fc2" "dx fc1" "dx proj" "dx qkv" >> $S 2>&1
+  for c in FETCH_SIZE WRITE_SIZE; do rm -rf gpurun_out/pmc_$c; (cd /tmp && timeout 300 rocprofv3 --pmc $c -d $R/gpurun_out/pmc_$c -o p --output-format csv -- python $R/tools/encoder_gemms.py > $R/gpurun_out/pmc_$c.log 2>&1); done
+  echo "== encoder products: HBM bytes per launch" >> $S
+  python tools/pmc_cases.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE 12 "fwd qkv" "fwd proj" "fwd fc1" "fwd fc2" "dx fc2" "dx fc1" "dx proj" "dx qkv" "dw fc2" "dw fc1" "dw proj" "dw qkv" >> $S 2>&1
+  rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
+  ;;
+dephase)   # odd workgroups of the two-stream-epilogue products start ~4 us late (experiments library)
+  export MMAE_LIB=$EXP
+  run "exp library, defaults" timeout 300 $B
+  MMAE_PP_DEPHASE=1 MMAE_PP_DEPHASE_SEL=1 run "exp, dephase 1 on GELU / dGELU epilogues, K >= 512" timeout 300 $B
+  run "exp library, defaults again" timeout 300 $B
+  MMAE_PP_DEPHASE=1 MMAE_PP_DEPHASE_SEL=1 run "exp, dephase 1 sel again" timeout 300 $B
+  MMAE_PP_DEPHASE=1 MMAE_PP_DEPHASE_SEL=1 table encoder_gemms.py "encoder GEMMs, dephase 1 on the two-stream epilogues"
+  table encoder_gemms.py "encoder GEMMs, defaults"
+  ;;
 baseline)
   run "production library, defaults" timeout 300 $B
   table encoder_gemms.py "encoder GEMMs"
