@@ -61,3 +61,22 @@ for c,deg in ((4.0,8),(4.0,9),(4.5,9),(4.5,10)):
     print(f"c={c} deg={deg}: fp32 Phi err {e1:.2e}, dGELU err {e2:.2e}; gelu max abs err {np.abs(y-yt).max():.2e}; rel err at x>-2: {rel[x>-2].max():.2e}, x>-3: {rel[x>-3].max():.2e}")
     print("  Q:", ", ".join(f"{v:.9e}" for v in mq))
     print("  R:", ", ".join(f"{v:.9e}" for v in mr))
+
+print("---- the shipped routine (common.h gelu_both_fast2: the c = 4, degree-8 pair inside |x| <= 4, step(x) beyond), emulated in fp32 over |x| <= 20 (ADVICE r4)")
+QC = [3.989227094e-01, -6.641059427e-02, 9.877475989e-03, -1.133921717e-03, 9.890799001e-05, -6.294988571e-06, 2.716148569e-07, -7.003438364e-09, 8.063375031e-11]
+RC = [7.976095497e-01, -2.648265329e-01, 5.845610030e-02, -8.716320413e-03, 9.073266031e-04, -6.495757385e-05, 3.028347546e-06, -8.218800834e-08, 9.796052989e-10]
+x = np.concatenate([np.linspace(-20, 20, 2000001), np.array([-4.0, 4.0, np.nextafter(4.0, 5.0), -np.nextafter(4.0, 5.0)])]).astype(np.float32)
+t = np.clip(x, -4.0, 4.0)
+s = (t.astype(np.float64) ** 2).astype(np.float32)
+cdf = (0.5 + t.astype(np.float64) * horner32(QC, s)).astype(np.float32)
+dg = (0.5 + t.astype(np.float64) * horner32(RC, s)).astype(np.float32)
+out = np.abs(x) > 4.0
+step = (x > 0).astype(np.float32)
+cdf = np.where(out, step, cdf); dg = np.where(out, step, dg)
+xx = x.astype(np.float64)
+y = (xx * cdf).astype(np.float32)
+for name, lo, hi in (('|x| <= 4', 0.0, 4.0), ('4 < |x| <= 20', 4.0, 20.0)):
+    m = (np.abs(xx) > lo) & (np.abs(xx) <= hi) if lo > 0 else (np.abs(xx) <= hi)
+    print(f"{name:14s}: |Phi err| {np.abs(cdf[m] - Phi(xx[m])).max():.2e}   |GELU' err| {np.abs(dg[m] - (Phi(xx[m]) + xx[m] * phi(xx[m]))).max():.2e}   |gelu err| {np.abs(y[m] - xx[m] * Phi(xx[m])).max():.2e}")
+old = (xx * np.where(out, (0.5 + np.sign(xx) * 4.0 * horner32(QC, np.full_like(s, 16.0))).astype(np.float32), cdf)).astype(np.float32)
+print(f"(round 4's form -- the polynomial held at +-4 -- on 4 < |x| <= 20: |gelu err| {np.abs(old[out] - xx[out] * Phi(xx[out])).max():.2e})")
