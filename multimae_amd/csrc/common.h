@@ -34,6 +34,9 @@ static inline int mmae_env_int(const char* name, int dflt) {
 }
 int mmae_gemm_ex(const mmae_gemm_desc* d, void* stream, int timing_cls, double flop_scale);   // runtime.hip
 
+// query_norm / context_norm outputs of the fused decoder build (tokens.hip: decoder_build_kernel<.., true>; composite.hip: mmae_adapter_fwd)
+struct BuildLn { const float *qg, *qb, *cg, *cb; void *qn, *cn; float *qmean, *qrstd, *cmean, *crstd; float eps; };
+
 #define MMAE_REQUIRE(cond, msg) do { if (!(cond)) { mmae_set_error(msg); return MMAE_EINVAL; } } while (0)
 
 // ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) -------------------------------

@@ -555,6 +555,9 @@ int run_blocks_bwd(const StackRun& s, int lo, int hi, const float* dx_top, const
 int mmae_decoder_build_rows(const float* ctx, const int64_t* ids_keep, const int64_t* ids_restore, const float* mask_token,
                             const float* const* task_emb_rows, const float* pos, const int32_t* task_offsets_host, int T, int q_task, int B,
                             int n_keep, int G, int D, int n_q, float* queries, float* context, void* stream);      // tokens.hip
+int mmae_decoder_build_rows_ln(const float* ctx, const int64_t* ids_keep, const int64_t* ids_restore, const float* mask_token,
+                               const float* const* task_emb_rows, const float* pos, const int32_t* task_offsets_host, int T, int q_task, int B,
+                               int n_keep, int G, int D, int n_q, float* queries, float* context, const BuildLn* ln, int ln_dtype, void* stream);
 
 extern "C" {
 
@@ -965,10 +968,17 @@ int mmae_adapter_fwd(const mmae_adapter_desc* d, void* stream) {
     }
     if ((rc = lin_fwd(c, enc_act, pcw, pcb, a.ctx_tok, MMAE_F32, Rc, D, d->Denc, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;      // :258
     // the task-embedding rows are read where the parameters live (no staging copies)
-    if ((rc = mmae_decoder_build_rows(a.ctx_tok, d->ids_keep, d->ids_restore, d->mask_token, (const float* const*)d->task_emb, d->pos, d->task_offsets_host, T,
-                                      d->q_task, B, NC - d->G, d->G, D, n_q, a.queries, a.context, st))) return rc;                    // :183-234
-    if ((rc = mmae_layernorm_fwd(a.queries, qnw, qnb, a.qn, act, a.qmean, a.qrstd, Rq, D, d->eps, st))) return rc;
-    if ((rc = mmae_layernorm_fwd(a.context, cnw, cnb, a.cn, act, a.cmean, a.crstd, Rc, D, d->eps, st))) return rc;
+    if (D <= 256) {
+        // queries / context AND their query_norm / context_norm (:259-260) in one launch: a wave holds the row it assembled (round 5)
+        const BuildLn ln = {qnw, qnb, cnw, cnb, a.qn, a.cn, a.qmean, a.qrstd, a.cmean, a.crstd, d->eps};
+        if ((rc = mmae_decoder_build_rows_ln(a.ctx_tok, d->ids_keep, d->ids_restore, d->mask_token, (const float* const*)d->task_emb, d->pos, d->task_offsets_host,
+                                             T, d->q_task, B, NC - d->G, d->G, D, n_q, a.queries, a.context, &ln, act, st))) return rc;    // :183-234
+    } else {
+        if ((rc = mmae_decoder_build_rows(a.ctx_tok, d->ids_keep, d->ids_restore, d->mask_token, (const float* const*)d->task_emb, d->pos, d->task_offsets_host, T,
+                                          d->q_task, B, NC - d->G, d->G, D, n_q, a.queries, a.context, st))) return rc;                    // :183-234
+        if ((rc = mmae_layernorm_fwd(a.queries, qnw, qnb, a.qn, act, a.qmean, a.qrstd, Rq, D, d->eps, st))) return rc;
+        if ((rc = mmae_layernorm_fwd(a.context, cnw, cnb, a.cn, act, a.cmean, a.crstd, Rc, D, d->eps, st))) return rc;
+    }
     if ((rc = lin_fwd(c, a.qn, qw, qb, a.q, act, Rq, D, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;
     if ((rc = lin_fwd(c, a.cn, kvw, kvb, a.kv, act, Rc, 2 * D, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;
     {

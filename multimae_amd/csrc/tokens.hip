@@ -199,12 +199,40 @@ __global__ void __launch_bounds__(256) tokens_assemble_bwd_kernel(const float* _
 // one task-embedding row per INPUT task, by pointer (NULL = that task has none: zeros) -- the rows live wherever the parameters do,
 // no staging copy (round 3 issued one hipMemcpyAsync per task and adapter: 12 of a cfg3 step's 91 copyBuffer launches)
 struct TePtrs { const float* p[MAX_TASKS]; };
+// query_norm / context_norm of the adapter (output_adapters.py:120-122, applied at :259-260) folded into the build (round 5): at D <= 256 a
+// wave owns a whole row -- one float4 per lane -- so the LayerNorm of the row it has just assembled is two wave reductions and one more
+// store, instead of two further launches that re-read 76 MB.  The arithmetic is ln_fwd_kernel<1>'s, operation for operation.
+// (struct BuildLn: common.h)
 
+template <typename YT>
+__device__ __forceinline__ void build_ln_row(const f32x4 v, bool has, int c, int D, float eps, const float* __restrict__ g, const float* __restrict__ b,
+                                              YT* __restrict__ yrow, float* __restrict__ mean, float* __restrict__ rstd, long long row, int lane) {
+    const float s = has ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+    if (has) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[j] - mu; q += d * d; }
+    }
+    const float var = wave_sum(q) / (float)D;
+    const float rs = 1.0f / sqrtf(var + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    if (has) {
+        const f32x4 g4 = ld4(g + c), b4 = ld4(b + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[j] - mu) * rs * g4[j] + b4[j];
+        st4(yrow + c, o);
+    }
+}
+
+template <typename YT, bool LN>
 __global__ void __launch_bounds__(256) decoder_build_kernel(const float* __restrict__ ctx, const long long* __restrict__ ids_keep,
                                                             const long long* __restrict__ ids_restore, const float* __restrict__ mask_token,
                                                             const TePtrs tep, const float* __restrict__ pos, const TaskTable tt,
                                                             int q_task, int n_keep, int G, int D, int n_q, int Ntot,
-                                                            float* __restrict__ queries, float* __restrict__ context, long long total_rows) {
+                                                            float* __restrict__ queries, float* __restrict__ context, long long total_rows,
+                                                            const BuildLn ln) {
     // a row per group of `lpr` lanes: four rows per workgroup at the decoders' D = 256 (one workgroup per 1 KB row with 192 idle lanes, as
     // built in round 1, ran at 2.4 TB/s: every row is two dependent round trips -- index, then data)
     const int lpr = D <= 256 ? 64 : (D <= 512 ? 128 : 256);
@@ -224,28 +252,39 @@ __global__ void __launch_bounds__(256) decoder_build_kernel(const float* __restr
         const float* te = q_task < 0 ? nullptr : tep.p[q_task];
         const float* pe = pos + (long long)j * D;
         float* o = queries + ((long long)b * n_q + j) * D;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
         for (int c = tl * 4; c < D; c += cstep) {
             const f32x4 a = ld4(base + c), t4 = te ? ld4(te + c) : f32x4{0.f, 0.f, 0.f, 0.f}, p4 = ld4(pe + c);
-            f32x4 v;
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = a[k] + (t4[k] + p4[k]);
             st4(o + c, v);
+        }
+        if (LN) {                                        // D <= 256: lpr = 64, the loop above ran at most once
+            const long long row = (long long)b * n_q + j;
+            build_ln_row<YT>(v, tl * 4 < D, tl * 4, D, ln.eps, ln.qg, ln.qb, (YT*)ln.qn + row * D, ln.qmean, ln.qrstd, row, tl);
         }
     } else {
         const int r = rr - n_q;
         const float* src = ctx + ((long long)b * NC + r) * D;
         float* o = context + ((long long)b * NC + r) * D;
-        if (r >= n_keep) { for (int c = tl * 4; c < D; c += cstep) st4(o + c, ld4(src + c)); return; }
-        const int idx = (int)ids_keep[(long long)b * n_keep + r];
-        const int t = task_of(tt, idx);
-        const float* te = tep.p[t];
-        const float* pe = pos + (long long)(idx - tt.off[t]) * D;
-        for (int c = tl * 4; c < D; c += cstep) {
-            const f32x4 a = ld4(src + c), t4 = te ? ld4(te + c) : f32x4{0.f, 0.f, 0.f, 0.f}, p4 = ld4(pe + c);
-            f32x4 v;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r >= n_keep) {                               // global tokens: copied as they are
+            for (int c = tl * 4; c < D; c += cstep) { v = ld4(src + c); st4(o + c, v); }
+        } else {
+            const int idx = (int)ids_keep[(long long)b * n_keep + r];
+            const int t = task_of(tt, idx);
+            const float* te = tep.p[t];
+            const float* pe = pos + (long long)(idx - tt.off[t]) * D;
+            for (int c = tl * 4; c < D; c += cstep) {
+                const f32x4 a = ld4(src + c), t4 = te ? ld4(te + c) : f32x4{0.f, 0.f, 0.f, 0.f}, p4 = ld4(pe + c);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = a[k] + (t4[k] + p4[k]);
-            st4(o + c, v);
+                for (int k = 0; k < 4; ++k) v[k] = a[k] + (t4[k] + p4[k]);
+                st4(o + c, v);
+            }
+        }
+        if (LN) {
+            const long long row = (long long)b * NC + r;
+            build_ln_row<YT>(v, tl * 4 < D, tl * 4, D, ln.eps, ln.cg, ln.cb, (YT*)ln.cn + row * D, ln.cmean, ln.crstd, row, tl);
         }
     }
 }
@@ -629,9 +668,19 @@ int mmae_tokens_assemble_bwd(const float* d_tok, void* d_proj, int proj_dtype, c
 
 }  // extern "C"
 // the same with the task-embedding rows given one by one (device pointers, NULL = zeros); used by mmae_adapter_fwd
+// ln (optional, D <= 256): also the adapter's query_norm / context_norm of the rows -- outputs in act dtype `ln_dtype` + row statistics
+int mmae_decoder_build_rows_ln(const float* ctx, const int64_t* ids_keep, const int64_t* ids_restore, const float* mask_token,
+                               const float* const* task_emb_rows, const float* pos, const int32_t* task_offsets_host, int T, int q_task, int B,
+                               int n_keep, int G, int D, int n_q, float* queries, float* context, const BuildLn* ln, int ln_dtype, void* stream);
 int mmae_decoder_build_rows(const float* ctx, const int64_t* ids_keep, const int64_t* ids_restore, const float* mask_token,
                             const float* const* task_emb_rows, const float* pos, const int32_t* task_offsets_host, int T, int q_task, int B,
                             int n_keep, int G, int D, int n_q, float* queries, float* context, void* stream) {
+    return mmae_decoder_build_rows_ln(ctx, ids_keep, ids_restore, mask_token, task_emb_rows, pos, task_offsets_host, T, q_task, B, n_keep, G, D, n_q,
+                                      queries, context, nullptr, MMAE_F32, stream);
+}
+int mmae_decoder_build_rows_ln(const float* ctx, const int64_t* ids_keep, const int64_t* ids_restore, const float* mask_token,
+                               const float* const* task_emb_rows, const float* pos, const int32_t* task_offsets_host, int T, int q_task, int B,
+                               int n_keep, int G, int D, int n_q, float* queries, float* context, const BuildLn* ln, int ln_dtype, void* stream) {
     MMAE_REQUIRE(ctx && ids_keep && ids_restore && mask_token && task_emb_rows && pos && queries && context, "decoder_build: null pointer");
     MMAE_REQUIRE(D % 4 == 0 && D <= 1024 && B > 0, "decoder_build: bad sizes");
     TaskTable tt;
@@ -644,9 +693,19 @@ int mmae_decoder_build_rows(const float* ctx, const int64_t* ids_keep, const int
     }
     const int rpw = D <= 256 ? 4 : (D <= 512 ? 2 : 1);
     const long long total_rows = (long long)B * (n_q + n_keep + G);
-    hipLaunchKernelGGL(decoder_build_kernel, dim3((unsigned)((total_rows + rpw - 1) / rpw)), dim3(256), 0, (hipStream_t)stream, ctx,
-                       (const long long*)ids_keep, (const long long*)ids_restore, mask_token, tep, pos, tt, q_task, n_keep, G, D,
-                       n_q, tt.off[T], queries, context, total_rows);
+    const dim3 grid((unsigned)((total_rows + rpw - 1) / rpw));
+    hipStream_t st = (hipStream_t)stream;
+    const BuildLn none = {};
+#define DB_LAUNCH(YT, LN, L) hipLaunchKernelGGL((decoder_build_kernel<YT, LN>), grid, dim3(256), 0, st, ctx, (const long long*)ids_keep, \
+                       (const long long*)ids_restore, mask_token, tep, pos, tt, q_task, n_keep, G, D, n_q, tt.off[T], queries, context, total_rows, L)
+    if (ln) {
+        MMAE_REQUIRE(D <= 256 && ln->qg && ln->qb && ln->cg && ln->cb && ln->qn && ln->cn && ln->qmean && ln->qrstd && ln->cmean && ln->crstd,
+                     "decoder_build: the fused LayerNorm needs D <= 256 and every output");
+        if (ln_dtype == MMAE_BF16) DB_LAUNCH(uint16_t, true, *ln);
+        else if (ln_dtype == MMAE_F16) DB_LAUNCH(h16_t, true, *ln);
+        else DB_LAUNCH(float, true, *ln);
+    } else DB_LAUNCH(float, false, none);
+#undef DB_LAUNCH
     return mmae_check_launch("decoder_build");
 }
 extern "C" {

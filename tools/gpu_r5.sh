@@ -62,6 +62,11 @@ dephase)   # odd workgroups of the two-stream-epilogue products start ~4 us late
   MMAE_PP_DEPHASE=1 MMAE_PP_DEPHASE_SEL=1 table encoder_gemms.py "encoder GEMMs, dephase 1 on the two-stream epilogues"
   table encoder_gemms.py "encoder GEMMs, defaults"
   ;;
+quick)   # the adapter-level parity tests + the default line (after a change inside mmae_adapter_fwd / _bwd)
+  timeout 1500 python -m pytest tests/test_parity_geometry_gpu.py tests/test_kernels_gpu.py tests/test_h16_gpu.py tests/test_model_gpu.py -x -q -k "per_tensor or mask_token or decoder or adapter or build or golden or h16 or smoke or mini" 2>&1 | tail -8 >> $S
+  run "production library, defaults" timeout 300 $B
+  run "production library, defaults again" timeout 300 $B
+  ;;
 baseline)
   run "production library, defaults" timeout 300 $B
   table encoder_gemms.py "encoder GEMMs"
