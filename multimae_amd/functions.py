@@ -351,6 +351,8 @@ class EncoderStackFn(torch.autograd.Function):
                 d_outs[L - 1] = torch.zeros((B * N, D), device=params[0].device, dtype=torch.float32)
             dsts, acc = _grad_targets(sink, params)
             use_side = sink.side is not None and acc
+            # first write since zero_grad(): the library stores instead of accumulating onto zeros (engine.claim_first_write)
+            lib_acc = acc and not engine.claim_first_write(params)
             chunks, on_chunk = None, None
             # readiness reports only when the gradients really are final in the arena at that point: with fresh tensors handed to
             # autograd (acc False) AccumulateGrad writes them later, and a bucket reduced now would miss them
@@ -364,7 +366,7 @@ class EncoderStackFn(torch.autograd.Function):
             side_cus = engine.enc_bwd_side_cus() if use_side else 0       # A/B switch: dX chain and weight gradients side by side
             prev_side = ops.gemm_side_cus(side_cus) if side_cus > 0 else 0
             try:
-                dx, keep = ops.stack_bwd(ctx.stack, d_outs, dsts, acc, sink.side.cuda_stream if use_side else None, chunks, on_chunk)
+                dx, keep = ops.stack_bwd(ctx.stack, d_outs, dsts, lib_acc, sink.side.cuda_stream if use_side else None, chunks, on_chunk)
             finally:
                 if side_cus > 0:
                     ops.gemm_side_cus(prev_side)
@@ -751,7 +753,8 @@ class SpatialAdapterFn(torch.autograd.Function):
                 rows = d_pat if d_pat is not None else ops.patchify(d_img.contiguous().float(), cfg.C, cfg.nh, cfg.nw, cfg.ph, cfg.pw, torch.float32)
                 dy_amax = rows.detach().abs().amax().reshape(1).float()
                 d_pat, d_img = ops.cast_f16(rows, scale_amax=dy_amax), None
-            d_enc, keep = ops.adapter_bwd(ctx.comp, d_img, d_pat, [None if t is None else t.view(-1) for t in dsts], acc,
+            lib_acc = acc and not engine.claim_first_write(params)      # first write since zero_grad(): store, do not accumulate
+            d_enc, keep = ops.adapter_bwd(ctx.comp, d_img, d_pat, [None if t is None else t.view(-1) for t in dsts], lib_acc,
                                           sink.side.cuda_stream if use_side else None, dy_amax=dy_amax)
             ctx.comp = None
             if use_side:

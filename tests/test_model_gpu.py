@@ -531,3 +531,51 @@ def test_vit_large_geometry_cfg5():
     for k in po:
         assert rel_err(preds[k], po[k]) < 5e-5, (k, rel_err(preds[k], po[k]))
         assert rel_err(preds16[k], po[k]) < 3e-2, (k, rel_err(preds16[k], po[k]))
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_first_write_stores_equal_accumulation_and_a_second_backward_accumulates(mode):
+    """engine.claim_first_write (round 5): the first composite backward after ParamArena.zero_grad() STORES its parameter gradients
+    (the weight-gradient reduction then does not read its destination); it must give bit for bit what accumulating onto the zeros
+    gives, and a second backward without zero_grad() -- gradient accumulation -- must still ADD."""
+    import multimae_amd as M
+    g = load_mini()
+    model = build_mini_engine()
+    model.load_state_dict(g['sd'])
+    model.to(DEV)
+    arena = model.build_arena()
+    x = {k: v.to(DEV) for k, v in g['x'].items()}
+    tm = {d: g['mask'][d].to(DEV) for d in MINI['doms']}
+    ids = (g['ids_keep'].to(DEV), g['ids_restore'].to(DEV))
+    model.generate_random_masks = lambda *a, **k: (tm, ids[0], ids[1])
+    fns = _loss_fns(MINI['P'])
+
+    def fwd_bwd():
+        preds, masks = model(x, num_encoded_tokens=MINI['nvis'], alphas=1.0, fp32_output_adapters=['semseg'])
+        tgt = dict(x, norm_rgb=x['rgb'])
+        mk = dict(masks, norm_rgb=masks['rgb'])
+        sum(fns[k](preds[k].float(), tgt[k], mask=mk[k]) for k in preds).backward()
+        M.engine.join_wgrad_streams()
+        torch.cuda.synchronize()
+    M.engine.set_direct_grads(True)
+    M.engine.set_adapter_streams(True)
+    M.engine.set_wgrad_stream(True)
+    try:
+        with M.engine.precision(mode):
+            arena.zero_grad()
+            fwd_bwd()                                        # first write: store mode
+            g1 = arena.grad.clone()
+            fwd_bwd()                                        # no zero_grad: must accumulate
+            g2 = arena.grad.clone()
+            M.engine.set_first_write_stores(False)
+            arena.zero_grad()
+            fwd_bwd()                                        # the same step, accumulating onto the zeros
+            g3 = arena.grad.clone()
+    finally:
+        M.engine.set_first_write_stores(True)
+        M.engine.set_direct_grads(False)
+        M.engine.set_adapter_streams(False)
+        M.engine.set_wgrad_stream(False)
+    assert float(g1.abs().max()) > 0
+    assert torch.equal(g1, g3), float((g1 - g3).abs().max())
+    assert torch.allclose(g2, 2.0 * g1, rtol=1e-6, atol=1e-9), float((g2 - 2.0 * g1).abs().max())
