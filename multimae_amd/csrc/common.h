@@ -139,16 +139,20 @@ __device__ __forceinline__ void gelu_both(float x, float& y, float& dy) { float 
 __device__ __forceinline__ float gelu_erf_grad(float x) { float c, e; gelu_cdf_exp(x, c, e); return c + x * e * 0.39894228040143268f; }
 
 // ---- the same pair for bf16 OUTPUTS: no transcendental, packed fp32 math ---------------------------------------------------------
-// Phi(x) - 1/2 and GELU'(x) - 1/2 are odd: x Q(x^2) and x R(x^2) with degree-8 minimax polynomials in s = x^2 on |x| <= 4.  Beyond
-// |x| = 4 (round 5) the pair is the limit itself -- Phi = GELU' = step(x), i.e. gelu(x) = max(x, 0) -- instead of the
-// polynomial held at +-4, which left gelu(x) = x Phi(-4) = -3.2e-5 |x| on the negative tail and GELU' = -5e-4 / 1 + 5e-4: the true
-// values there are |gelu(x) - max(x, 0)| <= 1.3e-4 and |GELU' - step| <= 5.1e-4 (at |x| = 4, falling like the Gaussian tail).
-// Evaluated in fp32 Horner form (measured against fp64 over |x| <= 20, tools/gelu_poly_fit.py): |Phi error| 3.2e-5 (the cut at 4;
-// 6.6e-6 inside), |GELU' error| 5.1e-4 at the cut (8.4e-5 inside), |gelu error| <= 1.3e-4 everywhere -- all below the bf16 rounding
-// (2^-9 = 2e-3 relative) the result gets anyway.  Two elements per instruction (v_pk_fma_f32 / v_pk_mul_f32): 8 + 8 packed FMAs
-// per pair against one v_exp, one v_rcp and ~17 scalar FMA-class operations per ELEMENT of the exact form, which kept the bias +
-// GELU epilogue of fc1 VALU-bound behind its two store streams (profiles/r02_epilogue_dissection.txt: 17-30 us of 166).  The exact
-// form above stays for every f32 output (the parity mode) and for the fp16-storage adapters (H16 epilogues).
+// Phi(x) - 1/2 and GELU'(x) - 1/2 are odd: x Q(x^2) and x R(x^2) with degree-8 minimax polynomials in s = x^2 on |x| <= 4, evaluated at
+// the argument clamped to that range (t).  Inside |x| <= 4 (fp32 Horner form, measured against fp64, tools/gelu_poly_fit.py): |Phi error|
+// 6.6e-6, |GELU' error| 8.4e-5, |gelu error| 2.7e-5.  Beyond it (round 5) gelu(x) = max(x, t) Phi(t): x Phi(4) on the positive
+// side (relative error 3.2e-5) and the CONSTANT gelu(-4) = -1.27e-4 on the negative one -- round 4 multiplied by x there, -3.2e-5 |x|
+// without bound (5.2e-4 at x = -20); now |gelu error| <= 1.3e-4 for every x <= 4 and 3.2e-5 RELATIVE above -- and GELU' holds the polynomial's
+// boundary values -5.0e-4 | 1 + 5.0e-4, within 5.5e-4 of the true derivative (which approaches 0 | 1 from those values): a bf16 store turns
+// 1 + 5e-4 into 1.  All of it below
+// the bf16 rounding (2^-9 = 2e-3 relative) the results get anyway.  Two variants were measured and dropped this round: selecting
+// step(x) beyond |x| = 4 (four more VALU operations per element: +11 us on fc1's epilogue, 0.2 ms per step), and a fit constrained to
+// hit 0 | 1 exactly at a clamp point of 4.5 (no extra instruction, but degree 8 then leaves 3.0e-4 on GELU' INSIDE the range, where
+// every element lives: the bias-gradient column sums moved by 3e-4).  One v_max per element it is.
+// Two elements per instruction (v_pk_fma_f32 / v_pk_mul_f32): 8 + 8 packed FMAs per pair against one v_exp, one v_rcp and ~17 scalar
+// FMA-class operations per ELEMENT of the exact form.  The exact form above stays for every f32 output (the parity mode) and for the
+// fp16-storage adapters (H16 epilogues).
 __device__ __forceinline__ void gelu_both_fast2(f32x2 x, f32x2& y, f32x2& dy) {
     f32x2 t;
     t[0] = __builtin_amdgcn_fmed3f(x[0], -4.0f, 4.0f);
@@ -166,16 +170,11 @@ __device__ __forceinline__ void gelu_both_fast2(f32x2 x, f32x2& y, f32x2& dy) {
     MMAE_PK_STEP(q, 3.989227094e-01f);  MMAE_PK_STEP(r, 7.976095497e-01f);
 #undef MMAE_PK_STEP
     const f32x2 half = {0.5f, 0.5f};
-    f32x2 cdf = __builtin_elementwise_fma(t, q, half);
+    const f32x2 cdf = __builtin_elementwise_fma(t, q, half);
+    f32x2 xm;
+    xm[0] = fmaxf(x[0], t[0]); xm[1] = fmaxf(x[1], t[1]);          // x beyond -4 stops growing: gelu(x < -4) = gelu(-4)
+    y = xm * cdf;
     dy = __builtin_elementwise_fma(t, r, half);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {                          // the tails: step(x) (one clamped multiply, one compare, two selects per element)
-        const float st = __builtin_amdgcn_fmed3f(x[j] * 1e30f, 0.0f, 1.0f);
-        const bool out = fabsf(x[j]) > 4.0f;
-        cdf[j] = out ? st : cdf[j];
-        dy[j] = out ? st : dy[j];
-    }
-    y = x * cdf;
 }
 __device__ __forceinline__ void gelu_both_fast4(f32x4 x, f32x4& y, f32x4& dy) {
     f32x2 ya, da, yb, db;

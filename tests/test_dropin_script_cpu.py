@@ -15,7 +15,8 @@ REF = '/root/reference/run_pretraining_multimae.py'
 @pytest.mark.parametrize('patched', [False, True])
 def test_reference_training_script_runs_through_the_dropin_package(patched):
     cmd = [sys.executable, os.path.join(ROOT, 'tools', 'run_reference_script_dryrun.py')] + (['--patched'] if patched else [])
-    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}      # (earlier tests of the session set them)
+    env['PYTHONDONTWRITEBYTECODE'] = '1'
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]

@@ -129,6 +129,15 @@ retest)   # re-run of the tests that failed in the last full run + the default l
   timeout 1500 python -m pytest tests/test_dropin_loop_gpu.py tests/test_model_gpu.py tests/test_parity_geometry_gpu.py -x -q -k "reference_loop_with or first_write or fused_optimizer" 2>&1 | tail -6 >> $S
   [ -f gpurun_out/dropin_fast_loop.json ] && cp gpurun_out/dropin_fast_loop.json gpurun_out/r5_dropin_fast_loop.json
   ;;
+gelu)   # after a change of the GELU epilogue: kernel + parity tests, the encoder table, the default line twice
+  timeout 1500 python -m pytest tests/test_kernels_gpu.py tests/test_parity_geometry_gpu.py tests/test_curves_gpu.py -x -q -k "gelu or mlp or gemm or per_tensor or bench_batch or curve" 2>&1 | tail -5 >> $S
+  table encoder_gemms.py "encoder GEMMs"
+  run "production library, defaults" timeout 300 $B
+  run "production library, defaults again" timeout 300 $B
+  ;;
+kernels)   # the kernel-level test file + the first-write / optimiser tests
+  timeout 1500 python -m pytest tests/test_kernels_gpu.py tests/test_h16_gpu.py tests/test_mxfp8_gpu.py -q 2>&1 | tail -6 >> $S
+  ;;
 baseline)
   run "production library, defaults" timeout 300 $B
   table encoder_gemms.py "encoder GEMMs"
