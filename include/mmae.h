@@ -146,6 +146,13 @@ typedef struct mmae_gemm_desc {
                                     operands (1e-6 .. 1e-3) keep their 11 bits instead of falling into fp16's subnormals.  NULL = as is.
                                     MMAE_F16 products with an f32 C (a gradient leaving the fp16-storage domain, e.g. d_enc): the dy_amax scalar
                                     of MMAE_F16 above; C is multiplied by 1/S.  NULL = as is. */
+    /* LayerNorm side output (round 5; 16-bit operands, f32 C, bias [+ residual] epilogue, N == 256, unbatched, unsplit, k-contiguous
+       operands, K % 32 == 0: the D = 256 decoder products whose 256-column tile spans the row).  Besides C the kernel writes
+       ln_out[M][N] in the operands' 16-bit format: LayerNorm(C) with ln_gamma / ln_beta / ln_eps and the row statistics into ln_mean /
+       ln_rstd [M] -- the nn.LayerNorm that follows the Linear (multimae_utils.py:229-232, output_adapters.py:265-266) without its own
+       pass -- or, with ln_gamma == NULL, the plain 16-bit cast of C (the autocast cast in front of the next Linear).  ln_out == NULL = off.
+       MMAE_ESUPPORT for any other product. */
+    const float* ln_gamma; const float* ln_beta; void* ln_out; float* ln_mean; float* ln_rstd; float ln_eps;
 } mmae_gemm_desc;
 
 int mmae_gemm(const mmae_gemm_desc* d, void* stream);
@@ -208,6 +215,10 @@ int mmae_mx_wgrad(int on);
  * the backward epilogue re-evaluates the derivative (MMAE_EPI_GELU / MMAE_EPI_DGELU), as autograd does.  Must not change between a
  * forward call and its backward.  Returns the previous value; on < 0 only queries. */
 int mmae_gelu_grad_aux(int on);
+/* Policy of the composite calls (default on): in a D = 256 output adapter with 16-bit activations every nn.LayerNorm forward (and the final
+ * 16-bit cast) is the LayerNorm side output of the Linear product in front of it (mmae_gemm_desc.ln_out) instead of its own launch.
+ * on < 0 only reads.  Returns the previous value. */
+int mmae_ln_fuse(int on);
 /* zero a packed scale array (only needed by producers that write the blocks of a width that is not a multiple of 256) */
 int mmae_mx_scale_clear(void* scales, int rows, int cols, void* stream);
 /* nn.LayerNorm forward (mmae_layernorm_fwd, bf16 y) that also emits the MX-fp8 quantisation of y -- bit-identical to

@@ -46,6 +46,8 @@ class GemmDesc(ctypes.Structure):
         ('a_scale', ctypes.c_void_p), ('b_scale', ctypes.c_void_p),
         ('q_out', ctypes.c_void_p), ('q_scale', ctypes.c_void_p), ('ldq', ctypes.c_int64),
         ('a_amax', ctypes.c_void_p),
+        ('ln_gamma', ctypes.c_void_p), ('ln_beta', ctypes.c_void_p), ('ln_out', ctypes.c_void_p), ('ln_mean', ctypes.c_void_p),
+        ('ln_rstd', ctypes.c_void_p), ('ln_eps', ctypes.c_float),
     ]
 
 
@@ -181,6 +183,8 @@ def load() -> ctypes.CDLL:
             raise RuntimeError(f'{cls.__name__}: ctypes mirror ({ctypes.sizeof(cls)} B) != library struct ({lib.mmae_struct_size(which)} B)')
     if os.environ.get('MMAE_MX_WGRAD') is not None:      # A/B: bf16 (0) or MX-fp8 (1) weight gradients in MX-fp8 mode (ops.mx_wgrad)
         lib.mmae_mx_wgrad(int(os.environ['MMAE_MX_WGRAD'] != '0'))
+    if os.environ.get('MMAE_LN_FUSE') is not None:       # A/B: decoder LayerNorms as side outputs of the preceding products (1) or own launches (0)
+        lib.mmae_ln_fuse(int(os.environ['MMAE_LN_FUSE'] != '0'))
     if os.environ.get('MMAE_GELU_GRAD_AUX') is not None:  # A/B: the MLP pair with the derivative stored by the forward (1) or re-evaluated (0)
         lib.mmae_gelu_grad_aux(int(os.environ['MMAE_GELU_GRAD_AUX'] != '0'))
     _lib = lib

@@ -114,9 +114,19 @@ int fork_to(hipStream_t from, hipStream_t to) {      // `to` continues after eve
 // out[M,N] = x[M,K] w[N,K]^T (+ bias, epilogue, residual) -- ops.linear_fwd
 // mxw: {e4m3 weight [N][K], its scales, ...} of mmae_mx_prepare_weights, or NULL for the act-dtype product.  mx_in >= 0: x is
 // already quantised in that half of the MX scratch; mx_out >= 0: the epilogue also leaves the quantised output there.
+// LayerNorm (g != NULL) or plain 16-bit cast (g == NULL) of the f32 rows a Linear product completes, written by the product's own
+// epilogue (mmae_gemm_desc.ln_out): the D = 256 decoder products, whose 256-column tile spans the row
+struct LnSide { const float* g; const float* b; void* out; float* mean; float* rstd; float eps; };
+std::atomic<int> g_ln_fuse{1};
+bool ln_side_ok(const Ctx& c, int N, int K, int out_dtype) {
+    return g_ln_fuse.load(std::memory_order_relaxed) != 0 && is16(c.act_dtype) && out_dtype == MMAE_F32 && N == 256 && (K % 32) == 0 && !c.x3_w;
+}
+
 int lin_fwd(const Ctx& c, const void* x, const void* w, const float* bias, void* out, int out_dtype, int M, int N, int K,
-            const float* resid, void* aux, int epi, hipStream_t st, const void* const* mxw = nullptr, int mx_in = -1, int mx_out = -1) {
+            const float* resid, void* aux, int epi, hipStream_t st, const void* const* mxw = nullptr, int mx_in = -1, int mx_out = -1,
+            const LnSide* ln = nullptr) {
     mmae_gemm_desc g = {};
+    if (ln) { g.ln_gamma = ln->g; g.ln_beta = ln->b; g.ln_out = ln->out; g.ln_mean = ln->mean; g.ln_rstd = ln->rstd; g.ln_eps = ln->eps; }
     g.A = x; g.B = w; g.C = out;
     g.ab_dtype = c.ab();
     g.c_dtype = out_dtype;
@@ -561,7 +571,12 @@ int mmae_decoder_build_rows_ln(const float* ctx, const int64_t* ids_keep, const 
 
 extern "C" {
 
-int mmae_block_fwd(const mmae_block_desc* d, void* stream) {
+static int block_fwd_impl(const mmae_block_desc* d, void* stream, bool ln1_done, const LnSide* next);
+int mmae_block_fwd(const mmae_block_desc* d, void* stream) { return block_fwd_impl(d, stream, false, nullptr); }
+
+// ln1_done: the producer of x0 already wrote norm1(x0) and its statistics into d->ln1 / mean1 / rstd1 (LayerNorm side output of its
+// epilogue); next: what the fc2 product should write beside x2 -- the next block's norm1, or the 16-bit copy the following Linear reads
+static int block_fwd_impl(const mmae_block_desc* d, void* stream, bool ln1_done, const LnSide* next) {
     int rc = check_desc(d);
     if (rc) return rc;
     MMAE_REQUIRE(d->x2, "block_fwd: null output");
@@ -580,8 +595,11 @@ int mmae_block_fwd(const mmae_block_desc* d, void* stream) {
         const int r0 = mx_slot(c, 0, R, D, &q, &s);
         return r0 ? r0 : mmae_layernorm_fwd_mx(x, w, b, y, mu, rs, R, D, d->eps, q, s, st);
     };
-    if ((rc = ln(d->x0, d->n1_w, d->n1_b, d->ln1, d->mean1, d->rstd1))) return rc;
+    if (!ln1_done && (rc = ln(d->x0, d->n1_w, d->n1_b, d->ln1, d->mean1, d->rstd1))) return rc;
     if ((rc = lin_fwd(c, d->ln1, d->qkv_w, d->qkv_b, d->qkv, act, R, 3 * D, D, nullptr, nullptr, MMAE_EPI_NONE, st, mx, pre))) return rc;
+    // norm2 as the side output of the proj product's epilogue (D = 256: the tile spans the row), next's norm1 / cast of the fc2 product's
+    const bool side = !mx && !d->dp1 && !d->dp2 && ln_side_ok(c, D, D, MMAE_F32) && (Hd % 32) == 0;
+    const LnSide ln2s = {d->n2_w, d->n2_b, d->ln2, d->mean2, d->rstd2, d->eps};
     if (pre >= 0) {                                       // the attention kernel leaves the quantised copy of its output in half 0
         void *aq, *as;
         if ((rc = mx_slot(c, 0, R, D, &aq, &as)) || (rc = attn_strides_fwd(d, st, aq, as))) return rc;
@@ -590,16 +608,30 @@ int mmae_block_fwd(const mmae_block_desc* d, void* stream) {
         if ((rc = lin_fwd(c, d->ao, d->proj_w, d->proj_b, d->branch, MMAE_F32, R, D, D, nullptr, nullptr, MMAE_EPI_NONE, st, mx ? mx + 4 : nullptr, pre))) return rc;
         if ((rc = mmae_rowscale_add(d->x0, d->branch, d->dp1, d->x1, R, d->N, D, st))) return rc;
     } else {
-        if ((rc = lin_fwd(c, d->ao, d->proj_w, d->proj_b, d->x1, MMAE_F32, R, D, D, d->x0, nullptr, MMAE_EPI_NONE, st, mx ? mx + 4 : nullptr, pre))) return rc;
+        if ((rc = lin_fwd(c, d->ao, d->proj_w, d->proj_b, d->x1, MMAE_F32, R, D, D, d->x0, nullptr, MMAE_EPI_NONE, st, mx ? mx + 4 : nullptr, pre, -1,
+                          side ? &ln2s : nullptr))) return rc;
     }
-    if ((rc = ln(d->x1, d->n2_w, d->n2_b, d->ln2, d->mean2, d->rstd2))) return rc;
+    if (!side && (rc = ln(d->x1, d->n2_w, d->n2_b, d->ln2, d->mean2, d->rstd2))) return rc;
     const int hq = pre < 0 ? -1 : 1;                     // quantised GELU output: half 1
     if ((rc = lin_fwd(c, d->ln2, d->fc1_w, d->fc1_b, d->hact, act, R, Hd, D, nullptr, d->hpre, epi_gelu(act), st, mx ? mx + 8 : nullptr, pre, hq))) return rc;
     if (d->dp2) {
         if ((rc = lin_fwd(c, d->hact, d->fc2_w, d->fc2_b, d->branch, MMAE_F32, R, D, Hd, nullptr, nullptr, MMAE_EPI_NONE, st, mx ? mx + 12 : nullptr, hq))) return rc;
         return mmae_rowscale_add(d->x1, d->branch, d->dp2, d->x2, R, d->N, D, st);
     }
-    return lin_fwd(c, d->hact, d->fc2_w, d->fc2_b, d->x2, MMAE_F32, R, D, Hd, d->x1, nullptr, MMAE_EPI_NONE, st, mx ? mx + 12 : nullptr, hq);
+    return lin_fwd(c, d->hact, d->fc2_w, d->fc2_b, d->x2, MMAE_F32, R, D, Hd, d->x1, nullptr, MMAE_EPI_NONE, st, mx ? mx + 12 : nullptr, hq, -1,
+                   (side && next) ? next : nullptr);
+}
+
+// can block_fwd_impl's fc2 product carry a side output for this geometry?  (the adapter asks before it skips its own LayerNorm / cast)
+static bool block_side_ok(const mmae_block_desc& b) {
+    const Ctx c = ctx_of(&b);
+    return !(b.mx_w && b.act_dtype == MMAE_BF16) && !b.dp1 && !b.dp2 && ln_side_ok(c, b.D, b.D, MMAE_F32) && (b.Hd % 32) == 0;
+}
+
+int mmae_ln_fuse(int on) {
+    const int prev = g_ln_fuse.load(std::memory_order_relaxed);
+    if (on >= 0) g_ln_fuse.store(on ? 1 : 0, std::memory_order_relaxed);
+    return prev;
 }
 
 int mmae_gelu_grad_aux(int on) {
@@ -987,22 +1019,46 @@ int mmae_adapter_fwd(const mmae_adapter_desc* d, void* stream) {
         if ((rc = fn(a.q, kv, kv + (size_t)D * es, a.xo, a.lse, B, d->heads, n_q, NC, hd, (int64_t)n_q * D, D, (int64_t)NC * 2 * D, 2 * D,
                      (int64_t)NC * 2 * D, 2 * D, (int64_t)n_q * D, D, 1.0f / sqrtf((float)hd), st))) return rc;
     }
-    if ((rc = lin_fwd(c, a.xo, pw, pb, a.x, MMAE_F32, Rq, D, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;                      // :265
-    if ((rc = mmae_layernorm_fwd(a.x, onw, onb, a.on, act, a.omean, a.orstd, Rq, D, d->eps, st))) return rc;
+    // every LayerNorm (and the final 16-bit cast) of the D = 256 decoder is the side output of the Linear product in front of it (round 5):
+    // out_norm of the cross-attention's proj, norm1 of a block of the product that completes its input (the MLP's fc2, the block before's
+    // fc2), norm2 of the block's own proj, the copy out_proj reads of the last fc2 -- 20 LayerNorm launches + 4 casts of a cfg3 step gone
+    const bool side = ln_side_ok(c, D, D, MMAE_F32) && (Hd % 32) == 0;
+    const LnSide ons = {onw, onb, a.on, a.omean, a.orstd, d->eps};
+    if ((rc = lin_fwd(c, a.xo, pw, pb, a.x, MMAE_F32, Rq, D, D, nullptr, nullptr, MMAE_EPI_NONE, st, nullptr, -1, -1, side ? &ons : nullptr))) return rc;   // :265
+    if (!side && (rc = mmae_layernorm_fwd(a.x, onw, onb, a.on, act, a.omean, a.orstd, Rq, D, d->eps, st))) return rc;
     if ((rc = lin_fwd(c, a.on, f1w, f1b, a.hact, act, Rq, Hd, D, nullptr, a.hpre, epi_gelu(act), st))) return rc;
-    if ((rc = lin_fwd(c, a.hact, f2w, f2b, a.x1, MMAE_F32, Rq, D, Hd, a.x, nullptr, MMAE_EPI_NONE, st))) return rc;                    // :266
+    // what follows the product that writes stack position l's input (l = depth: the stack's output)
+    auto after = [&](int l, LnSide* s) -> bool {
+        if (!side) return false;
+        if (l < depth) {
+            const float* const* pl = p + 11 + 8 * l;
+            *s = LnSide{pl[0], pl[1], a.blocks[l].ln1, a.blocks[l].mean1, a.blocks[l].rstd1, d->eps};
+            return true;
+        }
+        if (!is16(act)) return false;
+        *s = LnSide{nullptr, nullptr, a.h_act, nullptr, nullptr, 0.f};                 // the 16-bit copy out_proj reads
+        return true;
+    };
+    LnSide nx;
+    bool have = after(0, &nx);
+    if ((rc = lin_fwd(c, a.hact, f2w, f2b, a.x1, MMAE_F32, Rq, D, Hd, a.x, nullptr, MMAE_EPI_NONE, st, nullptr, -1, -1, have ? &nx : nullptr))) return rc;   // :266
     const float* h = a.x1;
+    bool h_act_done = have && depth == 0;
     for (int l = 0; l < depth; ++l) {                                                                                                // :271
         mmae_block_desc b = {};
         fill_block_params(b, B, n_q, D, d->heads, Hd, act, d->f32_gemm, d->eps, w + 5 + 4 * l, p + 11 + 8 * l);
         fill_block_act(b, h, a.blocks[l]);
         b.ws_main = d->ws_main; b.ws_main_elems = d->ws_main_elems;
         b.x3_w = c.x3_w; b.x3_n = c.x3_n; b.x3_tmp = c.x3_tmp; b.x3_tmp_bytes = c.x3_tmp_bytes;
-        if ((rc = mmae_block_fwd(&b, st))) return rc;
+        const bool ln1_done = have;                      // written by the product that completed h
+        LnSide nl;
+        have = block_side_ok(b) && after(l + 1, &nl);
+        if ((rc = block_fwd_impl(&b, st, ln1_done, have ? &nl : nullptr))) return rc;
         h = a.blocks[l].x2;
+        if (l == depth - 1) h_act_done = have;
     }
     const void* h_act = h;
-    if (is16(act)) { if ((rc = cast_to_act(act, h, a.h_act, (int64_t)Rq * D, st))) return rc; h_act = a.h_act; }
+    if (is16(act)) { if (!h_act_done && (rc = cast_to_act(act, h, a.h_act, (int64_t)Rq * D, st))) return rc; h_act = a.h_act; }
     if ((rc = lin_fwd(c, h_act, ow, ob, a.pat, MMAE_F32, Rq, KP, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;                  // :274
     if (d->img) return mmae_unpatchify(a.pat, d->img, B, d->C, d->nh, d->nw, d->ph, d->pw, st);                                       // :277-280
     return 0;

@@ -81,6 +81,7 @@ int mmae_gemm_bf16_pp_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code,
             if (rc != MMAE_ESUPPORT) return rc;
         }
     }
+    if (g.ln_out) { mmae_set_error("gemm: no instantiation with the LayerNorm side output for this product"); return MMAE_ESUPPORT; }
     if (code == 10 && !aks) {
         return bks ? launch<5, false, true>(g, d->batch, st) : launch<5, false, false>(g, d->batch, st);
     }

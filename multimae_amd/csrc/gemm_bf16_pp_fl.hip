@@ -17,6 +17,17 @@ int mmae_gemm_bf16_pp_fl_impl(const mmae_gemm_desc* d, const GemmArgs& g, int co
     if (g.h16 && !d->a_trans && bks && fl == FL_BF16 && (g.K & 31))    // out_proj's dX of the semseg adapter contracts over C * ph * pw = 2128 columns:
         return launch<4, false, true, FL_BF16, false, true>(g, d->batch, st);   // the general address walk (zero-filled K tail)
     if (d->a_trans || (KFV && (g.K & 31))) return MMAE_ESUPPORT;       // these instantiations carry the K % 32 == 0 address walk (KF)
+    if (g.ln_out) {                               // LayerNorm / cast side output: the f32 flavours of the 256 x 256 tile, N == 256 (runtime.hip checks)
+        if (bks || t10 || g.N != 256) return MMAE_ESUPPORT;
+        if (g.h16) {
+            if (fl == FL_F32_BIAS_RESID) return launch<4, false, false, FL_F32_BIAS_RESID, KFV, true, true>(g, d->batch, st);
+            if (fl == FL_F32_BIAS) return launch<4, false, false, FL_F32_BIAS, KFV, true, true>(g, d->batch, st);
+            return MMAE_ESUPPORT;
+        }
+        if (fl == FL_F32_BIAS_RESID) return launch<4, false, false, FL_F32_BIAS_RESID, KFV, false, true>(g, d->batch, st);
+        if (fl == FL_F32_BIAS) return launch<4, false, false, FL_F32_BIAS, KFV, false, true>(g, d->batch, st);
+        return MMAE_ESUPPORT;
+    }
     if (g.h16) {                                  // fp16 storage (MMAE_F16): the 256 x 256 tile, the flavours an output adapter launches
         if (t10) return MMAE_ESUPPORT;
         if (!bks) {

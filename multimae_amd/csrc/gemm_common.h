@@ -26,6 +26,9 @@ struct GemmArgs {
     unsigned char* qout; unsigned char* qsc; long long ldq;   // ..._Q flavours: also emit the MX-fp8 quantisation of the bf16 output C ([M][ldq] bytes + packed scales)
     int h16;                      // the 16-bit operands / outputs / aux of this product are fp16 (MMAE_F16), not bf16: flavoured ping-pong kernels only
     const float* a_amax;          // MMAE_F32F16 products: device scalar whose power of two pre-scales the A operand (gemm_f32x3.hip), or NULL
+    // LayerNorm (or plain 16-bit cast) of the f32 rows this product completes, written beside C (mmae_gemm_desc.ln_out; N == 256: the
+    // 256-column tile spans the row): gamma / beta NULL = cast only
+    const float* ln_g; const float* ln_b; void* ln_out; float* ln_mean; float* ln_rstd; float ln_eps;
     int dbg;                      // epilogue dissection for profiling (env MMAE_EPI_DBG, GELU flavour only): 1 = no GELU arithmetic, 2 = no pre-activation store,
                                   // 3 = arithmetic but no stores, 4 = nothing.  0 in production.
 };
@@ -193,9 +196,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(T* base, long long ro
     return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x80000000, 0x00020000);
 }
 
-template <bool BIAS, int EPI, bool RESID, bool C_F32, bool ACC, bool AUX_F32 = false, bool COLSUM = false>
+// KEEP: also hand the final values back (keep[tm * 8 + it] = the four columns of row tm * 32 + it * 4 + (lane >> 4)): the LayerNorm side
+// output of the ping-pong kernel normalises them once the row statistics of all four column quarters are known (gemm_pp_body.h)
+template <bool BIAS, int EPI, bool RESID, bool C_F32, bool ACC, bool AUX_F32 = false, bool COLSUM = false, bool KEEP = false>
 __device__ __forceinline__ void store_tile64_fast(const GemmArgs& g, char* Cbase, long long ldc, char* wave_lds, int lane,
-                                                  const f32x16 (&acc)[2][2], int m_base, int n_base, int ntm = 2) {
+                                                  const f32x16 (&acc)[2][2], int m_base, int n_base, int ntm = 2, f32x4* keep = nullptr) {
     constexpr unsigned OOB_OFF = 0x80000000u;
     const int c16 = lane & 15, rsub = lane >> 4;
     const int n = n_base + c16 * 4;
@@ -279,6 +284,7 @@ __device__ __forceinline__ void store_tile64_fast(const GemmArgs& g, char* Cbase
                     for (int j = 0; j < 4; ++j) v[j] += t[j];
                 }
                 if ((RESID || EPI == MMAE_EPI_DGELU) && tm * 8 + it + PD < 16) prefetch(tm * 8 + it + PD);   // refill this slot
+                if (KEEP) keep[tm * 8 + it] = v;
                 if (COLSUM) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) cs[j] += ok ? v[j] : 0.f;

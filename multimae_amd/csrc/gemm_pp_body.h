@@ -63,6 +63,15 @@ __device__ __forceinline__ T* sgpr_ptr(T* p) {            // wave-uniform pointe
     return (T*)(((unsigned long long)hi << 32) | lo);
 }
 
+// sum over the 16 lanes of a DPP row (all of them end up with it): two quad permutes, a half-row and a row mirror -- VALU only
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
+
 __device__ __forceinline__ void wg_barrier() {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
@@ -97,7 +106,12 @@ __device__ __forceinline__ void dot2_ones(float& acc, int w) {          // acc +
     else asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(w), "v"(0x3f803f80));
 }
 
-template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false, bool UNR = false, bool WIDE = false, bool H16 = false>
+// LNE (f32 bias [+ residual] flavours, TM = 4, N == 256 -- the tile spans the row): besides C, write the LayerNorm (gamma / beta given) or
+// the plain 16-bit cast (gamma NULL) of the rows this tile completed -- the nn.LayerNorm / autocast cast that follows the Linear in a
+// D = 256 decoder block (multimae_utils.py:229-232, output_adapters.py:265-266) without its own pass over the residual stream.  The final
+// values stay in registers (where the accumulators were); per-row (sum, sum of squares) of a wave's 64 columns are reduced over the 16
+// lanes that share a row, exchanged through 8 KiB of LDS behind ONE workgroup barrier, and every wave normalises its own columns.
+template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false, bool UNR = false, bool WIDE = false, bool H16 = false, bool LNE = false>
 __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const int vstep) {
     constexpr int WMR = TM * 32;                         // output rows per wave
     constexpr int BM = 2 * WMR, BN = 256, NW = 8;
@@ -501,6 +515,80 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
             dma_first(0, 0); dma_second(0, 0);
             dma_first(1, 1); dma_second(1, 1);
         }
+        if constexpr (LNE) {
+            static_assert(TM == 4 && !AKS && (FL == FL_F32_BIAS_RESID || FL == FL_F32_BIAS), "LayerNorm side output: f32 bias [+ residual] flavours on 256-row tiles");
+            constexpr bool RES = FL == FL_F32_BIAS_RESID;
+            f32x4 keep[2][16];
+            {
+                f32x16 sub[2][2] = {{acc[0][0], acc[0][1]}, {acc[1][0], acc[1][1]}};
+                store_tile64_fast<true, 0, RES, true, false, false, false, true>(g, Cz, g.ldc, stage, lane, sub, mw, nw, 2, keep[0]);
+            }
+            {
+                f32x16 sub[2][2] = {{acc[0][2], acc[0][3]}, {acc[1][2], acc[1][3]}};
+                store_tile64_fast<true, 0, RES, true, false, false, false, true>(g, Cz, g.ldc, stage, lane, sub, mw + 64, nw, 2, keep[1]);
+            }
+            float* part = reinterpret_cast<float*>(smem + NST * STAGE + 1024);         // [256 rows][4 column quarters][sum, sum of squares]
+            const int c16 = lane & 15, rsub = lane >> 4;
+            const bool do_ln = g.ln_g != nullptr;
+            if (do_ln) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const f32x4 v = keep[s][k];
+                        float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+                        float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                        s1 = row16_sum(s1); s2 = row16_sum(s2);             // the 16 lanes that share the row: DPP, no LDS traffic
+                        const int row_l = wm * WMR + s * 64 + (k >> 3) * 32 + (k & 7) * 4 + rsub;
+                        if (c16 == 0) { part[(row_l * 4 + wn) * 2] = s1; part[(row_l * 4 + wn) * 2 + 1] = s2; }
+                    }
+                __syncthreads();
+            }
+            const int ncol = nw + c16 * 4;
+            f32x4 g4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+            if (do_ln) { g4 = ld4(g.ln_g + ncol); b4 = ld4(g.ln_b + ncol); }
+            const float inv_n = 1.0f / (float)g.N;
+            const auto rsL = row_rsrc((uint16_t*)g.ln_out, mw, (long long)g.N);
+            const int rows_left = g.M - mw;
+            // two rows per store: lanes c16 and c16 ^ 1 swap halves (one DPP quad_perm each way), so that the even lane writes eight
+            // columns of row k and the odd lane eight columns of row k + 1 -- 16 dwordx4 stores per lane instead of 32 dwordx2
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int k2 = 0; k2 < 16; k2 += 2) {
+                    i32x2 pk[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int k = k2 + u;
+                        const int r = s * 64 + (k >> 3) * 32 + (k & 7) * 4 + rsub;        // row of this wave's 128
+                        f32x4 o = keep[s][k];
+                        if (do_ln) {
+                            const f32x4 p0 = *reinterpret_cast<const f32x4*>(part + (wm * WMR + r) * 8);
+                            const f32x4 p1 = *reinterpret_cast<const f32x4*>(part + (wm * WMR + r) * 8 + 4);
+                            const float mu = ((p0[0] + p0[2]) + (p1[0] + p1[2])) * inv_n;
+                            const float var = fmaxf(((p0[1] + p0[3]) + (p1[1] + p1[3])) * inv_n - mu * mu, 0.f);
+                            const float rs = 1.0f / sqrtf(var + g.ln_eps);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[j] = (o[j] - mu) * rs * g4[j] + b4[j];
+                            if (wn == 0 && c16 == 0 && r < rows_left) { g.ln_mean[mw + r] = mu; g.ln_rstd[mw + r] = rs; }
+                        }
+                        pk[u] = pack4_16<H16>(o);
+                    }
+                    // even lane keeps row k (its own 4 columns + the neighbour's), odd lane row k + 1
+                    const bool odd = (c16 & 1) != 0;
+                    const i32x2 give = odd ? pk[0] : pk[1], mine = odd ? pk[1] : pk[0];
+                    i32x2 got;
+                    got[0] = __builtin_amdgcn_update_dpp(0, give[0], 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]: lane ^ 1
+                    got[1] = __builtin_amdgcn_update_dpp(0, give[1], 0xB1, 0xF, 0xF, true);
+                    i32x4 w4;
+                    if (odd) { w4[0] = got[0]; w4[1] = got[1]; w4[2] = mine[0]; w4[3] = mine[1]; }
+                    else { w4[0] = mine[0]; w4[1] = mine[1]; w4[2] = got[0]; w4[3] = got[1]; }
+                    const int k = k2 + (odd ? 1 : 0);
+                    const int r = s * 64 + (k >> 3) * 32 + (k & 7) * 4 + rsub;
+                    const int off = (r < rows_left) ? (int)(((long long)r * g.N + nw + (c16 & ~1) * 4) * 2) : (int)OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(w4, rsL, off, 0, 0);
+                }
+        } else {
         {
             f32x16 sub[2][2] = {{acc[0][0], acc[0][1]}, {acc[1][0], acc[1][1]}};
             gemm_store_tile64_fl<FL, H16>(g, Cz, stage, lane, sub, mw, nw);
@@ -509,7 +597,8 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
             f32x16 sub[2][2] = {{acc[0][2], acc[0][3]}, {acc[1][2], acc[1][3]}};
             gemm_store_tile64_fl<FL, H16>(g, Cz, stage, lane, sub, mw + 64, nw);
         }
-        if (TM & 1) {
+        }
+        if (!LNE && (TM & 1)) {
             f32x16 sub[2][2] = {{acc[0][TM - 1], acc[0][TM - 1]}, {acc[1][TM - 1], acc[1][TM - 1]}};
             gemm_store_tile64_fl<FL, H16>(g, Cz, stage, lane, sub, mw + (TM - 1) * 32, nw, 1);
         }
@@ -524,13 +613,13 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
     }
 }
 
-template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false, bool H16 = false>
+template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false, bool H16 = false, bool LNE = false>
 __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(const GemmArgs g) {
     // unrolled wherever the flavoured instantiation has the registers for it (measured: no scratch)
-    pp_body<TM, AKS, BKS, FL, KF, (FL != 0 && KF && !(TM == 5 && BKS)), false, H16>(g, blockIdx.x, gridDim.x);
+    pp_body<TM, AKS, BKS, FL, KF, (FL != 0 && KF && !(TM == 5 && BKS)), false, H16, LNE>(g, blockIdx.x, gridDim.x);
 }
 
-template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false, bool H16 = false>
+template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false, bool H16 = false, bool LNE = false>
 int launch(const GemmArgs& g, int batch, hipStream_t st) {
     constexpr int BM = TM * 64, BN = 256;
     const int tiles_m = (g.M + BM - 1) / BM;
@@ -542,12 +631,12 @@ int launch(const GemmArgs& g, int batch, hipStream_t st) {
     static const int env_persist = mmae_env_int("MMAE_PP_PERSIST", 1);
     const int gx = (env_persist && a.tiles_total > n_cu) ? n_cu : a.tiles_total;      // one resident workgroup per CU walks the tile list
     dim3 grid(gx, batch, a.splitk), block(512);
-    const size_t lds = (size_t)4 * (BM + BN) * 64 + 1024;
+    const size_t lds = (size_t)4 * (BM + BN) * 64 + 1024 + (LNE ? (size_t)BM * 4 * 2 * 4 : 0);      // + the row-statistics exchange of the LayerNorm side output
     static std::once_flag attr_once;
     std::call_once(attr_once, [&] {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<TM, AKS, BKS, FL, KF, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<TM, AKS, BKS, FL, KF, H16, LNE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
-    hipLaunchKernelGGL((gemm_bf16_pp_kernel<TM, AKS, BKS, FL, KF, H16>), grid, block, lds, st, a);
+    hipLaunchKernelGGL((gemm_bf16_pp_kernel<TM, AKS, BKS, FL, KF, H16, LNE>), grid, block, lds, st, a);
     return mmae_check_launch("gemm_bf16_pp");
 }
 

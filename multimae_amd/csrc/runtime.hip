@@ -232,6 +232,14 @@ int mmae_gemm_ex(const mmae_gemm_desc* d, void* stream, int timing_cls, double f
     if (env_dephase_sel == 1 && (d->epi == MMAE_EPI_NONE || d->K < 512)) g.dephase = 0;
     g.scA = d->a_scale; g.scB = d->b_scale;
     g.a_amax = d->a_amax;
+    g.ln_g = d->ln_gamma; g.ln_b = d->ln_beta; g.ln_out = d->ln_out; g.ln_mean = d->ln_mean; g.ln_rstd = d->ln_rstd; g.ln_eps = d->ln_eps;
+    if (d->ln_out) {
+        const bool ok = (d->ab_dtype == MMAE_BF16 || h16) && d->c_dtype == MMAE_F32 && d->N == 256 && d->ldc == 256 && d->bias && d->epi == MMAE_EPI_NONE &&
+                        !d->accumulate && d->batch == 1 && d->split_k <= 1 && !d->a_trans && !d->b_trans && (d->K % 32) == 0 && d->alpha == 1.0f &&
+                        !d->a_amax && (!d->ln_gamma || (d->ln_beta && d->ln_mean && d->ln_rstd)) && ((uintptr_t)d->ln_out % 16) == 0 &&
+                        (!d->ln_gamma || (((uintptr_t)d->ln_gamma | (uintptr_t)d->ln_beta) % 16) == 0);
+        if (!ok) { mmae_set_error("gemm: ln_out needs a 16-bit x 16-bit -> f32 product with bias [+ residual], N = ldc = 256, unbatched, unsplit, k-contiguous operands, K % 32 == 0"); return MMAE_ESUPPORT; }
+    }
     g.h16 = h16 ? 1 : 0;
     g.qout = (unsigned char*)d->q_out; g.qsc = (unsigned char*)d->q_scale; g.ldq = d->ldq;
     MMAE_REQUIRE(!d->q_out || d->ab_dtype == MMAE_MXFP8, "gemm: q_out is an MX-fp8 product option");
@@ -271,6 +279,7 @@ int mmae_gemm_ex(const mmae_gemm_desc* d, void* stream, int timing_cls, double f
     g.ws = (float*)d->ws;
     int code = 0, unused = 0;
     gemm_plan(d, &code, &unused);
+    if (d->ln_out) code = 9;                                // the 256 x 256 ping-pong tile: the only kernel with the LayerNorm side output
     g.acs = nullptr;
     if (h16) return mmae_gemm_bf16_pp_impl(d, g, 9, st);    // fp16 storage: the 256 x 256 ping-pong tile, compiled flavours only
     if (d->a_colsum) {

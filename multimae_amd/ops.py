@@ -86,9 +86,10 @@ def gemm(A: Tensor, B: Tensor, C: Tensor, M: int, N: int, K: int, *, lda: int, l
          aux: Optional[Tensor] = None, ldaux: int = 0, epi: int = EPI_NONE, accumulate: bool = False,
          alpha: float = 1.0, tile: int = 0, split_k: int = 0, colsum_part: Optional[Tensor] = None,
          a_colsum: Optional[Tensor] = None, a_colsum_acc: bool = False, f32_as: Optional[int] = None,
-         a_amax: Optional[Tensor] = None) -> bool:
+         a_amax: Optional[Tensor] = None, ln: Optional[tuple] = None) -> bool:
     """C[M,N] (+)= alpha * A[M,K] . B[N,K]^T with the fused epilogue of mmae_gemm.
-    *_off are element offsets into the tensors' storage views (column offsets into packed qkv etc.)."""
+    *_off are element offsets into the tensors' storage views (column offsets into packed qkv etc.).
+    ln = (gamma, beta, out, mean, rstd, eps): the LayerNorm side output of mmae_gemm_desc.ln_out (gamma None: the plain 16-bit cast of C)."""
     _require_gpu(A, 'gemm A')
     assert A.dtype == B.dtype, (A.dtype, B.dtype)
     d = GemmDesc()
@@ -117,6 +118,10 @@ def gemm(A: Tensor, B: Tensor, C: Tensor, M: int, N: int, K: int, *, lda: int, l
     d.aux, d.ldaux = _p(aux), ldaux
     d.aux_dtype = dcode(aux.dtype) if aux is not None else F32
     d.epi, d.accumulate, d.alpha, d.tile = epi, int(accumulate), alpha, tile
+    if ln is not None:
+        gam, bet, lo, lm, lr, le = ln
+        d.ln_gamma, d.ln_beta, d.ln_out, d.ln_mean, d.ln_rstd, d.ln_eps = _p(gam), _p(bet), lo.data_ptr(), _p(lm), _p(lr), float(le)
+        split_k = 1
     ws = None
     lib = _lib.load()
     d.colsum_part = _p(colsum_part)
@@ -256,6 +261,12 @@ def gemm_cu_reserve(k: Optional[int] = None) -> int:
     return int(_lib.load().mmae_gemm_cu_reserve(-1 if k is None else int(k)))
 
 
+def ln_fuse(on: Optional[bool] = None) -> bool:
+    """Policy switch of the composite adapter calls (mmae_ln_fuse): LayerNorm forwards of a D = 256 decoder as side outputs of the
+    preceding Linear products' epilogues (default on); returns the previous value."""
+    return bool(_lib.load().mmae_ln_fuse(-1 if on is None else int(bool(on))))
+
+
 def gemm_cu_share(k: Optional[int] = None) -> int:
     """The second slot of the same launch policy (mmae_gemm_cu_share): grids leave max(reserve, share) CUs free; returns the previous value."""
     return int(_lib.load().mmae_gemm_cu_share(-1 if k is None else int(k)))
@@ -267,11 +278,11 @@ def gemm_side_cus(k: Optional[int] = None) -> int:
 
 
 def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], out: Tensor, *, resid: Optional[Tensor] = None,
-               aux: Optional[Tensor] = None, epi: int = EPI_NONE, tile: int = 0) -> Tensor:
-    """out[M,N] = x[M,K] @ w[N,K]^T + bias (+ epilogue).  x, w act dtype, contiguous 2-D."""
+               aux: Optional[Tensor] = None, epi: int = EPI_NONE, tile: int = 0, ln: Optional[tuple] = None) -> Tensor:
+    """out[M,N] = x[M,K] @ w[N,K]^T + bias (+ epilogue).  x, w act dtype, contiguous 2-D.  ln: see gemm()."""
     M, K = x.shape
     N = w.shape[0]
-    gemm(x, w, out, M, N, K, lda=K, ldb=K, ldc=N, bias=bias, resid=resid, ldr=N, aux=aux, ldaux=N, epi=epi, tile=tile)
+    gemm(x, w, out, M, N, K, lda=K, ldb=K, ldc=N, bias=bias, resid=resid, ldr=N, aux=aux, ldaux=N, epi=epi, tile=tile, ln=ln)
     return out
 
 

@@ -1016,3 +1016,52 @@ def test_gemm_f32f16_gradient_operand_prescale_and_loss_amax():
     MaskedCEPatFn.apply(h.token, h, tgt.to(DEV), mask.to(DEV), P, 0.0).backward()
     torch.cuda.synchronize()
     assert float(h.dy_amax) == float(h.d_pat.abs().max()) > 0
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('resid', [True, False])
+@pytest.mark.parametrize('M,K', [(1000, 256), (2560, 1024), (50176, 256)])
+def test_gemm_layernorm_side_output(dtype, resid, M, K):
+    """mmae_gemm_desc.ln_out (round 5): the f32 bias [+ residual] epilogue of an N = 256 product also writes LayerNorm(C) -- and the row
+    statistics -- or the plain 16-bit cast of C, in the operands' format (bf16 / fp16 storage).  Against the product followed by the
+    stand-alone LayerNorm kernel (the path it replaces) and against the fp64 formula; C itself must not change."""
+    from multimae_amd import ops
+    g = torch.Generator().manual_seed(7)
+    N = 256
+    x = (torch.randn(M, K, generator=g) * 0.5).to(dtype)
+    w = (torch.randn(N, K, generator=g) * 0.1).to(dtype)
+    bias = torch.randn(N, generator=g) * 0.3
+    r = torch.randn(M, N, generator=g) + 0.7 if resid else None          # (a residual stream with a mean)
+    gam, bet = 1 + 0.2 * torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g)
+    xd, wd, bd = x.to(DEV), w.to(DEV), bias.to(DEV)
+    rd = r.to(DEV) if resid else None
+    c0 = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(xd, wd, bd, c0, resid=rd, tile=9)
+    y0, m0, s0 = ops.layernorm_fwd(c0, gam.to(DEV), bet.to(DEV), 1e-6, dtype)
+    c1 = torch.empty(M, N, device=DEV)
+    y1 = torch.full((M, N), float('nan'), device=DEV, dtype=dtype)
+    m1, s1 = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    ops.linear_fwd(xd, wd, bd, c1, resid=rd, ln=(gam.to(DEV), bet.to(DEV), y1, m1, s1, 1e-6))
+    torch.cuda.synchronize()
+    assert torch.equal(c0, c1)                                            # the f32 output is the same kernel's
+    ref = torch.nn.functional.layer_norm(c0.double().cpu(), (N,), gam.double(), bet.double(), 1e-6)
+    tol = 4e-3 if dtype == torch.bfloat16 else 6e-4                        # output rounding: 2^-9 / 2^-12
+    assert not torch.isnan(y1.float()).any()
+    assert rel_err(y1.float(), ref) < tol and rel_err(y0.float(), ref) < tol
+    assert rel_err(y1.float(), y0.float()) < tol                          # one-pass (E[x^2] - mean^2) against the two-pass kernel
+    assert rel_err(m1, m0) < 1e-5 and rel_err(s1, s0) < 1e-4
+    # cast-only form (gamma NULL): the 16-bit copy the next Linear reads
+    y2 = torch.full((M, N), float('nan'), device=DEV, dtype=dtype)
+    c2 = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(xd, wd, bd, c2, resid=rd, ln=(None, None, y2, None, None, 0.0))
+    torch.cuda.synchronize()
+    assert torch.equal(c2, c0) and torch.equal(y2, c0.to(dtype))
+
+
+def test_gemm_layernorm_side_output_refuses_what_it_cannot_do():
+    from multimae_amd import ops
+    from multimae_amd._lib import KernelError
+    x, w = torch.randn(512, 256, device=DEV).bfloat16(), torch.randn(512, 256, device=DEV).bfloat16()      # N = 512: the row spans two tiles
+    out, y = torch.empty(512, 512, device=DEV), torch.empty(512, 512, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(KernelError):
+        ops.linear_fwd(x, w, torch.zeros(512, device=DEV), out, ln=(None, None, y, None, None, 0.0))

@@ -138,6 +138,22 @@ gelu)   # after a change of the GELU epilogue: kernel + parity tests, the encode
 kernels)   # the kernel-level test file + the first-write / optimiser tests
   timeout 1500 python -m pytest tests/test_kernels_gpu.py tests/test_h16_gpu.py tests/test_mxfp8_gpu.py -q 2>&1 | tail -6 >> $S
   ;;
+lnfuse)   # decoder LayerNorms as GEMM side outputs: kernel + adapter tests, then the policy A/B inside one visit
+  timeout 1500 python -m pytest tests/test_kernels_gpu.py tests/test_parity_geometry_gpu.py -x -q -k "layernorm_side or side_outputs or (per_tensor and cfg3)" 2>&1 | tail -6 >> $S
+  run "defaults (LayerNorms fused)" timeout 300 $B
+  MMAE_LN_FUSE=0 run "MMAE_LN_FUSE=0 (own launches)" timeout 300 $B
+  run "defaults again" timeout 300 $B
+  MMAE_LN_FUSE=0 run "MMAE_LN_FUSE=0 again" timeout 300 $B
+  kstats fused
+  python - >> $S <<'PY'
+import csv
+rows = list(csv.DictReader(open('gpurun_out/r5_lnfuse_kernel_stats_fused.csv')))
+print('== serialized ms/step', round(sum(float(r['TotalDurationNs']) for r in rows) / 8e6, 3), ' launches/step', sum(int(r['Calls']) for r in rows) / 8)
+for r in rows:
+    if 'ln_fwd' in r['Name'] or 'Lb1EEEv' in r['Name'] or ', true>(GemmArgs' in r['Name'] or 'cast_f32' in r['Name']:
+        print(f"{float(r['TotalDurationNs']) / 8e6:7.3f} ms/step  {int(r['Calls']) / 8:6.1f} calls  {float(r['AverageNs']) / 1e3:8.1f} us  {r['Name'][:140]}")
+PY
+  ;;
 baseline)
   run "production library, defaults" timeout 300 $B
   table encoder_gemms.py "encoder GEMMs"
