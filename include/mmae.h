@@ -571,6 +571,14 @@ int mmae_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream);
  *   rowscale_cast: out[r][:] = cast(s[r / N] * x[r][:])   (x f32; out act dtype) */
 int mmae_rowscale_add(const float* resid, const float* y, const float* s, float* out, int64_t R, int N, int D, void* stream);
 int mmae_rowscale_cast(const float* x, const float* s, void* out, int out_dtype, int64_t R, int N, int D, void* stream);
+/* nn.Dropout (Mlp.drop, attn_drop, proj_drop: multimae_utils.py:138-155, 158-214; the mask itself is drawn by the caller) as ONE
+ * elementwise pass, forward and backward alike:
+ *   out[i] = (resid ? resid[i] : 0) + (keep[i] ? x[i] * scale * (s ? s[i / per] : 1) : 0)
+ * x f32 / bf16 / fp16 (x_dtype), keep uint8 0 / 1, scale = 1 / (1 - p); s: optional per-sample stochastic-depth scale f32 (`per`
+ * elements per sample) so that x + drop_path(dropout(y)) is still one pass; resid f32 (then out_dtype must be MMAE_F32); out may
+ * alias x when the types agree.  n % 4 == 0. */
+int mmae_dropout(const void* x, int x_dtype, const void* keep, float scale, const float* s, int64_t per, const float* resid, void* out,
+                 int out_dtype, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Mask sampler: deterministic core of MultiMAE.generate_random_masks

@@ -446,6 +446,22 @@ __global__ void __launch_bounds__(256) rowscale_cast_kernel(const float* __restr
     }
 }
 
+// nn.Dropout as one elementwise pass (mmae_dropout): out = [resid +] keep ? x * scale [* s[i / per]] : 0
+template <typename XT, typename OT>
+__global__ void __launch_bounds__(256) dropout_kernel(const XT* __restrict__ x, const unsigned char* __restrict__ keep, float scale,
+                                                      const float* __restrict__ s, long long per4, const float* __restrict__ resid,
+                                                      OT* __restrict__ out, long long total4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const unsigned k4 = *reinterpret_cast<const unsigned*>(keep + i * 4);
+        const float sc = s ? scale * s[i / per4] : scale;
+        const f32x4 v = ld4(x + i * 4);
+        f32x4 o = resid ? ld4(resid + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += ((k4 >> (8 * j)) & 0xffu) ? v[j] * sc : 0.f;
+        st4(out + i * 4, o);
+    }
+}
+
 // y[b][:] = mean_n x[b][n][:]   and its backward  dx[b][n][:] = dy[b][:] / N   (LinearOutputAdapter's mean pooling)
 __global__ void __launch_bounds__(256) token_mean_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int D) {
     const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -897,6 +913,29 @@ int mmae_rowscale_cast(const float* x, const float* s, void* out, int out_dtype,
     if (out_dtype == MMAE_BF16) hipLaunchKernelGGL((rowscale_cast_kernel<uint16_t>), dim3(stream_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, s, (uint16_t*)out, total4, D / 4, N);
     else hipLaunchKernelGGL((rowscale_cast_kernel<float>), dim3(stream_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, s, (float*)out, total4, D / 4, N);
     return mmae_check_launch("rowscale_cast");
+}
+int mmae_dropout(const void* x, int x_dtype, const void* keep, float scale, const float* s, int64_t per, const float* resid, void* out,
+                 int out_dtype, int64_t n, void* stream) {
+    MMAE_REQUIRE(x && keep && out && n > 0 && n % 4 == 0, "dropout: bad argument (n must be a multiple of 4)");
+    MMAE_REQUIRE(!s || (per > 0 && per % 4 == 0 && n % per == 0), "dropout: the per-sample scale needs per % 4 == 0 and n % per == 0");
+    MMAE_REQUIRE(!resid || out_dtype == MMAE_F32, "dropout: a residual needs an f32 output");
+    MMAE_REQUIRE(((uintptr_t)x % 8 == 0) && ((uintptr_t)out % 8 == 0) && ((uintptr_t)keep % 4 == 0) && (!resid || (uintptr_t)resid % 16 == 0), "dropout: unaligned");
+    const long long total4 = n / 4, per4 = s ? per / 4 : 1;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned char* k = (const unsigned char*)keep;
+#define DROP(XT, OT) hipLaunchKernelGGL((dropout_kernel<XT, OT>), dim3(stream_grid(total4)), dim3(256), 0, st, (const XT*)x, k, scale, s, per4, resid, (OT*)out, total4)
+    if (x_dtype == MMAE_F32) {
+        if (out_dtype == MMAE_F32) DROP(float, float); else if (out_dtype == MMAE_BF16) DROP(float, uint16_t); else if (out_dtype == MMAE_F16) DROP(float, h16_t);
+        else { mmae_set_error("dropout: bad out_dtype"); return MMAE_EINVAL; }
+    } else if (x_dtype == MMAE_BF16) {
+        if (out_dtype == MMAE_BF16) DROP(uint16_t, uint16_t); else if (out_dtype == MMAE_F32) DROP(uint16_t, float);
+        else { mmae_set_error("dropout: bf16 input goes to bf16 or f32"); return MMAE_EINVAL; }
+    } else if (x_dtype == MMAE_F16) {
+        if (out_dtype == MMAE_F16) DROP(h16_t, h16_t); else if (out_dtype == MMAE_F32) DROP(h16_t, float);
+        else { mmae_set_error("dropout: fp16 input goes to fp16 or f32"); return MMAE_EINVAL; }
+    } else { mmae_set_error("dropout: bad x_dtype"); return MMAE_EINVAL; }
+#undef DROP
+    return mmae_check_launch("dropout");
 }
 int mmae_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream) {
     MMAE_REQUIRE(y && x && n >= 0, "axpy: bad argument");

@@ -166,32 +166,52 @@ BLOCK_PARAMS = ('norm1.weight', 'norm1.bias', 'attn.qkv.weight', 'attn.qkv.bias'
                 'norm2.weight', 'norm2.bias', 'mlp.fc1.weight', 'mlp.fc1.bias', 'mlp.fc2.weight', 'mlp.fc2.bias')
 
 
-def block_fwd(x: Tensor, P: Sequence[Tensor], wc, heads: int, eps: float, act, B: int, N: int, save: bool, dp=(None, None)):
-    """dp = (s1, s2): per-sample stochastic-depth scales f32 [B] of the attention / MLP branch (None = branch kept)."""
+def block_fwd(x: Tensor, P: Sequence[Tensor], wc, heads: int, eps: float, act, B: int, N: int, save: bool, dp=(None, None), drop=(0., 0.)):
+    """dp = (s1, s2): per-sample stochastic-depth scales f32 [B] of the attention / MLP branch (None = branch kept).
+    drop = (attn_drop, drop): the rates of Block(drop=, attn_drop=) in training mode (multimae_utils.py:217-227): nn.Dropout on the attention
+    probabilities (:177), after the attention's proj (:181) and after fc2 (:154; the reference's Mlp has its dropout behind the activation
+    commented out, :151-152) -- masks drawn in that (the reference's) order through ops._dropout_keep; the three sites leave the fused
+    paths (materialised probabilities, un-fused residual adds)."""
     n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b = P
     R, D = x.shape
     hd = D // heads
     s1, s2 = dp
-    if s1 is None and s2 is None and ops.block_composite_ok(x, act, heads, N):   # the whole block as one library call (same kernels)
+    p_attn, p_drop = drop
+    dropping = p_attn > 0. or p_drop > 0.
+    if s1 is None and s2 is None and not dropping and ops.block_composite_ok(x, act, heads, N):   # the whole block as one library call (same kernels)
         return ops.block_fwd_composite(x, P, (wc(qkvw), wc(projw), wc(fc1w), wc(fc2w)), heads, eps, act, B, N)
+    inv = 1.0 / (1.0 - p_drop) if p_drop > 0. else 1.0
     ln1, mean1, rstd1 = ops.layernorm_fwd(x, n1w, n1b, eps, act)
     qkv = ops.linear_fwd(ln1, wc(qkvw), qkvb, _new((R, 3 * D), x, act))
     ao = _new((R, D), x, act)
     Pm = ops.attention_fwd(AttnView(qkv, 0, 3 * D, N), AttnView(qkv, D, 3 * D, N), AttnView(qkv, 2 * D, 3 * D, N),
-                           AttnView(ao, 0, D, N), B, heads, hd, hd ** -0.5)
-    if s1 is None:
+                           AttnView(ao, 0, D, N), B, heads, hd, hd ** -0.5, drop_p=p_attn)
+    k_proj = k_out = None
+    if s1 is None and p_drop == 0.:
         x1 = ops.linear_fwd(ao, wc(projw), projb, _new((R, D), x, torch.float32), resid=x)
-    else:                                                   # x1 = x + s1[b] * attn(..)   (multimae_utils.py:229 with DropPath)
-        x1 = ops.rowscale_add(x, ops.linear_fwd(ao, wc(projw), projb, _new((R, D), x, torch.float32)), s1, N)
+    else:                                                   # x1 = x + s1[b] * proj_drop(attn(..))   (multimae_utils.py:181, 229)
+        y = ops.linear_fwd(ao, wc(projw), projb, _new((R, D), x, torch.float32))
+        if p_drop > 0.:
+            k_proj = ops._dropout_keep((R, D), p_drop, x.device)
+            x1 = ops.dropout_apply(y, k_proj, inv, resid=x, row_scale=s1, per=N * D)
+        else:
+            x1 = ops.rowscale_add(x, y, s1, N)
     ln2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w, n2b, eps, act)
     Hd = fc1w.shape[0]
     hpre = _new((R, Hd), x, act)
     hact = ops.linear_fwd(ln2, wc(fc1w), fc1b, _new((R, Hd), x, act), aux=hpre, epi=EPI_GELU)
-    if s2 is None:
+    if s2 is None and p_drop == 0.:
         x2 = ops.linear_fwd(hact, wc(fc2w), fc2b, _new((R, D), x, torch.float32), resid=x1)
     else:
-        x2 = ops.rowscale_add(x1, ops.linear_fwd(hact, wc(fc2w), fc2b, _new((R, D), x, torch.float32)), s2, N)
+        y = ops.linear_fwd(hact, wc(fc2w), fc2b, _new((R, D), x, torch.float32))
+        if p_drop > 0.:                                     # Mlp.drop behind fc2 (:154)
+            k_out = ops._dropout_keep((R, D), p_drop, x.device)
+            x2 = ops.dropout_apply(y, k_out, inv, resid=x1, row_scale=s2, per=N * D)
+        else:
+            x2 = ops.rowscale_add(x1, y, s2, N)
     saved = (x, ln1, mean1, rstd1, qkv, Pm, ao, x1, ln2, mean2, rstd2, hpre, hact) if save else None
+    if save and dropping:
+        saved = saved + ((k_proj, k_out, inv),)
     return x2, saved
 
 
@@ -202,22 +222,31 @@ def block_bwd(dx: Tensor, dx_act: Tensor, fc2b_done: bool, saved, P: Sequence[Te
     cs_param: the parameter whose gradient is colsum(dx0) -- the bias of the Linear that produced this block's input
     (the previous block's fc2); its gradient rides along with the LayerNorm-1 reduction and comes back as g_cs."""
     n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b = P
+    k_proj = k_out = None
+    inv = 1.0
+    if len(saved) == 14:                                    # a forward with dropout: the keep masks of its two element-wise sites
+        k_proj, k_out, inv = saved[13]
+        saved = saved[:13]
     x0, ln1, mean1, rstd1, qkv, Pm, ao, x1, ln2, mean2, rstd2, hpre, hact = saved
     R, D = x0.shape
     hd = D // heads
     Hd = fc1w.shape[0]
     lnact = None if act == torch.float32 else act
     s1, s2 = dp
-    if s1 is None and s2 is None and Pm[0] == 'fused' and ops.block_composite_ok(x0, act, heads, N):
+    dropping = k_proj is not None or len(Pm) > 3
+    if s1 is None and s2 is None and not dropping and Pm[0] == 'fused' and ops.block_composite_ok(x0, act, heads, N):
         out = _block_bwd_composite(dx, dx_act, fc2b_done, saved, P, wc, sink, heads, act, B, N, cs_param)
         if out is not None:
             return out
     # MLP: x2 = x1 + s2[b] * mlp(norm2(x1)); the branch sees the per-sample rescaled gradient
-    dm_act = dx_act if s2 is None else ops.rowscale_cast(dx, s2, N, act)
-    assert not (s2 is not None and fc2b_done)
+    if k_out is not None:                                   # the gradient through fc2's dropout (and the branch's stochastic-depth scale)
+        dm_act = ops.dropout_apply(dx, k_out, inv, out_dtype=act, row_scale=s2, per=N * D)
+    else:
+        dm_act = dx_act if s2 is None else ops.rowscale_cast(dx, s2, N, act)
+    assert not ((s2 is not None or k_out is not None) and fc2b_done)
     part_h = _new(ops.dx_colsum_part_shape(R, Hd), dx, torch.float32) if fc1b.requires_grad else None
     # a composite forward with bf16 activations left GELU'(pre-activation) in hpre: multiply, do not differentiate again
-    epi_h = ops.EPI_MUL if (len(Pm) > 2 and Pm[2]) else EPI_DGELU
+    epi_h = ops.EPI_MUL if (Pm[0] == 'fused' and len(Pm) > 2 and Pm[2]) else EPI_DGELU
     d_hpre = ops.linear_dx(dm_act, wc(fc2w), _new(hpre.shape, dx, act), aux=hpre, epi=epi_h, colsum_part=part_h)
     if fc2b_done:
         g_fc2w, g_fc2b = sink.weight(fc2w, dm_act, hact), None
@@ -230,15 +259,15 @@ def block_bwd(dx: Tensor, dx_act: Tensor, fc2b_done: bool, saved, P: Sequence[Te
     if dx1_act is None:
         dx1_act = dx1
     # attention: x1 = x0 + s1[b] * attn(norm1(x0))
-    if s1 is None:
+    if s1 is None and k_proj is None:
         g_n2w, g_n2b, g_projb = sink.colsums(part2, D, [n2w, n2b, projb])
         da_act = dx1_act
         g_projw = None
     else:
         g_n2w, g_n2b, _ = sink.colsums(part2, D, [n2w, n2b, None])
-        da_act = ops.rowscale_cast(dx1, s1, N, act)
+        da_act = ops.dropout_apply(dx1, k_proj, inv, out_dtype=act, row_scale=s1, per=N * D) if k_proj is not None else ops.rowscale_cast(dx1, s1, N, act)
     d_ao = ops.linear_dx(da_act, wc(projw), _new((R, D), dx, act))
-    if s1 is None:
+    if s1 is None and k_proj is None:
         g_projw = sink.weight(projw, da_act, ao)
     else:
         g_projw, g_projb = sink.linear(projw, projb, da_act, ao)
@@ -314,9 +343,10 @@ class EncoderStackFn(torch.autograd.Function):
         save = any(ctx.needs_input_grad)
         h = x.contiguous().view(B * N, D)
         dp = getattr(cfg, 'dp', None)
+        drops = getattr(cfg, 'drops', None)                 # per block (attn_drop, drop) in training mode, or None: nn.Dropout sites (round 5)
         ctx.cfg, ctx.params, ctx.shape = cfg, params, (B, N, D)
         ctx.stack, ctx.saved = None, None
-        if ops.stack_composites() and L <= 64 and ops.block_composite_ok(h, cfg.act, cfg.heads, N):
+        if drops is None and ops.stack_composites() and L <= 64 and ops.block_composite_ok(h, cfg.act, cfg.heads, N):
             outs, state = ops.stack_fwd(h, params, cfg.wc, cfg.heads, cfg.eps, cfg.act, B, N, dp, mx=bool(getattr(cfg, 'mx', False)))
             ctx.stack = state if save else None
             if cfg.all_layers:
@@ -325,7 +355,8 @@ class EncoderStackFn(torch.autograd.Function):
         saved, outs = [], []
         for l in range(L):
             dpl = (None, None) if dp is None else (dp[2 * l], dp[2 * l + 1])
-            h, s = block_fwd(h, params[12 * l:12 * l + 12], cfg.wc, cfg.heads, cfg.eps, cfg.act, B, N, save, dpl)
+            h, s = block_fwd(h, params[12 * l:12 * l + 12], cfg.wc, cfg.heads, cfg.eps, cfg.act, B, N, save, dpl,
+                             drop=(0., 0.) if drops is None else drops[l])
             saved.append(s)
             if cfg.all_layers:
                 outs.append(h.view(B, N, D))
@@ -393,7 +424,9 @@ class EncoderStackFn(torch.autograd.Function):
             # block's LayerNorm-1 reduction -- unless more gradient is added to dx before block l-1 sees it (all_layers) or
             # block l-1's MLP branch was rescaled per sample (stochastic depth)
             below_scaled = dp is not None and l > 0 and dp[2 * (l - 1) + 1] is not None
-            cs_param = params[12 * (l - 1) + 11] if (l > 0 and not cfg.all_layers and not below_scaled) else None
+            drops = getattr(cfg, 'drops', None)
+            below_dropped = drops is not None and l > 0 and drops[l - 1][1] > 0.       # block l-1's fc2 output went through nn.Dropout
+            cs_param = params[12 * (l - 1) + 11] if (l > 0 and not cfg.all_layers and not below_scaled and not below_dropped) else None
             dpl = (None, None) if dp is None else (dp[2 * l], dp[2 * l + 1])
             dx, dx_act, g_cs_next, g = block_bwd(dx, dx_act, fc2b_done, ctx.saved[l], params[12 * l:12 * l + 12], cfg.wc, sink,
                                                  cfg.heads, cfg.act, B, N, cs_param, dpl)
@@ -639,9 +672,13 @@ class SpatialAdapterFn(torch.autograd.Function):
         # branch, MLP branch)] * depth; the one-call adapter has no such option, the per-block sequence below folds them into the residual adds
         dps = getattr(cfg, 'dp', None)
         dp_of = (lambda l: (dps[2 * l], dps[2 * l + 1])) if dps is not None else (lambda l: (None, None))
-        if dps is not None:
+        # nn.Dropout sites (SpatialOutputAdapter(drop_rate / attn_drop_rate > 0), training): cfg.drops = (attn_drop, drop) -- the cross
+        # attention's probabilities and proj output (output_adapters.py:118-119), the three sites of every decoder block (:131-132)
+        drops = getattr(cfg, 'drops', None)
+        p_attn, p_drop = drops if drops is not None else (0., 0.)
+        if dps is not None or drops is not None:
             h16 = ctx.h16 = False
-        if xattn and dps is None and (h16 or ops.adapter_composite_ok(enc2, act, heads, D, n_q, NC, cfg.depth, T, KP)):
+        if xattn and dps is None and drops is None and (h16 or ops.adapter_composite_ok(enc2, act, heads, D, n_q, NC, cfg.depth, T, KP)):
             # the whole adapter as ONE library call (same kernels, same order)
             w_list = [wc(qw), wc(kvw), wc(pw_), wc(f1w), wc(f2w)] + [wc(blocks[12 * l + i]) for l in range(cfg.depth) for i in (2, 4, 8, 10)] \
                 + [wc(ow), wc(pcw)]
@@ -688,7 +725,7 @@ class SpatialAdapterFn(torch.autograd.Function):
         if not xattn:                                # use_xattn=False (output_adapters.py:264-268): x = queries
             h, bsaved = queries, []
             for l in range(cfg.depth):
-                h, s = block_fwd(h, blocks[12 * l:12 * l + 12], wc, heads, eps, act, B, n_q, save, dp=dp_of(l))
+                h, s = block_fwd(h, blocks[12 * l:12 * l + 12], wc, heads, eps, act, B, n_q, save, dp=dp_of(l), drop=(p_attn, p_drop))
                 bsaved.append(s)
             h_act = ops.cast(h, act)
             pat = _lin_fwd(h_act, ow, ob, wc, torch.float32)
@@ -705,22 +742,26 @@ class SpatialAdapterFn(torch.autograd.Function):
         hd = D // heads
         xo = torch.empty((B * n_q, D), device=dev, dtype=act)
         Pm = ops.attention_fwd(AttnView(q, 0, D, n_q), AttnView(kv, 0, 2 * D, NC), AttnView(kv, D, 2 * D, NC),
-                               AttnView(xo, 0, D, n_q), B, heads, hd, hd ** -0.5)
+                               AttnView(xo, 0, D, n_q), B, heads, hd, hd ** -0.5, drop_p=p_attn)
         x = _lin_fwd(xo, pw_, pb, wc, torch.float32)                                    # :265, no residual
+        k_x = None
+        if p_drop > 0.:                                                                 # CrossAttention.proj_drop (multimae_utils.py:213)
+            k_x = ops._dropout_keep((B * n_q, D), p_drop, dev)
+            x = ops.dropout_apply(x, k_x, 1.0 / (1.0 - p_drop), out=x)
         on, omean, orstd = ops.layernorm_fwd(x, onw, onb, eps, act)
         hpre = torch.empty((B * n_q, f1w.shape[0]), device=dev, dtype=act)
         hact = _lin_fwd(on, f1w, f1b, wc, act, aux=hpre, epi=EPI_GELU)
         x1 = _lin_fwd(hact, f2w, f2b, wc, torch.float32, resid=x)                       # :266
         h, bsaved = x1, []
         for l in range(cfg.depth):
-            h, s = block_fwd(h, blocks[12 * l:12 * l + 12], wc, heads, eps, act, B, n_q, save, dp=dp_of(l))   # :271
+            h, s = block_fwd(h, blocks[12 * l:12 * l + 12], wc, heads, eps, act, B, n_q, save, dp=dp_of(l), drop=(p_attn, p_drop))   # :271
             bsaved.append(s)
         h_act = ops.cast(h, act)
         pat = _lin_fwd(h_act, ow, ob, wc, torch.float32)                                # :274
         img = ops.unpatchify(pat, B, cfg.C, cfg.nh, cfg.nw, cfg.ph, cfg.pw)             # :277-280
         if save:
             ctx.saved = (enc_act, queries, context, qn, qmean, qrstd, cn, cmean, crstd, q, kv, Pm, xo, x, on, omean, orstd,
-                         hpre, hact, h_act, bsaved)
+                         hpre, hact, h_act, bsaved, k_x)
         ctx.cfg, ctx.params, ctx.ids = cfg, params, (ids_keep, ids_restore)
         ctx.dims = (B, NC, Denc, n_keep, n_q, T)
         return img
@@ -766,7 +807,7 @@ class SpatialAdapterFn(torch.autograd.Function):
         xattn = bool(getattr(cfg, 'use_xattn', True))
         if xattn:
             (enc_act, queries, context, qn, qmean, qrstd, cn, cmean, crstd, q, kv, Pm, xo, x, on, omean, orstd, hpre, hact, h_act,
-             bsaved) = ctx.saved
+             bsaved, k_x) = ctx.saved
         else:
             enc_act, ctx_shape, h_act, bsaved = ctx.saved
         if d_img is None:
@@ -787,10 +828,13 @@ class SpatialAdapterFn(torch.autograd.Function):
         bgrads: List[Optional[Tensor]] = [None] * (12 * cfg.depth)
         fc2b_done, g_cs = False, None
         dps = getattr(cfg, 'dp', None)
+        drops = getattr(cfg, 'drops', None)
         for l in reversed(range(cfg.depth)):
             cs_param = blocks[12 * (l - 1) + 11] if l > 0 else (f2b if xattn else None)
             if dps is not None and l > 0 and dps[2 * (l - 1) + 1] is not None:
                 cs_param = None                      # the block below rescales its MLP branch: colsum(dx0) is not its fc2 bias gradient
+            if l > 0 and drops is not None and drops[1] > 0.:
+                cs_param = None                      # ... or drops elements of its fc2 output
             dh, dh_act, g_cs_next, g = block_bwd(dh, dh_act, fc2b_done, bsaved[l], blocks[12 * l:12 * l + 12], wc, sink, heads, act, B,
                                                  n_q, cs_param, dp=(dps[2 * l], dps[2 * l + 1]) if dps is not None else (None, None))
             bgrads[12 * l:12 * l + 12] = g
@@ -821,10 +865,15 @@ class SpatialAdapterFn(torch.autograd.Function):
         dx, dx_act, part_o = ops.layernorm_bwd_part(d_on, x, onw, omean, orstd, dh, lnact)
         if dx_act is None:
             dx_act = dx
-        g_onw, g_onb, g_pb = sink.colsums(part_o, D, [onw, onb, pb])
-        # x = proj(attn(q, k, v))
+        # x = proj_drop(proj(attn(q, k, v)))
+        if k_x is None:
+            g_onw, g_onb, g_pb = sink.colsums(part_o, D, [onw, onb, pb])
+            g_pw = sink.weight(pw_, dx_act, xo)
+        else:                                        # the bias gradient is the column sums of the gradient BEHIND the dropout
+            g_onw, g_onb, _ = sink.colsums(part_o, D, [onw, onb, None])
+            dx_act = ops.dropout_apply(dx, k_x, 1.0 / (1.0 - drops[1]), out_dtype=act)
+            g_pw, g_pb = sink.linear(pw_, pb, dx_act, xo)
         d_xo = ops.linear_dx(dx_act, wc(pw_), torch.empty((B * n_q, D), device=dev, dtype=act))
-        g_pw = sink.weight(pw_, dx_act, xo)
         d_q = torch.empty((B * n_q, D), device=dev, dtype=act)
         d_kv = torch.empty((B * NC, 2 * D), device=dev, dtype=act)
         ops.attention_bwd(AttnView(q, 0, D, n_q), AttnView(kv, 0, 2 * D, NC), AttnView(kv, D, 2 * D, NC), Pm,
@@ -926,14 +975,14 @@ class AttentionCoreFn(torch.autograd.Function):
     """softmax(q k^T scale) v on packed activations; used by the stand-alone Attention / CrossAttention modules."""
 
     @staticmethod
-    def forward(ctx, q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, act):
+    def forward(ctx, q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, act, drop_p: float = 0.):
         B, Nq, D = q.shape
         Nk = k.shape[1]
         hd = D // heads
         qa, ka, va = (ops.cast(t.contiguous().view(-1, D), act) for t in (q, k, v))
         o = torch.empty((B * Nq, D), device=q.device, dtype=act)
         Pm = ops.attention_fwd(AttnView(qa, 0, D, Nq), AttnView(ka, 0, D, Nk), AttnView(va, 0, D, Nk), AttnView(o, 0, D, Nq), B, heads,
-                               hd, scale)
+                               hd, scale, drop_p=drop_p)
         ctx.saved = (qa, ka, va, Pm, o)
         ctx.dims = (B, Nq, Nk, D, heads, hd, scale, act)
         return ops.cast(o, torch.float32).view(B, Nq, D)
@@ -949,7 +998,7 @@ class AttentionCoreFn(torch.autograd.Function):
         ops.attention_bwd(AttnView(qa, 0, D, Nq), AttnView(ka, 0, D, Nk), AttnView(va, 0, D, Nk), Pm, AttnView(o, 0, D, Nq), AttnView(do, 0, D, Nq),
                           AttnView(dq, 0, D, Nq), AttnView(dk, 0, D, Nk), AttnView(dv, 0, D, Nk), B, heads, hd, scale)
         f = torch.float32
-        return ops.cast(dq, f).view(B, Nq, D), ops.cast(dk, f).view(B, Nk, D), ops.cast(dv, f).view(B, Nk, D), None, None, None
+        return ops.cast(dq, f).view(B, Nq, D), ops.cast(dk, f).view(B, Nk, D), ops.cast(dv, f).view(B, Nk, D), None, None, None, None
 
 
 class MlpFn(torch.autograd.Function):
@@ -962,17 +1011,26 @@ class MlpFn(torch.autograd.Function):
         x2 = ops.cast(x.contiguous().view(-1, shp[-1]), cfg.act)
         hpre = torch.empty((x2.shape[0], f1w.shape[0]), device=x.device, dtype=cfg.act)
         hact = _lin_fwd(x2, f1w, f1b.detach(), cfg.wc, cfg.act, aux=hpre, epi=EPI_GELU)
+        p = float(getattr(cfg, 'drop', 0.))              # Mlp(drop=) in training mode: behind fc2 only (:154; :151-152 is commented out)
+        k_y = None
         y = _lin_fwd(hact, f2w, f2b.detach(), cfg.wc, torch.float32)
-        ctx.cfg, ctx.saved, ctx.params, ctx.shp = cfg, (x2, hpre, hact), (f1w, f1b, f2w, f2b), shp
+        if p > 0.:
+            k_y = ops._dropout_keep(tuple(y.shape), p, x.device)
+            y = ops.dropout_apply(y, k_y, 1.0 / (1.0 - p), out=y)
+        ctx.cfg, ctx.saved, ctx.params, ctx.shp = cfg, (x2, hpre, hact, k_y), (f1w, f1b, f2w, f2b), shp
         return y.view(*shp[:-1], f2w.shape[0])
 
     @staticmethod
     def backward(ctx, dy: Tensor):
         cfg = ctx.cfg
-        x2, hpre, hact = ctx.saved
+        x2, hpre, hact, k_y = ctx.saved
         f1w, f1b, f2w, f2b = ctx.params
         sink = GradSink(engine.direct_grads())
-        dy2 = ops.cast(dy.contiguous().view(-1, f2w.shape[0]), cfg.act)
+        inv = 1.0 / (1.0 - float(getattr(cfg, 'drop', 0.)))
+        if k_y is not None:
+            dy2 = ops.dropout_apply(dy.contiguous().view(-1, f2w.shape[0]).float(), k_y, inv, out_dtype=cfg.act)
+        else:
+            dy2 = ops.cast(dy.contiguous().view(-1, f2w.shape[0]), cfg.act)
         d_hpre = ops.linear_dx(dy2, cfg.wc(f2w), torch.empty(hpre.shape, device=dy.device, dtype=cfg.act), aux=hpre, epi=EPI_DGELU)
         dx = ops.linear_dx(d_hpre, cfg.wc(f1w), torch.empty((dy2.shape[0], f1w.shape[1]), device=dy.device, dtype=torch.float32))
         g1w, g1b = sink.linear(f1w, f1b, d_hpre, x2)

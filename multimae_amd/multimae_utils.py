@@ -91,6 +91,31 @@ class LayerNorm(nn.LayerNorm):
         return LayerNormFn.apply(x, self.weight, self.bias, self.eps)
 
 
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout on the HIP element-wise kernel (mmae_dropout): y = keep * x / (1 - p), the same pass on the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, p: float):
+        from . import ops
+        ops._require_gpu(x, 'dropout input')
+        xc = x.contiguous().float()
+        keep = ops._dropout_keep(tuple(xc.shape), p, xc.device)
+        ctx.keep, ctx.inv = keep, 1.0 / (1.0 - p)
+        return ops.dropout_apply(xc, keep, ctx.inv)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        return ops.dropout_apply(dy.contiguous().float(), ctx.keep, ctx.inv), None
+
+
+def dropout(x, p: float, training: bool):
+    """nn.Dropout(p)(x) (multimae_utils.py:152-154, 177, 181): identity in eval mode and at the pre-training default p = 0."""
+    if not training or p == 0.:
+        return x
+    return DropoutFn.apply(x, float(p))
+
+
 def _drop_path_rand(shape, device) -> torch.Tensor:
     """The uniform draw behind a stochastic-depth mask (multimae_utils.py:117: torch.rand(shape, device=x.device)).  Tests
     replace this hook to inject a fixed draw on both sides of a comparison."""
@@ -156,18 +181,15 @@ class Mlp(nn.Module):
         self.act = act_layer()
         self.fc2 = Linear(hidden_features, out_features)
         self.drop = nn.Dropout(drop)
-        if drop != 0.:
-            raise NotImplementedError('dropout > 0 is not implemented in the HIP engine (pre-training uses 0)')
 
     def forward(self, x):
-        return MlpFn.apply(_cfg(self), x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+        p = float(self.drop.p) if self.training else 0.
+        return MlpFn.apply(_cfg(self, drop=p), x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
 
 
 class Attention(nn.Module):
     def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0., proj_drop=0.):
         super().__init__()
-        if attn_drop != 0. or proj_drop != 0.:
-            raise NotImplementedError('attention/projection dropout > 0 is not implemented in the HIP engine')
         self.num_heads = num_heads
         head_dim = dim // num_heads
         self.scale = head_dim ** -0.5
@@ -182,15 +204,13 @@ class Attention(nn.Module):
         B, N, C = x.shape
         qkv = self.qkv(x)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
-        o = AttentionCoreFn.apply(q, k, v, self.num_heads, self.scale, engine.act_dtype())
-        return self.proj(o)
+        o = AttentionCoreFn.apply(q, k, v, self.num_heads, self.scale, engine.act_dtype(), float(self.attn_drop.p) if self.training else 0.)
+        return dropout(self.proj(o), self.proj_drop.p, self.training)
 
 
 class CrossAttention(nn.Module):
     def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0., proj_drop=0.):
         super().__init__()
-        if attn_drop != 0. or proj_drop != 0.:
-            raise NotImplementedError('attention/projection dropout > 0 is not implemented in the HIP engine')
         self.num_heads = num_heads
         head_dim = dim // num_heads
         self.scale = head_dim ** -0.5
@@ -207,8 +227,9 @@ class CrossAttention(nn.Module):
         C = x.shape[-1]
         q = self.q(x)
         kv = self.kv(context)
-        o = AttentionCoreFn.apply(q, kv[..., :C], kv[..., C:], self.num_heads, self.scale, engine.act_dtype())
-        return self.proj(o)
+        o = AttentionCoreFn.apply(q, kv[..., :C], kv[..., C:], self.num_heads, self.scale, engine.act_dtype(),
+                                  float(self.attn_drop.p) if self.training else 0.)
+        return dropout(self.proj(o), self.proj_drop.p, self.training)
 
 
 def bias_or_zero(lin: nn.Linear, zero: Optional[torch.Tensor]) -> torch.Tensor:
@@ -260,15 +281,26 @@ def _stack_drop_path(blocks, batch: int, device):
     return dp
 
 
+def _stack_dropout(blocks):
+    """Per-block (attn_drop, drop) rates of Block(drop=, attn_drop=) -- Attention.attn_drop / .proj_drop and Mlp.drop share `drop`
+    (multimae_utils.py:221-227) -- or None when no block drops anything (eval mode, the pre-training default 0)."""
+    rates = [((float(b.attn.attn_drop.p), float(b.mlp.drop.p)) if b.training else (0., 0.)) for b in blocks]
+    for b, r in zip(blocks, rates):
+        assert not b.training or float(b.attn.proj_drop.p) == r[1], 'Block: attn.proj_drop and mlp.drop carry one rate (multimae_utils.py:221-227)'
+    return rates if any(a > 0. or d > 0. for a, d in rates) else None
+
+
 def run_blocks(blocks, x, root=None, all_layers=False, on_layer_done=None, bwd_chunk: int = 1, mx: bool = False):
     """Run a sequence of Blocks as ONE autograd node (the encoder / decoder_transformer fast path), stochastic depth
-    included: the per-sample scales are drawn here and folded into the blocks' residual adds."""
+    included: the per-sample scales are drawn here and folded into the blocks' residual adds.  Blocks with dropout > 0 (training
+    mode) run their per-kernel sequence with the three nn.Dropout sites as element-wise passes."""
     blocks = list(blocks)
     if not blocks:
         return [] if all_layers else x
     b0 = blocks[0]
     cfg = _cfg(b0 if root is None else root, heads=b0.attn.num_heads, eps=b0.norm1.eps, all_layers=all_layers,
-               on_layer_done=on_layer_done, dp=_stack_drop_path(blocks, x.shape[0], x.device), bwd_chunk=bwd_chunk, mx=mx)
+               on_layer_done=on_layer_done, dp=_stack_drop_path(blocks, x.shape[0], x.device), bwd_chunk=bwd_chunk, mx=mx,
+               drops=_stack_dropout(blocks))
     params = [p for b in blocks for p in block_params(b)]
     out = EncoderStackFn.apply(cfg, x, *params)
     return list(out) if all_layers else out

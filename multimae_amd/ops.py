@@ -1000,6 +1000,29 @@ def axpy_(y: Tensor, x: Tensor, a: float = 1.0) -> Tensor:
     return y
 
 
+# --------------------------------------------------------------------------- dropout --
+def _dropout_keep(shape, p: float, device) -> Tensor:
+    """The keep mask of an nn.Dropout(p) call (uint8, 1 = kept): torch.rand(shape) >= p on the device generator.  Tests replace this
+    hook to replay the masks the reference drew (tests/golden/make_golden_dropout.py)."""
+    return (torch.rand(shape, device=device) >= p).to(torch.uint8)
+
+
+def dropout_apply(x: Tensor, keep: Tensor, scale: float, out_dtype: Optional[torch.dtype] = None, resid: Optional[Tensor] = None,
+                  row_scale: Optional[Tensor] = None, per: int = 0, out: Optional[Tensor] = None) -> Tensor:
+    """mmae_dropout: out = [resid +] keep ? x * scale [* row_scale[i // per]] : 0 -- forward and backward of nn.Dropout alike
+    (multimae_utils.py:138-155, 158-214).  keep: uint8 of x's shape; row_scale: a stochastic-depth scale per sample (per elements each)."""
+    _require_gpu(x, 'dropout input')
+    x = x.contiguous()
+    keep = keep.contiguous()
+    assert keep.dtype == torch.uint8 and keep.numel() == x.numel() and x.numel() % 4 == 0, (keep.dtype, keep.shape, x.shape)
+    odt = out_dtype or (torch.float32 if resid is not None else x.dtype)
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=odt)
+    check(_lib.load().mmae_dropout(x.data_ptr(), dcode(x.dtype), keep.data_ptr(), float(scale), _p(row_scale), int(per), _p(resid), out.data_ptr(),
+                                   dcode(out.dtype), x.numel(), _stream()), 'dropout')
+    return out
+
+
 # ------------------------------------------------------------- attention (unfused) --
 class AttnView:
     """A (B, N, heads, hd) operand living inside a packed 2-D activation [B*N, ld] at column `col`."""
@@ -1032,12 +1055,15 @@ def _fusable(q: AttnView, k: AttnView, hd: int) -> bool:
     return q.t.dtype == torch.float32 and _f32_split() and lds_bwd <= 160 * 1024
 
 
-def attention_fwd(q: AttnView, k: AttnView, v: AttnView, out: AttnView, B: int, H: int, hd: int, scale: float, f16: bool = False):
+def attention_fwd(q: AttnView, k: AttnView, v: AttnView, out: AttnView, B: int, H: int, hd: int, scale: float, f16: bool = False,
+                  drop_p: float = 0.0):
     """softmax(q k^T * scale) v.  Returns the state backward needs: ('fused', lse) or ('gemm', P).
-    multimae_utils.py:175-179 / 206-210.  f16 (f32 tensors only): fp16-operand products instead of the split-bf16 ones."""
+    multimae_utils.py:175-179 / 206-210.  f16 (f32 tensors only): fp16-operand products instead of the split-bf16 ones.
+    drop_p > 0: attn_drop (multimae_utils.py:177 / 208) on the materialised probabilities -- the batched-GEMM path, state
+    ('gemm', P, P_dropped, keep, 1 / (1 - p))."""
     Nq, Nk = q.N, k.N
     dev, act = q.t.device, q.t.dtype
-    if _fusable(q, k, hd):
+    if drop_p <= 0.0 and _fusable(q, k, hd):
         lse = torch.empty((B, H, Nq), device=dev, dtype=torch.float32)
         fwd = _lib.load().mmae_attn_fwd if act == torch.bfloat16 else (_lib.load().mmae_attn_fwd_f16 if act == torch.float16 else (
             _lib.load().mmae_attn_fwd_f32f16 if f16 else _lib.load().mmae_attn_fwd_f32x3))
@@ -1051,9 +1077,18 @@ def attention_fwd(q: AttnView, k: AttnView, v: AttnView, out: AttnView, B: int, 
          batch=B * H, batch_inner=H, sA=(Nq * q.ld, hd), sB=(Nk * k.ld, hd), sC=(H * Nq * Np, Nq * Np))
     P = torch.empty((B, H, Nq, Np), device=dev, dtype=act)
     softmax_fwd(S, P, B * H * Nq, Nk, scale)
-    gemm(P, v.t, out.t, Nq, hd, Nk, lda=Np, ldb=v.ld, ldc=out.ld, b_trans=True, b_off=v.col, c_off=out.col,
+    Pv, state = P, ('gemm', P)
+    if drop_p > 0.0:
+        keep = _dropout_keep((B, H, Nq, Nk), drop_p, dev)
+        if Np != Nk:                                       # the padded key columns hold zeros either way
+            kp = torch.zeros((B, H, Nq, Np), device=dev, dtype=torch.uint8)
+            kp[..., :Nk] = keep
+            keep = kp
+        Pv = dropout_apply(P, keep, 1.0 / (1.0 - drop_p))
+        state = ('gemm', P, Pv, keep, 1.0 / (1.0 - drop_p))
+    gemm(Pv, v.t, out.t, Nq, hd, Nk, lda=Np, ldb=v.ld, ldc=out.ld, b_trans=True, b_off=v.col, c_off=out.col,
          batch=B * H, batch_inner=H, sA=(H * Nq * Np, Nq * Np), sB=(Nk * v.ld, hd), sC=(Nq * out.ld, hd))
-    return ('gemm', P)
+    return state
 
 
 def attention_bwd(q: AttnView, k: AttnView, v: AttnView, state, out: AttnView, d_out: AttnView, dq: AttnView, dk: AttnView,
@@ -1080,10 +1115,14 @@ def attention_bwd(q: AttnView, k: AttnView, v: AttnView, state, out: AttnView, d
     dP = torch.empty((B, H, Nq, Np), device=dev, dtype=torch.float32)
     gemm(d_out.t, v.t, dP, Nq, Nk, hd, lda=d_out.ld, ldb=v.ld, ldc=Np, a_off=d_out.col, b_off=v.col,
          sA=(Nq * d_out.ld, hd), sB=(Nk * v.ld, hd), sC=sP, **bh)
+    Pv = P
+    if len(state) > 2:                                     # attn_drop: O = (keep * P / (1 - p)) V
+        Pv = state[2]
+        dP = dropout_apply(dP, state[3], state[4])
     dS = torch.empty((B, H, Nq, Np), device=dev, dtype=act)
     softmax_bwd(P, dP, dS, B * H * Nq, Nk, scale)
     # dV = P^T dO
-    gemm(P, d_out.t, dv.t, Nk, hd, Nq, lda=Np, ldb=d_out.ld, ldc=dv.ld, a_trans=True, b_trans=True, b_off=d_out.col,
+    gemm(Pv, d_out.t, dv.t, Nk, hd, Nq, lda=Np, ldb=d_out.ld, ldc=dv.ld, a_trans=True, b_trans=True, b_off=d_out.col,
          c_off=dv.col, sA=sP, sB=(Nq * d_out.ld, hd), sC=(Nk * dv.ld, hd), **bh)
     # dQ = dS K
     gemm(dS, k.t, dq.t, Nq, hd, Nk, lda=Np, ldb=k.ld, ldc=dq.ld, b_trans=True, b_off=k.col, c_off=dq.col,

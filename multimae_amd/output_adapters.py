@@ -49,12 +49,13 @@ class SpatialOutputAdapter(nn.Module):
         self.use_xattn = use_xattn
         self.num_heads = num_heads
         self.depth = depth
+        self._drop_rates = (float(attn_drop_rate), float(drop_rate))
         if learnable_pos_emb:
             # (the reference allocates this table as (1, h, w, D) but resizes it with F.interpolate as if it were (1, D, h, w),
             # output_adapters.py:108-111,172: not a behaviour worth mirroring)
             raise NotImplementedError('learnable decoder positional embeddings are not built in the HIP engine')
-        if drop_rate != 0.0 or attn_drop_rate != 0.0:
-            raise NotImplementedError('decoder dropout / attention dropout > 0 is not built in the HIP engine')
+        # (drop_rate / attn_drop_rate > 0: the nn.Dropout sites of the cross attention and of the decoder blocks run as element-wise
+        # passes between the per-kernel sequence of the adapter; 0 -- every shipped configuration -- keeps the one-call adapter)
         # (drop_path_rate > 0: stochastic depth in decoder_transformer, output_adapters.py:126-132 -- the per-sample scales are drawn in
         # forward() in the reference's order and folded into the blocks' residual adds, as in the encoder)
 
@@ -176,6 +177,8 @@ class SpatialOutputAdapter(nn.Module):
         if self.depth > 0:                                   # two draws per block with a rate > 0, as the blocks execute (multimae_utils.py:229-232)
             from .multimae_utils import _stack_drop_path
             cfg.dp = _stack_drop_path(list(self.decoder_transformer), encoder_tokens.shape[0], encoder_tokens.device)
+        if self.training and any(r > 0. for r in self._drop_rates):
+            cfg.drops = self._drop_rates
         params = self._params(in_tasks)
         if not task_queries and self.task_embeddings is not None and self.task in self.task_embeddings:
             # the query rows are mask_token + task_embeddings[task] + pos: one vector added to every row, passed in the mask-token

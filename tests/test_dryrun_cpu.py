@@ -201,8 +201,56 @@ def test_decoder_drop_path_and_fp16_storage_control_flow(stubbed, mode):
         assert draws == []
     finally:
         mu._drop_path_rand = real
-    with pytest.raises(NotImplementedError):
-        M.SpatialOutputAdapter(num_channels=3, stride_level=1, patch_size_full=P, dim_tokens=64, drop_rate=0.1)
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_dropout_control_flow(stubbed, mode):
+    """MultiMAE(drop_rate, attn_drop_rate > 0) with adapters built the same way, training mode, on the ABI stub: every nn.Dropout site of the
+    reference requests exactly one keep mask, in the reference's order (per block: attention probabilities (B, H, N, N), proj output, fc2
+    output -- multimae_utils.py:154, 177, 181; per adapter the cross attention's two first, output_adapters.py:118-119), every trainable
+    parameter receives a gradient, and eval mode requests none."""
+    import multimae_amd as M
+    from functools import partial
+    from torch import nn
+    from multimae_amd import ops
+    doms, P, S = MINI['doms'], MINI['P'], MINI['S']
+    torch.manual_seed(0)
+    ins = {}
+    for d in doms:
+        if d == 'semseg':
+            ins[d] = M.SemSegInputAdapter(num_classes=133, dim_class_emb=16, interpolate_class_emb=False, stride_level=4, patch_size_full=P,
+                                          image_size=S)
+        else:
+            ins[d] = M.PatchedInputAdapter(num_channels=3 if d == 'rgb' else 1, stride_level=1, patch_size_full=P, image_size=S)
+    outs = {}
+    for key, task in [(d, d) for d in doms] + [('norm_rgb', 'rgb')]:
+        ch = {'rgb': 3, 'depth': 1, 'semseg': 133}[task]
+        outs[key] = M.SpatialOutputAdapter(num_channels=ch, stride_level=4 if task == 'semseg' else 1, patch_size_full=P, dim_tokens=64, depth=2,
+                                           num_heads=2, use_task_queries=True, task=task, context_tasks=list(doms), use_xattn=(key != 'depth'),
+                                           image_size=S, drop_rate=0.1, attn_drop_rate=0.2)
+    model = M.MultiMAE(ins, outs, num_global_tokens=1, dim_tokens=128, depth=2, num_heads=2, mlp_ratio=4, qkv_bias=True, drop_rate=0.1,
+                       attn_drop_rate=0.2, norm_layer=partial(nn.LayerNorm, eps=1e-6)).train()
+    asked = []
+    real = ops._dropout_keep
+    ops._dropout_keep = lambda shape, p, device: (asked.append((p, len(shape))), real(shape, p, device))[1]
+    try:
+        g = load_mini()
+        _step(model, mode, False, g['x'], fp32_adapters=('semseg',))
+        block = [(0.2, 4), (0.1, 2), (0.1, 2)]
+        want = block * 2
+        for key in outs:
+            want += ([(0.2, 4), (0.1, 2)] if key != 'depth' else []) + block * 2
+        assert asked == want, asked
+        for n, p in model.named_parameters():
+            # (the depth adapter was built without cross attention: its unused xattn / MLP parameters do not exist)
+            assert (p.grad is not None) == p.requires_grad, n
+        model.eval()
+        asked.clear()
+        with torch.no_grad(), M.engine.precision(mode):
+            model(g['x'], num_encoded_tokens=MINI['nvis'], alphas=1.0)
+        assert asked == []
+    finally:
+        ops._dropout_keep = real
 
 
 def test_fp16_weight_copies_are_cached_by_storage_not_by_object():

@@ -1065,3 +1065,31 @@ def test_gemm_layernorm_side_output_refuses_what_it_cannot_do():
     out, y = torch.empty(512, 512, device=DEV), torch.empty(512, 512, device=DEV, dtype=torch.bfloat16)
     with pytest.raises(KernelError):
         ops.linear_fwd(x, w, torch.zeros(512, device=DEV), out, ln=(None, None, y, None, None, 0.0))
+
+
+@pytest.mark.parametrize('xdt,odt', [(torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.float32, torch.float16),
+                                     (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32), (torch.float16, torch.float16)])
+def test_dropout_kernel(xdt, odt):
+    """mmae_dropout: out = [resid +] keep ? x * scale [* s[i // per]] : 0 -- nn.Dropout forward and backward as one element-wise pass,
+    optionally folded with the residual add and the per-sample stochastic-depth scale of a Block branch (multimae_utils.py:229-232)."""
+    from multimae_amd import ops
+    torch.manual_seed(0)
+    B, N, D, p = 3, 7, 64, 0.3
+    x = torch.randn(B * N, D, device=DEV).to(xdt)
+    keep = ops._dropout_keep((B * N, D), p, DEV)
+    inv = 1.0 / (1.0 - p)
+    want = x.float() * keep.float() * inv
+    got = ops.dropout_apply(x, keep, inv, out_dtype=odt)
+    assert got.dtype == odt and torch.equal(got.float(), want.to(odt).float())
+    assert torch.equal((got == 0), (keep == 0) | (x == 0))
+    if xdt == torch.float32 and odt == torch.float32:
+        resid = torch.randn(B * N, D, device=DEV)
+        s = torch.tensor([0.0, 1.25, 2.0], device=DEV)
+        got = ops.dropout_apply(x, keep, inv, resid=resid, row_scale=s, per=N * D)
+        want = resid + x * keep.float() * (inv * s.repeat_interleave(N).view(-1, 1))
+        assert torch.allclose(got, want, atol=1e-6, rtol=1e-6)
+        # in place (the activation path of the stand-alone modules)
+        y = x.clone()
+        assert ops.dropout_apply(y, keep, inv, out=y) is y and torch.equal(y, x * keep.float() * inv)
+    with pytest.raises(AssertionError):
+        ops.dropout_apply(x[:, :63].contiguous(), keep[:, :63].contiguous(), inv)

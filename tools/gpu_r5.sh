@@ -125,6 +125,9 @@ final)   # the round's measurement visit: default line (+ secondaries), other co
   cat gpurun_out/r5_encoder_step.json >> $S
   python tools/hbm_probe.py >> $S 2>&1
   ;;
+dropout)   # nn.Dropout sites: kernel, modules, the reference-recorded step; stochastic depth beside them
+  timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_parity_geometry_gpu.py -x -q -k "dropout or drop_path" 2>&1 | tail -12 >> $S
+  ;;
 retest)   # re-run of the tests that failed in the last full run + the default line
   timeout 1500 python -m pytest tests/test_dropin_loop_gpu.py tests/test_model_gpu.py tests/test_parity_geometry_gpu.py -x -q -k "reference_loop_with or first_write or fused_optimizer" 2>&1 | tail -6 >> $S
   [ -f gpurun_out/dropin_fast_loop.json ] && cp gpurun_out/dropin_fast_loop.json gpurun_out/r5_dropin_fast_loop.json
