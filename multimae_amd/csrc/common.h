@@ -171,8 +171,12 @@ __device__ __forceinline__ void gelu_both_fast2(f32x2 x, f32x2& y, f32x2& dy) {
 #undef MMAE_PK_STEP
     const f32x2 half = {0.5f, 0.5f};
     const f32x2 cdf = __builtin_elementwise_fma(t, q, half);
+    // x beyond -4 stops growing: gelu(x < -4) = gelu(-4).  max(x, -4) written as ONE v_med3 against FLT_MAX: fmaxf costs a canonicalising
+    // v_max per operand beside the v_max itself (three operations per element in the ISA), and a med3 against +inf is folded back into
+    // that maxnum.  (+inf comes out as FLT_MAX * Phi(4), which the bf16 / fp16 store rounds to +inf again.)
     f32x2 xm;
-    xm[0] = fmaxf(x[0], t[0]); xm[1] = fmaxf(x[1], t[1]);          // x beyond -4 stops growing: gelu(x < -4) = gelu(-4)
+    xm[0] = __builtin_amdgcn_fmed3f(x[0], -4.0f, 3.402823466e38f);
+    xm[1] = __builtin_amdgcn_fmed3f(x[1], -4.0f, 3.402823466e38f);
     y = xm * cdf;
     dy = __builtin_elementwise_fma(t, r, half);
 }

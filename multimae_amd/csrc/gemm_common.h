@@ -21,7 +21,7 @@ struct GemmArgs {
     float* colpart;               // optional [ceil(M/32)][N] column sums of the epilogue output per 32-row block (dGELU flavour)
     int wide_st;                  // bf16 epilogues with 8-column (16-byte) lanes (store_tile64_bf16x8); env MMAE_EPI_WIDE=0 turns it off
     int aux_grad;                 // MMAE_EPI_GELU_G / MMAE_EPI_MUL: aux keeps GELU'(pre-activation) instead of the pre-activation (mmae.h)
-    int dephase;                  // experiment (env MMAE_PP_DEPHASE = n): odd workgroups of the ping-pong kernel start n x ~4 us late
+    int dephase;                  // experiment (env MMAE_PP_DEPHASE = n + 256 * mode): some workgroups of the ping-pong kernel start n x ~4 us late
     const void* scA; const void* scB;   // MX-fp8 products: packed E8M0 scales of the two operands (mxfp8.hip)
     unsigned char* qout; unsigned char* qsc; long long ldq;   // ..._Q flavours: also emit the MX-fp8 quantisation of the bf16 output C ([M][ldq] bytes + packed scales)
     int h16;                      // the 16-bit operands / outputs / aux of this product are fp16 (MMAE_F16), not bf16: flavoured ping-pong kernels only
@@ -328,7 +328,11 @@ template <bool H16> __device__ __forceinline__ i32x4 pack8_16(const f32x4 a, con
     i32x4 r; r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
     return r;
 }
-template <bool BIAS, int EPI, bool COLSUM, int DBG = 0, int PDEPTH = 4, bool MXQ = false, bool H16 = false>
+// AUXG: what aux holds (GemmArgs::aux_grad) fixed at compile time (1 / 0; -1 = read the argument).  As a run-time test of a uniform
+// argument hipcc if-converts it: BOTH forms computed per element and selected -- the dX product then evaluated the whole GELU' polynomial
+// (9 packed FMAs + clamps per pair) next to the multiply that replaces it, and fc1's epilogue paid a v_cndmask per element (round 5,
+// read off the ISA: 32 -> 15 and 34 -> 28 VALU operations per element pair).  The flavoured callers branch once per tile instead.
+template <bool BIAS, int EPI, bool COLSUM, int DBG = 0, int PDEPTH = 4, bool MXQ = false, bool H16 = false, int AUXG = -1>
 __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cbase, char* wave_lds, int lane, const f32x16 (&acc)[2][2],
                                                     int m_base, int n_base, int ntm) {
     constexpr unsigned OOB_OFF = 0x80000000u;
@@ -336,6 +340,7 @@ __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cba
     const int n = n_base + c8 * 8;
     const bool n_ok = n < g.N;
     const int rows_left = g.M - m_base;
+    const bool aux_grad = AUXG < 0 ? (g.aux_grad != 0) : (AUXG != 0);
     f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
     if (BIAS && n_ok) { b0 = ld4(g.bias + n); b1 = ld4(g.bias + n + 4); }
     f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = cs0;
@@ -381,7 +386,7 @@ __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cba
                             gelu_both_fast4(v0, y0, d0);
                             gelu_both_fast4(v1, y1, d1);
                         }
-                        if (g.aux_grad) { s0 = d0; s1 = d1; }
+                        if (aux_grad) { s0 = d0; s1 = d1; }
                         v0 = y0; v1 = y1;
                     }
                     if (DBG != 2 && DBG != 3) __builtin_amdgcn_raw_buffer_store_b128(pack8_16<H16>(s0, s1), rsAux, voff(gi, g.ldaux), 0, 0);
@@ -389,7 +394,7 @@ __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cba
                     const i32x4 pa = pre_aux[gi % PD];
                     i32x2 lo2, hi2; lo2[0] = pa[0]; lo2[1] = pa[1]; hi2[0] = pa[2]; hi2[1] = pa[3];
                     const f32x4 p0 = unpack4_16<H16>(lo2), p1 = unpack4_16<H16>(hi2);
-                    if (g.aux_grad) {                        // the forward stored GELU' itself: no transcendental work here
+                    if (aux_grad) {                          // the forward stored GELU' itself: no transcendental work here
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { v0[j] *= p0[j]; v1[j] *= p1[j]; }
                     } else if constexpr (H16) {
@@ -402,9 +407,10 @@ __device__ __forceinline__ void store_tile64_bf16x8(const GemmArgs& g, char* Cba
                     }
                     if (gi + PD < nsteps) pre_aux[gi % PD] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, voff(gi + PD, g.ldaux), 0, 0);
                 }
-                if (COLSUM) {
+                if (COLSUM) {                                // (rows / columns outside the matrix hold exact zeros: their operands were loaded as zeros)
+                    const float okf = ok ? 1.f : 0.f;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { cs0[j] += ok ? v0[j] : 0.f; cs1[j] += ok ? v1[j] : 0.f; }
+                    for (int j = 0; j < 4; ++j) { cs0[j] = __builtin_fmaf(okf, v0[j], cs0[j]); cs1[j] = __builtin_fmaf(okf, v1[j], cs1[j]); }
                 }
                 if (MXQ) {
                     const i32x4 pk = pack8_16<H16>(v0, v1);
@@ -557,13 +563,17 @@ __device__ __forceinline__ void gemm_store_tile64_fl(const GemmArgs& g, char* Cz
                                                      int ntm = 2) {
     if (FL == FL_BF16_BIAS) store_tile64_bf16x8<true, MMAE_EPI_NONE, false, 0, 4, false, H16>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
     else if (FL == FL_BF16) store_tile64_bf16x8<false, MMAE_EPI_NONE, false, 0, 4, false, H16>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
-    else if (FL == FL_BF16_BIAS_GELU) store_tile64_bf16x8<true, MMAE_EPI_GELU, false, 0, 4, false, H16>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
+    // the GELU flavours: one branch per tile on what aux holds (AUXG above), not a select per element
+#define MMAE_AUXG(...) do { if (g.aux_grad) store_tile64_bf16x8<__VA_ARGS__, 1>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm); \
+                            else store_tile64_bf16x8<__VA_ARGS__, 0>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm); } while (0)
+    else if (FL == FL_BF16_BIAS_GELU) MMAE_AUXG(true, MMAE_EPI_GELU, false, 0, 4, false, H16);
     // (with one flavour per instantiation there are registers to spare: all 8 pre-activation loads of a 64-row tile go out before its first use)
-    else if (FL == FL_BF16_DGELU_CS) store_tile64_bf16x8<false, MMAE_EPI_DGELU, true, 0, 4, false, H16>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
-    else if (FL == FL_BF16_DGELU) store_tile64_bf16x8<false, MMAE_EPI_DGELU, false, 0, 8, false, H16>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
-    else if (FL == FL_BF16_BIAS_GELU_Q) store_tile64_bf16x8<true, MMAE_EPI_GELU, false, 0, 4, true>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
-    else if (FL == FL_BF16_DGELU_CS_Q) store_tile64_bf16x8<false, MMAE_EPI_DGELU, true, 0, 4, true>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
-    else if (FL == FL_BF16_DGELU_Q) store_tile64_bf16x8<false, MMAE_EPI_DGELU, false, 0, 8, true>(g, Cz, wave_lds, lane, acc, m_base, n_base, ntm);
+    else if (FL == FL_BF16_DGELU_CS) MMAE_AUXG(false, MMAE_EPI_DGELU, true, 0, 4, false, H16);
+    else if (FL == FL_BF16_DGELU) MMAE_AUXG(false, MMAE_EPI_DGELU, false, 0, 8, false, H16);
+    else if (FL == FL_BF16_BIAS_GELU_Q) MMAE_AUXG(true, MMAE_EPI_GELU, false, 0, 4, true, false);
+    else if (FL == FL_BF16_DGELU_CS_Q) MMAE_AUXG(false, MMAE_EPI_DGELU, true, 0, 4, true, false);
+    else if (FL == FL_BF16_DGELU_Q) MMAE_AUXG(false, MMAE_EPI_DGELU, false, 0, 8, true, false);
+#undef MMAE_AUXG
     else if (FL == FL_F32_BIAS_RESID) store_tile64_fast<true, 0, true, true, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm);
     else if (FL == FL_F32_BIAS) store_tile64_fast<true, 0, false, true, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm);
     else if (FL == FL_F32) store_tile64_fast<false, 0, false, true, false>(g, Cz, g.ldc, wave_lds, lane, acc, m_base, n_base, ntm);

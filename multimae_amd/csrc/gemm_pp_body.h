@@ -360,8 +360,12 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
         if (LA == 3 && !has3) duo_like_wait<NPW - 1>(); else duo_like_wait<NPW>();
     };
 
-    if (g.dephase && (blockIdx.x & 1)) {                 // experiment: half of the CUs run out of phase with the other half
-        for (int i = 0; i < g.dephase; ++i) __builtin_amdgcn_s_sleep(127);
+    if (g.dephase) {                                     // experiment (env MMAE_PP_DEPHASE = n + 256 * mode): some CUs start n x ~4 us late
+        const int n_sleep = g.dephase & 0xff, mode = g.dephase >> 8;
+        const int n_mine = (g.tiles_total - v0 + vstep - 1) / vstep, n_max = (g.tiles_total + vstep - 1) / vstep;
+        // mode 0: the odd workgroups; 1: the workgroups with a tile less than the busiest (their delay is free); 2: the odd ones among those
+        const bool late = mode == 0 ? (blockIdx.x & 1) : (mode == 1 ? n_mine < n_max : (n_mine < n_max && (blockIdx.x & 1)));
+        if (late) for (int i = 0; i < n_sleep; ++i) __builtin_amdgcn_s_sleep(127);
     }
     // prologue of the first tile: K tiles 0, 1 and the first half of K tile 2
     dma_first(0, 0); dma_second(0, 0);

@@ -125,6 +125,23 @@ final)   # the round's measurement visit: default line (+ secondaries), other co
   cat gpurun_out/r5_encoder_step.json >> $S
   python tools/hbm_probe.py >> $S 2>&1
   ;;
+epivalu)   # epilogue VALU diet (aux_grad fixed per tile, one med3 for the tail, fma column sums): tests, tables and the line, previous build beside it
+  PREV=$R/multimae_amd/libmmae_hip_prev.so
+  timeout 1500 python -m pytest tests/test_kernels_gpu.py tests/test_parity_geometry_gpu.py tests/test_h16_gpu.py tests/test_mxfp8_gpu.py -x -q -k "gelu or mlp or gemm or per_tensor or colsum or epilogue or h16 or mx" 2>&1 | tail -5 >> $S
+  MMAE_LIB=$PREV table encoder_gemms.py "encoder GEMMs, previous build"
+  table encoder_gemms.py "encoder GEMMs, this build"
+  MMAE_LIB=$PREV table decoder_gemms.py "decoder GEMMs, previous build" 9 10
+  table decoder_gemms.py "decoder GEMMs, this build" 9 10
+  MMAE_LIB=$PREV run "previous build" timeout 300 $B
+  run "this build" timeout 300 $B
+  MMAE_LIB=$PREV run "previous build again" timeout 300 $B
+  run "this build again" timeout 300 $B
+  ;;
+dephase2)   # slack-aware start offsets (MMAE_PP_DEPHASE = n + 256 * mode, gemm_pp_body.h): per-product tables, each twice
+  for cfg in 0 260 0 260 4 258 262 516; do
+    MMAE_PP_DEPHASE=$cfg table encoder_gemms.py "encoder GEMMs, MMAE_PP_DEPHASE=$cfg"
+  done
+  ;;
 dropout)   # nn.Dropout sites: kernel, modules, the reference-recorded step; stochastic depth beside them
   timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_parity_geometry_gpu.py -x -q -k "dropout or drop_path" 2>&1 | tail -12 >> $S
   ;;
