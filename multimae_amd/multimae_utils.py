@@ -293,7 +293,8 @@ def _stack_dropout(blocks):
 def run_blocks(blocks, x, root=None, all_layers=False, on_layer_done=None, bwd_chunk: int = 1, mx: bool = False):
     """Run a sequence of Blocks as ONE autograd node (the encoder / decoder_transformer fast path), stochastic depth
     included: the per-sample scales are drawn here and folded into the blocks' residual adds.  Blocks with dropout > 0 (training
-    mode) run their per-kernel sequence with the three nn.Dropout sites as element-wise passes."""
+    mode) run their per-kernel sequence with the three nn.Dropout sites as element-wise passes (with bf16 products also in MX-fp8 mode:
+    the scaled-MFMA products are a property of the one-call stack)."""
     blocks = list(blocks)
     if not blocks:
         return [] if all_layers else x

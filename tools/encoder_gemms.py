@@ -5,7 +5,7 @@ Host launch cost hides short kernels from event timing, so run under rocprofv3 a
 import sys, os, glob, csv
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 R, D, H = 25344, 768, 3072
-REP = 5
+REP = int(os.environ.get('MMAE_TABLE_REP', '5'))     # launches per product; the table prints the median
 # name, flops
 CASES = [('fwd qkv  bias', 2.0 * R * D * 3 * D), ('fwd proj bias+resid f32', 2.0 * R * D * D), ('fwd fc1  bias+gelu, aux=gelu\'', 2.0 * R * D * H),
          ('fwd fc2  bias+resid f32', 2.0 * R * D * H), ('dx  fc2  x aux + colsum', 2.0 * R * D * H), ('dx  fc1', 2.0 * R * D * H),

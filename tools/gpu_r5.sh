@@ -20,6 +20,7 @@ kstats() { tag=$1; shift; rm -rf gpurun_out/prof; (cd /tmp && timeout 600 rocpro
 case $V in
 duo)   # the two-workgroups-per-CU GEMM (tile 11, experiments library) on the output adapters' short-K products
   run "production library, defaults" timeout 300 $B
+  [ -f $EXP ] || { echo "the experiments library did not travel: comment its line out of .gpurunignore (and run make -C multimae_amd/csrc exp)" >> $S; exit 1; }
   export MMAE_LIB=$EXP
   run "exp library, defaults" timeout 300 $B
   MMAE_DUO_MAX_K=256 run "exp, duo for K <= 256" timeout 300 $B
@@ -54,6 +55,7 @@ pmcdec)   # HBM bytes per launch of the decoder / encoder products (tile 10 or t
   rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
   ;;
 dephase)   # odd workgroups of the two-stream-epilogue products start ~4 us late (experiments library)
+  [ -f $EXP ] || { echo "the experiments library did not travel: comment its line out of .gpurunignore (and run make -C multimae_amd/csrc exp)" >> $S; exit 1; }
   export MMAE_LIB=$EXP
   run "exp library, defaults" timeout 300 $B
   MMAE_PP_DEPHASE=1 MMAE_PP_DEPHASE_SEL=1 run "exp, dephase 1 on GELU / dGELU epilogues, K >= 512" timeout 300 $B
@@ -137,8 +139,10 @@ epivalu)   # epilogue VALU diet (aux_grad fixed per tile, one med3 for the tail,
   MMAE_LIB=$PREV run "previous build again" timeout 300 $B
   run "this build again" timeout 300 $B
   ;;
-dephase2)   # slack-aware start offsets (MMAE_PP_DEPHASE = n + 256 * mode, gemm_pp_body.h): per-product tables, each twice
-  for cfg in 0 260 0 260 4 258 262 516; do
+dephase2)   # slack-aware start offsets (MMAE_PP_DEPHASE = n + 256 * mode, gemm_pp_body.h; experiments library: the production one reads no environment)
+  [ -f $EXP ] || { echo "the experiments library did not travel: comment its line out of .gpurunignore (and run make -C multimae_amd/csrc exp)" >> $S; exit 1; }
+  export MMAE_LIB=$EXP MMAE_TABLE_REP=15
+  for cfg in 0 260 0 260 258 264 4 516; do
     MMAE_PP_DEPHASE=$cfg table encoder_gemms.py "encoder GEMMs, MMAE_PP_DEPHASE=$cfg"
   done
   ;;
