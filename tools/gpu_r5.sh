@@ -92,6 +92,8 @@ final)   # the round's measurement visit: default line (+ secondaries), other co
   cat gpurun_out/r5_bench_cfg3.json >> $S
   echo "== other configurations" >> $S
   run "cfg3 default, again" timeout 300 $B
+  MMAE_GELU_GRAD_AUX=0 run "cfg3, the MLP pair with the pre-activation stored and GELU' re-evaluated by the backward (MMAE_GELU_GRAD_AUX=0)" timeout 300 $B
+  run "cfg3 default, a third time" timeout 300 $B
   run "cfg3, fp32 adapter as f32 tensors with fp16 operands (--fp32-adapter-gemm f16)" timeout 300 $B --fp32-adapter-gemm f16
   run "cfg3, fp32 adapter with split-bf16 operands (--fp32-adapter-gemm x3)" timeout 300 $B --fp32-adapter-gemm x3
   run "cfg3 serialized (one stream)" timeout 300 $B --adapter-streams 0 --wgrad-stream 0
