@@ -82,3 +82,9 @@ int mmae_gemm_bf16_pp_fl_impl(const mmae_gemm_desc* d, const GemmArgs& g, int co
         default: return MMAE_ESUPPORT;
     }
 }
+
+#ifdef MMAE_PP_TRACE
+// phase stamps of the last flavoured ping-pong launch (workgroup 0, waves 0 and 4): tools/pp_trace.py
+extern "C" int mmae_debug_pp_trace(long long* out_host_256) { return (int)hipMemcpyFromSymbol(out_host_256, HIP_SYMBOL(g_pp_trace), 2 * 128 * 8); }
+extern "C" int mmae_debug_pp_wg(long long* out_host_4096) { return (int)hipMemcpyFromSymbol(out_host_4096, HIP_SYMBOL(g_pp_wg), 1024 * 4 * 8); }
+#endif

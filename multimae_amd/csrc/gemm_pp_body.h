@@ -31,6 +31,21 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 
 namespace {
 
+// Phase stamps of workgroup 0 (waves 0 and 4: one of each half-phase group) -- builds with -DMMAE_PP_TRACE only (tools/pp_trace.py):
+// per output tile  A tile start | B main loop done | C ring drained + barrier | D next tile's first DMA issued | E, F, G store calls done |
+// H stores acknowledged + barrier.
+#ifdef MMAE_PP_TRACE
+__device__ long long g_pp_trace[2][128];
+__device__ long long g_pp_wg[1024][4];                   // per workgroup: start / end (100 MHz), XCC id, tiles done
+// each stamp: s_memrealtime (100 MHz, wall time) and s_memtime (shader-clock cycles) -- their ratio is the clock the phase ran at
+#define PP_STAMP() do { if (tr_on && tr_n < 126) { g_pp_trace[tr_w][1 + tr_n++] = (long long)__builtin_amdgcn_s_memrealtime(); \
+                                                    g_pp_trace[tr_w][1 + tr_n++] = (long long)__builtin_readcyclecounter(); } } while (0)
+#define PP_TRACE_END() do { if (tr_on) g_pp_trace[tr_w][0] = tr_n; } while (0)
+#else
+#define PP_STAMP() do {} while (0)
+#define PP_TRACE_END() do {} while (0)
+#endif
+
 constexpr int BK = 32;
 constexpr unsigned OOB = 0x80000000u;
 
@@ -382,7 +397,21 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
     // tiles while this tile's results are written out (the DMA latency and most of the prologue hide under the epilogue)
     char* stage = smem + 2 * STAGE + wave * 8192;
     static_assert(2 * STAGE >= 8 * 8192, "staging must fit in ring slots 2-3");
+#ifdef MMAE_PP_TRACE
+    const bool tr_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x == 0 || threadIdx.x == 256);
+    const int tr_w = threadIdx.x >> 8;
+    int tr_n = 0;
+    const bool wg_on = threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 1024;
+    int wg_tiles = 0;
+    if (wg_on) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_pp_wg[blockIdx.x][0] = (long long)__builtin_amdgcn_s_memrealtime();
+        g_pp_wg[blockIdx.x][2] = (long long)(xcc & 0xf);
+    }
+#endif
     for (int v = v0; v < g.tiles_total; v += vstep) {
+        PP_STAMP();                                          // A
         asm volatile("" : "+v"(lane));
         derive();
 #pragma unroll
@@ -497,8 +526,10 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
                 if (lane < 32 && m < g.M) g.acs[(long long)blockIdx.z * g.M + m] = sv;
             }
         }
+        PP_STAMP();                                          // B
         wait_vm<0>();                                        // the zero-fill tail pieces must not land on live data
         __syncthreads();                                     // every wave is out of the ring
+        PP_STAMP();                                          // C
 
         if constexpr (H16) {                                 // a gradient leaving the fp16-storage domain (f32 C): 1/S, mmae.h MMAE_F16
             if (g.a_amax) {
@@ -519,6 +550,7 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
             dma_first(0, 0); dma_second(0, 0);
             dma_first(1, 1); dma_second(1, 1);
         }
+        PP_STAMP();                                          // D
         if constexpr (LNE) {
             static_assert(TM == 4 && !AKS && (FL == FL_F32_BIAS_RESID || FL == FL_F32_BIAS), "LayerNorm side output: f32 bias [+ residual] flavours on 256-row tiles");
             constexpr bool RES = FL == FL_F32_BIAS_RESID;
@@ -597,15 +629,18 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
             f32x16 sub[2][2] = {{acc[0][0], acc[0][1]}, {acc[1][0], acc[1][1]}};
             gemm_store_tile64_fl<FL, H16>(g, Cz, stage, lane, sub, mw, nw);
         }
+        PP_STAMP();                                          // E
         {
             f32x16 sub[2][2] = {{acc[0][2], acc[0][3]}, {acc[1][2], acc[1][3]}};
             gemm_store_tile64_fl<FL, H16>(g, Cz, stage, lane, sub, mw + 64, nw);
         }
+        PP_STAMP();                                          // F
         }
         if (!LNE && (TM & 1)) {
             f32x16 sub[2][2] = {{acc[0][TM - 1], acc[0][TM - 1]}, {acc[1][TM - 1], acc[1][TM - 1]}};
             gemm_store_tile64_fl<FL, H16>(g, Cz, stage, lane, sub, mw + (TM - 1) * 32, nw, 1);
         }
+        PP_STAMP();                                          // G
         if (has_next) {
             // loads and stores share vmcnt and may retire out of order with respect to each other: drain everything (the
             // prefetched K tiles landed long ago; this waits for the last store acknowledgements only), then hand ring
@@ -614,7 +649,15 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
             __syncthreads();
             if (!WIDE) dma_first(2, 2);
         }
+        PP_STAMP();                                          // H
+#ifdef MMAE_PP_TRACE
+        ++wg_tiles;
+#endif
     }
+    PP_TRACE_END();
+#ifdef MMAE_PP_TRACE
+    if (wg_on) { g_pp_wg[blockIdx.x][1] = (long long)__builtin_amdgcn_s_memrealtime(); g_pp_wg[blockIdx.x][3] = wg_tiles; }
+#endif
 }
 
 template <int TM, bool AKS, bool BKS, int FL = 0, bool KF = false, bool H16 = false, bool LNE = false>

@@ -148,6 +148,11 @@ dephase2)   # slack-aware start offsets (MMAE_PP_DEPHASE = n + 256 * mode, gemm_
     MMAE_PP_DEPHASE=$cfg table encoder_gemms.py "encoder GEMMs, MMAE_PP_DEPHASE=$cfg"
   done
   ;;
+pptrace)   # phase stamps inside the ping-pong GEMM (trace build: make -C multimae_amd/csrc trace)
+  T=$R/multimae_amd/libmmae_hip_trace.so
+  [ -f $T ] || { echo "no trace library: make -C multimae_amd/csrc trace" >> $S; exit 1; }
+  MMAE_LIB=$T timeout 300 python tools/pp_trace.py >> $S 2>&1
+  ;;
 dropout)   # nn.Dropout sites: kernel, modules, the reference-recorded step; stochastic depth beside them
   timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_parity_geometry_gpu.py -x -q -k "dropout or drop_path" 2>&1 | tail -12 >> $S
   ;;
