@@ -252,3 +252,9 @@ extern "C" int mmae_gemm_dw_group(const mmae_dw_group_desc* d, void* stream) {
     mmae_timing_end(t_ev, st, flop, h16 ? 1 : 0);
     return mmae_check_launch("dw_group_reduce");
 }
+
+#ifdef MMAE_PP_TRACE
+// phase stamps of the last launch from THIS translation unit (the generic and the grouped weight-gradient ping-pong kernels): tools/pp_trace.py
+extern "C" int mmae_debug_pp_trace_dw(long long* out_host_256) { return (int)hipMemcpyFromSymbol(out_host_256, HIP_SYMBOL(g_pp_trace), 2 * 128 * 8); }
+extern "C" int mmae_debug_pp_wg_dw(long long* out_host_4096) { return (int)hipMemcpyFromSymbol(out_host_4096, HIP_SYMBOL(g_pp_wg), 1024 * 4 * 8); }
+#endif

@@ -24,11 +24,18 @@ x1 = torch.empty(R, D, device=dev)
 d_h, d_x = g(R, H).to(bf), g(R, D).to(bf)
 dout_d, dout_h = torch.empty(R, D, device=dev, dtype=bf), torch.empty(R, H, device=dev, dtype=bf)
 cs = torch.empty(H, device=dev)
+d_qkv = g(R, 3 * D).to(bf)
+gw = {k: torch.zeros(v.shape, device=dev) for k, v in dict(qkv=wqkv, proj=wproj, fc1=wfc1, fc2=wfc2).items()}
+gb = {k: torch.zeros(v.shape[0], device=dev) for k, v in dict(qkv=wqkv, proj=wproj, fc1=wfc1, fc2=wfc2).items()}
 cases = [('fwd qkv  bias -> bf16', lambda: ops.linear_fwd(x_act, wqkv, bqkv, qkv)),
          ('fwd fc1  bias + GELU + GELU\' -> 2 x bf16', lambda: ops.linear_fwd(x_act, wfc1, bfc1, hout, aux=hpre, epi=EPI_GELU_G)),
          ('fwd fc2  bias + residual -> f32', lambda: ops.linear_fwd(hact, wfc2, bfc2, x1, resid=x_res)),
          ('dx  fc2  x aux + column sums -> bf16', lambda: ops.linear_dx(d_x, wfc2, dout_h, aux=hpre, epi=EPI_MUL, colsum_out=cs)),
-         ('dx  fc1  -> bf16', lambda: ops.linear_dx(d_h, wfc1, dout_d))]
+         ('dx  fc1  -> bf16', lambda: ops.linear_dx(d_h, wfc1, dout_d)),
+         ('dW group {fc2, fc1} (the MLP half of a block backward)', lambda: ops.gemm_dw_group([(d_x, hact, gw['fc2'], gb['fc2']), (d_h, x_act, gw['fc1'], gb['fc1'])], False)),
+         ('dW group {proj, qkv} (the attention half)', lambda: ops.gemm_dw_group([(d_x, ao, gw['proj'], gb['proj']), (d_qkv, x_act, gw['qkv'], gb['qkv'])], False)),
+         ('dW group {fc2, fc1, proj, qkv} in one launch', lambda: ops.gemm_dw_group([(d_x, hact, gw['fc2'], gb['fc2']), (d_h, x_act, gw['fc1'], gb['fc1']),
+                                                                                       (d_x, ao, gw['proj'], gb['proj']), (d_qkv, x_act, gw['qkv'], gb['qkv'])], False))]
 lib = ctypes.CDLL(_lib.LIB_PATH)
 assert hasattr(lib, 'mmae_debug_pp_trace'), 'not a trace build: make -C multimae_amd/csrc trace; MMAE_LIB=.../libmmae_hip_trace.so'
 NAMES = 'ABCDEFGH'
@@ -40,10 +47,11 @@ for name, fn in cases:
     e0.record(); fn(); e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
     buf = (ctypes.c_longlong * 256)()
-    assert lib.mmae_debug_pp_trace(buf) == 0
+    dwk = name.startswith('dW')                          # the grouped weight-gradient kernel lives in the other translation unit
+    assert (lib.mmae_debug_pp_trace_dw if dwk else lib.mmae_debug_pp_trace)(buf) == 0
     print(f'== {name}: {ms * 1e3:.1f} us between events')
     wg = (ctypes.c_longlong * 4096)()
-    assert lib.mmae_debug_pp_wg(wg) == 0
+    assert (lib.mmae_debug_pp_wg_dw if dwk else lib.mmae_debug_pp_wg)(wg) == 0
     rows = [(wg[4 * i], wg[4 * i + 1], wg[4 * i + 2], wg[4 * i + 3]) for i in range(256) if wg[4 * i + 1] > wg[4 * i] > 0]
     if rows:
         t0 = min(r[0] for r in rows)
