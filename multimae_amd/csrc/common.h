@@ -149,7 +149,7 @@ __device__ __forceinline__ float gelu_erf_grad(float x) { float c, e; gelu_cdf_e
 // the bf16 rounding (2^-9 = 2e-3 relative) the results get anyway.  Two variants were measured and dropped this round: selecting
 // step(x) beyond |x| = 4 (four more VALU operations per element: +11 us on fc1's epilogue, 0.2 ms per step), and a fit constrained to
 // hit 0 | 1 exactly at a clamp point of 4.5 (no extra instruction, but degree 8 then leaves 3.0e-4 on GELU' INSIDE the range, where
-// every element lives: the bias-gradient column sums moved by 3e-4).  One v_max per element it is.
+// every element lives: the bias-gradient column sums moved by 3e-4).  One more clamp per element it is (a v_med3 against FLT_MAX, see below).
 // Two elements per instruction (v_pk_fma_f32 / v_pk_mul_f32): 8 + 8 packed FMAs per pair against one v_exp, one v_rcp and ~17 scalar
 // FMA-class operations per ELEMENT of the exact form.  The exact form above stays for every f32 output (the parity mode) and for the
 // fp16-storage adapters (H16 epilogues).
