@@ -152,6 +152,8 @@ pptrace)   # phase stamps inside the ping-pong GEMM (trace build: make -C multim
   T=$R/multimae_amd/libmmae_hip_trace.so
   [ -f $T ] || { echo "no trace library: make -C multimae_amd/csrc trace" >> $S; exit 1; }
   MMAE_LIB=$T timeout 300 python tools/pp_trace.py >> $S 2>&1
+  echo "#### the D = 256 block of an output adapter (50 176 rows)" >> $S
+  MMAE_LIB=$T timeout 300 python tools/pp_trace.py --decoder >> $S 2>&1
   ;;
 dropout)   # nn.Dropout sites: kernel, modules, the reference-recorded step; stochastic depth beside them
   timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_parity_geometry_gpu.py -x -q -k "dropout or drop_path" 2>&1 | tail -12 >> $S
