@@ -155,6 +155,14 @@ pptrace)   # phase stamps inside the ping-pong GEMM (trace build: make -C multim
   echo "#### the D = 256 block of an output adapter (50 176 rows)" >> $S
   MMAE_LIB=$T timeout 300 python tools/pp_trace.py --decoder >> $S 2>&1
   ;;
+launch)   # the driver's launch forms on the one GPU a lease has: torchrun at world size 1, and two ranks sharing the device over gloo
+  echo "== torchrun, world size 1 (the driver's N > 1 command line with N = 1)" >> $S
+  ( timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > gpurun_out/launch1.log 2> gpurun_out/launch1.err ); echo "rc=$?" >> $S
+  grep "timed region" gpurun_out/launch1.err | cut -c1-160 >> $S; grep "^{" gpurun_out/launch1.log | cut -c1-300 >> $S; grep -i "error\|Traceback" gpurun_out/launch1.err | tail -3 >> $S
+  echo "== two ranks on one device, gloo buckets (functional test of the N > 1 path with the real kernels)" >> $S
+  ( timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --share-device 1 --batch 64 > gpurun_out/launch2.log 2> gpurun_out/launch2.err ); echo "rc=$?" >> $S
+  grep "timed region" gpurun_out/launch2.err | cut -c1-160 >> $S; grep "^{" gpurun_out/launch2.log | cut -c1-700 >> $S; grep -i "error\|Traceback" gpurun_out/launch2.err | tail -3 >> $S
+  ;;
 dropout)   # nn.Dropout sites: kernel, modules, the reference-recorded step; stochastic depth beside them
   timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_parity_geometry_gpu.py -x -q -k "dropout or drop_path" 2>&1 | tail -12 >> $S
   ;;
