@@ -472,6 +472,19 @@ def claim_first_write(params: Iterable[Optional[torch.Tensor]]) -> bool:
     return fresh
 
 
+def mark_written(p: Optional[torch.Tensor]) -> None:
+    """A per-kernel gradient writer (functions.GradSink: the dropout / drop-path fall-back paths, ``MlpFn``, ``block_bwd`` off the
+    composite path) is about to ACCUMULATE into this parameter's arena-bound gradient: record it, so that a composite backward that
+    touches the same parameter later in the same ``zero_grad()`` epoch accumulates too instead of storing over the contribution
+    (``claim_first_write`` only saw marks that composites had set)."""
+    if p is None:
+        return
+    ref = getattr(p, '_mmae_arena_ref', None)
+    a = ref() if ref is not None else None
+    if a is not None:
+        p._mmae_written = a.zero_epoch
+
+
 def set_first_write_stores(flag: bool) -> None:
     _state['first_write_stores'] = bool(flag)
 

@@ -47,6 +47,7 @@ class GradSink:
     def _target(self, p: Tensor):
         g = _bound_grad(p) if self.direct else None
         if g is not None:
+            engine.mark_written(p)              # a later composite backward of this zero_grad() epoch must accumulate, not store
             return g, True
         return torch.empty(p.shape, device=p.device, dtype=torch.float32), False
 
@@ -109,6 +110,7 @@ class GradSink:
                 continue
             if self.direct and _bound_grad(p) is not None:
                 flat, acc = p.grad.view(-1), True
+                engine.mark_written(p)
             else:
                 acc = False
                 flat = fresh.get(id(p))
@@ -146,6 +148,7 @@ class GradSink:
         if not p.requires_grad:
             return None
         if self.direct and _bound_grad(p) is not None:
+            engine.mark_written(p)
             g = g.contiguous()
             if self.side is not None:       # same stream as the GEMM accumulations into the arena (no cross-stream races on .grad)
                 self._on_side(lambda: ops.axpy_(p.grad, g, 1.0), g)
@@ -292,6 +295,10 @@ def _block_bwd_composite(dx, dx_act, fc2b_done, saved, P, wc, sink: GradSink, he
     (ADVICE r3)."""
     n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b = P
     dsts, acc = _grad_targets(sink, list(P) + [cs_param])
+    if acc:                                             # accumulating straight into the arena: later composites of this epoch must accumulate too
+        for p in list(P) + [cs_param]:
+            if p is not None and p.requires_grad:
+                engine.mark_written(p)
     use_side = sink.side is not None and acc
     dx0, dx0_act, keep = ops.block_bwd_composite(dx, dx_act, fc2b_done, saved, P, (wc(qkvw), wc(projw), wc(fc1w), wc(fc2w)), dsts[:12],
                                                  dsts[12], acc, heads, act, B, N, sink.side.cuda_stream if use_side else None)
