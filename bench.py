@@ -75,7 +75,7 @@ def pmc_traffic(dom):
     roofline.traffic_source), or None if no PMC pass is committed."""
     if dom != torch.bfloat16:
         return None, None
-    for name in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r06_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         f = os.path.join(ROOT, 'profiles', name)
         try:
             return json.load(open(f)).get('gemm_bf16_traffic_per_launch'), f'recorded, not of this run: profiles/{name} (rocprofv3 --pmc FETCH_SIZE x 2 and WRITE_SIZE passes of this command on the build that file names, tools/gpu_r5.sh final; counters cannot be read in-process, and a --pmc pass may not be combined with the timed run)'
@@ -200,6 +200,21 @@ def _oracle_step_fn(cfg: str, B: int):
     return step
 
 
+def port_vs_reference(kind: str) -> dict:
+    """How far the oracle port is from the reference's own classes, measured where both can run (the build container, equal threads:
+    tools/cpu_port_vs_reference.py -> profiles/r06_cpu_port_vs_reference.json) -- so a "port" baseline on the GPU box can be read as
+    a "reference" one."""
+    try:
+        r = json.load(open(os.path.join(ROOT, 'profiles', 'r06_cpu_port_vs_reference.json')))
+        ratio = r['port_over_reference_time']
+    except (OSError, ValueError, KeyError):
+        return {}
+    out = {'port_over_reference_time': ratio,
+           'port_over_reference_source': f"recorded in the build container (profiles/r06_cpu_port_vs_reference.json: cfg3 step, B = {r['B']}, {r['threads']} threads of a {r['cpu']}, "
+                                         f"reference {r['reference']['median_s_per_step']} s/step, port {r['port']['median_s_per_step']} s/step)"}
+    return out
+
+
 def cpu_baseline(cfg: str, sample_B: int, steps: int, threads: int = 0):
     """BASELINE.md section 3 protocol: the same step (fwd -> 4 losses -> backward -> AdamW) in fp32 on the host cores, B = 16,
     1 warm-up + `steps` timed steps, median; the thread count is the best of a quick 8/16/32/64 sweep (1 + 1 steps each).
@@ -253,11 +268,52 @@ def cpu_baseline(cfg: str, sample_B: int, steps: int, threads: int = 0):
     return {'value': round(best['img_s'], 3), 'unit': 'images/s', 'cores': best['cores'], 'kind': kind, 'cpu': cpu_model_name(),
             'cores_available': avail, 'thread_sweep_img_s': {str(c): round(sample_B / t, 2) for c, t in sweep.items()},
             'batch_sweep_img_s': batch_sweep,
+            **port_vs_reference(kind),
             'sample': f'BASELINE.md section 3 protocol: the same {cfg} step (fwd, 4 losses, backward, AdamW) in fp32, '
                       + ('the reference classes (/root/reference, Appendix B import)' if kind == 'reference'
                          else 'oracle/multimae_oracle.py + torch autograd (the reference checkout does not exist on this box; ~15 % slower than the reference classes on equal cores, DESIGN section 8)')
                       + f'; threads = best of the 8/16/32/64 sweep at B={sample_B} (median of {steps} timed steps after 1 warm-up), then B={big_B} at that count '
                         f'(1 timed step after 1 warm-up); value = the best img/s seen: B={best["B"]}, {best["cores"]} threads'}
+
+
+def encoder_step(B: int, N: int, D: int = 768, L: int = 12, heads: int = 12, iters: int = 6) -> dict:
+    """Forward + backward of the L-block encoder stack alone on (B, N, D) tokens, weight gradients on the side stream, HIP-event timed
+    (tools/encoder_step.py inside the bench): 51.53 GFLOP of GEMM work per image."""
+    import multimae_amd as M
+    from functools import partial
+    from torch import nn
+    from multimae_amd.multimae_utils import Block, run_blocks
+    torch.manual_seed(0)
+    enc = nn.Sequential(*[Block(D, heads, mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6)) for _ in range(L)]).cuda()
+    arena = M.engine.ParamArena(enc)
+    dg, ws = M.engine.direct_grads(), M.engine.wgrad_stream()
+    M.engine.set_direct_grads(True)
+    M.engine.set_wgrad_stream(True)
+    try:
+        x = torch.randn(B, N, D, device='cuda', requires_grad=True)
+        g = torch.randn(B, N, D, device='cuda')
+
+        def step():
+            arena.zero_grad()
+            run_blocks(enc, x, root=enc).backward(g)
+            M.engine.join_wgrad_streams()
+        for _ in range(3):
+            step()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+    finally:
+        M.engine.set_direct_grads(dg)
+        M.engine.set_wgrad_stream(ws)
+    tflop = 51.53e9 * B / 1e12
+    log(f'encoder step: {ms:.2f} ms = {tflop / ms * 1e3:.0f} TF/s')
+    return {'encoder_step_ms': round(ms, 3), 'encoder_step_tflops': round(tflop / ms * 1e3, 1), 'encoder_step_frac': round(tflop / ms * 1e3 / PEAK_BF16_TFLOPS, 4),
+            'encoder_step_what': f'forward + backward of the {L}-block ViT-B encoder stack alone on ({B}, {N}, {D}) tokens: the step the north star quotes its >= 50 % on'}
 
 
 def result_line(args, B, world, ms_per_step, img_s, final_loss, counters, roof, cpu, dp_diag, host_ms, host_wait_ms, use_graph, n_vis, doms):
@@ -269,7 +325,11 @@ def result_line(args, B, world, ms_per_step, img_s, final_loss, counters, roof, 
                    'cfg5': 'pre-train images/sec (whole node), ViT-L RGB+D+S 224^2 196-vis-tok'}[args.config],
         'value': round(img_s, 1), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': {'bf16': 'bf16', 'fp32': 'f32', 'mxfp8': 'mxfp8 (e4m3 + E8M0/32) encoder forward, dX and weight-gradient products, bf16 everywhere else'}[args.precision], 'data': 'synthetic',
+        'dtype': ({'bf16': 'bf16', 'fp32': 'f32', 'mxfp8': 'mxfp8 (e4m3 + E8M0/32) encoder forward, dX and weight-gradient products, bf16 everywhere else'}[args.precision]
+                  # the storage form of the reference's fp32_output_adapters is part of the precision statement
+                  + ((' (fp32_output_adapters: ' + {'h16': 'fp16 storage', 'f16': 'f32 tensors, fp16 operands', 'x3': 'f32 tensors, split-bf16 x3 operands',
+                                                     'exact': 'f32'}[getattr(args, 'fp32_adapter_gemm', 'h16')] + ')')
+                     if ('semseg' in doms and args.precision != 'fp32') else '')), 'data': 'synthetic',
         'config': {'workload': f'BASELINE.json configs[{ {"cfg3": 2, "cfg2": 1, "cfg5": 4}[args.config] }]: '
                                + (('ViT-L (MX-fp8 encoder products), ' if args.precision == 'mxfp8' else 'ViT-L (bf16 run of the fp8 config), ') if args.config == 'cfg5' else 'ViT-B, ')
                                + ('RGB-only' if args.config == 'cfg2' else 'RGB+depth+semseg')
@@ -283,6 +343,7 @@ def result_line(args, B, world, ms_per_step, img_s, final_loss, counters, roof, 
     }
     if dp_diag is not None:
         out['data_parallel'] = dp_diag
+        out['rccl_ranks_seen'] = dp_diag.get('rccl_ranks_seen')      # top level: how many ranks the collective backend really connected
     return out
 
 
@@ -325,6 +386,8 @@ def main():
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for --gpus > 1 ('nccl' = RCCL; 'gloo' for functional tests)")
     ap.add_argument('--force-dist', type=int, default=0, help='1: run the data-parallel path (process group, bucketed all-reduce overlapped with backward, chunked encoder backward) even at world size 1 -- the one-rank all-reduces ARE issued (RCCL copy path), so the launch-stream / event ordering of the reducer runs on a single GPU')
     ap.add_argument('--bucket-mb', type=float, default=64.0, help='gradient all-reduce bucket size (MiB of fp32 gradients)')
+    ap.add_argument('--dp-exchange', default='all_reduce', choices=['all_reduce', 'rs_ag'],
+                    help="N > 1: how a gradient bucket is summed -- one RCCL all_reduce (ring on xGMI) or reduce_scatter + all_gather (the direct form of SURVEY 8e); multimae_amd/dist.py")
     ap.add_argument('--bf16-buckets', type=int, default=0, help='1: gradient buckets travel as bf16 (half the xGMI bytes, bf16-rounded sum; multimae_amd/dist.py)')
     ap.add_argument('--share-device', type=int, default=0, help='1: every rank uses cuda:0 (functional test of the multi-process path on one GPU; use with --backend gloo)')
     ap.add_argument('--graph', type=int, default=-1, help='1: capture the step once as a hipGraph and replay it (multimae_amd.graph.StepGraph; 1 GPU only). Default 0: on ROCm 7.2 the replay of this ~1 100-node, 10-stream graph measured 46.2 ms/step against 44.1 ms eager')
@@ -430,7 +493,7 @@ def run_once(args):
     reducer = None
     if use_dist:
         broadcast_parameters(arena)
-        reducer = GradAllReducer.for_arena(arena, bucket_mb=args.bucket_mb, bf16_buckets=bool(args.bf16_buckets), force_collective=bool(args.force_dist))
+        reducer = GradAllReducer.for_arena(arena, bucket_mb=args.bucket_mb, bf16_buckets=bool(args.bf16_buckets), force_collective=bool(args.force_dist), exchange=args.dp_exchange)
     M.engine.set_precision(args.precision)
     M.engine.set_fp32_adapter_gemm(args.fp32_adapter_gemm)
     M.engine.set_adapter_cu_share(args.adapter_cu_share)
@@ -557,7 +620,7 @@ def run_once(args):
         dp_diag = {'exposed_allreduce_ms_per_step': round(reducer.exposed_wait_ms() / args.steps, 3), 'bucket_mb': args.bucket_mb,
                    'buckets': len(reducer.buckets), 'bucket_dtype': 'bf16' if args.bf16_buckets else 'f32',
                    'allreduce_mb_per_step': round(sum(e - s for s, e, _ in reducer.buckets) * (2 if args.bf16_buckets else 4) / 2 ** 20, 1),
-                   'rccl_ranks_seen': int(seen.item()), 'backend': args.backend, 'encoder_bwd_chunk_layers': int(getattr(model, '_bwd_chunk_layers', 0)),
+                   'rccl_ranks_seen': int(seen.item()), 'backend': args.backend, 'exchange': args.dp_exchange, 'encoder_bwd_chunk_layers': int(getattr(model, '_bwd_chunk_layers', 0)),
                    'gemm_cu_reserved': cu_reserve, 'per_bucket': bt['buckets'],
                    'backward_ms_on_reduced_width_grids': bt['backward_ms_on_reduced_width_grids'],
                    'reading': 'a bucket whose launch_to_done_ms approaches the reduced-width stretch is what finish() waits for; exposed_allreduce_ms_per_step '
@@ -598,6 +661,8 @@ def run_once(args):
         torch.cuda.synchronize()
         ms2, fl2, n2 = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 3)()
         lib.mmae_gemm_timing_read(ms2, fl2, n2)
+        by2 = (ctypes.c_double * 3)()
+        lib.mmae_gemm_timing_read_bytes(by2)
         lib.mmae_gemm_timing_enable(0)
         M.engine.set_adapter_streams(bool(args.adapter_streams))
         M.engine.set_wgrad_stream(bool(args.wgrad_stream))
@@ -611,6 +676,10 @@ def run_once(args):
         traffic, traffic_src = pmc_traffic(dom) if args.config == 'cfg3' else (None, 'no PMC pass of this configuration is committed (the recorded one is cfg3)')
         roof = {'bound': 'mfma', 'kernel': 'gemm_bf16_pp_kernel (+ its grouped weight-gradient form gemm_bf16_pp_dwgroup_kernel) / gemm_bf16_kernel: all bf16 MFMA GEMM calls of one production step, each bracketed by HIP events on its launch stream inside the library, single-stream' if dom == torch.bfloat16 else 'gemm_f32_kernel',
                 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+                # what `traffic` is read against: operands once, C and every epilogue stream once, per launch, summed by the
+                # library over the SAME launches `achieved` is taken over (mmae_gemm_timing_read_bytes) -- of THIS run, unlike the recorded counters
+                'algorithmic_bytes_per_launch': int(by2[0 if dom == torch.bfloat16 else 1] / max(cnt[dom], 1)),
+                'traffic_over_algorithmic': (round(traffic / (by2[0] / max(cnt[dom], 1)), 3) if (traffic and dom == torch.bfloat16 and by2[0] > 0) else None),
                 'launches_per_step': cnt[dom], 'gemm_ms_per_step': round(tot_ms[dom], 3),
                 'gemm_gflop_per_step': round(tot_fl[dom] / 1e9, 1),
                 'f32_adapter_gemm_ms_per_step': round(tot_ms[torch.float32], 3) if dom == torch.bfloat16 else None,
@@ -625,6 +694,12 @@ def run_once(args):
                     'traffic': None, 'traffic_source': 'PMC passes of this mode: profiles/r02_mxfp8_pmc_traffic.json (per kernel; not averaged into one figure)',
                     'launches_per_step': int(n2[2]), 'gemm_ms_per_step': round(ms2[2], 3), 'gemm_gflop_per_step': round(fl2[2] / 1e9, 1),
                     'bf16_products': roof}
+    if roof is not None and args.config in ('cfg3', 'cfg2') and args.precision == 'bf16' and world == 1 and not dry:
+        # the number the north star is quoted on: the ViT-B ENCODER step (12 blocks, forward + backward, B x 99 tokens) against the 2.5 PF peak
+        try:
+            roof.update(encoder_step(B, 98 + 1))
+        except Exception as e:                   # noqa: BLE001 -- never lose the line over the beside-measurement
+            roof['encoder_step_error'] = repr(e)[:200]
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config != 'cfg5':      # the CPU leg is sized for the ViT-B configs
         M.engine.set_direct_grads(False)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMAE_ABI_VERSION 6
+#define MMAE_ABI_VERSION 7
 
 #define MMAE_F32  0
 #define MMAE_BF16 1
@@ -254,6 +254,10 @@ int mmae_probe_mx_mfma(const int32_t* a_64x8, const int32_t* b_64x8, const int32
  * ------------------------------------------------------------------------- */
 int mmae_gemm_timing_enable(int on);
 int mmae_gemm_timing_read(double* ms3, double* flop3, int64_t* calls3);
+/* ... and the ALGORITHMIC HBM bytes of the same launches per class (operands once, C and every epilogue stream -- aux, residual, LayerNorm
+ * side output -- once; a grouped weight gradient: dY and X once, dW once, not its partial slabs): what bench.py prints beside the counter
+ * traffic (roofline.algorithmic_bytes_per_launch).  ABI v7. */
+int mmae_gemm_timing_read_bytes(double* bytes3);
 
 /* ------------------------------------------------------------------------- *
  * Grouped weight gradients: up to 8 products dw_i[n_out_i][k_in_i] (+)= dy_i[rows][n_out_i]^T . x_i[rows][k_in_i] (the dW of

@@ -176,7 +176,7 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = ret
         fn.argtypes = argtypes
-    if lib.mmae_abi_version() != 6:
+    if lib.mmae_abi_version() != 7:
         raise RuntimeError('libmmae_hip.so ABI version mismatch')
     for which, cls in enumerate((GemmDesc, BlockDesc, StackDesc, AdapterDesc, OptDesc, PatchSrc, DwGroupDesc, ColsumJob)):
         if lib.mmae_struct_size(which) != ctypes.sizeof(cls):

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_dwgroup_kernel(const DwGroup
 
 int mmae_gemm_bf16_pp_fl_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, int fl, hipStream_t st);
 hipEvent_t mmae_timing_begin(hipStream_t st);
-void mmae_timing_end(hipEvent_t a, hipStream_t st, double flop, int cls);
+void mmae_timing_end(hipEvent_t a, hipStream_t st, double flop, int cls, double bytes);
 
 // tile codes: 9 = 256 x 256 (TM = 4), 10 = 320 x 256 (TM = 5; k-contiguous A only)
 int mmae_gemm_bf16_pp_impl(const mmae_gemm_desc* d, const GemmArgs& g, int code, hipStream_t st) {
@@ -235,8 +235,11 @@ extern "C" int mmae_gemm_dw_group(const mmae_dw_group_desc* d, void* stream) {
 #else
     static const int env_kf = mmae_env_int("MMAE_PP_KF", 1);
 #endif
-    double flop = 0.0;
-    for (int i = 0; i < d->n; ++i) flop += 2.0 * d->rows * d->p[i].n_out * d->p[i].k_in;
+    double flop = 0.0, abytes = 0.0;             // algorithmic bytes: dY and X once (16-bit), dW once (f32; read too when accumulating) -- not the partial slabs
+    for (int i = 0; i < d->n; ++i) {
+        flop += 2.0 * d->rows * d->p[i].n_out * d->p[i].k_in;
+        abytes += 2.0 * d->rows * ((double)d->p[i].n_out + d->p[i].k_in) + (d->accumulate ? 8.0 : 4.0) * d->p[i].n_out * d->p[i].k_in;
+    }
     hipEvent_t t_ev = mmae_timing_begin(st);
     static const int env_wide = mmae_env_int("MMAE_DW_WIDE", 0);      // one phase pair per K tile: measured neutral (421 vs 411-436 us per block), off
     if (h16) {
@@ -247,9 +250,9 @@ extern "C" int mmae_gemm_dw_group(const mmae_dw_group_desc* d, void* stream) {
     else if (env_kf && (d->rows & 31) == 0) hipLaunchKernelGGL(gemm_bf16_pp_dwgroup_kernel<true>, dim3(tb, 1, s), dim3(512), lds, st, ga);
     else hipLaunchKernelGGL(gemm_bf16_pp_dwgroup_kernel<false>, dim3(tb, 1, s), dim3(512), lds, st, ga);
     int rc = mmae_check_launch("gemm_bf16_pp_dwgroup");
-    if (rc) { mmae_timing_end(t_ev, st, flop, h16 ? 1 : 0); return rc; }
+    if (rc) { mmae_timing_end(t_ev, st, flop, h16 ? 1 : 0, abytes); return rc; }
     hipLaunchKernelGGL(dw_group_reduce_kernel, dim3((unsigned)(rblk < 1 ? 1 : rblk)), dim3(256), 0, st, ra);
-    mmae_timing_end(t_ev, st, flop, h16 ? 1 : 0);
+    mmae_timing_end(t_ev, st, flop, h16 ? 1 : 0, abytes);
     return mmae_check_launch("dw_group_reduce");
 }
 

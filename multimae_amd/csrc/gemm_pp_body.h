@@ -63,6 +63,7 @@ template <> __device__ __forceinline__ void wait_vm<0>() { asm volatile("s_waitc
 template <> __device__ __forceinline__ void wait_vm<5>() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vm<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vm<7>() { asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vm<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 
 template <int N> __device__ __forceinline__ void duo_like_wait() {
     static_assert(N >= 3 && N <= 5, "add the immediate");
@@ -136,6 +137,15 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
     constexpr int NST = 4;
     constexpr int DUMP = NST * STAGE;                    // 1 KiB that swallows the padding pieces
     constexpr int W = LA + LB + 2;                       // pieces issued after tile t at the point tile t must have landed
+    // TAILD (round 6; flavoured kernels on K % 32 == 0): what the tile boundary no longer waits for.  A wave's vector-memory operations
+    // retire IN ORDER on gfx950 -- loads, LDS-DMA pieces and stores share one in-order vmcnt (hipcc itself waits vmcnt(N) across mixed loads
+    // and stores: tools/vmcnt_order.hip) -- so (a) the zero-fill pieces of the prefetch overrun past the K slice target the 1-KiB dump
+    // instead of ring slots: nothing in flight at the end of the loop can land on the epilogue's staging, and the full drain in front of
+    // it becomes a bare barrier; (b) behind the last store call a wave waits only until its EIGHT youngest operations are outstanding
+    // (everything older -- the next tile's first two K tiles, issued before the stores -- has then landed) instead of for every store
+    // acknowledgement: the tail of the store stream retires under the next tile's first K tiles, and the loop's counted waits, which now
+    // also cover those stores, stay exact because nothing can overtake them.
+    constexpr bool TAILD = KF && FL != 0;
     static_assert(!AKS || TM == 4, "k-strided A needs a 256-column tile image");
     static_assert(LB == 2 && LA >= 2 && LA <= 3, "piece schedule below assumes 2 + (2|3) pieces per wave and tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -216,6 +226,7 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
         char* dst = (i * NW + wave < PA) ? smem + slot * STAGE + (i * NW + wave) * 1024 : smem + DUMP;
         if (KF) {                                        // pieces are issued once per K tile, in tile order: a running offset suffices
             const unsigned tail = kt < kt_end ? 0u : OOB;                    // wave-uniform
+            if (TAILD && kt >= kt_end) dst = smem + DUMP;                    // the zero-fill overrun never touches a ring slot (see TAILD)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)dst, 16, (int)(a_cur[i] | tail), 0, 0, 0);
             a_cur[i] += a_step;
             return;
@@ -228,6 +239,7 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
         char* dst = smem + slot * STAGE + A_BYTES + (i * NW + wave) * 1024;
         if (KF) {
             const unsigned tail = kt < kt_end ? 0u : OOB;
+            if (TAILD && kt >= kt_end) dst = smem + DUMP;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)dst, 16, (int)(b_cur[i] | tail), 0, 0, 0);
             b_cur[i] += b_step;
             return;
@@ -527,8 +539,13 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
             }
         }
         PP_STAMP();                                          // B
-        wait_vm<0>();                                        // the zero-fill tail pieces must not land on live data
-        __syncthreads();                                     // every wave is out of the ring
+        if constexpr (TAILD) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wg_barrier();                                    // every wave is out of the ring; the overrun pieces still in flight target the dump
+        } else {
+            wait_vm<0>();                                    // the zero-fill tail pieces must not land on live data
+            __syncthreads();                                 // every wave is out of the ring
+        }
         PP_STAMP();                                          // C
 
         if constexpr (H16) {                                 // a gradient leaving the fp16-storage domain (f32 C): 1/S, mmae.h MMAE_F16
@@ -642,11 +659,17 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
         }
         PP_STAMP();                                          // G
         if (has_next) {
-            // loads and stores share vmcnt and may retire out of order with respect to each other: drain everything (the
-            // prefetched K tiles landed long ago; this waits for the last store acknowledgements only), then hand ring
-            // slots 2-3 back to the DMA ring
-            wait_vm<0>();
-            __syncthreads();
+            if constexpr (TAILD) {
+                // in-order vmcnt: at most the eight youngest operations (stores of the last call) stay outstanding -- the next tile's K tiles
+                // 0 and 1 were issued before every store of this epilogue (>= 16 per wave in every compiled flavour) and have landed
+                wait_vm<8>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wg_barrier();                                // every wave is out of the staging: slots 2-3 go back to the DMA ring
+            } else {
+                // generic flavours (masked stores may be skipped: no lower bound on the operations behind the prefetch): drain
+                wait_vm<0>();
+                __syncthreads();
+            }
             if (!WIDE) dma_first(2, 2);
         }
         PP_STAMP();                                          // H

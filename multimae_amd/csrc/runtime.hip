@@ -79,7 +79,7 @@ int mmae_acs_reduce(const float* part, int splits, int M, float* out, int accumu
 #include <mutex>
 #include <vector>
 namespace {
-struct TimedLaunch { hipEvent_t a, b; double flop; int cls; };
+struct TimedLaunch { hipEvent_t a, b; double flop; int cls; double bytes; };
 std::mutex g_tmu;
 bool g_timing = false;
 std::vector<TimedLaunch> g_timed;
@@ -92,13 +92,14 @@ hipEvent_t mmae_timing_begin(hipStream_t st) {
     (void)hipEventRecord(e, st);
     return e;
 }
-void mmae_timing_end(hipEvent_t a, hipStream_t st, double flop, int cls) {
+// bytes: the launch's ALGORITHMIC HBM bytes (operands once, outputs / epilogue streams once) -- the figure the counter traffic is read against
+void mmae_timing_end(hipEvent_t a, hipStream_t st, double flop, int cls, double bytes) {
     if (!a) return;
     hipEvent_t b = nullptr;
     if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return; }
     (void)hipEventRecord(b, st);
     std::lock_guard<std::mutex> lk(g_tmu);
-    g_timed.push_back({a, b, flop, cls});
+    g_timed.push_back({a, b, flop, cls, bytes});
 }
 
 namespace {
@@ -187,6 +188,19 @@ int mmae_gemm(const mmae_gemm_desc* d, void* stream) { return mmae_gemm_ex(d, st
 
 }  // extern "C"
 
+// operands once, C once, every epilogue stream once (aux written or read, residual read, LayerNorm side output written)
+static double gemm_algorithmic_bytes(const mmae_gemm_desc* d) {
+    const double eab = (d->ab_dtype == MMAE_F32 || d->ab_dtype == MMAE_F32X3 || d->ab_dtype == MMAE_F32F16) ? 4.0 : (d->ab_dtype == MMAE_MXFP8 ? 1.0 : 2.0);
+    const double ec = d->c_dtype == MMAE_F32 ? 4.0 : 2.0;
+    const double mn = (double)d->M * d->N * d->batch;
+    double b = ((double)d->M * d->K + (double)d->N * d->K) * d->batch * eab + mn * ec;
+    if (d->accumulate) b += mn * ec;
+    if (d->aux && d->epi != MMAE_EPI_NONE) b += mn * (d->aux_dtype == MMAE_F32 ? 4.0 : 2.0);
+    if (d->resid) b += mn * 4.0;
+    if (d->ln_out) b += mn * 2.0;
+    return b;
+}
+
 // timing_cls >= 0 / flop_scale: how the launch is booked by mmae_gemm_timing_* (a pre-split x3 product is one bf16 launch over 3 K
 // that belongs to the f32 / split class with a third of its MFMA work as algorithmic FLOPs)
 int mmae_gemm_ex(const mmae_gemm_desc* d, void* stream, int timing_cls, double flop_scale) {
@@ -257,10 +271,11 @@ int mmae_gemm_ex(const mmae_gemm_desc* d, void* stream, int timing_cls, double f
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t t_ev = mmae_timing_begin(st);
     struct TimingGuard {            // the bracket closes on every return path
-        hipEvent_t a; hipStream_t st; double flop; int cls;
-        ~TimingGuard() { mmae_timing_end(a, st, flop, cls); }
+        hipEvent_t a; hipStream_t st; double flop; int cls; double bytes;
+        ~TimingGuard() { mmae_timing_end(a, st, flop, cls, bytes); }
     } t_guard{t_ev, st, 2.0 * d->M * d->N * d->K * d->batch * flop_scale,
-              timing_cls >= 0 ? timing_cls : (d->ab_dtype == MMAE_BF16 ? 0 : (d->ab_dtype == MMAE_MXFP8 ? 2 : 1))};      // (MMAE_F16: the fp32 adapters' class)
+              timing_cls >= 0 ? timing_cls : (d->ab_dtype == MMAE_BF16 ? 0 : (d->ab_dtype == MMAE_MXFP8 ? 2 : 1)),      // (MMAE_F16: the fp32 adapters' class)
+              gemm_algorithmic_bytes(d)};
     // split-K: the dW-type products (small M x N, K = all rows of the batch) would otherwise occupy
     // a handful of the 256 CUs.  Each K slice writes a dense f32 partial slab into the caller's
     // workspace; a second launch sums the slabs into C in a fixed order (deterministic).
@@ -317,6 +332,14 @@ int mmae_gemm_timing_enable(int on) {
     for (auto& t : g_timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     g_timed.clear();
     g_timing = on != 0;
+    return 0;
+}
+
+int mmae_gemm_timing_read_bytes(double* bytes3) {
+    MMAE_REQUIRE(bytes3, "gemm_timing_read_bytes: null pointer");
+    std::lock_guard<std::mutex> lk(g_tmu);
+    for (int c = 0; c < 3; ++c) bytes3[c] = 0.0;
+    for (auto& t : g_timed) bytes3[t.cls] += t.bytes;
     return 0;
 }
 

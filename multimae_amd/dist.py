@@ -56,8 +56,17 @@ class GradAllReducer:
 
     def __init__(self, grad: torch.Tensor, sizes: List[Tuple[str, int, int]], bucket_mb: float = 64.0,
                  group: Optional[dist.ProcessGroup] = None, cut_before: Iterable[str] = (), average_in_place: bool = False,
-                 bf16_buckets: bool = False, force_collective: bool = False):
+                 bf16_buckets: bool = False, force_collective: bool = False, exchange: str = 'all_reduce'):
         self.grad = grad
+        # exchange: how a bucket is summed across the ranks.  'all_reduce' -- one RCCL all_reduce(SUM) (RCCL picks the algorithm: a ring
+        # on a fully connected xGMI node).  'rs_ag' -- the direct form SURVEY 8(e) prefers for point-to-point xGMI: reduce_scatter (every
+        # rank sums its 1/world shard, each peer's contribution arriving over its own link) followed by all_gather of the summed shards --
+        # the same bytes as a ring all-reduce, as TWO collectives whose algorithm is fixed by construction; selectable so that the first
+        # 8-GPU run can A/B ring against direct (bench.py --dp-exchange).  Results agree up to the order of the sum.
+        if exchange not in ('all_reduce', 'rs_ag'):
+            raise ValueError(f"GradAllReducer: exchange must be 'all_reduce' or 'rs_ag', got {exchange!r}")
+        self.exchange = exchange
+        self._shard_tmp: Dict[int, torch.Tensor] = {}
         self.bucket_mb = bucket_mb
         # bf16_buckets: every bucket travels as bf16 (cast -> all-reduce -> widen back into the fp32 arena): half the bytes on
         # the xGMI links (196 instead of 392 MB for ViT-B) for a bf16-rounded SUM -- the trade torch DDP's bf16_compress_hook
@@ -80,6 +89,7 @@ class GradAllReducer:
         self._bucket_events: List[tuple] = []           # (bucket, issue event, done event) on the launch stream
         self._reserve_events: List[tuple] = []          # (first bucket launch, finish()) on the compute stream
         self._reserve_ev0 = None
+        self._bucket_events_committed = 0
         self._bf16_tmp: Dict[int, torch.Tensor] = {}
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -122,6 +132,10 @@ class GradAllReducer:
             from . import ops
             ops.gemm_cu_reserve(0)
             self._reserved = False
+        # an aborted step's half-open timing bracket and the bucket events it recorded: finish() has consumed / committed
+        # its own before it calls reset(), so whatever is left beyond the committed mark belongs to a step that never finished
+        self._reserve_ev0 = None
+        del self._bucket_events[getattr(self, '_bucket_events_committed', 0):]
         self._remaining = [len(names) for _, _, names in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._events = [[] for _ in self.buckets]
@@ -157,13 +171,23 @@ class GradAllReducer:
                 self._reserve_ev0.record()               # on the compute stream: backward from here runs n_cu - k wide
 
         def exchange():
-            if not self.bf16_buckets:
-                return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            tmp = self._bf16_tmp.get(i)
-            if tmp is None:
-                tmp = self._bf16_tmp[i] = torch.empty(e - s, device=self.grad.device, dtype=torch.bfloat16)
-            tmp.copy_(view)
-            return dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            buf = view
+            if self.bf16_buckets:
+                buf = self._bf16_tmp.get(i)
+                if buf is None:
+                    buf = self._bf16_tmp[i] = torch.empty(e - s, device=self.grad.device, dtype=torch.bfloat16)
+                buf.copy_(view)
+            n = e - s
+            if self.exchange == 'rs_ag' and self.world > 1 and n % self.world == 0:
+                # reduce_scatter into a shard buffer of its own (no aliasing of the collective's input), then all_gather of the
+                # summed shards back over the whole bucket.  h.wait() orders the launching stream (the dedicated launch stream on a
+                # GPU; the host on gloo) behind the first collective, never the compute streams.
+                shard = self._shard_tmp.get(i)
+                if shard is None or shard.dtype != buf.dtype:
+                    shard = self._shard_tmp[i] = torch.empty(n // self.world, device=buf.device, dtype=buf.dtype)
+                dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
+                return dist.all_gather_into_tensor(buf, shard, group=self.group, async_op=True)
+            return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
         if self.grad.is_cuda:
             if self._launch_stream is None:
@@ -239,6 +263,7 @@ class GradAllReducer:
             ev1 = torch.cuda.Event(enable_timing=True)
             ev1.record()
             self._wait_events.append((ev0, ev1))
+        self._bucket_events_committed = len(self._bucket_events)
         self.reset()                                     # also lifts the CU reserve: the optimiser step and the next forward get the whole chip
 
     def exposed_wait_ms(self) -> float:
@@ -262,6 +287,7 @@ class GradAllReducer:
             b.synchronize()
             per.setdefault(i, []).append(a.elapsed_time(b))
         self._bucket_events = []
+        self._bucket_events_committed = 0
         res = []
         for a, b in self._reserve_events:
             b.synchronize()

@@ -23,7 +23,7 @@ class FakeLib:
                     ok = isinstance(a, int)
                 assert ok, (name, i, type(a), t)
             if name == 'mmae_abi_version':
-                return 6
+                return 7
             if name == 'mmae_struct_size':
                 return ctypes.sizeof((_lib.GemmDesc, _lib.BlockDesc, _lib.StackDesc, _lib.AdapterDesc, _lib.OptDesc, _lib.PatchSrc, _lib.DwGroupDesc, _lib.ColsumJob)[args[0]])
             # slab layouts of the composite entry points: enough room for the views the host code cuts out of them

@@ -16,7 +16,7 @@ def test_cabi_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f'libmmae_hip.so does not export {n}'
-    assert _lib.load().mmae_abi_version() == 6        # load() also checks every ctypes struct mirror against mmae_struct_size()
+    assert _lib.load().mmae_abi_version() == 7        # load() also checks every ctypes struct mirror against mmae_struct_size()
 
 
 def test_state_dict_contract_and_seeded_init_base():
@@ -203,12 +203,17 @@ def test_bench_result_line_keeps_the_measurement_contract():
               'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
     assert d['unit'] == 'images/s' and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
-    assert d['dtype'] == 'bf16' and d['data'] == 'synthetic' and 'workload' in d['config'] and 'model' not in d['config']
+    # the storage form of the fp32 output adapter is part of the precision statement, where a truncated workload string cannot lose it
+    assert d['dtype'] == 'bf16 (fp32_output_adapters: fp16 storage)' and d['data'] == 'synthetic' and 'workload' in d['config'] and 'model' not in d['config']
     assert d['n_gpus'] == 1 and d['steps'] == 20 and d['warmup'] == 5 and d['config']['global_batch'] == 256 and d['config']['parallelism'] == 'dp1'
     assert 'fp16 STORAGE' in d['config']['workload'] and 'TF32' in d['config']['workload'] and 'configs[2]' in d['config']['workload']
     args_f16 = argparse.Namespace(config='cfg3', precision='bf16', steps=20, warmup=5, fp32_adapter_gemm='f16')
     assert 'fp16 operands' in bench.result_line(args_f16, 256, 1, 32.0, 8000.0, 8.08, {'steps': 25}, roof, cpu, None, 9.0, 20.0, False, 98,
                                                 ['rgb', 'depth', 'semseg'])['config']['workload']
+    assert bench.result_line(args_f16, 256, 1, 32.0, 8000.0, 8.08, {'steps': 25}, roof, cpu, None, 9.0, 20.0, False, 98,
+                             ['rgb', 'depth', 'semseg'])['dtype'] == 'bf16 (fp32_output_adapters: f32 tensors, fp16 operands)'
+    assert bench.result_line(argparse.Namespace(config='cfg2', precision='bf16', steps=20, warmup=5), 256, 1, 32.0, 8000.0, 8.08, {'steps': 25}, roof, cpu, None,
+                             9.0, 20.0, False, 98, ['rgb'])['dtype'] == 'bf16'
     args_x3 = argparse.Namespace(config='cfg3', precision='bf16', steps=20, warmup=5, fp32_adapter_gemm='x3')
     assert 'x3 split-bf16' in bench.result_line(args_x3, 256, 1, 32.0, 8000.0, 8.08, {'steps': 25}, roof, cpu, None, 9.0, 20.0, False, 98,
                                                 ['rgb', 'depth', 'semseg'])['config']['workload']

@@ -81,7 +81,7 @@ def test_grad_allreduce_world2_gloo():
         assert any(launched_mid) and not all(launched_mid), 'buckets must launch incrementally as layers finish'
 
 
-def _model_worker(rank, world, port, q, direct=True, average=False, learnable_pos=False, bf16_buckets=False):
+def _model_worker(rank, world, port, q, direct=True, average=False, learnable_pos=False, bf16_buckets=False, exchange='all_reduce'):
     try:
         import sys
         here = os.path.dirname(os.path.abspath(__file__))
@@ -101,7 +101,7 @@ def _model_worker(rank, world, port, q, direct=True, average=False, learnable_po
         gathered = [torch.empty_like(arena.param) for _ in range(world)]
         dist.all_gather(gathered, arena.param)
         same_params = all(torch.equal(g, gathered[0]) for g in gathered)
-        red = GradAllReducer.for_arena(arena, bucket_mb=0.25, average_in_place=average, bf16_buckets=bf16_buckets)
+        red = GradAllReducer.for_arena(arena, bucket_mb=0.25, average_in_place=average, bf16_buckets=bf16_buckets, exchange=exchange)
         attach(model, red)
         # arena = gradient-readiness order: last output adapter first, encoder from the top down, embedding parameters last
         names = [n for n in arena.names if arena.trainable[n]]
@@ -227,6 +227,63 @@ def test_bf16_gradient_buckets_world2_gloo():
     for rank, ok, order, mid, nb in res:
         assert ok, f'rank {rank}: {order}'
     assert res[0][2] == res[1][2]
+
+
+def test_reduce_scatter_all_gather_buckets_world4_gloo():
+    """exchange='rs_ag' (the direct form for point-to-point xGMI): every bucket is summed by a
+    reduce_scatter followed by an all_gather of the summed shards.  Same readiness-ordered launches, same sums (the stand-in gradients
+    are small integers: exact in any order), identical bucket order on every rank -- at world 4 and, with bf16 buckets, at world 2."""
+    res = _run_model_workers(4, exchange='rs_ag')
+    for rank, ok, order, mid, nb in res:
+        assert ok, f'rank {rank}: {order}'
+        assert order == sorted(order) and mid >= nb - 1, (order, mid, nb)
+    assert all(r[2] == res[0][2] for r in res)
+    res = _run_model_workers(2, exchange='rs_ag', bf16_buckets=True)
+    for rank, ok, order, mid, nb in res:
+        assert ok, f'rank {rank}: {order}'
+    assert res[0][2] == res[1][2]
+
+
+def _rs_ag_numeric_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        n = 64 * 37                                      # arena tensors are 64-element aligned: every bucket divides by 2 / 4 / 8 ranks
+        sizes = [(f'p{i}', 64 * i * 1, 64) for i in range(37)]
+        out = {}
+        for mode in ('all_reduce', 'rs_ag'):
+            torch.manual_seed(7 + rank)
+            grad = torch.randn(n)
+            red = GradAllReducer(grad, sizes, bucket_mb=64 * 8 * 4 / (1024 * 1024), exchange=mode)
+            assert len(red.buckets) >= 4
+            red.finish()
+            out[mode] = grad.clone()
+        torch.manual_seed(7)
+        ref = sum(torch.randn(n, generator=torch.Generator().manual_seed(7 + r)) for r in range(world))
+        q.put((rank, bool(torch.allclose(out['rs_ag'], out['all_reduce'], rtol=0, atol=1e-5)), bool(torch.allclose(out['rs_ag'], ref, rtol=0, atol=1e-5)),
+               bool(torch.equal(out['rs_ag'], out['rs_ag']))))
+        # a bucket that the world size does not divide falls back to all_reduce (stand-alone use with unaligned tensors)
+        grad = torch.full((10,), float(rank + 1))
+        red = GradAllReducer(grad, [('a', 0, 10)], bucket_mb=1.0, exchange='rs_ag')
+        red.finish()
+        assert torch.allclose(grad, torch.full((10,), float(sum(range(1, world + 1))))), grad
+        dist.destroy_process_group()
+    except Exception as e:                               # noqa: BLE001
+        import traceback
+        q.put((rank, False, False, traceback.format_exc()))
+
+
+def test_reduce_scatter_all_gather_matches_all_reduce_on_random_gradients_world4_gloo():
+    import torch.multiprocessing as mp
+    world, port = 4, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_rs_ag_numeric_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=180) for _ in range(world)]
+    [p.join(60) for p in ps]
+    for rank, same_as_allreduce, same_as_sum, extra in res:
+        assert same_as_allreduce and same_as_sum, (rank, extra)
 
 
 def test_reducer_reserves_compute_units_only_while_buckets_are_in_flight(monkeypatch):

@@ -24,6 +24,32 @@ probe1)   # two half-batch encoder pipelines side by side vs one that owns the c
   timeout 300 python tools/two_pipe_probe.py --fwd-only >> $S 2>&1
   table encoder_gemms.py "encoder GEMMs"
   ;;
+probe2)   # the duo structure (two 4-wave workgroups per CU, tile 11) on TODAY's encoder epilogues; start offsets of half a tile period
+  [ -f $EXP ] || { echo "the experiments library did not travel: comment its line out of .gpurunignore (and run make -C multimae_amd/csrc exp)" >> $S; exit 1; }
+  export MMAE_LIB=$EXP
+  table encoder_gemms.py "encoder GEMMs, exp library, planner's tiles"
+  MMAE_GEMM_TILE=11 table encoder_gemms.py "encoder GEMMs, duo (tile 11) where it applies"
+  MMAE_GEMM_TILE=11 MMAE_PP_DEPHASE=2 table encoder_gemms.py "encoder GEMMs, duo, second half of the grid ~8 us late"
+  MMAE_GEMM_TILE=11 MMAE_PP_DEPHASE=4 table encoder_gemms.py "encoder GEMMs, duo, second half of the grid ~16 us late"
+  MMAE_PP_DEPHASE=2 table encoder_gemms.py "encoder GEMMs, ping-pong, odd workgroups ~8 us late"
+  MMAE_PP_DEPHASE=4 table encoder_gemms.py "encoder GEMMs, ping-pong, odd workgroups ~16 us late"
+  MMAE_PP_DEPHASE=260 table encoder_gemms.py "encoder GEMMs, ping-pong, the workgroups with a tile less ~16 us late"
+  table encoder_gemms.py "encoder GEMMs, exp library, planner's tiles, again"
+  ;;
+ab)   # same-visit A/B of the production library against the kept previous build (multimae_amd/libmmae_hip_prev.so); optional pytest -k filter in $1
+  [ -f $PREV ] || { echo "no previous library: cp multimae_amd/libmmae_hip.so multimae_amd/libmmae_hip_prev.so before the change, and un-ignore it in .gpurunignore" >> $S; exit 1; }
+  if [ -n "$1" ]; then echo "== pytest -m gpu -k '$1'" >> $S; timeout 1500 python -m pytest tests -m gpu -x -q -k "$1" 2>&1 | tail -6 >> $S; fi
+  MMAE_LIB=$PREV table encoder_gemms.py "encoder GEMMs, previous build"
+  table encoder_gemms.py "encoder GEMMs, this build"
+  MMAE_LIB=$PREV table decoder_gemms.py "decoder GEMMs, previous build" 9 10
+  table decoder_gemms.py "decoder GEMMs, this build" 9 10
+  MMAE_LIB=$PREV run "previous build" timeout 300 $B
+  run "this build" timeout 300 $B
+  MMAE_LIB=$PREV run "previous build" timeout 300 $B
+  run "this build" timeout 300 $B
+  MMAE_LIB=$PREV table encoder_gemms.py "encoder GEMMs, previous build, again"
+  table encoder_gemms.py "encoder GEMMs, this build, again"
+  ;;
 *)
   echo "unknown visit $V" >> $S
   ;;
