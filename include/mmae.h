@@ -219,6 +219,10 @@ int mmae_gelu_grad_aux(int on);
  * 16-bit cast) is the LayerNorm side output of the Linear product in front of it (mmae_gemm_desc.ln_out) instead of its own launch.
  * on < 0 only reads.  Returns the previous value. */
 int mmae_ln_fuse(int on);
+/* Policy of mmae_adapter_fwd (default off -- measured: profiles/r06_xattn_fused_ab.txt): the cross-attention of a D = 256 bf16 output adapter
+ * as ONE launch, mmae_xattn_fwd_fused (q-projection + kv-projection + softmax + PV), instead of two Linear products and the attention core.
+ * on < 0 only reads.  Returns the previous value. */
+int mmae_xattn_fuse(int on);
 /* zero a packed scale array (only needed by producers that write the blocks of a width that is not a multiple of 256) */
 int mmae_mx_scale_clear(void* scales, int rows, int cols, void* stream);
 /* nn.LayerNorm forward (mmae_layernorm_fwd, bf16 y) that also emits the MX-fp8 quantisation of y -- bit-identical to
@@ -355,6 +359,13 @@ int mmae_softmax_bwd(const void* P, int p_dtype, int64_t ldp, const float* dP, i
  * delta = sum_j P_j dP_j is formed from the kernel's own fp32 P and dP -- the flash-attention shortcut rowsum(dO . O) with the
  * stored 16-bit O cost 22 % on dQ of the cfg5 decoders, profiles/r04_xattn_delta_probe.txt; the argument stays for ABI stability.)
  * ------------------------------------------------------------------------- */
+/* The fusion BASELINE.json's north star names, for CrossAttention.forward (multimae_utils.py:199-214) at D = H * 32 = 256, Nk <= 128, bf16:
+ * q = qn Wq^T + bq, [k | v] = cn Wkv^T + bkv, out = softmax(q k^T * scale) v per head, one workgroup per (image, head), the context rows staged
+ * in LDS once and projected there.  qn [B * Nq][D], cn [B * Nk][D] dense rows; wq [D][D], wkv [2 D][D] in nn.Linear layout.  Writes q [B * Nq][D]
+ * and kv [B * Nk][2 D] (the tensors mmae_attn_bwd and the weight gradients read), out [B * Nq][D] and lse [B][H][Nq] -- bit-identical to
+ * mmae_gemm (bias -> bf16) x 2 + mmae_attn_fwd.  MMAE_ESUPPORT for any other geometry.  ABI v7. */
+int mmae_xattn_fwd_fused(const void* qn, const void* cn, const void* wq, const float* bq, const void* wkv, const float* bkv, void* q, void* kv,
+                         void* out, float* lse, int B, int H, int Nq, int Nk, int D, float scale, void* stream);
 int mmae_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,
                   int64_t q_sb, int64_t q_sr, int64_t k_sb, int64_t k_sr, int64_t v_sb, int64_t v_sr, int64_t o_sb,
                   int64_t o_sr, float scale, void* stream);
@@ -630,6 +641,14 @@ int mmae_patch_rows(const mmae_patch_src* srcs_host, const int32_t* task_offsets
 int mmae_semseg_emb_bwd(const void* d_rows, int rows_dtype, int64_t ld, const int64_t* cls, const int64_t* sel, float* d_emb,
                         int B, int H, int W, int E, int ph, int pw, int n_sel, int k_off, int tok_off, int n_patches, int n_cls,
                         void* stream);
+/* The same gradient without atomics: every table entry is summed in a fixed order (per-thread columns of workgroup-private LDS tables, partial
+ * tables per workgroup in ws, a second launch that sums them in index order) -- bit-identical from run to run.  ws: f32 scratch of
+ * mmae_semseg_emb_bwd_ws_elems() elements (-1: geometry not supported); accumulate 0: d_emb = gradient (no zero-fill needed), 1: d_emb += gradient.
+ * rows_dtype MMAE_BF16 / MMAE_F32.  ABI v7. */
+int64_t mmae_semseg_emb_bwd_ws_elems(int B, int n_sel, int E, int n_cls);
+int mmae_semseg_emb_bwd_det(const void* d_rows, int rows_dtype, int64_t ld, const int64_t* cls, const int64_t* sel, float* d_emb,
+                            int B, int H, int W, int E, int ph, int pw, int n_sel, int k_off, int tok_off, int n_patches, int n_cls,
+                            float* ws, int64_t ws_elems, int accumulate, void* stream);
 /* tok[b][r][:] = proj[b*n_sel+r][:] + bias_t[:] + pos_t[p][:] (t, p = owner task / patch of
  * sel[b][r]); tok[b][n_sel+g][:] = global_tok[g][:].  tok f32 [B][n_sel+G][D];
  * bias / pos: host arrays of T device pointers (pos_t f32 [n_patches_t][D]). */

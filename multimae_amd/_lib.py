@@ -185,6 +185,8 @@ def load() -> ctypes.CDLL:
         lib.mmae_mx_wgrad(int(os.environ['MMAE_MX_WGRAD'] != '0'))
     if os.environ.get('MMAE_LN_FUSE') is not None:       # A/B: decoder LayerNorms as side outputs of the preceding products (1) or own launches (0)
         lib.mmae_ln_fuse(int(os.environ['MMAE_LN_FUSE'] != '0'))
+    if os.environ.get('MMAE_XATTN_FUSE') is not None:    # A/B: the adapters' cross-attention with its two projections inside the attention launch (1) or as three launches (0)
+        lib.mmae_xattn_fuse(int(os.environ['MMAE_XATTN_FUSE'] != '0'))
     if os.environ.get('MMAE_GELU_GRAD_AUX') is not None:  # A/B: the MLP pair with the derivative stored by the forward (1) or re-evaluated (0)
         lib.mmae_gelu_grad_aux(int(os.environ['MMAE_GELU_GRAD_AUX'] != '0'))
     _lib = lib

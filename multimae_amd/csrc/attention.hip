@@ -22,6 +22,7 @@
 //
 // Replaces Attention.forward / CrossAttention.forward cores (multimae_utils.py:175-179, 206-210) + autograd.
 #include "common.h"
+#include <mutex>
 
 #define LDS_AS __attribute__((address_space(3)))
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -706,6 +707,157 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_bwd_kernel(cons
     }
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// Round 6: the fusion the north star names, for the output adapters' cross-attention (D = 256: 8 heads x 32, <= 128 context rows, bf16) --
+// q-projection + kv-projection + softmax + PV in ONE kernel, one workgroup per (image, head):
+//   1. the image's normalised context rows (<= 128 x 256 bf16 = 64 KiB) are staged in LDS once and projected by the head's 64 rows of the
+//      kv weight ([K_h ; V_h] = cn . Wkv_h^T + b, one 32-key block per wave, 2 x 16 MFMAs on 256-wide contractions); the results go to the
+//      K / V tiles the attention core reads (over the staged context, behind a barrier) AND to the kv activation the backward differentiates;
+//   2. a wave projects each of its 32-query blocks straight from global memory (qn rows and the head's 32 rows of Wq as MFMA operands, no
+//      staging: every fragment is used once), writes q for the backward and keeps the bf16 fragments for
+//   3. the attention core of attn_fwd_kernel<32, 4, 0>, unchanged.
+// The weight rows are fetched in the order i -> d(i) = i with bits 2 and 3 swapped, so that accumulator registers 8 s .. 8 s + 7 of a lane hold
+// the eight CONSECUTIVE head-dim columns 16 s + 8 (lane >> 5) .. + 7 of its row: the projected values are MFMA operand fragments (and 16-byte
+// store units) as they leave the accumulator.  Same arithmetic as the three-launch form: fp32 accumulation over k = 0 .. 255 in steps of 16,
+// bias in fp32, one rounding to bf16 -- q / kv / out equal the GEMM + attention path's (tests/test_kernels_gpu.py::test_fused_cross_attention_forward).
+// Replaces CrossAttention.forward, multimae_utils.py:199-214 (q, kv, softmax(q k^T) v; the output projection stays the next GEMM).
+struct XAttnArgs {
+    const uint16_t *qn, *cn, *wq, *wkv;
+    const float *bq, *bkv;
+    uint16_t *q, *kv, *out;
+    float* lse;
+    int B, H, Nq, Nk;
+    float scale;
+};
+__device__ __forceinline__ int xa_coff(int row, int ch) { return row * 512 + ((ch ^ (row & 31)) << 4); }       // 256-wide bf16 rows, 16-byte chunks
+__device__ __forceinline__ int xa_dperm(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+
+__global__ void __launch_bounds__(256, 2) xattn_fwd_fused_kernel(const XAttnArgs a) {
+    constexpr int D = 256, HD = 32, NT = 4, KS = D / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    char* Cs = smem;                                       // [128][256] bf16 context (phase 1-2), then K | V tiles of the head (phase 3)
+    char* Ks = smem;
+    char* Vs = smem + 128 * HD * 2;
+    // ---- 1. stage the context rows (zero padded to 128)
+    {
+        const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(a.cn + (long long)b * a.Nk * D), 0, 0x80000000, 0x00020000);
+        i32x4 r[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = tid + i * 256, row = c >> 5, ch = c & 31;
+            r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsC, row < a.Nk ? (unsigned)((row * D + ch * 8) * 2) : OOB, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = tid + i * 256;
+            *reinterpret_cast<i32x4*>(Cs + xa_coff(c >> 5, c & 31)) = r[i];
+        }
+    }
+    __syncthreads();
+    // ---- 2. K_h, V_h of key block `wave`: D[i -> d(i)][j = key] = sum_k Wkv[s D + h 32 + d][k] cn[key][k]
+    const int wrow = h * HD + xa_dperm(lane & 31);
+    f32x16 kv2[2];
+    {
+        const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wkv, 0, 0x80000000, 0x00020000);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) kv2[s][r] = 0.f;
+#pragma unroll 4
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 cf = *reinterpret_cast<const bf16x8*>(Cs + xa_coff(wave * 32 + (lane & 31), ks * 2 + hi));
+            const bf16x8 wk = load_frag_global(rsW, true, wrow, D, ks, hi);
+            const bf16x8 wv = load_frag_global(rsW, true, D + wrow, D, ks, hi);
+            kv2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk, cf, kv2[0], 0, 0, 0);
+            kv2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, cf, kv2[1], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                       // every wave is done with the staged context: its first 16 KiB become the K / V tiles
+    {
+        const int key = wave * 32 + (lane & 31);
+        const bool kok = key < a.Nk;
+        uint16_t* kvg = a.kv + ((long long)b * a.Nk + key) * (2 * D) + h * HD;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            char* T = s ? Vs : Ks;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const f32x4 b0 = ld4(a.bkv + s * D + h * HD + 16 * ks + 8 * hi), b1 = ld4(a.bkv + s * D + h * HD + 16 * ks + 8 * hi + 4);
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { o[j] = (__bf16)(kv2[s][8 * ks + j] + b0[j]); o[4 + j] = (__bf16)(kv2[s][8 * ks + 4 + j] + b1[j]); }
+                *reinterpret_cast<bf16x8*>(T + tile_off<HD>(key, 2 * ks + hi)) = o;
+                if (kok) *reinterpret_cast<bf16x8*>(kvg + s * D + 16 * ks + 8 * hi) = o;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 3. per 32-query block: project, then attend
+    const int nqb = (a.Nq + 31) >> 5;
+    const float sc2 = a.scale * 1.44269504089f;
+    const auto rsQn = __builtin_amdgcn_make_buffer_rsrc((void*)(a.qn + (long long)b * a.Nq * D), 0, 0x80000000, 0x00020000);
+    const auto rsWq = __builtin_amdgcn_make_buffer_rsrc((void*)a.wq, 0, 0x80000000, 0x00020000);
+    for (int qblk = wave; qblk < nqb; qblk += 4) {
+        const int q = qblk * 32 + (lane & 31);
+        const bool qok = q < a.Nq;
+        bf16x8 qf[2];
+        {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 4
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 wf = load_frag_global(rsWq, true, wrow, D, ks, hi);
+                const bf16x8 xf = load_frag_global(rsQn, qok, q, D, ks, hi);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc, 0, 0, 0);
+            }
+            uint16_t* qg = a.q + ((long long)b * a.Nq + q) * D + h * HD;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const f32x4 b0 = ld4(a.bq + h * HD + 16 * ks + 8 * hi), b1 = ld4(a.bq + h * HD + 16 * ks + 8 * hi + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { qf[ks][j] = (__bf16)(acc[8 * ks + j] + b0[j]); qf[ks][4 + j] = (__bf16)(acc[8 * ks + 4 + j] + b1[j]); }
+                if (qok) *reinterpret_cast<bf16x8*>(qg + 16 * ks + 8 * hi) = qf[ks];
+            }
+        }
+        f32x16 s[NT];
+        float m = -INFINITY, l = 0.f;
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Ks, t * 32, ks, lane), qf[ks], s[t], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float v = key < a.Nk ? s[t][r] * sc2 : -INFINITY;
+                s[t][r] = v;
+                m = fmaxf(m, v);
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float p = __builtin_amdgcn_exp2f(s[t][r] - m); s[t][r] = p; l += p; }
+        l += __shfl_xor(l, 32, 64);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int sI = 0; sI < 2; ++sI) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<HD>(Vs, 0, t * 32 + 16 * sI, lane), pack8(s[t], sI), o, 0, 0, 0);
+        store_row32<false>(a.out + ((long long)b * a.Nq + q) * D + h * HD, o, 1.0f / l, hi, qok);
+        if (qok && hi == 0) a.lse[((long long)b * a.H + h) * a.Nq + q] = m * 0.69314718056f + __logf(l);
+    }
+}
+
 int check_common(int B, int H, int Nq, int Nk, int hd, const long long* strides, int n) {
     if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || Nq > 256 || Nk > 256) return -1;
     if (hd != 32 && hd != 64) return -2;
@@ -809,6 +961,25 @@ static int attn_bwd_impl(int mode, const void* q, const void* k, const void* v, 
     else LAUNCH_BWD(32, 0, 8);
 #undef LAUNCH_BWD
     return mmae_check_launch("attn_bwd");
+}
+
+
+/* q-projection + kv-projection + cross-attention forward in one launch (xattn_fwd_fused_kernel): D = H * 32 = 256, Nk <= 128, bf16, dense rows.
+ * qn [B * Nq][D], cn [B * Nk][D]; wq [D][D], wkv [2 D][D] (nn.Linear layout), bq [D], bkv [2 D] f32.  Writes q [B * Nq][D] and kv [B * Nk][2 D]
+ * (what the backward differentiates), out [B * Nq][D] and lse [B][H][Nq].  MMAE_ESUPPORT for any other geometry. */
+int mmae_xattn_fwd_fused(const void* qn, const void* cn, const void* wq, const float* bq, const void* wkv, const float* bkv, void* q, void* kv,
+                         void* out, float* lse, int B, int H, int Nq, int Nk, int D, float scale, void* stream) {
+    MMAE_REQUIRE(qn && cn && wq && bq && wkv && bkv && q && kv && out && lse, "xattn_fwd_fused: null pointer");
+    if (D != 256 || H != 8 || Nk < 1 || Nk > 128 || Nq < 1 || B < 1) { mmae_set_error("xattn_fwd_fused: D = 8 x 32 = 256 and 1 <= Nk <= 128 only"); return MMAE_ESUPPORT; }
+    MMAE_REQUIRE(((uintptr_t)qn | (uintptr_t)cn | (uintptr_t)wq | (uintptr_t)wkv | (uintptr_t)q | (uintptr_t)kv | (uintptr_t)out | (uintptr_t)bq | (uintptr_t)bkv) % 16 == 0,
+                 "xattn_fwd_fused: unaligned pointer");
+    XAttnArgs a = {(const uint16_t*)qn, (const uint16_t*)cn, (const uint16_t*)wq, (const uint16_t*)wkv, bq, bkv, (uint16_t*)q, (uint16_t*)kv, (uint16_t*)out, lse,
+                   B, H, Nq, Nk, scale};
+    const size_t lds = (size_t)128 * 256 * 2;
+    static std::once_flag once;
+    std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)xattn_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    hipLaunchKernelGGL(xattn_fwd_fused_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, a);
+    return mmae_check_launch("xattn_fwd_fused");
 }
 
 int mmae_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd,

@@ -177,7 +177,10 @@ __device__ __forceinline__ void gelu_both_fast2(f32x2 x, f32x2& y, f32x2& dy) {
     f32x2 xm;
     xm[0] = __builtin_amdgcn_fmed3f(x[0], -4.0f, 3.402823466e38f);
     xm[1] = __builtin_amdgcn_fmed3f(x[1], -4.0f, 3.402823466e38f);
-    y = xm * cdf;
+    // (a NaN pre-activation must stay a NaN: v_med3 returns the smaller of its two other operands for one, i.e. the finite gelu(-4) -- the term
+    // 0 * x restores it, so the non-finite loss / gradient-norm guard of mmae_opt_step still sees a poisoned activation; +-inf comes out as NaN
+    // instead of +inf / gelu(-4): non-finite either way.  One packed multiply per pair -- ADVICE r5)
+    y = __builtin_elementwise_fma(xm, cdf, x * (f32x2){0.f, 0.f});
     dy = __builtin_elementwise_fma(t, r, half);
 }
 __device__ __forceinline__ void gelu_both_fast4(f32x4 x, f32x4& y, f32x4& dy) {

@@ -628,6 +628,13 @@ static bool block_side_ok(const mmae_block_desc& b) {
     return !(b.mx_w && b.act_dtype == MMAE_BF16) && !b.dp1 && !b.dp2 && ln_side_ok(c, b.D, b.D, MMAE_F32) && (b.Hd % 32) == 0;
 }
 
+std::atomic<int> g_xattn_fuse{0};
+int mmae_xattn_fuse(int on) {
+    const int prev = g_xattn_fuse.load(std::memory_order_relaxed);
+    if (on >= 0) g_xattn_fuse.store(on ? 1 : 0, std::memory_order_relaxed);
+    return prev;
+}
+
 int mmae_ln_fuse(int on) {
     const int prev = g_ln_fuse.load(std::memory_order_relaxed);
     if (on >= 0) g_ln_fuse.store(on ? 1 : 0, std::memory_order_relaxed);
@@ -1011,6 +1018,11 @@ int mmae_adapter_fwd(const mmae_adapter_desc* d, void* stream) {
         if ((rc = mmae_layernorm_fwd(a.queries, qnw, qnb, a.qn, act, a.qmean, a.qrstd, Rq, D, d->eps, st))) return rc;
         if ((rc = mmae_layernorm_fwd(a.context, cnw, cnb, a.cn, act, a.cmean, a.crstd, Rc, D, d->eps, st))) return rc;
     }
+    // round 6: the two projections inside the attention launch (attention.hip: xattn_fwd_fused_kernel) -- policy switch, off by default
+    const bool xfuse = g_xattn_fuse.load(std::memory_order_relaxed) != 0 && act == MMAE_BF16 && D == 256 && d->heads == 8 && NC <= 128 && !c.x3_w;
+    if (xfuse) {
+        if ((rc = mmae_xattn_fwd_fused(a.qn, a.cn, qw, qb, kvw, kvb, a.q, a.kv, a.xo, a.lse, B, d->heads, n_q, NC, D, 1.0f / sqrtf((float)hd), st))) return rc;
+    } else {
     if ((rc = lin_fwd(c, a.qn, qw, qb, a.q, act, Rq, D, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;
     if ((rc = lin_fwd(c, a.cn, kvw, kvb, a.kv, act, Rc, 2 * D, D, nullptr, nullptr, MMAE_EPI_NONE, st))) return rc;
     {
@@ -1018,6 +1030,7 @@ int mmae_adapter_fwd(const mmae_adapter_desc* d, void* stream) {
         const char* kv = (const char*)a.kv;
         if ((rc = fn(a.q, kv, kv + (size_t)D * es, a.xo, a.lse, B, d->heads, n_q, NC, hd, (int64_t)n_q * D, D, (int64_t)NC * 2 * D, 2 * D,
                      (int64_t)NC * 2 * D, 2 * D, (int64_t)n_q * D, D, 1.0f / sqrtf((float)hd), st))) return rc;
+    }
     }
     // every LayerNorm (and the final 16-bit cast) of the D = 256 decoder is the side output of the Linear product in front of it (round 5):
     // out_norm of the cross-attention's proj, norm1 of a block of the product that completes its input (the MLP's fc2, the block before's

@@ -570,6 +570,7 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
         PP_STAMP();                                          // D
         if constexpr (LNE) {
             static_assert(TM == 4 && !AKS && (FL == FL_F32_BIAS_RESID || FL == FL_F32_BIAS), "LayerNorm side output: f32 bias [+ residual] flavours on 256-row tiles");
+            // (N == 256 = four 64-column quarters of a row, one per wn: runtime.hip checks)
             constexpr bool RES = FL == FL_F32_BIAS_RESID;
             f32x4 keep[2][16];
             {
@@ -588,12 +589,14 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
                     for (int k = 0; k < 16; ++k) {
+                        // per 64-column quarter of the row: its mean and the sum of squared deviations FROM THAT MEAN (two DPP row sums: the values
+                        // are still in registers) -- not (sum, sum of squares), whose difference cancels for rows with |mean| >> std
                         const f32x4 v = keep[s][k];
-                        float s1 = (v[0] + v[1]) + (v[2] + v[3]);
-                        float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                        s1 = row16_sum(s1); s2 = row16_sum(s2);             // the 16 lanes that share the row: DPP, no LDS traffic
+                        const float mq = row16_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 64.0f);   // the 16 lanes that share the row: DPP, no LDS traffic
+                        const float d0 = v[0] - mq, d1 = v[1] - mq, d2 = v[2] - mq, d3 = v[3] - mq;
+                        const float m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
                         const int row_l = wm * WMR + s * 64 + (k >> 3) * 32 + (k & 7) * 4 + rsub;
-                        if (c16 == 0) { part[(row_l * 4 + wn) * 2] = s1; part[(row_l * 4 + wn) * 2 + 1] = s2; }
+                        if (c16 == 0) { part[(row_l * 4 + wn) * 2] = mq; part[(row_l * 4 + wn) * 2 + 1] = m2; }
                     }
                 __syncthreads();
             }
@@ -618,8 +621,10 @@ __device__ __forceinline__ void pp_body(const GemmArgs& g, const int v0, const i
                         if (do_ln) {
                             const f32x4 p0 = *reinterpret_cast<const f32x4*>(part + (wm * WMR + r) * 8);
                             const f32x4 p1 = *reinterpret_cast<const f32x4*>(part + (wm * WMR + r) * 8 + 4);
-                            const float mu = ((p0[0] + p0[2]) + (p1[0] + p1[2])) * inv_n;
-                            const float var = fmaxf(((p0[1] + p0[3]) + (p1[1] + p1[3])) * inv_n - mu * mu, 0.f);
+                            // the four quarters (64 columns each) combined as in Chan et al.: M2 = sum M2_q + 64 sum (mean_q - mu)^2
+                            const float mu = ((p0[0] + p0[2]) + (p1[0] + p1[2])) * 0.25f;
+                            const float e0 = p0[0] - mu, e1 = p0[2] - mu, e2 = p1[0] - mu, e3 = p1[2] - mu;
+                            const float var = (((p0[1] + p0[3]) + (p1[1] + p1[3])) + 64.0f * ((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3))) * inv_n;
                             const float rs = 1.0f / sqrtf(var + g.ln_eps);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) o[j] = (o[j] - mu) * rs * g4[j] + b4[j];

@@ -919,7 +919,9 @@ int mmae_dropout(const void* x, int x_dtype, const void* keep, float scale, cons
     MMAE_REQUIRE(x && keep && out && n > 0 && n % 4 == 0, "dropout: bad argument (n must be a multiple of 4)");
     MMAE_REQUIRE(!s || (per > 0 && per % 4 == 0 && n % per == 0), "dropout: the per-sample scale needs per % 4 == 0 and n % per == 0");
     MMAE_REQUIRE(!resid || out_dtype == MMAE_F32, "dropout: a residual needs an f32 output");
-    MMAE_REQUIRE(((uintptr_t)x % 8 == 0) && ((uintptr_t)out % 8 == 0) && ((uintptr_t)keep % 4 == 0) && (!resid || (uintptr_t)resid % 16 == 0), "dropout: unaligned");
+    // four elements per lane: 16-byte accesses on f32 tensors, 8-byte on 16-bit ones (an f32 view at an odd element offset passed the old 8-byte check)
+    MMAE_REQUIRE(((uintptr_t)x % (x_dtype == MMAE_F32 ? 16 : 8) == 0) && ((uintptr_t)out % (out_dtype == MMAE_F32 ? 16 : 8) == 0) && ((uintptr_t)keep % 4 == 0) &&
+                 (!resid || (uintptr_t)resid % 16 == 0), "dropout: unaligned (f32 tensors 16 bytes, 16-bit tensors 8 bytes, keep 4 bytes)");
     const long long total4 = n / 4, per4 = s ? per / 4 : 1;
     hipStream_t st = (hipStream_t)stream;
     const unsigned char* k = (const unsigned char*)keep;

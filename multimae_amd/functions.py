@@ -542,10 +542,10 @@ class EmbedFn(torch.autograd.Function):
                 gdata = ops.rows_to_image(d_rows, 0, sel, B, n_sel, cfg.task_offsets[i], t['n_patches'], t['C'], t['H'], t['W'], t['ph'], t['pw'])
             if emb is not None and emb.requires_grad:
                 d_rows = ops.linear_dx(d_proj, wc(w).view(D, t['K']), torch.empty((B * n_sel, t['K']), device=sel.device, dtype=act))
-                ge_buf = torch.zeros(emb.shape, device=sel.device, dtype=torch.float32)
+                ge_buf = torch.empty(emb.shape, device=sel.device, dtype=torch.float32)      # stored, not accumulated: no zero-fill launch
                 s = ctx.srcs[i]
                 ops.semseg_emb_bwd(d_rows, s['data'], sel, ge_buf, B=B, H=t['H'], W=t['W'], E=t['C'], ph=t['ph'], pw=t['pw'],
-                                   n_sel=n_sel, k_off=0, tok_off=cfg.task_offsets[i], n_patches=t['n_patches'], n_cls=emb.shape[0])
+                                   n_sel=n_sel, k_off=0, tok_off=cfg.task_offsets[i], n_patches=t['n_patches'], n_cls=emb.shape[0], accumulate=False)
                 if t.get('pad_idx') is not None:              # nn.Embedding(padding_idx=...): that row receives no gradient
                     ge_buf[t['pad_idx']].zero_()
                 ge = sink.vec(emb, ge_buf)

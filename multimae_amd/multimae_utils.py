@@ -270,8 +270,11 @@ def _as_hip_norm(norm_layer, dim):
 
 
 def _stack_drop_path(blocks, batch: int, device):
-    """Per-block stochastic-depth scales [(attention branch, MLP branch)] * L, drawn in the reference's order (two draws per
-    block as the blocks execute, multimae_utils.py:229-232); None when no block drops paths (eval mode, rate 0)."""
+    """Per-block stochastic-depth scales [(attention branch, MLP branch)] * L, drawn in the reference's order AMONG THEMSELVES (two draws
+    per block, block by block, multimae_utils.py:229-232); None when no block drops paths (eval mode, rate 0).  All of them are drawn here,
+    up front: with drop_path_rate > 0 AND drop_rate / attn_drop_rate > 0 together the reference interleaves attn_drop, proj_drop, DropPath,
+    mlp.drop, DropPath per block on one generator, so under a shared seed its random STREAM differs from this engine's (same distributions,
+    same sites; each kind of mask keeps its own order -- ADVICE r5)."""
     if not any((not isinstance(b.drop_path, nn.Identity)) and b.training and (b.drop_path.drop_prob or 0.) > 0. for b in blocks):
         return None
     dp = []

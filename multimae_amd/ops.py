@@ -7,6 +7,7 @@ module has a CPU or torch-op fallback: tensors must live on the GPU.
 from __future__ import annotations
 
 import ctypes
+import math
 from typing import Optional, Sequence
 
 import torch
@@ -265,6 +266,12 @@ def ln_fuse(on: Optional[bool] = None) -> bool:
     """Policy switch of the composite adapter calls (mmae_ln_fuse): LayerNorm forwards of a D = 256 decoder as side outputs of the
     preceding Linear products' epilogues (default on); returns the previous value."""
     return bool(_lib.load().mmae_ln_fuse(-1 if on is None else int(bool(on))))
+
+
+def xattn_fuse(on: Optional[bool] = None) -> bool:
+    """Policy switch of mmae_adapter_fwd (mmae_xattn_fuse, default off): the cross-attention of a D = 256 bf16 output adapter as ONE launch
+    (q-projection + kv-projection + softmax + PV, xattn_fwd_fused) instead of two Linear products + the attention core; returns the previous value."""
+    return bool(_lib.load().mmae_xattn_fuse(-1 if on is None else int(bool(on))))
 
 
 def gemm_cu_share(k: Optional[int] = None) -> int:
@@ -1091,6 +1098,23 @@ def attention_fwd(q: AttnView, k: AttnView, v: AttnView, out: AttnView, B: int, 
     return state
 
 
+def xattn_fwd_fused(qn: Tensor, cn: Tensor, wq: Tensor, bq: Tensor, wkv: Tensor, bkv: Tensor, B: int, Nq: int, Nk: int, heads: int = 8):
+    """CrossAttention.forward up to (not including) its output projection, multimae_utils.py:199-214, as ONE launch (mmae_xattn_fwd_fused): qn [B * Nq, D]
+    and cn [B * Nk, D] bf16 (the normalised queries / context), nn.Linear weights wq [D, D], wkv [2 D, D] bf16, biases f32; D = heads * 32 = 256, Nk <= 128.
+    Returns (q, kv, out, lse) -- q and kv are what the backward differentiates."""
+    D = qn.shape[1]
+    dev = qn.device
+    q = torch.empty((B * Nq, D), device=dev, dtype=torch.bfloat16)
+    kv = torch.empty((B * Nk, 2 * D), device=dev, dtype=torch.bfloat16)
+    out = torch.empty((B * Nq, D), device=dev, dtype=torch.bfloat16)
+    lse = torch.empty((B, heads, Nq), device=dev, dtype=torch.float32)
+    for t in (qn, cn, wq, wkv):
+        assert t.dtype == torch.bfloat16 and t.is_contiguous()
+    check(_lib.load().mmae_xattn_fwd_fused(qn.data_ptr(), cn.data_ptr(), wq.data_ptr(), bq.data_ptr(), wkv.data_ptr(), bkv.data_ptr(), q.data_ptr(), kv.data_ptr(),
+                                           out.data_ptr(), lse.data_ptr(), B, heads, Nq, Nk, D, 1.0 / math.sqrt(D // heads), _stream()), 'xattn_fwd_fused')
+    return q, kv, out, lse
+
+
 def attention_bwd(q: AttnView, k: AttnView, v: AttnView, state, out: AttnView, d_out: AttnView, dq: AttnView, dk: AttnView,
                   dv: AttnView, B: int, H: int, hd: int, scale: float, f16: bool = False, dy_amax: Optional[Tensor] = None) -> None:
     Nq, Nk = q.N, k.N
@@ -1219,10 +1243,23 @@ def patch_embed_fwd(srcs: Sequence[dict], weights_bf16: Sequence[Tensor], biases
 
 
 def semseg_emb_bwd(d_rows: Tensor, cls: Tensor, sel: Tensor, d_emb: Tensor, *, B, H, W, E, ph, pw, n_sel, k_off, tok_off,
-                   n_patches, n_cls) -> None:
-    check(_lib.load().mmae_semseg_emb_bwd(d_rows.data_ptr(), dcode(d_rows.dtype), d_rows.stride(0), cls.data_ptr(), sel.data_ptr(),
-                                          d_emb.data_ptr(), B, H, W, E, ph, pw, n_sel, k_off, tok_off, n_patches, n_cls,
-                                          _stream()), 'semseg_emb_bwd')
+                   n_patches, n_cls, accumulate: bool = True, deterministic: bool = True) -> None:
+    """Gradient of the class-embedding table.  deterministic (default, round 6): fixed summation order, no atomics (mmae_semseg_emb_bwd_det) for
+    bf16 / f32 rows whose table fits the LDS; accumulate=False stores the gradient, so d_emb needs no zero-fill.  Otherwise (fp16 rows, huge tables)
+    the float-atomic form, which ADDS into d_emb (accumulate=False then zero-fills it first)."""
+    lib = _lib.load()
+    ws_elems = int(lib.mmae_semseg_emb_bwd_ws_elems(B, n_sel, E, n_cls)) if (deterministic and d_rows.dtype in (torch.bfloat16, torch.float32)) else -1
+    if ws_elems > 0:
+        ws = torch.empty(ws_elems, device=d_rows.device, dtype=torch.float32)
+        check(lib.mmae_semseg_emb_bwd_det(d_rows.data_ptr(), dcode(d_rows.dtype), d_rows.stride(0), cls.data_ptr(), sel.data_ptr(), d_emb.data_ptr(),
+                                          B, H, W, E, ph, pw, n_sel, k_off, tok_off, n_patches, n_cls, ws.data_ptr(), ws_elems, int(bool(accumulate)),
+                                          _stream()), 'semseg_emb_bwd_det')
+        return
+    if not accumulate:
+        d_emb.zero_()
+    check(lib.mmae_semseg_emb_bwd(d_rows.data_ptr(), dcode(d_rows.dtype), d_rows.stride(0), cls.data_ptr(), sel.data_ptr(),
+                                  d_emb.data_ptr(), B, H, W, E, ph, pw, n_sel, k_off, tok_off, n_patches, n_cls,
+                                  _stream()), 'semseg_emb_bwd')
 
 
 def _ptr_array(ts: Sequence[Tensor]):

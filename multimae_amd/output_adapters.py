@@ -174,7 +174,7 @@ class SpatialOutputAdapter(nn.Module):
                    q_task=in_tasks.index(self.task) if task_queries else -1, G=G, D=self.dim_tokens, pos=self._pos_tokens(nh, nw), depth=self.depth,
                    C=self.num_channels, nh=nh, nw=nw, ph=self.P_H, pw=self.P_W, on_done=on_done, f32_gemm=f32_gemm,
                    enc_act=encoder_tokens_act)
-        if self.depth > 0:                                   # two draws per block with a rate > 0, as the blocks execute (multimae_utils.py:229-232)
+        if self.depth > 0:                                   # two draws per block with a rate > 0, block by block, all up front (see _stack_drop_path on the stream order)
             from .multimae_utils import _stack_drop_path
             cfg.dp = _stack_drop_path(list(self.decoder_transformer), encoder_tokens.shape[0], encoder_tokens.device)
         if self.training and any(r > 0. for r in self._drop_rates):

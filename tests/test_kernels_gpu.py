@@ -220,6 +220,84 @@ def test_gemm_epilogues(dtype):
     assert rel_err(c16.float(), 0.5 * (x @ w.t())) < 4e-3
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_semseg_class_embedding_gradient_is_deterministic(dtype):
+    """mmae_semseg_emb_bwd_det (round 6): d_emb[class of every pixel of a selected semseg patch][e] += the patch row's gradient
+    (SemSegInputAdapter's nn.Embedding backward, input_adapters.py:215-241) summed in a FIXED order -- against an fp64 index_add, bit-identical
+    between two runs and to the accumulate form, where the float-atomic kernel it replaces differs from run to run."""
+    from multimae_amd import ops
+    B, H, W, E, ph, pw, n_cls, n_sel = 6, 16, 24, 64, 4, 4, 133, 20
+    nh, nw = H // ph, W // pw
+    n_patches, tok_off = nh * nw, 7                        # the semseg task owns tokens [7, 7 + 24)
+    torch.manual_seed(3)
+    cls = torch.randint(-1, n_cls + 1, (B, H, W))          # also ids outside [0, n_cls): no gradient
+    sel = torch.stack([torch.randperm(tok_off + n_patches + 5)[:n_sel] for _ in range(B)])       # some tokens belong to other tasks
+    K = E * ph * pw
+    d_rows = torch.randn(B * n_sel, K)
+    if dtype == torch.bfloat16:
+        d_rows = bf(d_rows)
+    ref = torch.zeros(n_cls, E, dtype=torch.float64)
+    for b in range(B):
+        for r in range(n_sel):
+            p = int(sel[b, r]) - tok_off
+            if p < 0 or p >= n_patches:
+                continue
+            py, px = divmod(p, nw)
+            row = d_rows[b * n_sel + r].double().view(E, ph, pw)
+            c = cls[b, py * ph:(py + 1) * ph, px * pw:(px + 1) * pw]
+            ok = (c >= 0) & (c < n_cls)
+            ref.index_add_(0, c[ok], row[:, ok].T.contiguous())
+    dr, dc, ds = d_rows.to(DEV, dtype), cls.to(DEV), sel.to(DEV)
+    kw = dict(B=B, H=H, W=W, E=E, ph=ph, pw=pw, n_sel=n_sel, k_off=0, tok_off=tok_off, n_patches=n_patches, n_cls=n_cls)
+    outs = []
+    for _ in range(2):
+        g = torch.full((n_cls, E), 7.0, device=DEV)         # store mode: whatever the buffer held is overwritten
+        ops.semseg_emb_bwd(dr, dc, ds, g, accumulate=False, **kw)
+        outs.append(g.clone())
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0].double().cpu() - ref).abs().max() < 2e-4 * max(1.0, float(ref.abs().max()))
+    g = torch.ones(n_cls, E, device=DEV)
+    ops.semseg_emb_bwd(dr, dc, ds, g, accumulate=True, **kw)
+    assert torch.equal(g, outs[0] + 1.0)
+    ga = torch.zeros(n_cls, E, device=DEV)                 # the atomic form still agrees numerically
+    ops.semseg_emb_bwd(dr, dc, ds, ga, accumulate=True, deterministic=False, **kw)
+    assert (ga - outs[0]).abs().max() < 1e-3 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize('geom', [(3, 196, 99), (2, 196, 128), (2, 50, 33), (1, 1, 1)])
+def test_fused_cross_attention_forward(geom):
+    """mmae_xattn_fwd_fused (round 6: q-projection + kv-projection + softmax + PV in one launch, CrossAttention.forward of multimae_utils.py:199-214
+    at the output adapters' D = 8 x 32 = 256): q, kv, out and lse against the three-launch form it replaces (bias GEMM -> bf16 twice + mmae_attn_fwd:
+    the same fp32 accumulation order and the same single rounding -- bit for bit) and against the fp32 formula."""
+    from multimae_amd import ops
+    from multimae_amd.ops import AttnView
+    B, Nq, Nk = geom
+    D, H, hd = 256, 8, 32
+    torch.manual_seed(11)
+    qn, cn = bf(torch.randn(B * Nq, D)).to(DEV, torch.bfloat16), bf(torch.randn(B * Nk, D)).to(DEV, torch.bfloat16)
+    wq, wkv = bf(torch.randn(D, D) * 0.06).to(DEV, torch.bfloat16), bf(torch.randn(2 * D, D) * 0.06).to(DEV, torch.bfloat16)
+    bq, bkv = torch.randn(D, device=DEV), torch.randn(2 * D, device=DEV)
+    q, kv, out, lse = ops.xattn_fwd_fused(qn, cn, wq, bq, wkv, bkv, B, Nq, Nk)
+    # the three launches
+    q3 = torch.empty_like(q); kv3 = torch.empty_like(kv); out3 = torch.empty_like(out)
+    ops.linear_fwd(qn, wq, bq, q3)
+    ops.linear_fwd(cn, wkv, bkv, kv3)
+    st = ops.attention_fwd(AttnView(q3, 0, D, Nq), AttnView(kv3, 0, 2 * D, Nk), AttnView(kv3, D, 2 * D, Nk), AttnView(out3, 0, D, Nq), B, H, hd, hd ** -0.5)
+    assert st[0] == 'fused'
+    assert torch.equal(q, q3), (q.float() - q3.float()).abs().max()
+    assert torch.equal(kv, kv3), (kv.float() - kv3.float()).abs().max()
+    assert torch.equal(out, out3), (out.float() - out3.float()).abs().max()
+    assert torch.equal(lse, st[1])
+    # the formula, in fp32 on the bf16-rounded projections
+    sp = lambda t, n: t.float().cpu().reshape(B, n, H, hd).permute(0, 2, 1, 3)
+    qr = bf(qn.float().cpu() @ wq.float().cpu().T + bq.cpu())
+    kvr = bf(cn.float().cpu() @ wkv.float().cpu().T + bkv.cpu())
+    a = ((sp(qr, Nq) @ sp(kvr[:, :D], Nk).transpose(-2, -1)) * hd ** -0.5).softmax(-1)
+    o_ref = (a @ sp(kvr[:, D:], Nk)).transpose(1, 2).reshape(B * Nq, D)
+    assert rel_err(q.float().cpu(), qr) < 4e-3 and rel_err(kv.float().cpu(), kvr) < 4e-3
+    assert rel_err(out.float().cpu(), o_ref) < 1e-2
+
+
 @pytest.mark.parametrize('path', ['fused', 'gemm', 'f32', 'f32x3', 'f32f16'])
 @pytest.mark.parametrize('geom', [(3, 2, 17, 17, 64), (2, 12, 99, 99, 64), (2, 8, 196, 99, 32), (2, 8, 196, 196, 32), (1, 3, 50, 50, 64),
                                   (2, 16, 197, 197, 64), (1, 2, 256, 256, 32), (2, 3, 1, 33, 64)])

@@ -50,6 +50,18 @@ ab)   # same-visit A/B of the production library against the kept previous build
   MMAE_LIB=$PREV table encoder_gemms.py "encoder GEMMs, previous build, again"
   table encoder_gemms.py "encoder GEMMs, this build, again"
   ;;
+xattn)   # the fused q/kv-projection + cross-attention launch: kernel test, stand-alone A/B, adapter-level parity with the switch on, step A/B
+  echo "== pytest fused cross-attention kernel + deterministic embedding gradient" >> $S
+  timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -k "fused_cross_attention or semseg_class_embedding" 2>&1 | tail -4 >> $S
+  echo "== tools/xattn_fused_ab.py" >> $S
+  timeout 300 python tools/xattn_fused_ab.py >> $S 2>&1
+  echo "== adapter / model parity tests with MMAE_XATTN_FUSE=1" >> $S
+  MMAE_XATTN_FUSE=1 timeout 1500 python -m pytest tests/test_parity_geometry_gpu.py tests/test_model_gpu.py -x -q -k "per_tensor or mask_token or adapter or golden or mini" 2>&1 | tail -4 >> $S
+  run "three launches (default)" timeout 300 $B
+  MMAE_XATTN_FUSE=1 run "fused cross-attention" timeout 300 $B
+  run "three launches (default), again" timeout 300 $B
+  MMAE_XATTN_FUSE=1 run "fused cross-attention, again" timeout 300 $B
+  ;;
 *)
   echo "unknown visit $V" >> $S
   ;;
