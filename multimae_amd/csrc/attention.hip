@@ -956,9 +956,14 @@ static int attn_bwd_impl(int mode, const void* q, const void* k, const void* v, 
     const bool rs = env_rs && a.nkp <= 128 && lds <= 80 * 1024;
     if (mode == 1) { if (hd == 64) LAUNCH_BWD(64, 1, 8); else LAUNCH_BWD(32, 1, 8); }
     else if (mode == 2) { if (hd == 64) { if (lds <= 80 * 1024) LAUNCH_BWD(64, 2, 4); else LAUNCH_BWD(64, 2, 8); } else LAUNCH_BWD(32, 2, 8); }
-    else if (mode == 3) { if (hd == 64) { if (lds <= 80 * 1024) LAUNCH_BWD(64, 3, 4); else LAUNCH_BWD(64, 3, 8); } else LAUNCH_BWD(32, 3, 8); }
+    else if (mode == 3) { if (hd == 64) { if (lds <= 80 * 1024) LAUNCH_BWD(64, 3, 4); else LAUNCH_BWD(64, 3, 8); } else if (rs) LAUNCH_BWD(32, 3, 4, true); else LAUNCH_BWD(32, 3, 8); }
     else if (hd == 64) { if (rs) LAUNCH_BWD(64, 0, 4, true); else if (lds <= 80 * 1024) LAUNCH_BWD(64, 0, 4); else LAUNCH_BWD(64, 0, 8); }
-    else LAUNCH_BWD(32, 0, 8);
+    else {
+        // head_dim 32 (the output adapters' cross-attention: 196 queries x 99 keys): the register-resident pass 1 too where the keys fit four tiles
+        // (round 6: one evaluation of S / dP and the exponentials less -- the separate delta sweep was a third of the kernel's v_exp work)
+        static const int env_rs32 = mmae_env_int("MMAE_ATTN_BWD_RS32", 1);
+        if (rs && env_rs32) LAUNCH_BWD(32, 0, 4, true); else LAUNCH_BWD(32, 0, 8);
+    }
 #undef LAUNCH_BWD
     return mmae_check_launch("attn_bwd");
 }

@@ -62,6 +62,72 @@ xattn)   # the fused q/kv-projection + cross-attention launch: kernel test, stan
   run "three launches (default), again" timeout 300 $B
   MMAE_XATTN_FUSE=1 run "fused cross-attention, again" timeout 300 $B
   ;;
+ab2)   # light same-visit A/B against the kept previous build: optional pytest -k filter, then the default line twice each
+  [ -f $PREV ] || { echo "no previous library (multimae_amd/libmmae_hip_prev.so; un-ignore it in .gpurunignore)" >> $S; exit 1; }
+  if [ -n "$1" ]; then echo "== pytest -m gpu -k '$1'" >> $S; timeout 1500 python -m pytest tests -m gpu -x -q -k "$1" 2>&1 | tail -6 >> $S; fi
+  MMAE_LIB=$PREV run "previous build" timeout 300 $B
+  run "this build" timeout 300 $B
+  MMAE_LIB=$PREV run "previous build" timeout 300 $B
+  run "this build" timeout 300 $B
+  MMAE_LIB=$PREV run "previous build" timeout 300 $B
+  run "this build" timeout 300 $B
+  if [ -n "$2" ]; then echo "== $2 (previous build)" >> $S; MMAE_LIB=$PREV timeout 300 python $2 >> $S 2>&1; echo "== $2 (this build)" >> $S; timeout 300 python $2 >> $S 2>&1; fi
+  ;;
+tests)   # the whole GPU suite + smoke
+  echo "== pytest -m gpu" >> $S
+  timeout 3000 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/r6_pytest_gpu.log 2>&1
+  tail -8 gpurun_out/r6_pytest_gpu.log >> $S
+  echo "== smoke" >> $S
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | cut -c1-220 >> $S
+  for f in curve_cfg3_bf16_h16.json adapter_modes_train_cfg3.json mxfp8_trains_cfg5.json dropin_fast_loop.json; do [ -f gpurun_out/$f ] && cp gpurun_out/$f gpurun_out/r6_$f; done
+  ;;
+final)   # the round's measurement visit: default line (+ secondaries), other configurations, kernel statistics, PMC traffic, tables, encoder step
+  echo "== bench (default flags)" >> $S
+  timeout 1200 python bench.py > gpurun_out/bench.log 2> gpurun_out/bench.err
+  grep "timed region\|cpu_baseline\|encoder step" gpurun_out/bench.err | cut -c1-200 >> $S
+  grep "^{" gpurun_out/bench.log | tail -1 > gpurun_out/r6_bench_cfg3.json
+  cat gpurun_out/r6_bench_cfg3.json >> $S
+  echo "== other configurations" >> $S
+  run "cfg3 default, again" timeout 300 $B
+  MMAE_XATTN_FUSE=1 run "cfg3, the adapters' cross-attention as one fused launch (MMAE_XATTN_FUSE=1)" timeout 300 $B
+  run "cfg3 default, a third time" timeout 300 $B
+  run "cfg3, fp32 adapter as f32 tensors with fp16 operands (--fp32-adapter-gemm f16)" timeout 300 $B --fp32-adapter-gemm f16
+  run "cfg3, fp32 adapter with split-bf16 operands (--fp32-adapter-gemm x3)" timeout 300 $B --fp32-adapter-gemm x3
+  run "cfg3 serialized (one stream)" timeout 300 $B --adapter-streams 0 --wgrad-stream 0
+  run "cfg2 (RGB only) B=256" timeout 300 $B --config cfg2
+  run "cfg5 geometry (ViT-L, bf16) B=128" timeout 600 $B --config cfg5 --precision bf16 --steps 10 --warmup 3
+  timeout 600 python bench.py --no-cpu-baseline --no-secondary --config cfg5 --precision mxfp8 --steps 10 --warmup 3 > gpurun_out/bench_cfg5_mxfp8.log 2> gpurun_out/x.err
+  grep "^{" gpurun_out/bench_cfg5_mxfp8.log | tail -1 > gpurun_out/r6_bench_cfg5_mxfp8.json
+  echo "cfg5 (ViT-L, mxfp8) B=128: $(grep 'timed region' gpurun_out/x.err | sed 's/.*done: //' | cut -c1-120)" >> $S
+  timeout 300 python bench.py --no-cpu-baseline --no-kernel-timing --no-secondary --steps 20 --warmup 5 --force-dist 1 > gpurun_out/dist_world1.log 2> gpurun_out/x.err
+  echo "cfg3, data-parallel path over RCCL at world size 1, all_reduce buckets issued (--force-dist 1): $(grep 'timed region' gpurun_out/x.err | sed 's/.*done: //' | cut -c1-120)" >> $S
+  grep "^{" gpurun_out/dist_world1.log | tail -1 > gpurun_out/r6_dist_world1_rccl.json
+  timeout 300 python bench.py --no-cpu-baseline --no-kernel-timing --no-secondary --steps 20 --warmup 5 --force-dist 1 --dp-exchange rs_ag > gpurun_out/dist_world1_rsag.log 2> gpurun_out/x.err
+  echo "cfg3, the same with reduce_scatter + all_gather buckets (--dp-exchange rs_ag): $(grep 'timed region' gpurun_out/x.err | sed 's/.*done: //' | cut -c1-120)" >> $S
+  grep -i "error\|Traceback" gpurun_out/x.err | tail -3 >> $S
+  PROF="--steps 5 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-secondary"
+  for mode in default serialized; do
+    EXTRA=""; [ $mode = serialized ] && EXTRA="--adapter-streams 0 --wgrad-stream 0"
+    rm -rf gpurun_out/prof_$mode
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$mode -o p --output-format csv -- python $R/bench.py $PROF $EXTRA > $R/gpurun_out/prof_$mode.log 2>&1)
+    f=$(find gpurun_out/prof_$mode -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r6_bench_cfg3_kernel_stats_$mode.csv
+    python tools/trace_union.py gpurun_out/prof_$mode > gpurun_out/r6_trace_union_$mode.txt 2>&1
+    rm -rf gpurun_out/prof_$mode
+    grep "timed region" gpurun_out/prof_$mode.log | cut -c1-160 >> $S
+  done
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf gpurun_out/pmc_$c
+    (cd /tmp && timeout 600 rocprofv3 --pmc $c -d $R/gpurun_out/pmc_$c -o p --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-secondary --adapter-streams 0 --wgrad-stream 0 > $R/gpurun_out/pmc_$c.log 2>&1)
+  done
+  python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/r6_pmc_traffic.json >> $S 2>&1
+  rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
+  table encoder_gemms.py "encoder GEMMs"
+  table decoder_gemms.py "decoder GEMMs, tiles 9 10" 9 10
+  echo "== encoder step" >> $S
+  timeout 300 python tools/encoder_step.py > gpurun_out/r6_encoder_step.json 2> gpurun_out/encoder_step.err
+  cat gpurun_out/r6_encoder_step.json >> $S
+  python tools/hbm_probe.py >> $S 2>&1
+  ;;
 *)
   echo "unknown visit $V" >> $S
   ;;
