@@ -581,6 +581,9 @@ int mmae_token_mean_fwd(const float* x, float* y, int B, int N, int D, void* str
 int mmae_token_mean_bwd(const float* dy, float* dx, int B, int N, int D, void* stream);
 /* y (+)= a*x elementwise, f32 */
 int mmae_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream);
+/* out = in[0] + ... + in[n_in - 1] (f32, summed in index order; in_host: host array of 1 <= n_in <= 8 device pointers; n % 4 == 0; out may be in[0]).
+ * The sum autograd forms of the output adapters' gradients with respect to the shared encoder tokens (multimae.py:352-381), in one pass.  ABI v7. */
+int mmae_add_n_f32(float* out, const float* const* in_host, int n_in, int64_t n, void* stream);
 /* stochastic depth (multimae_utils.py:105-122) on 2-D activations, rows grouped N per sample, s f32 [R/N]:
  *   rowscale_add:  out[r][:] = resid[r][:] + s[r / N] * y[r][:]                 (f32, out may alias resid)
  *   rowscale_cast: out[r][:] = cast(s[r / N] * x[r][:])   (x f32; out act dtype) */

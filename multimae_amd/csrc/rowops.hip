@@ -409,6 +409,23 @@ __global__ void __launch_bounds__(256) transpose_cast_kernel(const float* __rest
         if (c < cols && r < rows) ActT<DT>::st(dst + (long long)c * rows + r, t[tx][i]);
     }
 }
+// out = in[0] + in[1] + ... + in[n - 1] in index order (n <= 8): the sum of the output adapters' encoder-token gradients in ONE pass (round 6; autograd's chain of
+// at::native add kernels read and wrote the running sum n - 1 times)
+struct AddNArgs { const float* in[8]; int n; };
+__global__ void __launch_bounds__(256) add_n_kernel(float* __restrict__ out, const AddNArgs a, long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        f32x4 s = ld4(a.in[0] + i * 4);
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            if (k < a.n) {
+                const f32x4 v = ld4(a.in[k] + i * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[j] += v[j];
+            }
+        }
+        st4(out + i * 4, s);
+    }
+}
 __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long long n) {
     const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const long long step = (long long)gridDim.x * blockDim.x * 4;
@@ -938,6 +955,19 @@ int mmae_dropout(const void* x, int x_dtype, const void* keep, float scale, cons
     } else { mmae_set_error("dropout: bad x_dtype"); return MMAE_EINVAL; }
 #undef DROP
     return mmae_check_launch("dropout");
+}
+int mmae_add_n_f32(float* out, const float* const* in_host, int n_in, int64_t n, void* stream) {
+    MMAE_REQUIRE(out && in_host && n_in >= 1 && n_in <= 8 && n >= 0 && n % 4 == 0, "add_n: 1 <= n_in <= 8 inputs, n a multiple of 4");
+    AddNArgs a = {};
+    a.n = n_in;
+    for (int k = 0; k < n_in; ++k) {
+        MMAE_REQUIRE(in_host[k] && (uintptr_t)in_host[k] % 16 == 0, "add_n: null / unaligned input");
+        a.in[k] = in_host[k];
+    }
+    MMAE_REQUIRE((uintptr_t)out % 16 == 0, "add_n: unaligned output");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(add_n_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, out, a, (long long)(n / 4));
+    return mmae_check_launch("add_n");
 }
 int mmae_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream) {
     MMAE_REQUIRE(y && x && n >= 0, "axpy: bad argument");

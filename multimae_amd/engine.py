@@ -32,6 +32,7 @@ _state = {
     'fp32_adapter_gemm': 'h16',      # fp32_output_adapters in bf16 speed mode: 'h16' (fp16 STORAGE: the bf16 pipeline's kernels with TF32's significand) | 'f16' (f32 tensors, fp16 operands) | 'x3' (split bf16) | 'exact'
     'patch_domain_loss': __import__('os').environ.get('MMAE_PATCH_LOSS', '1') != '0',
     'first_write_stores': __import__('os').environ.get('MMAE_FIRST_WRITE', '1') != '0',     # A/B switch of claim_first_write()
+    'encoder_fanout': __import__('os').environ.get('MMAE_ENC_FANOUT', '1') != '0',           # A/B switch of multimae._EncoderFanOut
 }
 
 
@@ -107,6 +108,16 @@ def set_adapter_cu_share(k: int) -> None:
     """Compute units the output adapters' persistent GEMM grids leave free while the adapters run on separate streams (A/B switch,
     default 0; see functions._adapter_cu_share)."""
     _state['adapter_cu_share'] = int(k)
+
+
+def encoder_fanout() -> bool:
+    return _state.get('encoder_fanout', True)
+
+
+def set_encoder_fanout(flag: bool) -> None:
+    """A/B switch (default on; env MMAE_ENC_FANOUT=0): the output adapters' gradients with respect to the shared encoder tokens are summed by ONE
+    kernel behind one autograd node (multimae._EncoderFanOut, ops.add_n) instead of autograd's chain of at::native adds."""
+    _state['encoder_fanout'] = bool(flag)
 
 
 def adapter_streams() -> bool:

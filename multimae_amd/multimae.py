@@ -264,6 +264,10 @@ class MultiMAE(nn.Module):
         if engine.act_dtype() == torch.bfloat16 and any(d not in fp32_output_adapters for d in self.output_adapters):
             Be, Ne, De = encoder_tokens.shape
             enc_bf16 = ops.cast(encoder_tokens.detach().contiguous().view(Be * Ne, De), torch.bfloat16)
+        # one autograd node in front of the adapters: their gradients with respect to the shared encoder tokens are summed in ONE pass
+        # (ops.add_n, index order) instead of autograd's chain of n - 1 at::native adds (round 6)
+        enc_for = _EncoderFanOut.apply(encoder_tokens, len(self.output_adapters)) if (
+            engine.encoder_fanout() and encoder_tokens.is_cuda and encoder_tokens.requires_grad and len(self.output_adapters) > 1 and torch.is_grad_enabled()) else None
         for i, domain in enumerate(self.output_adapters):
             # reference: adapters listed in fp32_output_adapters run with autocast disabled (:367-377);
             # here they run on the exact-f32 MFMA path
@@ -272,7 +276,7 @@ class MultiMAE(nn.Module):
             # engine.set_fp32_adapter_gemm; in the fp32 parity mode on the exact-f32 MFMA path
             fp32 = domain in fp32_output_adapters
             speed = engine.act_dtype() == torch.bfloat16
-            kw = dict(encoder_tokens=encoder_tokens, input_info=input_info, ids_keep=ids_keep, ids_restore=ids_restore,
+            kw = dict(encoder_tokens=encoder_tokens if enc_for is None else enc_for[i], input_info=input_info, ids_keep=ids_keep, ids_restore=ids_restore,
                       act_dtype=torch.float32 if fp32 else None, on_done=self._adapter_done_cb(domain),
                       encoder_tokens_act=None if fp32 else enc_bf16,
                       f32_gemm=engine.fp32_adapter_gemm() if (fp32 and speed and engine.fp32_adapter_gemm() in ('x3', 'f16', 'h16')) else 'exact')
@@ -318,6 +322,28 @@ class MultiMAE(nn.Module):
             cb('global_tokens')
             cb('input_adapters')
         return done
+
+
+class _EncoderFanOut(torch.autograd.Function):
+    """encoder_tokens -> n aliases of it (one per output adapter, multimae.py:352-381); backward: the adapters' n gradients summed by one kernel."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        if all(g.dtype == torch.float32 and g.is_cuda and g.numel() % 4 == 0 for g in gs) and len(gs) <= 8:
+            return ops.add_n(gs), None
+        out = gs[0]
+        for g in gs[1:]:
+            out = out + g
+        return out, None
 
 
 @register_model

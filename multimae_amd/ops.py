@@ -1001,6 +1001,16 @@ def rowscale_cast(x: Tensor, s: Tensor, N: int, dtype: torch.dtype) -> Tensor:
     return out
 
 
+def add_n(xs: Sequence[Tensor]) -> Tensor:
+    """Sum of 1 <= n <= 8 f32 tensors of one shape in ONE pass (mmae_add_n_f32), in index order."""
+    xs = [x.contiguous() for x in xs]
+    assert all(x.dtype == torch.float32 and x.shape == xs[0].shape for x in xs) and xs[0].numel() % 4 == 0
+    out = torch.empty_like(xs[0])
+    ptrs = (ctypes.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+    check(_lib.load().mmae_add_n_f32(out.data_ptr(), ctypes.cast(ptrs, ctypes.c_void_p), len(xs), out.numel(), _stream()), 'add_n')
+    return out
+
+
 def axpy_(y: Tensor, x: Tensor, a: float = 1.0) -> Tensor:
     assert y.dtype == torch.float32 and x.dtype == torch.float32 and y.numel() == x.numel()
     check(_lib.load().mmae_axpy_f32(y.data_ptr(), x.data_ptr(), a, y.numel(), _stream()), 'axpy')

@@ -220,6 +220,16 @@ def test_gemm_epilogues(dtype):
     assert rel_err(c16.float(), 0.5 * (x @ w.t())) < 4e-3
 
 
+def test_add_n_sums_in_index_order():
+    """mmae_add_n_f32 (round 6: the output adapters' encoder-token gradients in one pass): bit-equal to the left-to-right chain of additions."""
+    from multimae_amd import ops
+    torch.manual_seed(4)
+    xs = [torch.randn(3, 99, 768, device=DEV) * (10.0 ** (i - 2)) for i in range(4)]
+    ref = ((xs[0] + xs[1]) + xs[2]) + xs[3]
+    assert torch.equal(ops.add_n(xs), ref)
+    assert torch.equal(ops.add_n(xs[:1]), xs[0]) and torch.equal(ops.add_n(xs[:2]), xs[0] + xs[1])
+
+
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
 def test_semseg_class_embedding_gradient_is_deterministic(dtype):
     """mmae_semseg_emb_bwd_det (round 6): d_emb[class of every pixel of a selected semseg patch][e] += the patch row's gradient

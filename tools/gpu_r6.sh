@@ -128,6 +128,12 @@ final)   # the round's measurement visit: default line (+ secondaries), other co
   cat gpurun_out/r6_encoder_step.json >> $S
   python tools/hbm_probe.py >> $S 2>&1
   ;;
+envab)   # same-visit A/B of an environment switch of the production path: $1 = VAR=value of the alternative, $2 = label
+  for i in 1 2 3; do
+    run "defaults" timeout 300 $B
+    env $1 bash -c "$(declare -f run); S=$S; run \"$2 ($1)\" timeout 300 $B"
+  done
+  ;;
 *)
   echo "unknown visit $V" >> $S
   ;;
