@@ -134,6 +134,16 @@ envab)   # same-visit A/B of an environment switch of the production path: $1 = 
     env $1 bash -c "$(declare -f run); S=$S; run \"$2 ($1)\" timeout 300 $B"
   done
   ;;
+launch)   # the driver's launch forms on the one GPU a lease has: torchrun at world size 1, and two ranks sharing the device over gloo (all_reduce and rs_ag buckets)
+  echo "== torchrun, world size 1 (the driver's N > 1 command line with N = 1)" >> $S
+  ( timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > gpurun_out/launch1.log 2> gpurun_out/launch1.err ); echo "rc=$?" >> $S
+  grep "timed region" gpurun_out/launch1.err | cut -c1-160 >> $S; grep "^{" gpurun_out/launch1.log | cut -c1-300 >> $S; grep -i "error\|Traceback" gpurun_out/launch1.err | tail -3 >> $S
+  for ex in all_reduce rs_ag; do
+    echo "== two ranks on one device, gloo buckets, --dp-exchange $ex (functional test of the N > 1 path with the real kernels)" >> $S
+    ( timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --share-device 1 --batch 64 --dp-exchange $ex > gpurun_out/launch2.log 2> gpurun_out/launch2.err ); echo "rc=$?" >> $S
+    grep "timed region" gpurun_out/launch2.err | cut -c1-160 >> $S; grep "^{" gpurun_out/launch2.log | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print({k: d.get(k) for k in ('value','n_gpus','ms_per_step','rccl_ranks_seen')}, {k: d['data_parallel'].get(k) for k in ('exchange','buckets','backend','exposed_allreduce_ms_per_step')})" >> $S 2>&1; grep -i "error\|Traceback" gpurun_out/launch2.err | tail -3 >> $S
+  done
+  ;;
 *)
   echo "unknown visit $V" >> $S
   ;;
