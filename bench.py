@@ -506,6 +506,9 @@ def run_once(args):
     cu_reserve = args.gemm_cu_reserve if args.gemm_cu_reserve >= 0 else (16 if use_dist else 0)
     if reducer is not None:
         reducer.gemm_cu_reserve = cu_reserve
+    elif cu_reserve > 0 and not dry:
+        from multimae_amd import ops as _ops
+        _ops.gemm_cu_reserve(cu_reserve)                          # single process, no gradient exchange: narrower grids for the whole run (an experiment knob)
     n_vis = 196 if args.config == 'cfg5' else 98
     lr = 1e-4 * B * world / 256                                   # blr * global_bs / 256 (:372-373)
     opt = FusedAdamW(model, lr=lr, betas=(0.9, 0.95), weight_decay=0.05)

@@ -144,6 +144,9 @@ launch)   # the driver's launch forms on the one GPU a lease has: torchrun at wo
     grep "timed region" gpurun_out/launch2.err | cut -c1-160 >> $S; grep "^{" gpurun_out/launch2.log | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print({k: d.get(k) for k in ('value','n_gpus','ms_per_step','rccl_ranks_seen')}, {k: d['data_parallel'].get(k) for k in ('exchange','buckets','backend','exposed_allreduce_ms_per_step')})" >> $S 2>&1; grep -i "error\|Traceback" gpurun_out/launch2.err | tail -3 >> $S
   done
   ;;
+width)   # how wide must the persistent GEMM grids be?  the default line with 0 / 16 / 32 / 64 CUs left free for the WHOLE step (the loops are power-bound)
+  for k in 0 16 32 0 16 64 96; do run "GEMM grids leave $k CUs free" timeout 300 $B --gemm-cu-reserve $k; done
+  ;;
 *)
   echo "unknown visit $V" >> $S
   ;;
