@@ -205,5 +205,17 @@ def test_mxfp8_encoder_trains_like_bf16_at_the_cfg5_geometry():
         pass
     assert ca['skipped'] == 0 and cb['skipped'] == 0, (ca, cb)
     assert a[-1] < 0.8 * a[0] and b[-1] < 0.8 * b[0]
-    assert gap < 1.5e-2, (gap, mean(a), mean(b))
-    assert run_gap < 5e-2, run_gap
+    # round 6: every reduction of a step has a fixed order (the class-embedding gradient was the last float-atomic one), so the curves -- and these
+    # gaps -- are the same from run to run (measured 1.6e-3 / 1.6e-2); the bounds are the round-5 verdict's
+    assert gap < 8e-3, (gap, mean(a), mean(b))
+    assert run_gap < 3e-2, run_gap
+
+
+@pytest.mark.parametrize('cfg, precision, B, nvis', [('cfg3', 'bf16', 8, NVIS), ('cfg5', 'mxfp8', 4, 196)])
+def test_a_training_run_is_bit_reproducible(cfg, precision, B, nvis):
+    """Two runs of the same 8 steps (identical init / batch / mask seeds) give bit-identical loss curves: no float atomics are left in the step
+    (mmae_semseg_emb_bwd_det, round 6; split-K slabs, column sums and the gradient-norm reduction always had fixed orders)."""
+    r1 = _train(cfg, precision, 'h16', 8, B, nvis)
+    r2 = _train(cfg, precision, 'h16', 8, B, nvis)
+    assert r1[0] == r2[0], [abs(p - q) for p, q in zip(r1[0], r2[0])]
+    assert r1[1] == r2[1]
