@@ -220,6 +220,37 @@ def test_gemm_epilogues(dtype):
     assert rel_err(c16.float(), 0.5 * (x @ w.t())) < 4e-3
 
 
+def test_gemm_timing_books_flops_and_algorithmic_bytes():
+    """mmae_gemm_timing_* (bench.py's roofline object): while enabled every GEMM entry point is bracketed by events on its stream and booked with its
+    algorithmic FLOPs and -- ABI v7 -- its algorithmic HBM bytes (operands once, C and every epilogue stream once)."""
+    import ctypes
+    from multimae_amd import ops, _lib
+    from multimae_amd._lib import EPI_GELU_G
+    lib = _lib.load()
+    M_, N_, K_ = 1024, 512, 256
+    x = torch.randn(M_, K_, device=DEV).to(torch.bfloat16)
+    w = torch.randn(N_, K_, device=DEV).to(torch.bfloat16)
+    b = torch.randn(N_, device=DEV)
+    y, aux = torch.empty(M_, N_, device=DEV, dtype=torch.bfloat16), torch.empty(M_, N_, device=DEV, dtype=torch.bfloat16)
+    y32, res = torch.empty(M_, N_, device=DEV), torch.randn(M_, N_, device=DEV)
+    lib.mmae_gemm_timing_enable(1)
+    try:
+        ops.linear_fwd(x, w, b, y)                                   # A + B + C
+        ops.linear_fwd(x, w, b, y, aux=aux, epi=EPI_GELU_G)          # + the aux stream
+        ops.linear_fwd(x, w, b, y32, resid=res)                      # f32 C + f32 residual
+        torch.cuda.synchronize()
+        ms, fl, n = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 3)()
+        by = (ctypes.c_double * 3)()
+        assert lib.mmae_gemm_timing_read(ms, fl, n) == 0 and lib.mmae_gemm_timing_read_bytes(by) == 0
+    finally:
+        lib.mmae_gemm_timing_enable(0)
+    ab = (M_ * K_ + N_ * K_) * 2
+    want = (ab + M_ * N_ * 2) + (ab + 2 * M_ * N_ * 2) + (ab + 2 * M_ * N_ * 4)
+    assert n[0] == 3 and fl[0] == 3 * 2.0 * M_ * N_ * K_ and ms[0] > 0
+    assert by[0] == want, (by[0], want)
+    assert n[1] == 0 and by[1] == 0 and by[2] == 0
+
+
 def test_add_n_sums_in_index_order():
     """mmae_add_n_f32 (round 6: the output adapters' encoder-token gradients in one pass): bit-equal to the left-to-right chain of additions."""
     from multimae_amd import ops
