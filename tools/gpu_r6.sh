@@ -147,6 +147,12 @@ launch)   # the driver's launch forms on the one GPU a lease has: torchrun at wo
 width)   # how wide must the persistent GEMM grids be?  the default line with 0 / 16 / 32 / 64 CUs left free for the WHOLE step (the loops are power-bound)
   for k in 0 16 32 0 16 64 96; do run "GEMM grids leave $k CUs free" timeout 300 $B --gemm-cu-reserve $k; done
   ;;
+copies)   # where do the __amd_rocclr_copyBuffer / fill launches of a step come from?  (tools/copy_census.py on a kernel trace of the bench command)
+  rm -rf gpurun_out/prof_c
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $R/gpurun_out/prof_c -o p --output-format csv -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-secondary > $R/gpurun_out/prof_c.log 2>&1)
+  python tools/copy_census.py gpurun_out/prof_c 6 >> $S 2>&1
+  rm -rf gpurun_out/prof_c
+  ;;
 *)
   echo "unknown visit $V" >> $S
   ;;
