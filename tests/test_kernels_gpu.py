@@ -220,6 +220,49 @@ def test_gemm_epilogues(dtype):
     assert rel_err(c16.float(), 0.5 * (x @ w.t())) < 4e-3
 
 
+@pytest.mark.parametrize('shape', [(25344, 3072, 64), (25344, 2304, 96), (50176, 1024, 256)])
+def test_pingpong_tile_boundary_under_memory_load(shape):
+    """The flavoured ping-pong kernels leave a tile with stores in flight and take the next tile's first K tiles behind a COUNTED wait (round 6, TAILD:
+    a wave's loads, LDS-DMA pieces and stores retire in order).  Short contractions put that boundary under stress -- 3-4 tiles per persistent workgroup,
+    two or three K tiles each, so the next tile's operands are requested while most of the previous tile's stores are outstanding.  40 launches of each
+    epilogue flavour with a second stream hammering HBM beside them: every launch bit-equal to the first, the first equal to the fp32 product."""
+    from multimae_amd import ops
+    from multimae_amd._lib import EPI_GELU_G, EPI_MUL
+    M_, N_, K_ = shape
+    torch.manual_seed(9)
+    x = (torch.randn(M_, K_, device=DEV) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N_, K_, device=DEV) * 0.2).to(torch.bfloat16)
+    b = torch.randn(N_, device=DEV)
+    dy = (torch.randn(M_, N_, device=DEV) * 0.3).to(torch.bfloat16)
+    auxg = torch.rand(M_, K_, device=DEV).to(torch.bfloat16)
+    noise_a, noise_b = torch.empty(1 << 28, device=DEV, dtype=torch.uint8), torch.empty(1 << 28, device=DEV, dtype=torch.uint8)
+    side = torch.cuda.Stream()
+    y, aux = torch.empty(M_, N_, device=DEV, dtype=torch.bfloat16), torch.empty(M_, N_, device=DEV, dtype=torch.bfloat16)
+    dx = torch.empty(M_, K_, device=DEV, dtype=torch.bfloat16)
+    cs = torch.empty(K_, device=DEV)
+    cases = {'bias -> bf16': (lambda: ops.linear_fwd(x, w, b, y), lambda: (y,)),
+             'bias + GELU pair -> 2 x bf16': (lambda: ops.linear_fwd(x, w, b, y, aux=aux, epi=EPI_GELU_G), lambda: (y, aux)),
+             'dX x aux + column sums': (lambda: ops.linear_dx(dy, w, dx, aux=auxg, epi=EPI_MUL, colsum_out=cs), lambda: (dx, cs))}
+    ref_lin = x.float() @ w.float().t() + b
+    for name, (fn, outs) in cases.items():
+        fn()
+        torch.cuda.synchronize()
+        first = [t.clone() for t in outs()]
+        if name == 'bias -> bf16':
+            assert rel_err(first[0].float(), ref_lin) < 4e-3, name
+        if name.startswith('dX'):
+            assert rel_err(first[0].float(), (dy.float() @ w.float()) * auxg.float()) < 6e-3, name
+        for it in range(40):
+            with torch.cuda.stream(side):
+                noise_b.copy_(noise_a)                    # 256 MiB read + 256 MiB written beside the launch
+            for t in outs():
+                t.zero_()
+            fn()
+            torch.cuda.synchronize()
+            for a, r in zip(outs(), first):
+                assert torch.equal(a, r), (name, it, float((a.float() - r.float()).abs().max()))
+
+
 def test_gemm_timing_books_flops_and_algorithmic_bytes():
     """mmae_gemm_timing_* (bench.py's roofline object): while enabled every GEMM entry point is bracketed by events on its stream and booked with its
     algorithmic FLOPs and -- ABI v7 -- its algorithmic HBM bytes (operands once, C and every epilogue stream once)."""
