@@ -153,6 +153,11 @@ copies)   # where do the __amd_rocclr_copyBuffer / fill launches of a step come 
   python tools/copy_census.py gpurun_out/prof_c 6 >> $S 2>&1
   rm -rf gpurun_out/prof_c
   ;;
+pptrace)   # phase stamps inside the ping-pong GEMM on this round's tile boundary (trace build: make -C multimae_amd/csrc trace; un-ignore libmmae_hip_trace.so)
+  T=$R/multimae_amd/libmmae_hip_trace.so
+  [ -f $T ] || { echo "no trace library: make -C multimae_amd/csrc trace" >> $S; exit 1; }
+  MMAE_LIB=$T timeout 300 python tools/pp_trace.py >> $S 2>&1
+  ;;
 *)
   echo "unknown visit $V" >> $S
   ;;
