@@ -78,7 +78,7 @@ def pmc_traffic(dom):
     for name in ('r06_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         f = os.path.join(ROOT, 'profiles', name)
         try:
-            return json.load(open(f)).get('gemm_bf16_traffic_per_launch'), f'recorded, not of this run: profiles/{name} (rocprofv3 --pmc FETCH_SIZE x 2 and WRITE_SIZE passes of this command on the build that file names, tools/gpu_r5.sh final; counters cannot be read in-process, and a --pmc pass may not be combined with the timed run)'
+            return json.load(open(f)).get('gemm_bf16_traffic_per_launch'), f'recorded, not of this run: profiles/{name} (rocprofv3 --pmc FETCH_SIZE x 2 and WRITE_SIZE passes of this command on the build that file names, tools/gpu_r6.sh / gpu_r5.sh final; counters cannot be read in-process, and a --pmc pass may not be combined with the timed run)'
         except (OSError, ValueError):
             continue
     return None, None
